@@ -1,0 +1,205 @@
+/*
+ * tostore_hip.h -- C-ABI of libtostore_hip.so: MI355X (gfx950) exhaustive kNN
+ * behind ToStore's vectorSearch().
+ *
+ * The reference (tocreator/tostore v3.2.0, pure Dart) has no plugin/FFI hook
+ * for vector search; the seam this library plugs into is the single call
+ *   NghGraphEngine.search(...)   lib/src/core/ngh_graph_engine.dart:67-135
+ * made from VectorIndexManager.vectorSearch
+ *                                lib/src/core/vector_index_manager.dart:538-548
+ * plus the data-feed seams listed per function below.  Conventions mirror the
+ * reference's only existing FFI (lib/src/handler/system_ffi_helper.dart:21-55,
+ * 219-262): int32 status returns with 0 = success, caller-allocated
+ * out-params, no callbacks, every failure recoverable by falling back to the
+ * Dart path.  The `dart:ffi` binding a maintainer would add is in
+ * INTEGRATION.md and tostore_amd/dart/tostore_hip_bridge.dart.
+ *
+ * Ownership: the library owns only tsh_index handles and device memory.
+ * Every host pointer is caller-allocated and caller-freed; inputs are fully
+ * consumed before the call returns; no pointer is retained.
+ * Threading: every entry point is thread-safe; searches on one handle may
+ * run concurrently, append/delete/load take the handle exclusively.
+ * Errors: <0 = error class below; text via tsh_last_error (thread-local).
+ * The library never aborts, throws across the boundary, or falls back to a
+ * CPU implementation: without a usable GPU every compute entry returns
+ * TSH_E_NO_DEVICE.
+ */
+#ifndef TOSTORE_HIP_H
+#define TOSTORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSH_ABI_VERSION 1
+
+/* status codes */
+#define TSH_OK 0
+#define TSH_E_BAD_ARG (-1)
+#define TSH_E_DIM_MISMATCH (-2)
+#define TSH_E_OOM (-3)
+#define TSH_E_HIP (-4)
+#define TSH_E_NO_DEVICE (-5)
+#define TSH_E_OVERFLOW (-6) /* a candidate block was too small; retry with more entries */
+#define TSH_E_IO (-7)
+#define TSH_E_FORMAT (-8)
+
+/* metric = enum order of VectorDistanceMetric, lib/src/model/table_schema.dart:2511-2531 */
+#define TSH_METRIC_L2 0
+#define TSH_METRIC_IP 1
+#define TSH_METRIC_COSINE 2
+
+typedef struct tsh_index tsh_index;
+
+/* counters: replaces nothing in the reference (it has no tracing on this
+ * path); feeds Logger-style diagnostics on the Dart side */
+typedef struct tsh_counters {
+  int64_t rows;              /* rows ever appended (= next row id) */
+  int64_t deleted_rows;      /* tombstoned rows */
+  int64_t searches;          /* queries answered */
+  int64_t scan_launches;     /* single-query scan kernels launched */
+  int64_t batch_launches;    /* batched (MFMA) passes launched */
+  int64_t fallback_searches; /* queries that took the wide-band fallback */
+  int64_t candidates_total;  /* rows re-ranked in f64 */
+  int64_t bytes_resident;    /* device bytes held by this handle */
+  int32_t safe_mode;         /* !=0: corpus values outside the f32 error model; every
+                                search re-ranks all rows in f64 (exact, slow) */
+  int32_t device_id;
+} tsh_counters;
+
+int32_t tsh_abi_version(void);
+/* number of usable HIP devices; 0 when none (never an error) */
+int32_t tsh_device_count(void);
+/* copies the calling thread's last error text (NUL-terminated, truncated to
+ * len); returns the untruncated length */
+int32_t tsh_last_error(char *buf, int32_t len);
+
+/* Create an empty device index on the calling thread's current HIP device
+ * (n_devices == 1) or row-range sharded over devices 0..n_devices-1.
+ * Created lazily by the Dart side on the first vectorSearch / writeChanges of
+ * an index (the reference loads nothing vector-related at open:
+ * lib/src/core/data_store_impl.dart:822-846, vector_index_manager.dart:39-43).
+ * dim/metric come from NghIndexMeta (lib/src/model/ngh_index_meta.dart:82-100). */
+int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows,
+                         int32_t n_devices, tsh_index **out);
+
+/* One shard of a row-range partitioned corpus, for one-process-per-GPU
+ * deployments: holds global rows [row_base, row_base + size) on device
+ * `device_id` (-1 = current).  Ids reported by this handle are global. */
+int32_t tsh_index_create_shard(int32_t dim, int32_t metric, int64_t capacity_rows,
+                               int32_t device_id, int64_t row_base, tsh_index **out);
+
+/* Replaces cache teardown: VectorIndexManager.clearCacheForTable/Index, dispose
+ * (vector_index_manager.dart:1192-1216); also required after reorderByLocality
+ * renumbers node ids (:932-1159). */
+int32_t tsh_index_destroy(tsh_index *idx);
+
+/* Append (or overwrite) rows [first_row_id, first_row_id + n_rows); `rows` is
+ * row-major n_rows x dim float32, already converted exactly as the reference
+ * stores them (f64 -> f32, truncate / zero-pad: core/compute/
+ * vector_batch_prepare_compute.dart:79-86).  Mirrors NghGraphEngine.
+ * _writeRawVector / insertBatch (ngh_graph_engine.dart:691-720, :297-403):
+ * node ids are dense and monotonically assigned (:321).  Ids skipped by a gap
+ * are treated as absent rows (never returned), like a missing raw-vector page
+ * (ngh_graph_engine.dart:124-125).  Shard handles take GLOBAL ids. */
+int32_t tsh_index_append(tsh_index *idx, int64_t first_row_id, int64_t n_rows,
+                         const float *rows);
+/* Same, from a device pointer on the handle's device (bulk loaders that
+ * already hold the column in HBM). */
+int32_t tsh_index_append_device(tsh_index *idx, int64_t first_row_id, int64_t n_rows,
+                                const void *d_rows);
+
+/* Tombstones: mirrors NghGraphEngine.deleteBatch (ngh_graph_engine.dart:411-445),
+ * which sets NghNodeFlags.deleted (ngh_page.dart:105-108) and leaves the raw
+ * vector bytes in place.  Unlike the reference's beam search (which can leak
+ * deleted rows from other pages, :230-232) deleted rows are never returned.
+ * Unknown ids are ignored. */
+int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n);
+
+/* Cold load of one raw-vector partition file
+ * <index>/ngh/rawvec/dir_N/pP.ngh (lib/src/core/path_manager.dart:318-324):
+ * data pages 1..last of `page_size` bytes (page 0 is the partition meta page,
+ * core/ngh_page.dart:29-98), each a 20-byte 'TPG2' header + CRC32
+ * (core/btree_page.dart:132-234) + NghRawVectorPage payload
+ * (core/ngh_page.dart:310-450; f64 / f32 / i8 elements converted to f32 exactly
+ * as getVectorAsFloat32 does, :364-391).  `precision` is meta.json's
+ * VectorPrecision index (0 f64, 1 f32, 2 i8) and fixes vectorsPerRawPage
+ * (core/ngh_page.dart:575-579); data page p holds node ids
+ * first_row_id + (p-1)*vectorsPerRawPage + slot (model/ngh_index_meta.dart:480-490).
+ * Reader semantics follow readRawVectorPage (core/ngh_partition_manager.dart:239-295):
+ * a page past the end of the file, or with an undecodable payload, reads as a
+ * page of zero vectors; a bad magic / CRC is an error (the reference throws:
+ * core/btree_page.dart:215-233) -> TSH_E_FORMAT, nothing appended from that page on.
+ * Only ids < first_row_id + max_rows are loaded (meta.nextNodeId bounds them).
+ * *out_rows = rows appended. */
+int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size,
+                                   int32_t precision, int64_t first_row_id, int64_t max_rows,
+                                   int64_t *out_rows);
+
+int64_t tsh_index_size(tsh_index *idx); /* next row id (rows incl. tombstones) */
+int32_t tsh_index_dim(tsh_index *idx);
+int32_t tsh_index_metric(tsh_index *idx);
+
+/* The drop-in for NghGraphEngine.search (ngh_graph_engine.dart:67-135) with
+ * ef -> infinity: exact distances of EVERY live row, reference phase-3
+ * semantics (:122-134): distance = sqrt(sum) for L2, -dot for IP,
+ * 1 - cos for cosine, all in f64 accumulated left to right over f32 elements
+ * (:908-946); rows with distance > distance_threshold dropped (NaN = none);
+ * ascending by Dart double.compareTo, ties by row id; at most k per query.
+ *   queries     nq x dim float32, prepared by the caller exactly as
+ *               vector_index_manager.dart:514-520 does (_toFloat32, and
+ *               _normalizeFloat32 for cosine)
+ *   row_mask    nullable; ceil(size/8) bytes, bit i (LSB first) = 1 keeps row
+ *               i (WHERE pre-filter; new capability)
+ *   out_ids     nq x k      out_dist nq x k      out_count nq
+ * nq == 1 (or small) streams the corpus once per query (HBM-bound kernel);
+ * larger nq uses the batched matrix-core path.  Empty index or k <= 0 returns
+ * TSH_OK with counts 0 (the reference returns const []: :78). */
+int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
+                   double distance_threshold, const uint8_t *row_mask,
+                   int64_t *out_ids, double *out_dist, int32_t *out_count);
+
+/* ---- row-sharded deployments (one process per GPU) ----------------------
+ * Each rank scans its shard and emits, per query, one fixed-size candidate
+ * block into DEVICE memory; ranks all-gather the blocks (RCCL) and any rank
+ * merges them on the host.  A block = 64-byte header + entries x 24 bytes
+ * {int64 global id, f64 sum0, f64 sum1} holding the exact f64 accumulations
+ * of ngh_graph_engine.dart:920-946 for every row that can be in the shard's
+ * top k. */
+int64_t tsh_candidate_block_bytes(int32_t entries);
+int32_t tsh_default_block_entries(int32_t k);
+/* d_out_blocks: device buffer of nq * tsh_candidate_block_bytes(entries) on the
+ * handle's device.  stream: hipStream_t to order the final device-to-device
+ * copy on (NULL = library stream, synchronised before return).
+ * row_mask is GLOBAL (bit = global row id). */
+int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
+                         const uint8_t *row_mask, int32_t entries, void *d_out_blocks,
+                         void *stream);
+/* Host-side merge of n_blocks x nq candidate blocks (layout [block][query]),
+ * applying the final sqrt / negate / 1-cos, threshold, ordering and top-k cut.
+ * Pure host code (no device needed).  Returns TSH_E_OVERFLOW if any block was
+ * truncated: every rank sees the same headers, so all ranks retry with the
+ * entry count written to *needed_entries. */
+int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries,
+                             int32_t nq, int32_t k, double distance_threshold,
+                             const void *blocks, int32_t n_blocks, int32_t entries,
+                             int64_t *out_ids, double *out_dist, int32_t *out_count,
+                             int32_t *needed_entries);
+
+int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out);
+
+/* ---- measurement hooks (bench.py / profiles) -----------------------------
+ * Average device time in microseconds of the scan kernel alone, measured with
+ * HIP events on the library's own stream over `iters` launches of one query. */
+int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters,
+                       const uint8_t *row_mask, double *out_avg_us);
+/* Same for one batched pass over nq queries. */
+int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_t iters,
+                        double *out_avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOSTORE_HIP_H */

@@ -1,0 +1,228 @@
+"""ctypes loader for the C restatement (oracle/vs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this package from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from the
+product package (tostore_amd/).  PARITY UNPINNED, see vs_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+L2, IP, COSINE = 0, 1, 2
+
+_c_i64 = ctypes.c_int64
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_c_f64p = ctypes.POINTER(ctypes.c_double)
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force: bool = False) -> None:
+    """Compile the restatement with gcc (see oracle/Makefile)."""
+    so = os.path.join(_HERE, "libvs_oracle.so")
+    src = os.path.join(_HERE, "vs_oracle.c")
+    if (not force and os.path.exists(so)
+            and os.path.getmtime(so) >= os.path.getmtime(src)
+            and os.path.exists(os.path.join(_HERE, "libvs_oracle_mt.so"))):
+        return
+    subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_lib_mt = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(os.path.join(_HERE, "libvs_oracle.so"))
+        L.vso_to_float32.argtypes = [_c_f64p, _c_i64, ctypes.c_int, _c_f32p]
+        L.vso_to_float32.restype = None
+        L.vso_normalize_f32.argtypes = [_c_f32p, ctypes.c_int, _c_f32p]
+        L.vso_normalize_f32.restype = None
+        for name in ("vso_l2_distance", "vso_inner_product", "vso_cosine_similarity"):
+            f = getattr(L, name)
+            f.argtypes = [_c_f32p, _c_f32p, ctypes.c_int]
+            f.restype = ctypes.c_double
+        L.vso_exact_distance.argtypes = [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int]
+        L.vso_exact_distance.restype = ctypes.c_double
+        L.vso_distance_to_score.argtypes = [ctypes.c_double, ctypes.c_int]
+        L.vso_distance_to_score.restype = ctypes.c_double
+        L.vso_compare_double.argtypes = [ctypes.c_double, ctypes.c_double]
+        L.vso_compare_double.restype = ctypes.c_int
+        for name in ("vso_search_exhaustive", "vso_search_heap"):
+            f = getattr(L, name)
+            f.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int, _c_f32p, _c_i64,
+                          ctypes.c_double, _c_u8p, _c_i64p, _c_f64p]
+            f.restype = _c_i64
+        L.vso_all_distances.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int,
+                                        _c_f32p, _c_f64p]
+        L.vso_all_distances.restype = None
+        L.vso_crc32.argtypes = [_c_u8p, ctypes.c_size_t]
+        L.vso_crc32.restype = ctypes.c_uint32
+        L.vso_vectors_per_raw_page.argtypes = [ctypes.c_int] * 3
+        L.vso_vectors_per_raw_page.restype = ctypes.c_int
+        L.vso_rawvec_page_build.argtypes = [_c_f32p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, _c_u8p]
+        L.vso_rawvec_page_build.restype = ctypes.c_int
+        L.vso_rawvec_page_parse.argtypes = [_c_u8p, ctypes.c_int, ctypes.c_int, _c_f32p,
+                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.vso_rawvec_page_parse.restype = ctypes.c_int
+        L.vso_ngh_meta_page_build.argtypes = [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64,
+                                              ctypes.c_int, _c_u8p]
+        L.vso_ngh_meta_page_build.restype = ctypes.c_int
+        L.vso_rawvec_locate.argtypes = [_c_i64, ctypes.c_int, _c_i64, _c_i64p, _c_i64p,
+                                        ctypes.POINTER(ctypes.c_int)]
+        L.vso_rawvec_locate.restype = None
+        _lib = L
+    return _lib
+
+
+def lib_mt() -> ctypes.CDLL:
+    global _lib_mt
+    if _lib_mt is None:
+        build()
+        L = ctypes.CDLL(os.path.join(_HERE, "libvs_oracle_mt.so"))
+        L.vso_mt_max_threads.restype = ctypes.c_int
+        L.vso_search_heap_mt.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int,
+                                         _c_f32p, _c_i64, ctypes.c_double, _c_u8p,
+                                         ctypes.c_int, _c_i64p, _c_f64p]
+        L.vso_search_heap_mt.restype = _c_i64
+        _lib_mt = L
+    return _lib_mt
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def to_float32(values, dim: int) -> np.ndarray:
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    out = np.empty(dim, dtype=np.float32)
+    lib().vso_to_float32(_p(v, _c_f64p), v.shape[0], dim, _p(out, _c_f32p))
+    return out
+
+
+def normalize_f32(v) -> np.ndarray:
+    v = _f32(v)
+    out = np.empty_like(v)
+    lib().vso_normalize_f32(_p(v, _c_f32p), v.shape[0], _p(out, _c_f32p))
+    return out
+
+
+def exact_distance(a, b, metric: int) -> float:
+    a, b = _f32(a), _f32(b)
+    return lib().vso_exact_distance(_p(a, _c_f32p), _p(b, _c_f32p), a.shape[0], metric)
+
+
+def distance_to_score(distance: float, metric: int) -> float:
+    return lib().vso_distance_to_score(float(distance), metric)
+
+
+def compare_double(a: float, b: float) -> int:
+    return lib().vso_compare_double(a, b)
+
+
+def all_distances(query, rows, metric: int) -> np.ndarray:
+    rows, query = _f32(rows), _f32(query)
+    n, d = rows.shape
+    out = np.empty(n, dtype=np.float64)
+    lib().vso_all_distances(_p(rows, _c_f32p), n, d, metric, _p(query, _c_f32p),
+                            _p(out, _c_f64p))
+    return out
+
+
+def _search(fn, rows, query, metric, k, threshold, keep, *extra):
+    rows, query = _f32(rows), _f32(query)
+    n, d = rows.shape if rows.ndim == 2 else (0, query.shape[0])
+    k = int(k)
+    ids = np.empty(max(k, 1), dtype=np.int64)
+    dist = np.empty(max(k, 1), dtype=np.float64)
+    thr = math.nan if threshold is None else float(threshold)
+    kp = None
+    if keep is not None:
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        assert keep.shape[0] >= (n + 7) // 8
+        kp = _p(keep, _c_u8p)
+    m = fn(_p(rows, _c_f32p), n, d, metric, _p(query, _c_f32p), k, thr, kp, *extra,
+           _p(ids, _c_i64p), _p(dist, _c_f64p))
+    if m < 0:
+        raise MemoryError("oracle allocation failed")
+    return ids[:m].copy(), dist[:m].copy()
+
+
+def search_exhaustive(rows, query, metric: int, k: int, threshold=None, keep=None):
+    return _search(lib().vso_search_exhaustive, rows, query, metric, k, threshold, keep)
+
+
+def search_heap(rows, query, metric: int, k: int, threshold=None, keep=None):
+    return _search(lib().vso_search_heap, rows, query, metric, k, threshold, keep)
+
+
+def search_heap_mt(rows, query, metric: int, k: int, threshold=None, keep=None, threads=0):
+    return _search(lib_mt().vso_search_heap_mt, rows, query, metric, k, threshold, keep,
+                   int(threads))
+
+
+def mt_max_threads() -> int:
+    return lib_mt().vso_mt_max_threads()
+
+
+def crc32(data: bytes) -> int:
+    buf = np.frombuffer(data, dtype=np.uint8)
+    return lib().vso_crc32(_p(buf, _c_u8p), buf.shape[0])
+
+
+def vectors_per_raw_page(page_size: int, dims: int, bpe: int) -> int:
+    return lib().vso_vectors_per_raw_page(page_size, dims, bpe)
+
+
+def rawvec_page_build(vectors, precision: int, page_size: int) -> bytes:
+    v = _f32(vectors)
+    count, dims = v.shape
+    out = np.zeros(page_size, dtype=np.uint8)
+    rc = lib().vso_rawvec_page_build(_p(v, _c_f32p), count, dims, precision, page_size,
+                                     _p(out, _c_u8p))
+    if rc != 0:
+        raise ValueError("page overflow")
+    return out.tobytes()
+
+
+def rawvec_page_parse(page: bytes, dims: int, max_vectors: int):
+    buf = np.frombuffer(page, dtype=np.uint8)
+    out = np.zeros((max_vectors, dims), dtype=np.float32)
+    prec = ctypes.c_int(-1)
+    n = lib().vso_rawvec_page_parse(_p(buf, _c_u8p), buf.shape[0], dims, _p(out, _c_f32p),
+                                    max_vectors, ctypes.byref(prec))
+    if n < 0:
+        return None
+    return out[:n].copy(), prec.value
+
+
+def ngh_meta_page_build(partition_no: int, category: int, total_entries: int,
+                        file_size: int, page_size: int) -> bytes:
+    out = np.zeros(page_size, dtype=np.uint8)
+    rc = lib().vso_ngh_meta_page_build(partition_no, category, total_entries, file_size,
+                                       page_size, _p(out, _c_u8p))
+    assert rc == 0
+    return out.tobytes()
+
+
+def rawvec_locate(node_id: int, vectors_per_page: int, pages_per_partition: int):
+    part, page = ctypes.c_int64(), ctypes.c_int64()
+    slot = ctypes.c_int()
+    lib().vso_rawvec_locate(node_id, vectors_per_page, pages_per_partition,
+                            ctypes.byref(part), ctypes.byref(page), ctypes.byref(slot))
+    return part.value, page.value, slot.value

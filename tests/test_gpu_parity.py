@@ -1,0 +1,281 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): returned row ids bit-exact at a given k,
+distances within 1e-5 relative.  The re-rank reproduces the reference's f64
+accumulation order, so distances are in fact compared BIT-exact here.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L2, IP, COS = 0, 1, 2
+METRICS = [L2, IP, COS]
+
+
+def _mk(n, d, seed, normalize=False, scale=None):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if normalize:
+        x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    if scale is not None:
+        x *= rng.uniform(scale[0], scale[1], size=(n, 1)).astype(np.float32)
+    return x
+
+
+def _prep_query(oracle, q, metric):
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    return oracle.normalize_f32(q) if metric == COS else q
+
+
+def _check(oracle, idx, rows, q, metric, k, threshold=None, keep=None, tag=""):
+    ids, dist, cnt = idx.search(q, k, threshold, keep)
+    eids, edist = oracle.search_exhaustive(rows, q, metric, k, threshold, keep)
+    n = int(cnt[0])
+    assert n == len(eids), f"{tag}: count {n} != {len(eids)}"
+    assert np.array_equal(ids[0, :n], eids), f"{tag}: ids differ\n{ids[0, :n]}\n{eids}"
+    a, b = dist[0, :n], edist
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) or np.array_equal(
+        np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), \
+        f"{tag}: distances not bit-exact, max rel {np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))}"
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("d", [4, 7, 100, 128, 384, 768, 1536])
+def test_random_small(hip_lib, oracle_mod, metric, d):
+    from tostore_amd import HipVectorIndex
+
+    rows = _mk(3000, d, 100 + d, scale=(0.5, 2.0))
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        for qi in range(3):
+            q = _prep_query(oracle_mod, _mk(1, d, 7 + qi)[0], metric)
+            for k in (1, 10, 100):
+                _check(oracle_mod, idx, rows, q, metric, k, tag=f"d{d} m{metric} k{k}")
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_readme_example(hip_lib, oracle_mod, metric):
+    """rows/query of /root/reference/example/lib/tostore_example.dart:387-413."""
+    from tostore_amd import VectorIndexManager
+
+    d = 128
+    v1 = [i * 0.01 for i in range(d)]
+    v2 = [i * 0.02 + 0.5 for i in range(d)]
+    q = [i * 0.015 for i in range(d)]
+    kat = {COS: [(8.881784197001252e-16, 0.9999999999999991), (0.008631337545516038, 0.991368662454484)],
+           L2: [(4.155959577530976, 0.19395031806647095), (9.482193837605186, 0.09539987673310046)],
+           IP: [(-268.22400006248057, 1.0), (-103.63200000291876, 1.0)]}
+    m = VectorIndexManager(d, metric)
+    try:
+        m.insert_batch(["doc1", "doc2"], [v1, v2])
+        res = m.vectorSearch(q, topK=5)
+        assert len(res) == 2
+        for r, (ed, es) in zip(res, kat[metric]):
+            assert r.distance == ed
+            assert r.score == es
+        assert [r.primaryKey for r in res] == (["doc2", "doc1"] if metric == IP else ["doc1", "doc2"])
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_ties_duplicates_and_zero_rows(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d = 64
+    base = _mk(40, d, 5)
+    rows = np.concatenate([np.tile(base[:1], (500, 1)), base, np.zeros((70, d), np.float32),
+                           np.tile(base[1:2], (300, 1))]).astype(np.float32)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        for q in (base[0], base[1], base[2] * 0.5, np.zeros(d, np.float32)):
+            qq = _prep_query(oracle_mod, q, metric)
+            for k in (3, 100, 600, len(rows), len(rows) + 5):
+                _check(oracle_mod, idx, rows, qq, metric, k, tag=f"ties m{metric} k{k}")
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_all_rows_identical(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d = 128
+    rows = np.tile(_mk(1, d, 9), (5000, 1))
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        q = _prep_query(oracle_mod, _mk(1, d, 10)[0], metric)
+        _check(oracle_mod, idx, rows, q, metric, 100, tag="identical")
+        assert idx.counters()["fallback_searches"] >= 1  # the wide-band path ran, still on the GPU
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_near_ties_at_boundary(hip_lib, oracle_mod, metric):
+    """rows whose keys differ by ~1e-9 relative: f32 cannot order them, the f64 re-rank must."""
+    from tostore_amd import HipVectorIndex
+
+    d = 256
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal(d).astype(np.float32)
+    rows = np.tile(base, (4000, 1)).astype(np.float32)
+    # flip the last mantissa bit of a few coordinates per row
+    for i in range(len(rows)):
+        cols = rng.integers(0, d, size=3)
+        bits = rows[i, cols].view(np.uint32) ^ np.uint32(1)
+        rows[i, cols] = bits.view(np.float32)
+    q = _prep_query(oracle_mod, (base + rng.standard_normal(d).astype(np.float32) * 0.1), metric)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        for k in (10, 100):
+            _check(oracle_mod, idx, rows, q, metric, k, tag=f"nearties m{metric} k{k}")
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_neighbours_clustered_in_one_tile(hip_lib, oracle_mod, metric):
+    """all true neighbours stored contiguously (worst case for the tile-minimum bound)."""
+    from tostore_amd import HipVectorIndex
+
+    d = 128
+    rows = _mk(20000, d, 11, normalize=True)
+    q0 = _mk(1, d, 12, normalize=True)[0]
+    near = (q0[None, :] + 0.01 * _mk(150, d, 13)).astype(np.float32)
+    rows[6400:6550] = near
+    q = _prep_query(oracle_mod, q0, metric)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        _check(oracle_mod, idx, rows, q, metric, 100, tag=f"cluster m{metric}")
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_nan_inf_rows(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d = 32
+    rows = _mk(500, d, 21)
+    rows[3, 5] = np.nan
+    rows[77, 0] = np.inf
+    rows[78, 1] = -np.inf
+    rows[200] = np.nan
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        assert idx.counters()["safe_mode"] == 1
+        q = _prep_query(oracle_mod, _mk(1, d, 22)[0], metric)
+        for k in (10, 499, 500):
+            _check(oracle_mod, idx, rows, q, metric, k, tag=f"naninf m{metric} k{k}")
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_threshold_is_strict(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d = 48
+    rows = _mk(2000, d, 31)
+    q = _prep_query(oracle_mod, _mk(1, d, 32)[0], metric)
+    _, edist = oracle_mod.search_exhaustive(rows, q, metric, 50)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        thr = float(edist[20])  # exactly equal to a distance: that row is KEPT (`>` drops)
+        _check(oracle_mod, idx, rows, q, metric, 50, threshold=thr, tag="thr-eq")
+        ids, dist, cnt = idx.search(q, 50, thr)
+        assert cnt[0] >= 21 and dist[0, cnt[0] - 1] == thr
+        _check(oracle_mod, idx, rows, q, metric, 50, threshold=np.nextafter(thr, -np.inf), tag="thr-below")
+        _check(oracle_mod, idx, rows, q, metric, 50, threshold=-1e30, tag="thr-none-pass")
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_mask_and_tombstones(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d = 96
+    n = 7000  # not a multiple of 64
+    rows = _mk(n, d, 41)
+    rng = np.random.default_rng(42)
+    q = _prep_query(oracle_mod, _mk(1, d, 43)[0], metric)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows[:1000])
+        idx.append(1000, rows[1000:])  # growth path
+        for pct in (0.5, 0.1, 0.01, 1.0, 0.0):
+            keepbits = rng.random(n) < pct
+            keep = np.packbits(keepbits, bitorder="little")
+            _check(oracle_mod, idx, rows, q, metric, 100, keep=keep, tag=f"mask{pct}")
+        dead = rng.choice(n, size=900, replace=False)
+        idx.set_deleted(dead)
+        idx.set_deleted(dead[:10])  # idempotent
+        alive = np.ones(n, bool)
+        alive[dead] = False
+        _check(oracle_mod, idx, rows, q, metric, 100, keep=np.packbits(alive, bitorder="little"),
+               tag="tombstones-as-mask")
+        ids, dist, cnt = idx.search(q, 100)
+        eids, edist = oracle_mod.search_exhaustive(rows, q, metric, 100,
+                                                   keep=np.packbits(alive, bitorder="little"))
+        assert np.array_equal(ids[0, :cnt[0]], eids) and np.array_equal(dist[0, :cnt[0]], edist)
+        assert idx.counters()["deleted_rows"] == 900
+        # user mask AND tombstones
+        keepbits = rng.random(n) < 0.3
+        _check(oracle_mod, idx, rows, q, metric, 64,
+               keep=np.packbits(keepbits & alive, bitorder="little"), tag="mask+tomb") if False else None
+        ids, dist, cnt = idx.search(q, 64, None, np.packbits(keepbits, bitorder="little"))
+        eids, edist = oracle_mod.search_exhaustive(rows, q, metric, 64,
+                                                   keep=np.packbits(keepbits & alive, bitorder="little"))
+        assert np.array_equal(ids[0, :cnt[0]], eids) and np.array_equal(dist[0, :cnt[0]], edist)
+
+
+def test_empty_and_degenerate_calls(hip_lib, oracle_mod):
+    from tostore_amd import HipVectorBackend, HipVectorIndex
+
+    with HipVectorIndex(16, L2) as idx:
+        ids, dist, cnt = idx.search(np.zeros(16, np.float32), 5)
+        assert cnt[0] == 0  # empty index -> empty result (ngh_graph_engine.dart:78)
+        assert HipVectorBackend(idx).search(query=np.zeros(16, np.float32), topK=5) == []
+        rows = _mk(3, 16, 1)
+        idx.append(0, rows)
+        ids, dist, cnt = idx.search(rows[1], 0)
+        assert cnt[0] == 0  # topK <= 0
+        _check(oracle_mod, idx, rows, rows[1], L2, 10, tag="k>n")
+        # gap: ids 3..9 absent
+        idx.append(10, rows)
+        full = np.zeros((13, 16), np.float32)
+        full[:3] = rows
+        full[10:] = rows
+        keep = np.zeros(13, bool)
+        keep[:3] = keep[10:] = True
+        ids, dist, cnt = idx.search(rows[1], 13)
+        eids, edist = oracle_mod.search_exhaustive(full, rows[1], L2, 13, keep=np.packbits(keep, bitorder="little"))
+        assert np.array_equal(ids[0, :cnt[0]], eids) and np.array_equal(dist[0, :cnt[0]], edist)
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_multi_query_call(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq, k = 128, 10000, 40, 10
+    rows = _mk(n, d, 51, normalize=True)
+    qs = np.stack([_prep_query(oracle_mod, q, metric) for q in _mk(nq, d, 52)])
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        ids, dist, cnt = idx.search(qs, k)
+        for i in range(nq):
+            eids, edist = oracle_mod.search_exhaustive(rows, qs[i], metric, k)
+            assert cnt[i] == k and np.array_equal(ids[i], eids) and np.array_equal(dist[i], edist)
+
+
+@pytest.mark.parametrize("metric,n,d,k", [(L2, 10000, 128, 10), (L2, 200000, 768, 100),
+                                          (COS, 200000, 768, 100), (IP, 100000, 1536, 100)])
+def test_config_shapes_scaled(hip_lib, oracle_mod, metric, n, d, k):
+    """BASELINE.json configs C1 (full size) and C2-C4 at sizes the oracle finishes in seconds."""
+    from tostore_amd import HipVectorIndex
+
+    rows = _mk(n, d, 61, normalize=True, scale=None if metric == COS else (0.5, 2.0))
+    with HipVectorIndex(d, metric, capacity_rows=n) as idx:
+        idx.append(0, rows)
+        for qi in range(2):
+            q = _prep_query(oracle_mod, _mk(1, d, 70 + qi, normalize=True)[0], metric)
+            ids, dist, cnt = idx.search(q, k)
+            eids, edist = oracle_mod.search_heap_mt(rows, q, metric, k)
+            assert cnt[0] == k
+            assert np.array_equal(ids[0], eids)
+            assert np.array_equal(dist[0], edist)
+            assert np.allclose(dist[0], edist, rtol=1e-5, atol=1e-6)  # the stated tolerance
+        c = idx.counters()
+        assert c["fallback_searches"] == 0 and c["candidates_total"] < 4 * k * 2

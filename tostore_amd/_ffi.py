@@ -1,0 +1,111 @@
+"""ctypes binding of libtostore_hip.so (include/tostore_hip.h).
+
+The Python-side counterpart of the `dart:ffi` bridge in
+tostore_amd/dart/tostore_hip_bridge.dart: same entry points, same status-code
+convention (0 = ok, mirrors /root/reference/lib/src/handler/
+system_ffi_helper.dart:219-262).  There is no fallback: a missing library or
+a failing call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtostore_hip.so")
+
+TSH_OK = 0
+TSH_E_BAD_ARG = -1
+TSH_E_DIM_MISMATCH = -2
+TSH_E_OOM = -3
+TSH_E_HIP = -4
+TSH_E_NO_DEVICE = -5
+TSH_E_OVERFLOW = -6
+TSH_E_IO = -7
+TSH_E_FORMAT = -8
+
+METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+
+c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+p_f32 = ctypes.POINTER(ctypes.c_float)
+p_f64 = ctypes.POINTER(ctypes.c_double)
+p_i32 = ctypes.POINTER(ctypes.c_int32)
+p_i64 = ctypes.POINTER(ctypes.c_int64)
+p_u8 = ctypes.POINTER(ctypes.c_uint8)
+p_void = ctypes.c_void_p
+
+
+class TshCounters(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_i64), ("deleted_rows", c_i64), ("searches", c_i64),
+        ("scan_launches", c_i64), ("batch_launches", c_i64),
+        ("fallback_searches", c_i64), ("candidates_total", c_i64),
+        ("bytes_resident", c_i64), ("safe_mode", c_i32), ("device_id", c_i32),
+    ]
+
+
+# every symbol include/tostore_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "tsh_abi_version": (c_i32, []),
+    "tsh_device_count": (c_i32, []),
+    "tsh_last_error": (c_i32, [ctypes.c_char_p, c_i32]),
+    "tsh_index_create": (c_i32, [c_i32, c_i32, c_i64, c_i32, ctypes.POINTER(p_void)]),
+    "tsh_index_create_shard": (c_i32, [c_i32, c_i32, c_i64, c_i32, c_i64, ctypes.POINTER(p_void)]),
+    "tsh_index_destroy": (c_i32, [p_void]),
+    "tsh_index_append": (c_i32, [p_void, c_i64, c_i64, p_f32]),
+    "tsh_index_append_device": (c_i32, [p_void, c_i64, c_i64, p_void]),
+    "tsh_index_set_deleted": (c_i32, [p_void, p_i64, c_i64]),
+    "tsh_index_load_rawvec_file": (c_i32, [p_void, ctypes.c_char_p, c_i32, c_i32, c_i64, c_i64, p_i64]),
+    "tsh_index_size": (c_i64, [p_void]),
+    "tsh_index_dim": (c_i32, [p_void]),
+    "tsh_index_metric": (c_i32, [p_void]),
+    "tsh_search": (c_i32, [p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
+    "tsh_candidate_block_bytes": (c_i64, [c_i32]),
+    "tsh_default_block_entries": (c_i32, [c_i32]),
+    "tsh_search_shard": (c_i32, [p_void, p_f32, c_i32, c_i32, p_u8, c_i32, p_void, p_void]),
+    "tsh_merge_candidates": (c_i32, [c_i32, c_i32, p_f32, c_i32, c_i32, c_f64, p_void, c_i32, c_i32,
+                                     p_i64, p_f64, p_i32, p_i32]),
+    "tsh_get_counters": (c_i32, [p_void, ctypes.POINTER(TshCounters)]),
+    "tsh_bench_scan": (c_i32, [p_void, p_f32, c_i32, p_u8, p_f64]),
+    "tsh_bench_batch": (c_i32, [p_void, p_f32, c_i32, c_i32, p_f64]),
+}
+
+
+class TshError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libtostore_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the shared library (raises if it was not built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.tsh_abi_version() != 1:
+            raise RuntimeError("libtostore_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(1024)
+    lib().tsh_last_error(buf, 1024)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != TSH_OK:
+        raise TshError(rc, last_error())

@@ -1,0 +1,154 @@
+"""Host-side mirror of the seam the HIP path plugs into.
+
+`HipVectorIndex` wraps one `tsh_index*` handle (the device-resident copy of an
+index's raw-vector column).  `HipVectorBackend.search` has the signature and
+result shape of `NghGraphEngine.search`
+(/root/reference/lib/src/core/ngh_graph_engine.dart:67-135; result class
+:26-40), so `VectorIndexManager` can call it where the reference calls the
+graph engine (/root/reference/lib/src/core/vector_index_manager.dart:538-548).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import METRIC_COSINE, METRIC_IP, METRIC_L2  # noqa: F401
+
+
+@dataclass
+class NghSearchResult:
+    """ref: core/ngh_graph_engine.dart:26-40 (nodeId, distance, primaryKey)."""
+    nodeId: int
+    distance: float
+    primaryKey: Optional[str] = None
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HipVectorIndex:
+    """Owner of one `tsh_index*`.  Destroy exactly once (close / context manager)."""
+
+    def __init__(self, dim: int, metric: int, capacity_rows: int = 0, n_devices: int = 1,
+                 *, shard_device: Optional[int] = None, row_base: int = 0):
+        self._h = ctypes.c_void_p()
+        L = _ffi.lib()
+        if shard_device is None:
+            _ffi.check(L.tsh_index_create(dim, metric, capacity_rows, n_devices, ctypes.byref(self._h)))
+        else:
+            _ffi.check(L.tsh_index_create_shard(dim, metric, capacity_rows, shard_device, row_base,
+                                                ctypes.byref(self._h)))
+        self.dim, self.metric, self.row_base = dim, metric, row_base
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self) -> None:
+        if self._h:
+            _ffi.lib().tsh_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data feed (mirrors _writeRawVector / deleteBatch) --------------------
+    def append(self, first_row_id: int, rows) -> None:
+        rows = _f32c(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be n x {self.dim}")
+        _ffi.check(_ffi.lib().tsh_index_append(self._h, first_row_id, rows.shape[0],
+                                               rows.ctypes.data_as(_ffi.p_f32)))
+
+    def append_device(self, first_row_id: int, n_rows: int, device_ptr: int) -> None:
+        _ffi.check(_ffi.lib().tsh_index_append_device(self._h, first_row_id, n_rows,
+                                                      ctypes.c_void_p(device_ptr)))
+
+    def set_deleted(self, ids: Sequence[int]) -> None:
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        _ffi.check(_ffi.lib().tsh_index_set_deleted(self._h, ids.ctypes.data_as(_ffi.p_i64), ids.shape[0]))
+
+    def load_rawvec_file(self, path: str, page_size: int, precision: int, first_row_id: int,
+                         max_rows: int) -> int:
+        out = ctypes.c_int64(0)
+        _ffi.check(_ffi.lib().tsh_index_load_rawvec_file(self._h, path.encode(), page_size, precision,
+                                                         first_row_id, max_rows, ctypes.byref(out)))
+        return out.value
+
+    @property
+    def size(self) -> int:
+        return _ffi.lib().tsh_index_size(self._h)
+
+    def counters(self) -> dict:
+        c = _ffi.TshCounters()
+        _ffi.check(_ffi.lib().tsh_get_counters(self._h, ctypes.byref(c)))
+        return {k: getattr(c, k) for k, _ in c._fields_}
+
+    # -- search ---------------------------------------------------------------
+    def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
+        """Raw C-ABI search: (ids[nq,k], dist[nq,k], count[nq])."""
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"queries must be nq x {self.dim}")
+        nq, kk = q.shape[0], max(int(k), 0)
+        ids = np.full((nq, max(kk, 1)), -1, dtype=np.int64)
+        dist = np.full((nq, max(kk, 1)), np.nan, dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        thr = math.nan if distance_threshold is None else float(distance_threshold)
+        mp = None
+        if row_mask is not None:
+            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
+            need = (self.size + 7) // 8
+            if row_mask.shape[0] < need:
+                raise ValueError(f"row_mask needs {need} bytes")
+            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        _ffi.check(_ffi.lib().tsh_search(self._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, mp,
+                                         ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
+                                         cnt.ctypes.data_as(_ffi.p_i32)))
+        return ids[:, :kk], dist[:, :kk], cnt
+
+    def bench_scan(self, query, iters: int = 20, row_mask=None) -> float:
+        q = _f32c(query)
+        out = ctypes.c_double(0)
+        mp = None
+        if row_mask is not None:
+            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
+            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        _ffi.check(_ffi.lib().tsh_bench_scan(self._h, q.ctypes.data_as(_ffi.p_f32), iters, mp,
+                                             ctypes.byref(out)))
+        return out.value
+
+
+class HipVectorBackend:
+    """Drop-in for `NghGraphEngine.search` backed by a `HipVectorIndex`.
+
+    ref: core/ngh_graph_engine.dart:67-135.  `efSearch` is accepted and ignored:
+    the scan is exhaustive (ef -> infinity), so the k=100 / default-ef trap of
+    :80-82,168 (at most 64 rows returned) does not exist here.
+    """
+
+    def __init__(self, index: HipVectorIndex):
+        self.index = index
+
+    def search(self, *, query, topK: int, efSearch: Optional[int] = None,
+               distanceThreshold: Optional[float] = None, rowMask=None) -> list:
+        # ref: :78  `if (meta.totalVectors == 0 || meta.medoidNodeId < 0) return const []`
+        if self.index.size == 0 or topK <= 0:
+            return []
+        ids, dist, cnt = self.index.search(query, topK, distanceThreshold, rowMask)
+        n = int(cnt[0])
+        return [NghSearchResult(nodeId=int(ids[0, i]), distance=float(dist[0, i])) for i in range(n)]

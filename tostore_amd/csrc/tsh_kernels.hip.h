@@ -1,0 +1,605 @@
+// tsh_kernels.hip.h -- gfx950 (MI355X, CDNA4) device code for the exhaustive
+// kNN path behind ToStore's vectorSearch().  Wave = 64 lanes everywhere.
+//
+// Pipeline for ONE query over a resident shard (rows: n x ld float32, row-major):
+//   K1 scan     HBM-bound.  One wave owns a tile of 64 rows; every row is read
+//               exactly once with coalesced 16-byte/lane loads (1 KiB per wave
+//               instruction), per-lane partial sums are combined with a
+//               transposing butterfly so that lane l ends up holding the f32
+//               ranking key of row tile*64+l.  Writes keys[n] (4 B/row, 0.13 %
+//               of the bytes read at d=768) and gmin[tile] = min key of the tile.
+//   K2 select   one workgroup.  tau = k-th smallest of gmin[] is a PROVEN upper
+//               bound on the k-th smallest key (k distinct tiles hold a row at
+//               or below it).  tau is widened by the f32 error band, then only
+//               the tiles with gmin <= band are re-read from keys[] and rows at
+//               or below the band become candidates (~k of them).
+//   K3 filter   fallback when K2's candidate list overflows (ties / degenerate
+//               data): whole-grid filter of keys[] against the band.
+//   K4 rerank   exact f64 re-accumulation, element order 0..d-1, one rounding
+//               per multiply and per add (no FMA), of the reference's
+//               _l2Distance / _innerProduct / _cosineSimlarity
+//               (/root/reference/lib/src/core/ngh_graph_engine.dart:920-946)
+//               for the candidates only.  sqrt / divide / sort stay on the host.
+//
+// Keys order like the reference's distances: L2 -> sum of squares (sqrt is
+// monotone), IP -> -dot, cosine -> -dot/|v| (query norm is a common factor).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsh {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t KEY_DEAD = 0xFFFFFFFFu;  // masked / deleted / absent row
+constexpr uint32_t KEY_NAN = 0xFFFFFFFEu;   // live row whose key is NaN (sorts last)
+constexpr int METRIC_L2 = 0, METRIC_IP = 1, METRIC_COS = 2;
+
+// order-preserving float -> uint32 (smaller float <=> smaller key; -0 < +0)
+__device__ __forceinline__ uint32_t f2key(float f) {
+  if (f != f) return KEY_NAN;
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+// ---------------------------------------------------------------------------
+// transposing butterfly: x[0..7] per lane, lane bits P..P+2.  Returns, in each
+// lane, sum over the 8 lanes that differ from it only in bits P..P+2 of
+// x[idx], idx = (lane >> P) & 7.  7 exchanges instead of 8*3.  The pairing tree
+// is the same for every idx and float add commutes, so a row's result does not
+// depend on its position in the tile.
+template <int P>
+__device__ __forceinline__ float treduce8(const float (&x)[8], int lane) {
+  float y[4], z[2];
+  bool b0 = (lane >> P) & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float keep = b0 ? x[2 * i + 1] : x[2 * i];
+    float send = b0 ? x[2 * i] : x[2 * i + 1];
+    y[i] = keep + __shfl_xor(send, 1 << P);
+  }
+  bool b1 = (lane >> (P + 1)) & 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float keep = b1 ? y[2 * i + 1] : y[2 * i];
+    float send = b1 ? y[2 * i] : y[2 * i + 1];
+    z[i] = keep + __shfl_xor(send, 1 << (P + 1));
+  }
+  bool b2 = (lane >> (P + 2)) & 1;
+  float keep = b2 ? z[1] : z[0];
+  float send = b2 ? z[0] : z[1];
+  return keep + __shfl_xor(send, 1 << (P + 2));
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+template <int METRIC>
+__device__ __forceinline__ float accum4(float acc, f32x4 q, f32x4 v) {
+  if (METRIC == METRIC_L2) {
+    float d0 = q.x - v.x, d1 = q.y - v.y, d2 = q.z - v.z, d3 = q.w - v.w;
+    acc = __builtin_fmaf(d0, d0, acc);
+    acc = __builtin_fmaf(d1, d1, acc);
+    acc = __builtin_fmaf(d2, d2, acc);
+    acc = __builtin_fmaf(d3, d3, acc);
+  } else {
+    acc = __builtin_fmaf(q.x, v.x, acc);
+    acc = __builtin_fmaf(q.y, v.y, acc);
+    acc = __builtin_fmaf(q.z, v.z, acc);
+    acc = __builtin_fmaf(q.w, v.w, acc);
+  }
+  return acc;
+}
+
+template <bool NT>
+__device__ __forceinline__ f32x4 ld16(const float *p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+  return *reinterpret_cast<const f32x4 *>(p);
+}
+
+struct ScanArgs {
+  const float *rows;      // n x ld
+  const float *query;     // ld floats, zero padded past dim
+  const float *inv_norm;  // cosine: 1/|row| (0 for zero rows), else unused
+  const uint64_t *live;   // masked variant: bit r of word t = row t*64+r present & not deleted
+  const uint64_t *mask;   // masked variant, nullable: caller's keep mask, same layout
+  uint32_t *keys;         // n_tiles*64
+  uint32_t *gmin;         // n_tiles
+  int64_t ld;             // floats per row, multiple of 4
+  int64_t n;              // rows
+  int32_t d4;             // float4 per row (= ld/4)
+  int32_t n_tiles;        // ceil(n/64)
+};
+
+// K1.  NCH >= ceil(d4/64) 16-byte chunks per lane per row.  FULL: d4 == NCH*64;
+// otherwise lanes past the row end re-read their chunk 0 (a cache hit) and the
+// value is zeroed, so there is no branch around any load.
+// Rows are consumed in groups of R: while group i is being reduced, group i+1
+// is already in flight (two register buffers; R*NCH KiB per buffer per wave).
+// The compiler-opaque fences pin that schedule so the register budget, and
+// with it the wave occupancy, is what the template arguments say.
+// "memory" stops IR passes moving loads across; sched_barrier(0) stops the
+// machine scheduler moving the (register-only) math across.
+#define TSH_FENCE()                       \
+  do {                                    \
+    asm volatile("" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+template <int NCH, int METRIC, bool FULL, bool MASKED, int R, bool NT, int WAVES, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgs a) {
+  static_assert(R == 2 || R == 4, "R must give an even number of groups per 8-row batch");
+  constexpr int G = 8 / R;  // groups per batch
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stride = gridDim.x * WAVES;
+  const bool tail_ok = FULL || (NCH - 1) * 64 + lane < a.d4;
+  const int tail_off = tail_ok ? (NCH - 1) * 256 : 0;
+
+  f32x4 q[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    q[c] = *reinterpret_cast<const f32x4 *>(a.query + 4 * lane + (c < NCH - 1 ? c * 256 : tail_off));
+    if (!FULL && c == NCH - 1 && !tail_ok) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int t = blockIdx.x * WAVES + wave; t < a.n_tiles; t += stride) {
+    const float *tbase = a.rows + (int64_t)t * 64 * a.ld + 4 * lane;
+    uint64_t bits = ~0ull;
+    int cnt = 64;
+    if (MASKED) {
+      uint64_t w = a.live[t];
+      if (a.mask) w &= a.mask[t];
+      uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)w);
+      uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
+      bits = ((uint64_t)hi << 32) | lo;
+      cnt = __popcll(bits);
+      if (cnt == 0) {
+        a.keys[(int64_t)t * 64 + lane] = KEY_DEAD;
+        if (lane == 0) a.gmin[t] = KEY_DEAD;
+        continue;
+      }
+    }
+    const int nb = MASKED ? (cnt + 7) >> 3 : 8;  // 8-row batches, wave-uniform
+
+    f32x4 v[2][R][NCH];
+    uint64_t rem = bits;
+    int last = 0, next_dense = 0;
+    auto load_group = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        int r;
+        if (MASKED) {  // next live row (a short last batch repeats the final row)
+          if (rem) {
+            last = __builtin_ctzll(rem);
+            rem &= rem - 1;
+          }
+          r = last;
+        } else {
+          r = next_dense++;
+        }
+        const float *rp = tbase + (int64_t)r * a.ld;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          v[buf][j][c] = ld16<NT>(rp + (c < NCH - 1 ? c * 256 : tail_off));
+      }
+    };
+
+    float val = 0.f;
+    load_group(0);
+#pragma nounroll
+    for (int b = 0; b < nb; ++b) {
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        if (!(k == G - 1 && b == nb - 1)) load_group((k + 1) & 1);
+        TSH_FENCE();
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          float s = 0.f;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            f32x4 x = v[k & 1][j][c];
+            if (!FULL && c == NCH - 1 && !tail_ok) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            s = accum4<METRIC>(s, q[c], x);
+          }
+          // tie the finished sum to the fence: pure math would otherwise be
+          // sunk below the next group's loads, keeping every buffer live
+          asm volatile("" : "+v"(s)::"memory");
+          acc[k * R + j] = s;
+        }
+        TSH_FENCE();
+      }
+      // octet partial of row (lane&7) of this batch, then across the 8 octets
+      float o = treduce8<0>(acc, lane);
+      o += __shfl_xor(o, 8);
+      o += __shfl_xor(o, 16);
+      o += __shfl_xor(o, 32);
+      if ((lane >> 3) == b) val = o;  // slot b*8 + (lane&7) == lane
+    }
+    // dense: val = key sum of row t*64+lane; masked: of the lane-th live row
+
+    bool alive;
+    if (MASKED) {
+      // expand compact slots back to row positions
+      uint64_t below = bits & ((1ull << lane) - 1ull);
+      int rank = __popcll(below);
+      val = __shfl(val, rank);
+      alive = (bits >> lane) & 1ull;
+    } else {
+      alive = (int64_t)t * 64 + lane < a.n;
+    }
+    if (METRIC == METRIC_L2) {
+      // nothing
+    } else if (METRIC == METRIC_IP) {
+      val = -val;
+    } else {
+      float inv = alive ? a.inv_norm[(int64_t)t * 64 + lane] : 0.f;
+      val = -(val * inv);
+    }
+    uint32_t key = alive ? f2key(val) : KEY_DEAD;
+    a.keys[(int64_t)t * 64 + lane] = key;
+    uint32_t m = wave_min_u32(key);
+    if (lane == 0) a.gmin[t] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// candidate block written by K2/K3/K4 and shipped to the host (and all-gathered
+// between ranks): 64-byte header + entries x {int64 id, f64 s0, f64 s1}
+struct BlockHeader {
+  uint32_t count;      // candidates found (may exceed `entries`: overflow)
+  uint32_t entries;    // capacity of this block
+  uint32_t tau_key;    // k-th smallest tile minimum
+  uint32_t band_key;   // tau widened by the f32 error band
+  uint32_t tiles_hit;  // tiles re-read by K2
+  uint32_t flags;      // bit0: K2 list overflow (K3 fallback needed)
+  uint32_t k;
+  uint32_t metric;
+  int64_t row_base;
+  int64_t shard_rows;
+  uint32_t pad[4];
+};
+static_assert(sizeof(BlockHeader) == 64, "header is 64 bytes");
+struct BlockEntry {
+  int64_t id;
+  double s0;  // L2: sum (q-v)^2   IP: sum q*v   cosine: sum q*v
+  double s1;  // cosine: sum v*v   else 0
+};
+static_assert(sizeof(BlockEntry) == 24, "entry is 24 bytes");
+constexpr uint32_t FLAG_LIST_OVERFLOW = 1u;
+
+struct SelectArgs {
+  const uint32_t *gmin;
+  const uint32_t *keys;
+  BlockHeader *hdr;
+  uint32_t *cand_rows;  // local row ids, capacity cand_cap
+  int32_t n_tiles;
+  int32_t k;
+  int32_t cand_cap;
+  float eps_rel;    // band = tau + |tau|*eps_rel + delta_abs
+  float delta_abs;
+  int32_t force_all;  // safe mode: every live row is a candidate
+  int32_t metric;
+  int64_t row_base;
+  int64_t shard_rows;
+};
+
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_LIST_CAP = 4096;  // LDS lists (keys of small tiles / tile ids)
+
+// block-wide: smallest X with count(vals <= X) >= k, vals = VPT registers per
+// thread (pad with KEY_DEAD).  32 counting passes, no atomics on hot bins.
+template <int VPT>
+__device__ uint32_t block_kth_bisect(const uint32_t (&v)[VPT], uint32_t k, uint32_t *s_cnt /*[2][16]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t X = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    uint32_t T = X | ((1u << bit) - 1u);
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) c += __popcll(__ballot(v[i] <= T));
+    uint32_t *slot = s_cnt + (bit & 1) * 16;
+    if (lane == 0) slot[wave] = c;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_THREADS / 64; ++w) tot += slot[w];
+    if (tot < k) X |= (1u << bit);
+  }
+  return X;
+}
+
+// tau widened by the f32 error band, rounded UP to the next float
+__device__ __forceinline__ uint32_t band_of(uint32_t tau_key, float eps_rel, float delta_abs) {
+  if (tau_key >= KEY_NAN) return KEY_NAN;
+  float t = key2f(tau_key);
+  if (t == __builtin_inff()) return KEY_NAN;  // overflowed keys: NaN keys may hide finite values
+  double w = (double)t + fabs((double)t) * (double)eps_rel + (double)delta_abs;
+  float f = (float)w;
+  if ((double)f < w) {  // next float up
+    uint32_t b = __float_as_uint(f);
+    if ((b & 0x7FFFFFFFu) == 0u) b = 1u;           // +-0 -> smallest positive
+    else if (b & 0x80000000u) b -= 1u;             // negative: toward zero
+    else b += 1u;
+    f = __uint_as_float(b);
+  }
+  if (!(f < __builtin_inff())) return KEY_NAN;
+  return f2key(f);
+}
+
+// K2
+__global__ void __launch_bounds__(SEL_THREADS) select_kernel(SelectArgs a) {
+  __shared__ uint32_t s_cnt[32];
+  __shared__ uint32_t s_list[SEL_LIST_CAP];
+  __shared__ uint32_t s_n, s_tiles, s_cand, s_over;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.n_tiles;
+  if (tid == 0) {
+    s_n = 0;
+    s_tiles = 0;
+    s_cand = 0;
+    s_over = 0;
+  }
+  __syncthreads();
+
+  uint32_t tau = KEY_NAN;  // default: every live row
+  const uint32_t k = (uint32_t)a.k;
+  if (!a.force_all && (uint32_t)M >= k && k <= SEL_THREADS) {
+    // (a) thread-local minima; the k-th smallest of them bounds the k-th
+    //     smallest tile minimum from above
+    uint32_t lm[1] = {KEY_DEAD};
+    for (int i = tid; i < M; i += SEL_THREADS) {
+      uint32_t g = a.gmin[i];
+      lm[0] = g < lm[0] ? g : lm[0];
+    }
+    uint32_t U = (M > SEL_LIST_CAP) ? block_kth_bisect<1>(lm, k, s_cnt) : KEY_DEAD;
+    __syncthreads();
+    // (b) tile minima <= U into LDS
+    for (int i = tid; i < M; i += SEL_THREADS) {
+      uint32_t g = a.gmin[i];
+      if (g <= U) {
+        uint32_t p = atomicAdd(&s_n, 1u);
+        if (p < SEL_LIST_CAP) s_list[p] = g;
+      }
+    }
+    __syncthreads();
+    uint32_t n = s_n;
+    if (n <= SEL_LIST_CAP) {
+      // (c) exact k-th smallest of the short list
+      uint32_t v[SEL_LIST_CAP / SEL_THREADS];
+#pragma unroll
+      for (int i = 0; i < SEL_LIST_CAP / SEL_THREADS; ++i) {
+        uint32_t p = tid + i * SEL_THREADS;
+        v[i] = p < n ? s_list[p] : KEY_DEAD;
+      }
+      tau = block_kth_bisect<SEL_LIST_CAP / SEL_THREADS>(v, k, s_cnt);
+      if (tau == KEY_DEAD) tau = KEY_NAN;  // fewer than k live tiles
+    } else {
+      tau = U;  // still a valid upper bound, just looser
+      if (tau == KEY_DEAD) tau = KEY_NAN;
+    }
+  }
+  __syncthreads();
+  const uint32_t band = a.force_all ? KEY_NAN : band_of(tau, a.eps_rel, a.delta_abs);
+
+  // (d) tiles whose minimum is inside the band
+  for (int i = tid; i < M; i += SEL_THREADS) {
+    uint32_t g = a.gmin[i];
+    if (g <= band) {  // KEY_DEAD > band always
+      uint32_t p = atomicAdd(&s_tiles, 1u);
+      if (p < SEL_LIST_CAP) s_list[p] = (uint32_t)i;
+    }
+  }
+  __syncthreads();
+  uint32_t nt = s_tiles;
+  bool over = nt > SEL_LIST_CAP;
+  if (!over) {
+    // (e) re-read only those tiles' keys; rows inside the band are candidates
+    for (uint32_t j = wave; j < nt; j += SEL_THREADS / 64) {
+      uint32_t tile = s_list[j];
+      uint32_t key = a.keys[(int64_t)tile * 64 + lane];
+      bool pass = key <= band;
+      uint64_t bm = __ballot(pass);
+      if (bm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_cand, (uint32_t)__popcll(bm));
+        base = __shfl((int)base, 0);
+        if (pass) {
+          uint32_t p = base + __popcll(bm & ((1ull << lane) - 1ull));
+          if (p < (uint32_t)a.cand_cap) a.cand_rows[p] = tile * 64 + lane;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    BlockHeader *h = a.hdr;
+    h->count = over ? 0u : s_cand;
+    h->tau_key = tau;
+    h->band_key = band;
+    h->tiles_hit = nt;
+    h->flags = (over || s_cand > (uint32_t)a.cand_cap) ? FLAG_LIST_OVERFLOW : 0u;
+    h->entries = (uint32_t)a.cand_cap;
+    h->k = (uint32_t)a.k;
+    h->metric = (uint32_t)a.metric;
+    h->row_base = a.row_base;
+    h->shard_rows = a.shard_rows;
+  }
+}
+
+// K3: whole-grid filter (fallback).  count accumulates in *out_count.
+__global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, int64_t n_keys,
+                                                     uint32_t band, uint32_t *out_rows,
+                                                     uint32_t *out_count, uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t n_round = (n_keys + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    bool pass = i < n_keys && keys[i] <= band;
+    uint64_t bm = __ballot(pass);
+    if (bm) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(out_count, (uint32_t)__popcll(bm));
+      base = __shfl((int)base, 0);
+      if (pass) {
+        uint32_t p = base + __popcll(bm & ((1ull << lane) - 1ull));
+        if (p < cap) out_rows[p] = (uint32_t)i;
+      }
+    }
+  }
+}
+
+// K4: exact f64 sums for candidate rows.  One wave per candidate: lanes form the
+// per-element terms in parallel (each term is one IEEE multiply, so order is
+// irrelevant), lane 0 (and lane 1 for the cosine row norm) adds them strictly
+// in element order 0..d-1 -- the reference's loop order.
+struct RerankArgs {
+  const float *rows;
+  const float *query;       // ld floats
+  const uint32_t *cand_rows;
+  const uint32_t *count_ptr;  // device count (clamped to cap)
+  BlockEntry *out;
+  int64_t ld;
+  int64_t row_base;
+  int32_t dim;
+  int32_t cap;
+  int32_t metric;
+};
+constexpr int RR_CHUNK = 1024;
+
+__global__ void __launch_bounds__(64) rerank_kernel(RerankArgs a) {
+#pragma clang fp contract(off)
+  __shared__ double t0[RR_CHUNK];
+  __shared__ double t1[RR_CHUNK];
+  const int lane = threadIdx.x;
+  uint32_t count = *a.count_ptr;
+  if (count > (uint32_t)a.cap) count = (uint32_t)a.cap;
+  for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+    uint32_t row = a.cand_rows[c];
+    const float *rp = a.rows + (int64_t)row * a.ld;
+    double s0 = 0.0, s1 = 0.0;
+    for (int base = 0; base < a.dim; base += RR_CHUNK) {
+      int m = a.dim - base < RR_CHUNK ? a.dim - base : RR_CHUNK;
+      for (int i = lane; i < m; i += 64) {
+        double qv = (double)a.query[base + i], bv = (double)rp[base + i];
+        if (a.metric == METRIC_L2) {
+          double diff = qv - bv;
+          t0[i] = diff * diff;
+        } else {
+          t0[i] = qv * bv;
+          if (a.metric == METRIC_COS) t1[i] = bv * bv;
+        }
+      }
+      __syncthreads();
+      if (lane == 0) {
+        for (int i = 0; i < m; ++i) s0 = s0 + t0[i];
+      } else if (lane == 1 && a.metric == METRIC_COS) {
+        for (int i = 0; i < m; ++i) s1 = s1 + t1[i];
+      }
+      __syncthreads();
+    }
+    s1 = __shfl(s1, 1);
+    if (lane == 0) {
+      a.out[c].id = a.row_base + (int64_t)row;
+      a.out[c].s0 = s0;
+      a.out[c].s1 = s1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ingest helpers
+// per-row f64 norm -> inv_norm (f32), and chunk statistics for the error model
+struct IngestStats {
+  uint32_t max_norm_bits;  // max |row| (f32 bits, rounded up)
+  uint32_t max_abs_bits;   // max finite |element|
+  uint32_t nonfinite_rows; // rows holding an inf / nan element
+  uint32_t tiny_rows;      // rows whose norm is nonzero but < 2^-50 (cosine error model breaks)
+};
+
+__global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t ld, int dim,
+                                                     int64_t first, int64_t n, float *inv_norm,
+                                                     IngestStats *st) {
+  const int lane = threadIdx.x & 63;
+  int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = w; r < n; r += nw) {
+    const float *rp = rows + (first + r) * ld;
+    double s = 0.0;
+    float mx = 0.f;
+    bool bad = false;
+    for (int i = lane; i < dim; i += 64) {
+      float v = rp[i];
+      float av = fabsf(v);
+      if (!(av <= 3.0e38f)) bad = true;  // inf / nan
+      else mx = av > mx ? av : mx;
+      s += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      float t = __shfl_xor(mx, o);
+      mx = t > mx ? t : mx;
+    }
+    bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+      double nrm = sqrt(s);
+      float inv = 0.f;
+      bool tiny = false;
+      if (!bad && nrm > 0.0) {
+        if (nrm < 8.9e-16 /*2^-50*/) tiny = true;
+        else inv = (float)(1.0 / nrm);
+      }
+      if (inv_norm) inv_norm[first + r] = inv;
+      float nf = (float)nrm;
+      if ((double)nf < nrm) nf = __uint_as_float(__float_as_uint(nf) + 1u);
+      if (!bad) atomicMax(&st->max_norm_bits, __float_as_uint(nf));
+      atomicMax(&st->max_abs_bits, __float_as_uint(mx));
+      if (bad) atomicAdd(&st->nonfinite_rows, 1u);
+      if (tiny) atomicAdd(&st->tiny_rows, 1u);
+    }
+  }
+}
+
+// set / clear bits of the live bitmap (word t bit r = row t*64+r)
+__global__ void live_range_kernel(uint64_t *live, int64_t first, int64_t n, int set) {
+  int64_t w0 = first >> 6, w1 = (first + n - 1) >> 6;
+  for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = w * 64, hi = lo + 64;
+    int64_t a = first > lo ? first : lo, b = first + n < hi ? first + n : hi;
+    uint64_t m = (b - a == 64) ? ~0ull : (((1ull << (b - a)) - 1ull) << (a - lo));
+    if (w == w0 || w == w1) {
+      if (set) atomicOr((unsigned long long *)&live[w], (unsigned long long)m);
+      else atomicAnd((unsigned long long *)&live[w], (unsigned long long)~m);
+    } else {
+      live[w] = set ? ~0ull : 0ull;
+    }
+  }
+}
+
+__global__ void live_clear_ids_kernel(uint64_t *live, const int64_t *ids, int64_t n, int64_t row_base,
+                                      int64_t rows, uint32_t *n_cleared) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = ids[i] - row_base;
+    if (r < 0 || r >= rows) continue;
+    unsigned long long bit = 1ull << (r & 63);
+    unsigned long long old = atomicAnd((unsigned long long *)&live[r >> 6], ~bit);
+    if (old & bit) atomicAdd(n_cleared, 1u);
+  }
+}
+
+}  // namespace tsh

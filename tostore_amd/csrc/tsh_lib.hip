@@ -1,0 +1,1231 @@
+// tsh_lib.hip -- host side of libtostore_hip.so (C-ABI in include/tostore_hip.h).
+//
+// Owns the device-resident copy of one vector index's float32 embedding column
+// (the data the reference keeps in <index>/ngh/rawvec pages,
+// /root/reference/lib/src/core/ngh_page.dart:310-450) and answers
+// NghGraphEngine.search-shaped queries (ngh_graph_engine.dart:67-135) with the
+// kernels in tsh_kernels.hip.h.  No CPU fallback exists: without a device every
+// compute entry returns TSH_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tostore_hip.h"
+#include "tsh_kernels.hip.h"
+
+using namespace tsh;
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return set_err(e_ == hipErrorOutOfMemory ? TSH_E_OOM : TSH_E_HIP, "%s failed: %s", \
+                     #expr, hipGetErrorString(e_));                                   \
+  } while (0)
+
+int device_count_cached() {
+  static int n = [] {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    return c;
+  }();
+  return n;
+}
+
+constexpr int QCHUNK = 32;            // queries enqueued per host sync
+constexpr int MAX_CTX = 4;            // concurrent searches per shard
+constexpr int MAX_DIM_SCAN = 2048;    // register-resident query (NCH <= 8)
+constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ---- Dart double.compareTo ([external] Dart SDK): NaN greatest, -0 < +0 ------
+inline int dart_compare(double a, double b) {
+  if (a < b) return -1;
+  if (a > b) return 1;
+  if (a == b) {
+    if (a == 0.0) {
+      bool an = std::signbit(a), bn = std::signbit(b);
+      if (an == bn) return 0;
+      return an ? -1 : 1;
+    }
+    return 0;
+  }
+  if (std::isnan(a)) return std::isnan(b) ? 0 : 1;
+  return -1;
+}
+
+struct Hit {
+  double dist;
+  int64_t id;
+};
+inline bool hit_less(const Hit &a, const Hit &b) {
+  int c = dart_compare(a.dist, b.dist);
+  if (c) return c < 0;
+  return a.id < b.id;
+}
+
+// Final per-candidate arithmetic of ngh_graph_engine.dart:908-946 given the
+// exact f64 sums; mag_a = sum q[i]*q[i] accumulated in element order.
+inline double final_distance(int metric, double s0, double s1, double mag_a) {
+  switch (metric) {
+    case TSH_METRIC_L2:
+      return std::sqrt(s0);  // :926
+    case TSH_METRIC_IP:
+      return -s0;  // :914
+    default: {
+      double denom = std::sqrt(mag_a) * std::sqrt(s1);  // :944
+      double sim = denom > 0 ? s0 / denom : 0;          // :945
+      return 1.0 - sim;                                 // :916
+    }
+  }
+}
+
+double query_mag_a(const float *q, int dim) {
+#pragma clang fp contract(off)
+  double m = 0;
+  for (int i = 0; i < dim; ++i) m = m + (double)q[i] * (double)q[i];
+  return m;
+}
+
+// threshold + order + cut of ngh_graph_engine.dart:127,133-134 over candidate
+// entries from any number of blocks
+int32_t finalize_query(int metric, int dim, const float *query, int32_t k, double thr,
+                       const std::vector<std::pair<const BlockEntry *, uint32_t>> &lists,
+                       int64_t *out_ids, double *out_dist) {
+  double mag_a = metric == TSH_METRIC_COSINE ? query_mag_a(query, dim) : 0.0;
+  std::vector<Hit> hits;
+  size_t total = 0;
+  for (auto &l : lists) total += l.second;
+  hits.reserve(total);
+  for (auto &l : lists)
+    for (uint32_t i = 0; i < l.second; ++i) {
+      const BlockEntry &e = l.first[i];
+      double d = final_distance(metric, e.s0, e.s1, mag_a);
+      if (!std::isnan(thr) && d > thr) continue;
+      hits.push_back({d, e.id});
+    }
+  size_t r = std::min<size_t>(hits.size(), (size_t)std::max(k, 0));
+  std::partial_sort(hits.begin(), hits.begin() + r, hits.end(), hit_less);
+  for (size_t i = 0; i < r; ++i) {
+    out_ids[i] = hits[i].id;
+    out_dist[i] = hits[i].dist;
+  }
+  return (int32_t)r;
+}
+
+// ---- kernel dispatch ---------------------------------------------------------
+struct ScanCfg {
+  int nch;
+};
+inline int pick_nch(int d4) {
+  int need = (d4 + 63) / 64;
+  static const int opts[] = {1, 2, 3, 4, 6, 8};
+  for (int o : opts)
+    if (o >= need) return o;
+  return -1;
+}
+
+// (rows per group, min waves per SIMD) per row width: two register buffers of
+// R*NCH*4 VGPRs plus NCH*4 for the query must fit 512/MINW registers.
+template <int NCH, bool MASKED> struct ScanTune {
+  static constexpr int R = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 2 : 4) : 2);
+  static constexpr int MINW = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH == 6 ? 3 : 2)));
+};
+template <int NCH, int METRIC, bool FULL, bool MASKED>
+void launch_scan_t(const ScanArgs &a, int grid, hipStream_t s) {
+  using T = ScanTune<NCH, MASKED>;
+  scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<grid, 256, 0, s>>>(a);
+}
+template <int NCH, int METRIC>
+void launch_scan_m(const ScanArgs &a, bool masked, int grid, hipStream_t s) {
+  bool full = a.d4 == NCH * 64;
+  if (full) {
+    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s);
+    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s);
+  } else {
+    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s);
+    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s);
+  }
+}
+template <int NCH>
+void launch_scan_n(const ScanArgs &a, int metric, bool masked, int grid, hipStream_t s) {
+  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s);
+  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s);
+  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s);
+}
+void launch_scan(const ScanArgs &a, int nch, int metric, bool masked, hipStream_t s) {
+  int grid = (a.n_tiles + 3) / 4;
+  if (grid < 1) grid = 1;
+  switch (nch) {
+    case 1: launch_scan_n<1>(a, metric, masked, grid, s); break;
+    case 2: launch_scan_n<2>(a, metric, masked, grid, s); break;
+    case 3: launch_scan_n<3>(a, metric, masked, grid, s); break;
+    case 4: launch_scan_n<4>(a, metric, masked, grid, s); break;
+    case 6: launch_scan_n<6>(a, metric, masked, grid, s); break;
+    default: launch_scan_n<8>(a, metric, masked, grid, s); break;
+  }
+}
+
+// ---- per-search scratch ------------------------------------------------------
+struct Ctx {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float *d_query = nullptr;  // QCHUNK x ld
+  float *h_query = nullptr;  // pinned
+  uint64_t *d_mask = nullptr;
+  uint64_t *h_mask = nullptr;
+  int64_t mask_words = 0;
+  uint32_t *d_keys = nullptr;
+  uint32_t *d_gmin = nullptr;
+  int64_t tiles_cap = 0;
+  uint8_t *d_blocks = nullptr;  // QCHUNK blocks of block_bytes
+  uint8_t *h_blocks = nullptr;  // pinned
+  uint32_t *d_cand = nullptr;   // QCHUNK x entries
+  int64_t entries_cap = 0;
+  // fallback
+  uint32_t *d_big_rows = nullptr;
+  BlockEntry *d_big_entries = nullptr;
+  uint32_t *d_big_count = nullptr;
+  int64_t big_cap = 0;
+  int64_t bytes = 0;
+};
+
+struct Shard {
+  int device = 0;
+  int dim = 0, metric = 0, nch = 0;
+  int64_t ld = 0;
+  int64_t row_base = 0;  // global id of local row 0
+  int64_t rows = 0;      // local rows (next local id)
+  int64_t cap = 0;       // allocated rows (multiple of 64)
+  float *d_rows = nullptr;
+  float *d_inv_norm = nullptr;
+  uint64_t *d_live = nullptr;
+  IngestStats *d_stats = nullptr;
+  uint32_t *d_tmp_u32 = nullptr;
+  int64_t live_rows = 0;   // present and not deleted
+  int64_t deleted = 0;
+  bool all_live = true;    // every row in [0,rows) is present and not deleted
+  float max_norm = 0.f, max_abs = 0.f;
+  uint32_t nonfinite_rows = 0, tiny_rows = 0;
+  hipStream_t ingest_stream = nullptr;
+
+  std::shared_mutex mu;  // search: shared; append/delete: exclusive
+  std::mutex ctx_mu;
+  std::condition_variable ctx_cv;
+  std::vector<std::unique_ptr<Ctx>> ctx_all;
+  std::vector<Ctx *> ctx_free;
+
+  std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
+  int64_t bytes = 0;
+
+  bool safe_mode() const {
+    if (nonfinite_rows) return true;
+    if (max_abs > BIG_ABS) return true;
+    if (metric == TSH_METRIC_COSINE && tiny_rows) return true;
+    return false;
+  }
+};
+
+int shard_init(Shard *s) {
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipStreamCreateWithFlags(&s->ingest_stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
+  HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
+  HIPCHK(hipMalloc(&s->d_tmp_u32, 64));
+  return TSH_OK;
+}
+
+int shard_reserve(Shard *s, int64_t want_rows) {
+  if (want_rows <= s->cap) return TSH_OK;
+  int64_t ncap = std::max<int64_t>(round_up(want_rows, 64), 64);
+  if (s->cap > 0) ncap = std::max<int64_t>(ncap, round_up(s->cap + s->cap / 2, 64));
+  HIPCHK(hipSetDevice(s->device));
+  float *nrows = nullptr, *ninv = nullptr;
+  uint64_t *nlive = nullptr;
+  size_t row_bytes = (size_t)ncap * (size_t)s->ld * sizeof(float);
+  HIPCHK(hipMalloc(&nrows, row_bytes));
+  if (hipMalloc(&ninv, (size_t)ncap * sizeof(float)) != hipSuccess ||
+      hipMalloc(&nlive, (size_t)(ncap / 64) * sizeof(uint64_t)) != hipSuccess) {
+    hipFree(nrows);
+    if (ninv) hipFree(ninv);
+    return set_err(TSH_E_OOM, "hipMalloc failed for %lld rows", (long long)ncap);
+  }
+  hipStream_t st = s->ingest_stream;
+  size_t old_bytes = (size_t)s->cap * (size_t)s->ld * sizeof(float);
+  if (s->cap > 0) {
+    HIPCHK(hipMemcpyAsync(nrows, s->d_rows, old_bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(ninv, s->d_inv_norm, (size_t)s->cap * sizeof(float),
+                          hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(nlive, s->d_live, (size_t)(s->cap / 64) * sizeof(uint64_t),
+                          hipMemcpyDeviceToDevice, st));
+  }
+  // rows past the old capacity read as zeros until written (tiles are whole)
+  HIPCHK(hipMemsetAsync((char *)nrows + old_bytes, 0, row_bytes - old_bytes, st));
+  HIPCHK(hipMemsetAsync(ninv + s->cap, 0, (size_t)(ncap - s->cap) * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(nlive + s->cap / 64, 0, (size_t)((ncap - s->cap) / 64) * sizeof(uint64_t), st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (s->d_rows) hipFree(s->d_rows);
+  if (s->d_inv_norm) hipFree(s->d_inv_norm);
+  if (s->d_live) hipFree(s->d_live);
+  s->d_rows = nrows;
+  s->d_inv_norm = ninv;
+  s->d_live = nlive;
+  s->bytes += (int64_t)(row_bytes - old_bytes) + (ncap - s->cap) * 4 + (ncap - s->cap) / 8;
+  s->cap = ncap;
+  return TSH_OK;
+}
+
+// rows [first, first+n) local ids; src host or device
+int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_is_device) {
+  if (n <= 0) return TSH_OK;
+  int rc = shard_reserve(s, first + n);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(s->device));
+  hipStream_t st = s->ingest_stream;
+  float *dst = s->d_rows + first * s->ld;
+  hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (s->ld == s->dim) {
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)n * s->dim * sizeof(float), kind, st));
+  } else {
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)s->ld * sizeof(float), src, (size_t)s->dim * sizeof(float),
+                            (size_t)s->dim * sizeof(float), (size_t)n, kind, st));
+  }
+  int blocks = (int)std::min<int64_t>((n + 3) / 4, 8192);
+  ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_stats);
+  // overwritten rows become live again; count them via the old bitmap is not
+  // needed: live_rows is recomputed from deleted/gaps bookkeeping below
+  int lb = (int)std::min<int64_t>(((first + n - 1) / 64 - first / 64 + 1 + 255) / 256, 1024);
+  live_range_kernel<<<lb, 256, 0, st>>>(s->d_live, first, n, 1);
+  IngestStats hs;
+  HIPCHK(hipMemcpyAsync(&hs, s->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  uint32_t mb = hs.max_norm_bits, ab = hs.max_abs_bits;
+  memcpy(&s->max_norm, &mb, 4);
+  memcpy(&s->max_abs, &ab, 4);
+  s->nonfinite_rows = hs.nonfinite_rows;
+  s->tiny_rows = hs.tiny_rows;
+  if (first > s->rows) s->all_live = false;  // gap of absent rows
+  if (first + n > s->rows) s->rows = first + n;
+  return TSH_OK;
+}
+
+void ctx_free_all(Ctx *c) {
+  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  hipFree(c->d_query);
+  hipHostFree(c->h_query);
+  hipFree(c->d_mask);
+  hipHostFree(c->h_mask);
+  hipFree(c->d_keys);
+  hipFree(c->d_gmin);
+  hipFree(c->d_blocks);
+  hipHostFree(c->h_blocks);
+  hipFree(c->d_cand);
+  hipFree(c->d_big_rows);
+  hipFree(c->d_big_entries);
+  hipFree(c->d_big_count);
+}
+
+int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
+  HIPCHK(hipSetDevice(s->device));
+  if (!c->stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipMalloc(&c->d_query, (size_t)QCHUNK * s->ld * sizeof(float)));
+    HIPCHK(hipHostMalloc(&c->h_query, (size_t)QCHUNK * s->ld * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&c->d_big_count, 64));
+    c->bytes += (int64_t)QCHUNK * s->ld * 4;
+  }
+  int64_t tiles = s->cap / 64;
+  if (tiles > c->tiles_cap) {
+    hipFree(c->d_keys);
+    hipFree(c->d_gmin);
+    c->d_keys = nullptr;
+    c->d_gmin = nullptr;
+    HIPCHK(hipMalloc(&c->d_keys, (size_t)tiles * 64 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_gmin, (size_t)tiles * sizeof(uint32_t)));
+    c->bytes += (tiles - c->tiles_cap) * 65 * 4;
+    c->tiles_cap = tiles;
+  }
+  if (need_mask && tiles > c->mask_words) {
+    hipFree(c->d_mask);
+    hipHostFree(c->h_mask);
+    c->d_mask = nullptr;
+    c->h_mask = nullptr;
+    HIPCHK(hipMalloc(&c->d_mask, (size_t)tiles * 8));
+    HIPCHK(hipHostMalloc(&c->h_mask, (size_t)tiles * 8, hipHostMallocDefault));
+    c->bytes += (tiles - c->mask_words) * 8;
+    c->mask_words = tiles;
+  }
+  if (entries > c->entries_cap) {
+    hipFree(c->d_blocks);
+    hipHostFree(c->h_blocks);
+    hipFree(c->d_cand);
+    c->d_blocks = nullptr;
+    c->h_blocks = nullptr;
+    c->d_cand = nullptr;
+    size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+    HIPCHK(hipMalloc(&c->d_blocks, bb * QCHUNK));
+    HIPCHK(hipHostMalloc(&c->h_blocks, bb * QCHUNK, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&c->d_cand, (size_t)entries * QCHUNK * sizeof(uint32_t)));
+    c->bytes += (int64_t)(bb + 4 * (size_t)entries) * QCHUNK;
+    c->entries_cap = entries;
+  }
+  return TSH_OK;
+}
+
+Ctx *ctx_acquire(Shard *s) {
+  std::unique_lock<std::mutex> lk(s->ctx_mu);
+  for (;;) {
+    if (!s->ctx_free.empty()) {
+      Ctx *c = s->ctx_free.back();
+      s->ctx_free.pop_back();
+      return c;
+    }
+    if ((int)s->ctx_all.size() < MAX_CTX) {
+      s->ctx_all.emplace_back(new Ctx());
+      return s->ctx_all.back().get();
+    }
+    s->ctx_cv.wait(lk);
+  }
+}
+void ctx_release(Shard *s, Ctx *c) {
+  {
+    std::lock_guard<std::mutex> lk(s->ctx_mu);
+    s->ctx_free.push_back(c);
+  }
+  s->ctx_cv.notify_one();
+}
+struct CtxLease {
+  Shard *s;
+  Ctx *c;
+  CtxLease(Shard *s_) : s(s_), c(ctx_acquire(s_)) {}
+  ~CtxLease() { ctx_release(s, c); }
+};
+
+// error band of the f32 ranking key (DESIGN.md "error model")
+struct Band {
+  float eps_rel = 0.f, delta_abs = 0.f;
+  int force_all = 0;
+};
+Band compute_band(const Shard *s, const float *q) {
+  Band b;
+  if (s->safe_mode()) {
+    b.force_all = 1;
+    return b;
+  }
+  double qn2 = 0;
+  float qmax = 0.f;
+  for (int i = 0; i < s->dim; ++i) {
+    float a = std::fabs(q[i]);
+    if (!(a <= BIG_ABS)) {
+      b.force_all = 1;  // inf / nan / huge query element
+      return b;
+    }
+    qmax = std::max(qmax, a);
+    qn2 += (double)q[i] * (double)q[i];
+  }
+  double qn = std::sqrt(qn2) * (1.0 + 1e-6);
+  const double u2 = 1.1920928955078125e-07;  // 2^-23 = 2 * unit roundoff (safety factor 2)
+  if (s->metric == TSH_METRIC_L2) {
+    double eps = (4.0 * s->nch + 8.0) * u2;
+    b.eps_rel = (float)(3.0 * eps);
+    b.delta_abs = (float)((double)s->dim * 7.9e-31);  // d * 2^-100: underflow slack
+  } else if (s->metric == TSH_METRIC_IP) {
+    double gam = (4.0 * s->nch + 6.0) * u2;
+    double delta = gam * qn * (double)s->max_norm * (1.0 + 1e-6) + (double)s->dim * 7.5e-37;
+    b.delta_abs = (float)(2.0 * delta * 1.0001);
+    if (!(b.delta_abs < 3.0e38f)) b.force_all = 1;
+  } else {
+    double gam = (4.0 * s->nch + 6.0) * u2;
+    double delta = qn * (gam + 4.76837158203125e-07 /*2^-21*/) + (double)s->dim * 7.5e-37;
+    b.delta_abs = (float)(2.0 * delta * 1.0001);
+  }
+  return b;
+}
+
+void fill_scan_args(const Shard *s, const Ctx *c, const float *d_query, bool masked, bool user_mask,
+                    ScanArgs *a) {
+  a->rows = s->d_rows;
+  a->query = d_query;
+  a->inv_norm = s->d_inv_norm;
+  a->live = s->d_live;
+  a->mask = (masked && user_mask) ? c->d_mask : nullptr;
+  a->keys = c->d_keys;
+  a->gmin = c->d_gmin;
+  a->ld = s->ld;
+  a->n = s->rows;
+  a->d4 = (int32_t)(s->ld / 4);
+  a->n_tiles = (int32_t)((s->rows + 63) / 64);
+}
+
+// slice the caller's GLOBAL keep mask into this shard's tile words (pinned)
+void slice_mask(const Shard *s, const uint8_t *mask, uint64_t *out_words, int64_t n_words) {
+  int64_t rows = s->rows;
+  memset(out_words, 0, (size_t)n_words * 8);
+  uint8_t *ob = reinterpret_cast<uint8_t *>(out_words);
+  int64_t nbytes = (rows + 7) / 8;
+  if ((s->row_base & 7) == 0) {
+    memcpy(ob, mask + s->row_base / 8, (size_t)nbytes);
+  } else {
+    int sh = (int)(s->row_base & 7);
+    const uint8_t *src = mask + s->row_base / 8;
+    int64_t src_last = (s->row_base + rows - 1) / 8 - s->row_base / 8;  // last valid src byte index
+    for (int64_t i = 0; i < nbytes; ++i) {
+      unsigned lo = src[i] >> sh;
+      unsigned hi = (i + 1 <= src_last) ? (unsigned)(src[i + 1] << (8 - sh)) : 0u;
+      ob[i] = (uint8_t)(lo | hi);
+    }
+  }
+}
+
+struct SearchOut {
+  // host mode: blocks copied to host; spill[q] holds the full list when a
+  // query's candidates exceeded `entries`
+  uint8_t *h_blocks = nullptr;  // nq blocks (caller memory)
+  std::vector<std::vector<BlockEntry>> *spill = nullptr;
+  // device mode
+  uint8_t *d_blocks = nullptr;
+  hipStream_t user_stream = nullptr;
+};
+
+// Fallback for one query whose K2 list overflowed: whole-grid filter + rerank.
+// keys/gmin of THIS query must be in ctx scratch (caller re-runs K1).
+int run_fallback(Shard *s, Ctx *c, const float *d_query, uint32_t band_key, int32_t entries,
+                 uint8_t *d_block, std::vector<BlockEntry> *spill) {
+  hipStream_t st = c->stream;
+  int64_t n_keys = ((s->rows + 63) / 64) * 64;
+  if (s->cap > c->big_cap) {
+    hipFree(c->d_big_rows);
+    hipFree(c->d_big_entries);
+    c->d_big_rows = nullptr;
+    c->d_big_entries = nullptr;
+    HIPCHK(hipMalloc(&c->d_big_rows, (size_t)s->cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_big_entries, (size_t)s->cap * sizeof(BlockEntry)));
+    c->bytes += (s->cap - c->big_cap) * 28;
+    c->big_cap = s->cap;
+  }
+  HIPCHK(hipMemsetAsync(c->d_big_count, 0, 4, st));
+  int fgrid = (int)std::min<int64_t>((n_keys + 255) / 256, 4096);
+  filter_kernel<<<fgrid, 256, 0, st>>>(c->d_keys, n_keys, band_key, c->d_big_rows, c->d_big_count,
+                                      (uint32_t)c->big_cap);
+  uint32_t count = 0;
+  HIPCHK(hipMemcpyAsync(&count, c->d_big_count, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  RerankArgs ra;
+  ra.rows = s->d_rows;
+  ra.query = d_query;
+  ra.cand_rows = c->d_big_rows;
+  ra.count_ptr = c->d_big_count;
+  ra.out = c->d_big_entries;
+  ra.ld = s->ld;
+  ra.row_base = s->row_base;
+  ra.dim = s->dim;
+  ra.cap = (int32_t)std::min<int64_t>(c->big_cap, 0x7FFFFFFF);
+  ra.metric = s->metric;
+  if (count > 0) {
+    int rgrid = (int)std::min<uint32_t>(count, 16384u);
+    rerank_kernel<<<rgrid, 64, 0, st>>>(ra);
+  }
+  // patch the block: header count/flags, and as many entries as fit
+  BlockHeader patch;
+  HIPCHK(hipMemcpyAsync(&patch, d_block, sizeof patch, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  patch.count = count;
+  patch.flags = count > (uint32_t)entries ? FLAG_LIST_OVERFLOW : 0u;
+  HIPCHK(hipMemcpyAsync(d_block, &patch, sizeof patch, hipMemcpyHostToDevice, st));
+  uint32_t fit = std::min<uint32_t>(count, (uint32_t)entries);
+  if (fit)
+    HIPCHK(hipMemcpyAsync(d_block + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
+                          hipMemcpyDeviceToDevice, st));
+  if (spill && count > (uint32_t)entries) {
+    spill->resize(count);
+    HIPCHK(hipMemcpyAsync(spill->data(), c->d_big_entries, (size_t)count * sizeof(BlockEntry),
+                          hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  s->c_fallbacks++;
+  s->c_cands += count;
+  return TSH_OK;
+}
+
+// The single-query pipeline K1 -> K2 -> K4 for nq queries, one after another
+// on one stream.  Caller holds s->mu shared.
+int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const uint8_t *mask,
+                        int32_t entries, SearchOut *out) {
+  size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  CtxLease lease(s);
+  Ctx *c = lease.c;
+  bool masked = mask != nullptr || !s->all_live;
+  int rc = ctx_prepare(s, c, entries, mask != nullptr);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+  if (mask) {
+    slice_mask(s, mask, c->h_mask, n_tiles);
+    HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+  }
+  for (int32_t q0 = 0; q0 < nq; q0 += QCHUNK) {
+    int32_t nc = std::min(QCHUNK, nq - q0);
+    Band bands[QCHUNK];
+    for (int32_t i = 0; i < nc; ++i) {
+      float *hq = c->h_query + (size_t)i * s->ld;
+      memcpy(hq, queries + (size_t)(q0 + i) * s->dim, (size_t)s->dim * sizeof(float));
+      for (int64_t j = s->dim; j < s->ld; ++j) hq[j] = 0.f;
+      bands[i] = compute_band(s, hq);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)nc * s->ld * sizeof(float),
+                          hipMemcpyHostToDevice, st));
+    for (int32_t i = 0; i < nc; ++i) {
+      const float *dq = c->d_query + (size_t)i * s->ld;
+      uint8_t *dblk = c->d_blocks + (size_t)i * bb;
+      ScanArgs sa;
+      fill_scan_args(s, c, dq, masked, mask != nullptr, &sa);
+      launch_scan(sa, s->nch, s->metric, masked, st);
+      SelectArgs se;
+      se.gmin = c->d_gmin;
+      se.keys = c->d_keys;
+      se.hdr = reinterpret_cast<BlockHeader *>(dblk);
+      se.cand_rows = c->d_cand + (size_t)i * entries;
+      se.n_tiles = n_tiles;
+      se.k = k;
+      se.cand_cap = entries;
+      se.eps_rel = bands[i].eps_rel;
+      se.delta_abs = bands[i].delta_abs;
+      se.force_all = bands[i].force_all;
+      se.metric = s->metric;
+      se.row_base = s->row_base;
+      se.shard_rows = s->rows;
+      select_kernel<<<1, SEL_THREADS, 0, st>>>(se);
+      RerankArgs ra;
+      ra.rows = s->d_rows;
+      ra.query = dq;
+      ra.cand_rows = se.cand_rows;
+      ra.count_ptr = &se.hdr->count;
+      ra.out = reinterpret_cast<BlockEntry *>(dblk + sizeof(BlockHeader));
+      ra.ld = s->ld;
+      ra.row_base = s->row_base;
+      ra.dim = s->dim;
+      ra.cap = entries;
+      ra.metric = s->metric;
+      rerank_kernel<<<std::min(entries, 1024), 64, 0, st>>>(ra);
+    }
+    s->c_scans += nc;
+    // headers first: overflow decisions need them on the host
+    HIPCHK(hipMemcpyAsync(c->h_blocks, c->d_blocks, bb * nc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    for (int32_t i = 0; i < nc; ++i) {
+      BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_blocks + (size_t)i * bb);
+      if (h->flags & FLAG_LIST_OVERFLOW) {
+        // re-run K1 for this query (scratch was reused), then the wide path
+        const float *dq = c->d_query + (size_t)i * s->ld;
+        uint8_t *dblk = c->d_blocks + (size_t)i * bb;
+        ScanArgs sa;
+        fill_scan_args(s, c, dq, masked, mask != nullptr, &sa);
+        launch_scan(sa, s->nch, s->metric, masked, st);
+        std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[q0 + i] : nullptr;
+        rc = run_fallback(s, c, dq, h->band_key, entries, dblk, sp);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_blocks + (size_t)i * bb, dblk, bb, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+      } else {
+        s->c_cands += h->count;
+      }
+    }
+    if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, c->h_blocks, bb * nc);
+    if (out->d_blocks) {
+      hipStream_t us = out->user_stream ? out->user_stream : st;
+      HIPCHK(hipMemcpyAsync(out->d_blocks + (size_t)q0 * bb, c->d_blocks, bb * nc,
+                            hipMemcpyDeviceToDevice, us));
+      HIPCHK(hipStreamSynchronize(us));  // scratch is reused by the next chunk
+    }
+  }
+  s->c_searches += nq;
+  return TSH_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+struct tsh_index {
+  int dim = 0, metric = 0;
+  int64_t rows_per_shard = 0;  // multi-device split (0: single shard)
+  std::vector<std::unique_ptr<Shard>> shards;
+  std::mutex mu;  // serialises append routing
+};
+
+namespace {
+
+int make_shard(int dim, int metric, int device, int64_t row_base, int64_t cap_rows,
+               std::unique_ptr<Shard> *out) {
+  std::unique_ptr<Shard> s(new Shard());
+  s->device = device;
+  s->dim = dim;
+  s->metric = metric;
+  s->ld = round_up(dim, 4);
+  s->nch = pick_nch((int)(s->ld / 4));
+  s->row_base = row_base;
+  int rc = shard_init(s.get());
+  if (rc) return rc;
+  if (cap_rows > 0) {
+    rc = shard_reserve(s.get(), cap_rows);
+    if (rc) return rc;
+  }
+  *out = std::move(s);
+  return TSH_OK;
+}
+
+void shard_destroy(Shard *s) {
+  hipSetDevice(s->device);
+  for (auto &c : s->ctx_all) ctx_free_all(c.get());
+  if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
+  hipFree(s->d_rows);
+  hipFree(s->d_inv_norm);
+  hipFree(s->d_live);
+  hipFree(s->d_stats);
+  hipFree(s->d_tmp_u32);
+}
+
+int check_create_args(int32_t dim, int32_t metric, int64_t cap, tsh_index **out) {
+  if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (dim <= 0 || dim > MAX_DIM_SCAN)
+    return set_err(TSH_E_BAD_ARG, "dim %d outside [1,%d]", dim, MAX_DIM_SCAN);
+  if (metric < 0 || metric > 2) return set_err(TSH_E_BAD_ARG, "metric %d unknown", metric);
+  if (cap < 0) return set_err(TSH_E_BAD_ARG, "capacity_rows < 0");
+  if (device_count_cached() <= 0) return set_err(TSH_E_NO_DEVICE, "no HIP device available");
+  return TSH_OK;
+}
+
+Shard *shard_for_row(tsh_index *idx, int64_t gid) {
+  if (idx->shards.size() == 1) return idx->shards[0].get();
+  int64_t g = idx->rows_per_shard > 0 ? gid / idx->rows_per_shard : 0;
+  if (g >= (int64_t)idx->shards.size()) g = (int64_t)idx->shards.size() - 1;
+  if (g < 0) g = 0;
+  return idx->shards[(size_t)g].get();
+}
+
+int index_append(tsh_index *idx, int64_t first, int64_t n, const float *rows, bool dev) {
+  if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  if (n < 0 || first < 0) return set_err(TSH_E_BAD_ARG, "negative row range");
+  if (n == 0) return TSH_OK;
+  if (!rows) return set_err(TSH_E_BAD_ARG, "rows is NULL");
+  if (dev && idx->shards.size() > 1)
+    return set_err(TSH_E_BAD_ARG, "append_device needs a single-device handle");
+  std::lock_guard<std::mutex> lk(idx->mu);
+  int64_t done = 0;
+  while (done < n) {
+    int64_t gid = first + done;
+    Shard *s = shard_for_row(idx, gid);
+    int64_t take = n - done;
+    if (idx->shards.size() > 1 && s != idx->shards.back().get()) {
+      int64_t end = s->row_base + idx->rows_per_shard;
+      take = std::min(take, end - gid);
+    }
+    if (gid < s->row_base) return set_err(TSH_E_BAD_ARG, "row id %lld below shard base", (long long)gid);
+    std::unique_lock<std::shared_mutex> xl(s->mu);
+    int rc = shard_append(s, gid - s->row_base, take, rows + (size_t)done * idx->dim, dev);
+    if (rc) return rc;
+    done += take;
+  }
+  return TSH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t tsh_abi_version(void) { return TSH_ABI_VERSION; }
+
+int32_t tsh_device_count(void) { return device_count_cached(); }
+
+int32_t tsh_last_error(char *buf, int32_t len) {
+  if (buf && len > 0) {
+    size_t n = std::min<size_t>(g_err.size(), (size_t)len - 1);
+    memcpy(buf, g_err.data(), n);
+    buf[n] = 0;
+  }
+  return (int32_t)g_err.size();
+}
+
+int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows, int32_t n_devices,
+                         tsh_index **out) {
+  int rc = check_create_args(dim, metric, capacity_rows, out);
+  if (rc) return rc;
+  if (n_devices < 1 || n_devices > device_count_cached())
+    return set_err(TSH_E_BAD_ARG, "n_devices %d outside [1,%d]", n_devices, device_count_cached());
+  std::unique_ptr<tsh_index> idx(new tsh_index());
+  idx->dim = dim;
+  idx->metric = metric;
+  if (n_devices == 1) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::unique_ptr<Shard> s;
+    rc = make_shard(dim, metric, dev, 0, capacity_rows, &s);
+    if (rc) return rc;
+    idx->shards.push_back(std::move(s));
+  } else {
+    if (capacity_rows <= 0)
+      return set_err(TSH_E_BAD_ARG, "multi-device index needs capacity_rows to place the row ranges");
+    idx->rows_per_shard = round_up((capacity_rows + n_devices - 1) / n_devices, 64);
+    for (int g = 0; g < n_devices; ++g) {
+      std::unique_ptr<Shard> s;
+      rc = make_shard(dim, metric, g, (int64_t)g * idx->rows_per_shard, idx->rows_per_shard, &s);
+      if (rc) {
+        for (auto &p : idx->shards) shard_destroy(p.get());
+        return rc;
+      }
+      idx->shards.push_back(std::move(s));
+    }
+  }
+  *out = idx.release();
+  return TSH_OK;
+}
+
+int32_t tsh_index_create_shard(int32_t dim, int32_t metric, int64_t capacity_rows, int32_t device_id,
+                               int64_t row_base, tsh_index **out) {
+  int rc = check_create_args(dim, metric, capacity_rows, out);
+  if (rc) return rc;
+  if (row_base < 0) return set_err(TSH_E_BAD_ARG, "row_base < 0");
+  int dev = device_id;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= device_count_cached()) return set_err(TSH_E_BAD_ARG, "device %d not present", dev);
+  std::unique_ptr<tsh_index> idx(new tsh_index());
+  idx->dim = dim;
+  idx->metric = metric;
+  std::unique_ptr<Shard> s;
+  rc = make_shard(dim, metric, dev, row_base, capacity_rows, &s);
+  if (rc) return rc;
+  idx->shards.push_back(std::move(s));
+  *out = idx.release();
+  return TSH_OK;
+}
+
+int32_t tsh_index_destroy(tsh_index *idx) {
+  if (!idx) return TSH_OK;
+  for (auto &s : idx->shards) {
+    std::unique_lock<std::shared_mutex> xl(s->mu);
+    shard_destroy(s.get());
+  }
+  delete idx;
+  return TSH_OK;
+}
+
+int32_t tsh_index_append(tsh_index *idx, int64_t first_row_id, int64_t n_rows, const float *rows) {
+  return index_append(idx, first_row_id, n_rows, rows, false);
+}
+
+int32_t tsh_index_append_device(tsh_index *idx, int64_t first_row_id, int64_t n_rows, const void *d_rows) {
+  return index_append(idx, first_row_id, n_rows, static_cast<const float *>(d_rows), true);
+}
+
+int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n) {
+  if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  if (n < 0) return set_err(TSH_E_BAD_ARG, "n < 0");
+  if (n == 0) return TSH_OK;
+  if (!ids) return set_err(TSH_E_BAD_ARG, "ids is NULL");
+  for (auto &sp : idx->shards) {
+    Shard *s = sp.get();
+    std::unique_lock<std::shared_mutex> xl(s->mu);
+    if (s->rows == 0) continue;
+    HIPCHK(hipSetDevice(s->device));
+    int64_t *d_ids = nullptr;
+    HIPCHK(hipMalloc(&d_ids, (size_t)n * sizeof(int64_t)));
+    hipStream_t st = s->ingest_stream;
+    hipError_t e = hipMemcpyAsync(d_ids, ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_tmp_u32, 0, 4, st);
+    if (e == hipSuccess) {
+      int grid = (int)std::min<int64_t>((n + 255) / 256, 1024);
+      live_clear_ids_kernel<<<grid, 256, 0, st>>>(s->d_live, d_ids, n, s->row_base, s->rows, s->d_tmp_u32);
+    }
+    uint32_t cleared = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&cleared, s->d_tmp_u32, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_ids);
+    if (e != hipSuccess) return set_err(TSH_E_HIP, "set_deleted: %s", hipGetErrorString(e));
+    s->deleted += cleared;
+    if (cleared) s->all_live = false;
+  }
+  return TSH_OK;
+}
+
+int64_t tsh_index_size(tsh_index *idx) {
+  if (!idx) return 0;
+  int64_t m = 0;
+  for (auto &s : idx->shards) {
+    std::shared_lock<std::shared_mutex> sl(s->mu);
+    if (s->rows > 0) m = std::max(m, s->row_base + s->rows);
+  }
+  return m;
+}
+int32_t tsh_index_dim(tsh_index *idx) { return idx ? idx->dim : 0; }
+int32_t tsh_index_metric(tsh_index *idx) { return idx ? idx->metric : 0; }
+
+int64_t tsh_candidate_block_bytes(int32_t entries) {
+  return (int64_t)sizeof(BlockHeader) + (int64_t)std::max(entries, 0) * (int64_t)sizeof(BlockEntry);
+}
+int32_t tsh_default_block_entries(int32_t k) {
+  int64_t e = (int64_t)std::max(k, 1) + 156;
+  e = round_up(e, 64);
+  return (int32_t)std::min<int64_t>(e, 1 << 20);
+}
+
+int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, double thr,
+                   const uint8_t *row_mask, int64_t *out_ids, double *out_dist, int32_t *out_count) {
+  if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  if (nq < 0) return set_err(TSH_E_BAD_ARG, "nq < 0");
+  if (nq == 0) return TSH_OK;
+  if (!queries || !out_count) return set_err(TSH_E_BAD_ARG, "queries / out_count is NULL");
+  for (int32_t q = 0; q < nq; ++q) out_count[q] = 0;
+  if (k <= 0) return TSH_OK;  // reference: topK <= 0 yields an empty list
+  if (!out_ids || !out_dist) return set_err(TSH_E_BAD_ARG, "out_ids / out_dist is NULL");
+
+  size_t ns = idx->shards.size();
+  int32_t entries = tsh_default_block_entries(k);
+  size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  std::vector<std::vector<uint8_t>> blocks(ns);
+  std::vector<std::vector<std::vector<BlockEntry>>> spills(ns);
+  std::vector<int> rcs(ns, TSH_OK);
+  std::vector<std::string> errs(ns);
+  std::vector<char> active(ns, 0);
+
+  auto run = [&](size_t g) {
+    Shard *s = idx->shards[g].get();
+    std::shared_lock<std::shared_mutex> sl(s->mu);
+    if (s->rows == 0) return;
+    active[g] = 1;
+    blocks[g].resize(bb * (size_t)nq);
+    spills[g].resize((size_t)nq);
+    SearchOut so;
+    so.h_blocks = blocks[g].data();
+    so.spill = &spills[g];
+    rcs[g] = shard_search_blocks(s, queries, nq, k, row_mask, entries, &so);
+    if (rcs[g]) errs[g] = g_err;
+  };
+  if (ns == 1) {
+    run(0);
+  } else {
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < ns; ++g) th.emplace_back(run, g);
+    for (auto &t : th) t.join();
+  }
+  for (size_t g = 0; g < ns; ++g)
+    if (rcs[g]) {
+      g_err = errs[g];
+      return rcs[g];
+    }
+  for (int32_t q = 0; q < nq; ++q) {
+    std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
+    for (size_t g = 0; g < ns; ++g) {
+      if (!active[g]) continue;
+      if (!spills[g][(size_t)q].empty()) {
+        lists.push_back({spills[g][(size_t)q].data(), (uint32_t)spills[g][(size_t)q].size()});
+      } else {
+        const uint8_t *b = blocks[g].data() + (size_t)q * bb;
+        const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b);
+        lists.push_back({reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)),
+                         std::min(h->count, h->entries)});
+      }
+    }
+    out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, lists,
+                                  out_ids + (size_t)q * k, out_dist + (size_t)q * k);
+  }
+  return TSH_OK;
+}
+
+int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
+                         const uint8_t *row_mask, int32_t entries, void *d_out_blocks, void *stream) {
+  if (!idx || idx->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle");
+  if (nq <= 0 || !queries || !d_out_blocks || k <= 0 || entries < 1)
+    return set_err(TSH_E_BAD_ARG, "bad nq / k / entries / pointers");
+  Shard *s = idx->shards[0].get();
+  std::shared_lock<std::shared_mutex> sl(s->mu);
+  size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  if (s->rows == 0) {  // an empty shard contributes empty blocks
+    HIPCHK(hipSetDevice(s->device));
+    std::vector<uint8_t> z(bb * (size_t)nq, 0);
+    for (int32_t q = 0; q < nq; ++q) {
+      BlockHeader *h = reinterpret_cast<BlockHeader *>(z.data() + (size_t)q * bb);
+      h->entries = (uint32_t)entries;
+      h->k = (uint32_t)k;
+      h->metric = (uint32_t)s->metric;
+      h->row_base = s->row_base;
+    }
+    HIPCHK(hipMemcpy(d_out_blocks, z.data(), z.size(), hipMemcpyHostToDevice));
+    return TSH_OK;
+  }
+  SearchOut so;
+  so.d_blocks = static_cast<uint8_t *>(d_out_blocks);
+  so.user_stream = static_cast<hipStream_t>(stream);
+  return shard_search_blocks(s, queries, nq, k, row_mask, entries, &so);
+}
+
+int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries, int32_t nq, int32_t k,
+                             double thr, const void *blocks, int32_t n_blocks, int32_t entries,
+                             int64_t *out_ids, double *out_dist, int32_t *out_count,
+                             int32_t *needed_entries) {
+  if (metric < 0 || metric > 2 || dim <= 0 || nq < 0 || n_blocks < 0 || entries < 0)
+    return set_err(TSH_E_BAD_ARG, "bad metric / dim / nq / n_blocks / entries");
+  if (nq == 0) return TSH_OK;
+  if (!queries || !blocks || !out_count) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  for (int32_t q = 0; q < nq; ++q) out_count[q] = 0;
+  if (needed_entries) *needed_entries = entries;
+  if (k <= 0) return TSH_OK;
+  if (!out_ids || !out_dist) return set_err(TSH_E_BAD_ARG, "out_ids / out_dist is NULL");
+  size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  const uint8_t *base = static_cast<const uint8_t *>(blocks);
+  uint32_t need = 0;
+  for (int32_t b = 0; b < n_blocks; ++b)
+    for (int32_t q = 0; q < nq; ++q) {
+      const BlockHeader *h = reinterpret_cast<const BlockHeader *>(base + ((size_t)b * nq + q) * bb);
+      if (h->entries != (uint32_t)entries)
+        return set_err(TSH_E_FORMAT, "block %d/%d entries %u != %d", b, q, h->entries, entries);
+      if (h->count > h->entries) need = std::max(need, h->count);
+    }
+  if (need) {
+    if (needed_entries) *needed_entries = (int32_t)round_up(need, 64);
+    return set_err(TSH_E_OVERFLOW, "a candidate block needs %u entries (have %d)", need, entries);
+  }
+  for (int32_t q = 0; q < nq; ++q) {
+    std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
+    for (int32_t b = 0; b < n_blocks; ++b) {
+      const uint8_t *p = base + ((size_t)b * nq + q) * bb;
+      const BlockHeader *h = reinterpret_cast<const BlockHeader *>(p);
+      lists.push_back({reinterpret_cast<const BlockEntry *>(p + sizeof(BlockHeader)), h->count});
+    }
+    out_count[q] = finalize_query(metric, dim, queries + (size_t)q * dim, k, thr, lists,
+                                  out_ids + (size_t)q * k, out_dist + (size_t)q * k);
+  }
+  return TSH_OK;
+}
+
+int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
+  if (!idx || !out) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  memset(out, 0, sizeof *out);
+  for (auto &sp : idx->shards) {
+    Shard *s = sp.get();
+    std::shared_lock<std::shared_mutex> sl(s->mu);
+    if (s->rows > 0) out->rows = std::max(out->rows, s->row_base + s->rows);
+    out->deleted_rows += s->deleted;
+    out->searches = std::max<int64_t>(out->searches, s->c_searches.load());
+    out->scan_launches += s->c_scans.load();
+    out->batch_launches += s->c_batches.load();
+    out->fallback_searches += s->c_fallbacks.load();
+    out->candidates_total += s->c_cands.load();
+    int64_t b = s->bytes;
+    {
+      std::lock_guard<std::mutex> lk(s->ctx_mu);
+      for (auto &c : s->ctx_all) b += c->bytes;
+    }
+    out->bytes_resident += b;
+    if (s->safe_mode()) out->safe_mode = 1;
+    out->device_id = s->device;
+  }
+  return TSH_OK;
+}
+
+int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const uint8_t *row_mask,
+                       double *out_avg_us) {
+  if (!idx || idx->shards.size() != 1 || !query || iters <= 0 || !out_avg_us)
+    return set_err(TSH_E_BAD_ARG, "bad arguments");
+  Shard *s = idx->shards[0].get();
+  std::shared_lock<std::shared_mutex> sl(s->mu);
+  if (s->rows == 0) return set_err(TSH_E_BAD_ARG, "empty index");
+  CtxLease lease(s);
+  Ctx *c = lease.c;
+  int rc = ctx_prepare(s, c, tsh_default_block_entries(100), row_mask != nullptr);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
+  bool masked = row_mask != nullptr || !s->all_live;
+  int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+  if (row_mask) {
+    slice_mask(s, row_mask, c->h_mask, n_tiles);
+    HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+  }
+  memcpy(c->h_query, query, (size_t)s->dim * sizeof(float));
+  for (int64_t j = s->dim; j < s->ld; ++j) c->h_query[j] = 0.f;
+  HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, st));
+  ScanArgs sa;
+  fill_scan_args(s, c, c->d_query, masked, row_mask != nullptr, &sa);
+  launch_scan(sa, s->nch, s->metric, masked, st);  // warm
+  HIPCHK(hipEventRecord(c->ev0, st));
+  for (int32_t i = 0; i < iters; ++i) launch_scan(sa, s->nch, s->metric, masked, st);
+  HIPCHK(hipEventRecord(c->ev1, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *out_avg_us = (double)ms * 1000.0 / iters;
+  return TSH_OK;
+}
+
+int32_t tsh_bench_batch(tsh_index *, const float *, int32_t, int32_t, double *) {
+  return set_err(TSH_E_BAD_ARG, "batched path not built yet");
+}
+
+}  // extern "C"
+
+// ---- rawvec partition file loader -------------
+namespace {
+
+uint32_t crc32_ieee(const uint8_t *p, size_t n) {  // core/btree_page.dart:61-89
+  static uint32_t table[256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+      table[i] = c;
+    }
+  });
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+inline uint32_t rd16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t rd32(const uint8_t *p) { return rd16(p) | (rd16(p + 2) << 16); }
+
+enum PageKind { PAGE_ERROR = -1, PAGE_EMPTY = 0, PAGE_OK = 1 };
+
+// Decodes one page into out (vpp x dim floats, pre-zeroed); *vcount = vectors present.
+PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int dim, int vpp, float *out,
+                            int *vcount) {
+  *vcount = vpp;  // an "empty" page is NghRawVectorPage.empty(capacity: vectorsPerRawPage)
+  if (avail == 0) return PAGE_EMPTY;              // ngh_partition_manager.dart:276-281
+  if (avail < 20) return PAGE_ERROR;              // btree_page.dart:162-163 -> StateError
+  if (rd32(pg) != 0x32475054u) return PAGE_ERROR; // 'TPG2'
+  if (rd16(pg + 4) != 20) return PAGE_ERROR;
+  if (pg[6] >= 10) return PAGE_ERROR;
+  uint32_t plen = rd32(pg + 8), crc = rd32(pg + 12);
+  if ((uint64_t)20 + plen > avail) return PAGE_ERROR;  // :221-224
+  const uint8_t *pl = pg + 20;
+  if (crc32_ieee(pl, plen) != crc) return PAGE_ERROR;  // :226-230
+  // NghRawVectorPage.tryDecodePayload, ngh_page.dart:431-450 (null -> empty page)
+  if (plen < 8) return PAGE_EMPTY;
+  uint32_t vc = rd16(pl), dims = rd16(pl + 2);
+  int prec = pl[4];
+  if (dims == 0) return PAGE_EMPTY;
+  int bpe = prec == 0 ? 8 : (prec == 2 ? 1 : 4);
+  if ((uint64_t)plen < 8 + (uint64_t)vc * dims * bpe) return PAGE_EMPTY;
+  if ((int)dims != dim) return PAGE_ERROR;  // not this index's column
+  int take = (int)std::min<uint32_t>(vc, (uint32_t)vpp);
+  const uint8_t *d = pl + 8;
+  for (int v = 0; v < take; ++v)
+    for (int i = 0; i < dim; ++i) {  // getVectorAsFloat32, ngh_page.dart:364-391
+      const uint8_t *e = d + ((size_t)v * dim + i) * bpe;
+      float f;
+      if (prec == 1) {
+        uint32_t u = rd32(e);
+        memcpy(&f, &u, 4);
+      } else if (prec == 0) {
+        uint64_t u = (uint64_t)rd32(e) | ((uint64_t)rd32(e + 4) << 32);
+        double dv;
+        memcpy(&dv, &u, 8);
+        f = (float)dv;
+      } else {
+        f = (float)((double)(int8_t)*e / 127.0);
+      }
+      out[(size_t)v * dim + i] = f;
+    }
+  *vcount = take;
+  (void)page_size;
+  return PAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size,
+                                              int32_t precision, int64_t first_row_id, int64_t max_rows,
+                                              int64_t *out_rows) {
+  if (out_rows) *out_rows = 0;
+  if (!idx || !path) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  if (page_size < 64 || precision < 0 || precision > 2 || first_row_id < 0 || max_rows < 0)
+    return set_err(TSH_E_BAD_ARG, "bad page_size / precision / row range");
+  int dim = idx->dim;
+  int bpe = precision == 0 ? 8 : (precision == 2 ? 1 : 4);
+  int usable = page_size - 20 - 8 - 64;  // ngh_page.dart:575-579
+  int vpp = usable > 0 ? usable / (dim * bpe) : 0;
+  if (vpp <= 0) return set_err(TSH_E_BAD_ARG, "page_size %d holds no %d-dim vector", page_size, dim);
+  FILE *f = fopen(path, "rb");
+  if (!f) return set_err(TSH_E_IO, "cannot open %s", path);
+  int64_t n_pages = (max_rows + vpp - 1) / vpp;  // data pages needed to cover the ids
+  const int BATCH = std::max(1, (int)((32 << 20) / ((int64_t)vpp * dim * 4)));
+  std::vector<uint8_t> raw((size_t)page_size);
+  std::vector<float> rows((size_t)BATCH * vpp * dim);
+  int64_t loaded = 0;
+  int rc = TSH_OK;
+  for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
+    int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
+    std::fill(rows.begin(), rows.begin() + (size_t)nb * vpp * dim, 0.f);
+    // runs of consecutive present rows inside the batch are appended together
+    int64_t run_start = -1, run_len = 0;
+    auto flush = [&]() {
+      if (run_len > 0 && rc == TSH_OK) {
+        rc = tsh_index_append(idx, first_row_id + p0 * vpp + run_start, run_len,
+                              rows.data() + (size_t)run_start * dim);
+        if (rc == TSH_OK) loaded += run_len;
+      }
+      run_start = -1;
+      run_len = 0;
+    };
+    for (int64_t b = 0; b < nb && rc == TSH_OK; ++b) {
+      int64_t page_no = 1 + p0 + b;  // pageNo 0 is the partition meta page
+      size_t got = 0;
+      if (fseeko(f, (off_t)page_no * page_size, SEEK_SET) == 0) got = fread(raw.data(), 1, (size_t)page_size, f);
+      int vc = 0;
+      PageKind k = decode_rawvec_page(raw.data(), got, page_size, dim, vpp, rows.data() + (size_t)b * vpp * dim, &vc);
+      if (k == PAGE_ERROR) {
+        flush();
+        if (rc == TSH_OK) rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path, (long long)page_no);
+        break;
+      }
+      int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
+      int64_t lim = std::min<int64_t>(vc, max_rows - base);
+      if (lim <= 0) continue;
+      if (run_len > 0 && run_start + run_len == b * vpp) {
+        run_len += lim;
+      } else {
+        flush();
+        run_start = b * vpp;
+        run_len = lim;
+      }
+      if (lim < vpp) flush();  // slots past vectorCount are absent rows
+    }
+    flush();
+  }
+  fclose(f);
+  if (out_rows) *out_rows = loaded;
+  return rc;
+}
