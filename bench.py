@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json headline metric: kNN queries/sec (+ recall@k) on
+1M x 768 f32 brute force, L2, k=100, single query per step (config C2).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one single-query search through the C-ABI: query H2D, K1 scan (reads
+every stored row once), K2 select, K4 f64 re-rank, candidates D2H, host merge.
+The corpus is resident in HBM before the timed region.  N > 1: the SAME corpus
+is row-range sharded over the ranks (strong scaling); every rank scans its
+shard, candidate blocks are all-gathered over RCCL, every rank merges.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--metric", default="l2", choices=["l2", "ip", "cosine"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_corpus(torch, n, d, metric, device):
+    """Recipe of the reference's demo (/root/reference/example/lib/tostore_example.dart:728-747):
+    i.i.d. N(0,1) components, rows L2-normalised, stored f32; for L2/IP each row is also scaled
+    by U(0.5,2) so the three metrics rank differently.  Seeded: every
+    rank builds identical rows."""
+    g = torch.Generator(device=device)
+    g.manual_seed(20260612)
+    chunk = 131072
+    out = torch.empty((n, d), dtype=torch.float32, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        x = torch.randn((e - s, d), generator=g, device=device, dtype=torch.float32)
+        x /= x.norm(dim=1, keepdim=True)
+        if metric != 2:
+            x *= torch.rand((e - s, 1), generator=g, device=device) * 1.5 + 0.5
+        out[s:e] = x
+    return out
+
+
+def make_queries(nq, d, metric):
+    rng = np.random.Generator(np.random.Philox(20260613))
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    if metric == 2:  # caller-side _normalizeFloat32 (vector_index_manager.dart:516-520)
+        from tostore_amd import normalize_float32
+        q = np.stack([normalize_float32(x) for x in q])
+    return np.ascontiguousarray(q)
+
+
+def main():
+    a = parse()
+    import torch
+
+    from tostore_amd import HipVectorIndex, _ffi
+    from tostore_amd.sharded import ShardedSearcher
+
+    metric = {"l2": 0, "ip": 1, "cosine": 2}[a.metric]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, d, k = a.rows, a.dim, a.k
+    assert _ffi.lib().tsh_device_count() >= 1, "libtostore_hip.so sees no device"
+
+    # ---- resident corpus (this rank's row range) -----------------------------------
+    corpus = make_corpus(torch, n, d, metric, dev)
+    per = (n + world - 1) // world
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    idx = HipVectorIndex(d, metric, capacity_rows=hi - lo, shard_device=local_rank, row_base=lo)
+    if hi > lo:
+        idx.append_device(lo, hi - lo, corpus[lo:hi].data_ptr())
+    torch.cuda.synchronize()
+    host_rows = None
+    if rank == 0 and not a.no_cpu_baseline:
+        host_rows = corpus.cpu().numpy()  # for the CPU baseline / recall check only
+    del corpus
+    torch.cuda.empty_cache()
+
+    nq_total = a.warmup + a.steps
+    queries = make_queries(max(nq_total, 1), d, metric)
+    searcher = ShardedSearcher(idx) if world > 1 else None
+
+    def one(i):
+        q = queries[i % len(queries)]
+        if searcher is not None:
+            return searcher.search(q, k)
+        return idx.search(q, k)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel (K1 scan), HIP events on the library's stream
+    scan_us = idx.bench_scan(queries[0], iters=50) if hi > lo else float("nan")
+    shard_bytes = float(hi - lo) * d * 4  # algorithmic: every stored f32 read once
+    if dist is not None:
+        tt = torch.tensor([scan_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        scan_us = float(tt.item())
+
+    # ---- recall + CPU baseline: oracle on rank 0, every rank joins the GPU searches ----
+    n_cpu, ref, cpu_elapsed = 0, None, 0.0
+    if rank == 0 and host_rows is not None:
+        import oracle
+
+        t1 = time.perf_counter()
+        oracle.search_heap(host_rows, queries[0], metric, k)
+        per_q = time.perf_counter() - t1
+        budget = a.cpu_seconds if world == 1 else min(a.cpu_seconds, 4.0)
+        n_cpu = int(max(2, min(32, budget / max(per_q, 1e-3))))
+        t1 = time.perf_counter()
+        ref = [oracle.search_heap(host_rows, queries[i], metric, k) for i in range(n_cpu)]
+        cpu_elapsed = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([n_cpu], dtype=torch.int64, device=dev)
+        dist.broadcast(tt, src=0)
+        n_cpu = int(tt.item())
+    got = [one(i) for i in range(n_cpu)]
+
+    out = None
+    if rank == 0:
+        achieved = shard_bytes / (scan_us * 1e-6) / 1e9
+        traffic = None  # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                ent = json.load(f).get("%dx%d" % (hi - lo, d))
+            if ent:
+                traffic = ent["traffic_bytes"]
+        except (OSError, ValueError):
+            pass
+        out = {
+            "metric": "kNN queries/sec, 1Mx768 f32 brute-force L2 k=100, single query",
+            "value": a.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: %dx%d f32, %s, k=%d, single query per step" % (n, d, a.metric, k),
+                       "rows": n, "dim": d, "k": k, "metric": a.metric,
+                       "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "tsh::scan_kernel", "kernel_us": scan_us,
+                         "algorithmic_bytes_per_launch": shard_bytes},
+        }
+        if ref is not None:
+            hits, tot, exact = 0, 0, True
+            for i in range(n_cpu):
+                ids, dd, cnt = got[i]
+                g = ids[0, :cnt[0]]
+                hits += len(set(g.tolist()) & set(ref[i][0].tolist()))
+                tot += len(ref[i][0])
+                exact &= bool(np.array_equal(g, ref[i][0]) and np.array_equal(dd[0, :cnt[0]], ref[i][1]))
+            out["recall_at_k"] = hits / max(tot, 1)
+            out["ids_and_distances_bit_exact"] = exact
+            if world == 1:
+                import oracle
+
+                out["cpu_baseline"] = {
+                    "value": n_cpu / cpu_elapsed, "unit": "queries/s", "cores": 1, "kind": "port",
+                    "sample": "%d of the same queries over the full %dx%d corpus, oracle/vs_oracle.c "
+                              "single thread (the reference searches on one isolate)" % (n_cpu, n, d)}
+                try:
+                    thr = oracle.mt_max_threads()
+                    t1 = time.perf_counter()
+                    m = max(2, min(n_cpu, 8))
+                    for i in range(m):
+                        oracle.search_heap_mt(host_rows, queries[i], metric, k)
+                    out["cpu_baseline_mt"] = {"value": m / (time.perf_counter() - t1), "unit": "queries/s",
+                                              "cores": thr, "kind": "port", "sample": "%d queries, OpenMP" % m}
+                except Exception:
+                    pass
+        c = idx.counters()
+        out["counters"] = {"fallback_searches": c["fallback_searches"],
+                           "candidates_per_query": c["candidates_total"] / max(c["searches"], 1)}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    idx.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

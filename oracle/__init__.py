@@ -54,6 +54,8 @@ def lib() -> ctypes.CDLL:
             f.restype = ctypes.c_double
         L.vso_exact_distance.argtypes = [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int]
         L.vso_exact_distance.restype = ctypes.c_double
+        L.vso_exact_sums.argtypes = [_c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, _c_f64p, _c_f64p]
+        L.vso_exact_sums.restype = None
         L.vso_distance_to_score.argtypes = [ctypes.c_double, ctypes.c_int]
         L.vso_distance_to_score.restype = ctypes.c_double
         L.vso_compare_double.argtypes = [ctypes.c_double, ctypes.c_double]
@@ -125,6 +127,13 @@ def normalize_f32(v) -> np.ndarray:
 def exact_distance(a, b, metric: int) -> float:
     a, b = _f32(a), _f32(b)
     return lib().vso_exact_distance(_p(a, _c_f32p), _p(b, _c_f32p), a.shape[0], metric)
+
+
+def exact_sums(a, b, metric: int):
+    a, b = _f32(a), _f32(b)
+    s0, s1 = ctypes.c_double(), ctypes.c_double()
+    lib().vso_exact_sums(_p(a, _c_f32p), _p(b, _c_f32p), a.shape[0], metric, ctypes.byref(s0), ctypes.byref(s1))
+    return s0.value, s1.value
 
 
 def distance_to_score(distance: float, metric: int) -> float:

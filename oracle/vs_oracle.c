@@ -89,6 +89,22 @@ double vso_exact_distance(const float *a, const float *b, int d, int metric) {
   }
 }
 
+void vso_exact_sums(const float *a, const float *b, int d, int metric, double *s0, double *s1) {
+  double x = 0, y = 0;
+  int i;
+  for (i = 0; i < d; i++) {
+    if (metric == VSO_L2) {
+      double diff = (double)a[i] - (double)b[i];
+      x += diff * diff;
+    } else {
+      x += (double)a[i] * (double)b[i];
+      if (metric == VSO_COSINE) y += (double)b[i] * (double)b[i];
+    }
+  }
+  *s0 = x;
+  *s1 = y;
+}
+
 /* ---- Dart double.compareTo [external: Dart SDK] ------------------------- */
 int vso_compare_double(double a, double b) {
   if (a < b) return -1;

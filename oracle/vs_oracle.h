@@ -43,6 +43,11 @@ double vso_cosine_similarity(const float *a, const float *b, int d);
 /* ref: core/ngh_graph_engine.dart:908-918 */
 double vso_exact_distance(const float *a, const float *b, int d, int metric);
 
+/* the raw f64 accumulations of :920-946 before sqrt / divide (tests build
+ * candidate blocks from them): L2 s0 = sum (a-b)^2; IP s0 = sum a*b;
+ * cosine s0 = dot, s1 = sum b*b */
+void vso_exact_sums(const float *a, const float *b, int d, int metric, double *s0, double *s1);
+
 /* A8  ref: core/vector_index_manager.dart:1411-1423 */
 double vso_distance_to_score(double distance, int metric);
 
@@ -94,8 +99,9 @@ int vso_rawvec_page_build(const float *vectors, int count, int dims,
 
 /* Parse one raw-vector page into float32 (ref: core/ngh_page.dart:431-450,
  * :364-391; core/btree_page.dart:215-233).  Returns vector count, or -1 for
- * an invalid page (bad magic / CRC / type / length): the reference treats
- * those as an empty page (ref: core/ngh_partition_manager.dart:270-295).
+ * an invalid page: the reference THROWS on a bad magic / CRC / length
+ * (btree_page.dart:215-233) and substitutes an all-zero page when the file
+ * is short or the payload does not decode (ngh_partition_manager.dart:276-295).
  * out_vectors must hold max_vectors x dims floats. */
 int vso_rawvec_page_parse(const uint8_t *page, int page_size, int dims,
                           float *out_vectors, int max_vectors,
@@ -107,7 +113,8 @@ int vso_ngh_meta_page_build(int partition_no, int data_category,
                             int page_size, uint8_t *out);
 
 /* nodeId -> (partition, pageNo, slot).  ref: model/ngh_index_meta.dart:480-490;
- * pages per partition = max(1, maxPartitionFileSize / pageSize - 1)?  see .c */
+ * pages_per_partition = maxPartitionFileSize ~/ nghPageSize (:163,178), data
+ * pages start at pageNo 1 (:232) */
 void vso_rawvec_locate(int64_t node_id, int vectors_per_page,
                        int64_t pages_per_partition, int64_t *partition,
                        int64_t *page_no, int *slot);

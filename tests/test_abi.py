@@ -1,0 +1,122 @@
+"""CPU: libtostore_hip.so loads without a GPU, exports every symbol that
+include/tostore_hip.h declares, refuses compute without a device, and its
+host-only merge entry point works."""
+import ctypes
+import math
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L2, IP, COS = 0, 1, 2
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "tostore_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(tsh_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from tostore_amd import _ffi
+
+    names = _declared_symbols()
+    assert len(names) >= 20
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in tostore_hip.h but not exported"
+    assert sorted(_ffi.SIGNATURES) == names, "ctypes SIGNATURES out of sync with the header"
+    assert _ffi.lib().tsh_abi_version() == 1
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    from tostore_amd import _ffi
+
+    L = _ffi.lib()
+    if L.tsh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert L.tsh_index_create(128, 0, 0, 1, ctypes.byref(h)) == _ffi.TSH_E_NO_DEVICE
+    assert not h
+    assert "no HIP device" in _ffi.last_error()
+    with pytest.raises(_ffi.TshError) as e:
+        from tostore_amd import HipVectorIndex
+        HipVectorIndex(128, 0)
+    assert e.value.code == _ffi.TSH_E_NO_DEVICE
+
+
+def test_argument_validation():
+    from tostore_amd import _ffi
+
+    L = _ffi.lib()
+    h = ctypes.c_void_p()
+    assert L.tsh_index_create(0, 0, 0, 1, ctypes.byref(h)) == _ffi.TSH_E_BAD_ARG
+    assert L.tsh_index_create(128, 7, 0, 1, ctypes.byref(h)) == _ffi.TSH_E_BAD_ARG
+    assert L.tsh_index_create(128, 0, -1, 1, ctypes.byref(h)) == _ffi.TSH_E_BAD_ARG
+    assert L.tsh_index_destroy(None) == 0
+    assert L.tsh_index_size(None) == 0
+    assert L.tsh_index_append(None, 0, 1, None) == _ffi.TSH_E_BAD_ARG
+    assert L.tsh_candidate_block_bytes(256) == 64 + 24 * 256
+    assert L.tsh_default_block_entries(100) == 256 and L.tsh_default_block_entries(1000) >= 1156
+
+
+def _block(entries, cands, k, metric, row_base=0):
+    """A candidate block exactly as the device writes it (tsh_kernels.hip.h BlockHeader/BlockEntry)."""
+    b = bytearray(64 + 24 * entries)
+    struct.pack_into("<8IqqI", b, 0, len(cands), entries, 0, 0, 0, 1 if len(cands) > entries else 0, k, metric,
+                     row_base, 0, 0)
+    for i, (rid, s0, s1) in enumerate(cands[:entries]):
+        struct.pack_into("<qdd", b, 64 + 24 * i, rid, s0, s1)
+    return bytes(b)
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_merge_candidates_is_the_reference_ordering(oracle_mod, metric):
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    rng = np.random.default_rng(3)
+    n, d, k, entries = 500, 32, 20, 128
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[40] = rows[41] = rows[7]  # ties -> id order
+    q = rng.standard_normal(d).astype(np.float32)
+    if metric == COS:
+        q = oracle_mod.normalize_f32(q)
+    # three "shards", each contributing its exact local top-k (plus a few extras)
+    bounds = [(0, 170), (170, 330), (330, 500)]
+    blocks = b""
+    for lo, hi in bounds:
+        ids, _ = oracle_mod.search_exhaustive(rows[lo:hi], q, metric, k + 5)
+        cands = [(lo + int(i),) + oracle_mod.exact_sums(q, rows[lo + int(i)], metric) for i in ids]
+        blocks += _block(entries, cands, k, metric, lo)
+    for thr in (None, float(oracle_mod.search_exhaustive(rows, q, metric, k)[1][k // 2])):
+        ids, dist, cnt = merge_candidate_blocks(metric, d, q, k, thr, np.frombuffer(blocks, np.uint8), 3, entries)
+        eids, edist = oracle_mod.search_exhaustive(rows, q, metric, k, thr)
+        assert cnt[0] == len(eids)
+        assert np.array_equal(ids[0, :cnt[0]], eids)
+        assert np.array_equal(dist[0, :cnt[0]].view(np.uint64), edist.view(np.uint64))
+
+
+def test_merge_reports_truncated_blocks(oracle_mod):
+    from tostore_amd import _ffi
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    cands = [(i, float(i), 0.0) for i in range(300)]
+    blk = _block(128, cands, 10, L2)
+    with pytest.raises(_ffi.TshError) as e:
+        merge_candidate_blocks(L2, 4, np.zeros(4, np.float32), 10, None, np.frombuffer(blk, np.uint8), 1, 128)
+    assert e.value.code == _ffi.TSH_E_OVERFLOW and e.value.needed_entries >= 300
+    ids, dist, cnt = merge_candidate_blocks(L2, 4, np.zeros(4, np.float32), 10, None,
+                                            np.frombuffer(_block(320, cands, 10, L2), np.uint8), 1, 320)
+    assert ids[0].tolist() == list(range(10)) and dist[0].tolist() == [math.sqrt(i) for i in range(10)]
+    # NaN distances sort last, -0.0 before +0.0 (double.compareTo)
+    c2 = [(0, math.nan, 0.0), (1, 4.0, 0.0), (2, math.inf, 0.0)]
+    ids, dist, cnt = merge_candidate_blocks(L2, 4, np.zeros(4, np.float32), 3, None,
+                                            np.frombuffer(_block(8, c2, 3, L2), np.uint8), 1, 8)
+    assert ids[0].tolist() == [1, 2, 0]
+    c3 = [(5, 0.0, 0.0), (6, -0.0, 0.0)]  # IP: dist = -s0 -> id 5 gives -0.0, id 6 gives +0.0
+    ids, dist, cnt = merge_candidate_blocks(IP, 4, np.zeros(4, np.float32), 2, None,
+                                            np.frombuffer(_block(8, c3, 2, IP), np.uint8), 1, 8)
+    assert ids[0].tolist() == [5, 6]

@@ -1,0 +1,111 @@
+"""Row-range sharded search, one process per GPU.
+
+Rank g holds global rows [base_g, base_g + n_g) in its own `HipVectorIndex`
+shard.  A query is scanned by every rank; each rank's fixed-size candidate
+block (exact f64 sums of every row that can be in ITS top k) stays in device
+memory, the blocks are all-gathered with `torch.distributed` (backend "nccl"
+is RCCL over xGMI on ROCm; k'*24 B per rank per query, latency-bound), and the
+host merge (`tsh_merge_candidates`: sqrt / negate / 1-cos, threshold, ordering,
+top-k cut) runs on whichever ranks want the answer.  The reference has no
+counterpart (it has no distributed compute at all); the
+result is identical to one un-sharded index over the same rows.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+
+
+def merge_candidate_blocks(metric: int, dim: int, queries: np.ndarray, k: int,
+                           distance_threshold: Optional[float], blocks: np.ndarray, n_blocks: int,
+                           entries: int):
+    """Host merge of `n_blocks` x nq candidate blocks (uint8 array, layout [block][query]).
+
+    Returns (ids[nq,k], dist[nq,k], count[nq]); raises _ffi.TshError(TSH_E_OVERFLOW) with
+    `.needed_entries` set when a block was truncated."""
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    if q.ndim == 1:
+        q = q[None, :]
+    nq = q.shape[0]
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    bb = _ffi.lib().tsh_candidate_block_bytes(entries)
+    if blocks.size != n_blocks * nq * bb:
+        raise ValueError("blocks buffer has the wrong size")
+    kk = max(int(k), 0)
+    ids = np.full((nq, max(kk, 1)), -1, dtype=np.int64)
+    dist = np.full((nq, max(kk, 1)), np.nan, dtype=np.float64)
+    cnt = np.zeros(nq, dtype=np.int32)
+    need = ctypes.c_int32(entries)
+    thr = math.nan if distance_threshold is None else float(distance_threshold)
+    rc = _ffi.lib().tsh_merge_candidates(metric, dim, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr,
+                                         blocks.ctypes.data_as(ctypes.c_void_p), n_blocks, entries,
+                                         ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
+                                         cnt.ctypes.data_as(_ffi.p_i32), ctypes.byref(need))
+    if rc != _ffi.TSH_OK:
+        err = _ffi.TshError(rc, _ffi.last_error())
+        err.needed_entries = need.value
+        raise err
+    return ids[:, :kk], dist[:, :kk], cnt
+
+
+class ShardedSearcher:
+    """All-gather + merge around one local shard.  `group=None` = default process group."""
+
+    def __init__(self, shard_index, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist = torch, dist
+        self.index = shard_index
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._bufs = {}
+
+    def _buffers(self, nq: int, entries: int):
+        key = (nq, entries)
+        if key not in self._bufs:
+            t = self._torch
+            bb = _ffi.lib().tsh_candidate_block_bytes(entries)
+            mine = t.empty(nq * bb, dtype=t.uint8, device="cuda")
+            allb = t.empty(self.world * nq * bb, dtype=t.uint8, device="cuda")
+            host = t.empty(self.world * nq * bb, dtype=t.uint8, pin_memory=True)
+            self._bufs = {key: (mine, allb, host)}  # keep one shape resident
+        return self._bufs[key]
+
+    def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
+        t = self._torch
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        L = _ffi.lib()
+        entries = L.tsh_default_block_entries(int(k))
+        mp = None
+        if row_mask is not None:
+            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
+            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        for _attempt in range(3):
+            mine, allb, host = self._buffers(nq, entries)
+            stream = t.cuda.current_stream().cuda_stream
+            _ffi.check(L.tsh_search_shard(self.index._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), mp,
+                                          entries, ctypes.c_void_p(mine.data_ptr()),
+                                          ctypes.c_void_p(stream)))
+            if self.world > 1:
+                self._dist.all_gather_into_tensor(allb, mine, group=self.group)
+            else:
+                allb = mine
+            host[: allb.numel()].copy_(allb, non_blocking=True)
+            t.cuda.current_stream().synchronize()
+            try:
+                return merge_candidate_blocks(self.index.metric, self.index.dim, q, k, distance_threshold,
+                                              host[: allb.numel()].numpy(), self.world, entries)
+            except _ffi.TshError as e:
+                if e.code != _ffi.TSH_E_OVERFLOW:
+                    raise
+                entries = int(e.needed_entries)  # identical on every rank: all saw the same headers
+        raise RuntimeError("candidate blocks kept overflowing")
