@@ -36,8 +36,12 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--metric", default="l2", choices=["l2", "ip", "cosine"])
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="independent single-query searches kept in flight (1 = strictly one at a time)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the N>1 code path (process group, all-gather, merge) even with one rank")
     return ap.parse_args()
 
 
@@ -87,10 +91,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, d, k = a.rows, a.dim, a.k
     assert _ffi.lib().tsh_device_count() >= 1, "libtostore_hip.so sees no device"
@@ -111,7 +117,7 @@ def main():
 
     nq_total = a.warmup + a.steps
     queries = make_queries(max(nq_total, 1), d, metric)
-    searcher = ShardedSearcher(idx) if world > 1 else None
+    searcher = ShardedSearcher(idx) if dist is not None else None
 
     def one(i):
         q = queries[i % len(queries)]
@@ -119,23 +125,51 @@ def main():
             return searcher.search(q, k)
         return idx.search(q, k)
 
+    def run(first, count):
+        """`count` single-query searches, `--inflight` of them in flight.  Each query still
+        streams the whole (shard of the) corpus on its own; only the select / re-rank /
+        copy tail of one query overlaps the scan of the next."""
+        if a.inflight <= 1:
+            for i in range(count):
+                one(first + i)
+        elif searcher is not None:
+            # N > 1: groups of `inflight` queries share one all-gather + one merge call
+            for g0 in range(0, count, a.inflight):
+                ids = [(first + g0 + j) % len(queries) for j in range(min(a.inflight, count - g0))]
+                searcher.search(queries[ids], k)
+        else:
+            from collections import deque
+            pend = deque()
+            for i in range(count):
+                if len(pend) == a.inflight:
+                    idx.wait(pend.popleft())
+                pend.append(idx.submit(queries[(first + i) % len(queries)], k))
+            while pend:
+                idx.wait(pend.popleft())
+
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        one(i)
+    run(0, a.warmup)
     fence()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        one(a.warmup + i)
+    run(a.warmup, a.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # single-query latency, one at a time (not the headline value)
+    lat = []
+    for i in range(min(200, max(20, a.steps // 5))):
+        t1 = time.perf_counter()
+        one(i)
+        lat.append(time.perf_counter() - t1)
+    lat = np.sort(np.asarray(lat)) * 1e3
 
     # ---- roofline of the dominant kernel (K1 scan), HIP events on the library's stream
     scan_us = idx.bench_scan(queries[0], iters=50) if hi > lo else float("nan")
@@ -189,7 +223,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: %dx%d f32, %s, k=%d, single query per step" % (n, d, a.metric, k),
-                       "rows": n, "dim": d, "k": k, "metric": a.metric,
+                       "rows": n, "dim": d, "k": k, "metric": a.metric, "queries_in_flight": a.inflight,
                        "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,6 +258,8 @@ def main():
                                               "cores": thr, "kind": "port", "sample": "%d queries, OpenMP" % m}
                 except Exception:
                     pass
+        out["latency_ms_one_at_a_time"] = {"p50": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)]),
+                                           "mean": float(lat.mean()), "queries": int(len(lat))}
         c = idx.counters()
         out["counters"] = {"fallback_searches": c["fallback_searches"],
                            "candidates_per_query": c["candidates_total"] / max(c["searches"], 1)}

@@ -45,6 +45,7 @@ extern "C" {
 #define TSH_E_OVERFLOW (-6) /* a candidate block was too small; retry with more entries */
 #define TSH_E_IO (-7)
 #define TSH_E_FORMAT (-8)
+#define TSH_E_BUSY (-9) /* too many un-waited asynchronous searches on the handle */
 
 /* metric = enum order of VectorDistanceMetric, lib/src/model/table_schema.dart:2511-2531 */
 #define TSH_METRIC_L2 0
@@ -160,6 +161,20 @@ int32_t tsh_index_metric(tsh_index *idx);
 int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                    double distance_threshold, const uint8_t *row_mask,
                    int64_t *out_ids, double *out_dist, int32_t *out_count);
+
+/* Asynchronous form of a single-query tsh_search, for callers that keep several
+ * independent queries in flight (the reference serves concurrent vectorSearch
+ * calls from its isolate pool, lib/src/Interface/compute_native.dart:18-300): a
+ * submitted query's select / re-rank / copies overlap the next query's corpus
+ * scan.  At most tsh_max_inflight() un-waited tickets per handle (TSH_E_BUSY
+ * beyond).  The handle is share-locked from submit to wait: appends and deletes
+ * block until every ticket is waited.  Every ticket must be waited exactly once
+ * before tsh_index_destroy.  Results are identical to tsh_search. */
+int32_t tsh_max_inflight(void);
+int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const uint8_t *row_mask,
+                          int32_t *out_ticket);
+int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double distance_threshold, int64_t *out_ids,
+                        double *out_dist, int32_t *out_count);
 
 /* ---- row-sharded deployments (one process per GPU) ----------------------
  * Each rank scans its shard and emits, per query, one fixed-size candidate

@@ -279,3 +279,72 @@ def test_config_shapes_scaled(hip_lib, oracle_mod, metric, n, d, k):
             assert np.allclose(dist[0], edist, rtol=1e-5, atol=1e-6)  # the stated tolerance
         c = idx.counters()
         assert c["fallback_searches"] == 0 and c["candidates_total"] < 4 * k * 2
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_async_submit_wait_matches_sync(hip_lib, oracle_mod, metric):
+    """several independent single queries in flight (tsh_search_submit / tsh_search_wait)."""
+    from collections import deque
+
+    from tostore_amd import HipVectorIndex, _ffi
+
+    d, n, k = 256, 30000, 50
+    rows = _mk(n, d, 81, normalize=True)
+    qs = np.stack([_prep_query(oracle_mod, q, metric) for q in _mk(24, d, 82)])
+    keep = np.packbits(np.random.default_rng(83).random(n) < 0.5, bitorder="little")
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        depth = _ffi.lib().tsh_max_inflight()
+        assert depth >= 4
+        pend, got = deque(), []
+        for i, q in enumerate(qs):
+            if len(pend) == depth:
+                got.append(idx.wait(pend.popleft()))
+            pend.append(idx.submit(q, k, keep if i % 3 == 0 else None))
+        with pytest.raises(_ffi.TshError) as e:  # one more than the handle allows
+            while True:
+                pend.append(idx.submit(qs[0], k))
+        assert e.value.code == _ffi.TSH_E_BUSY
+        while pend:
+            got.append(idx.wait(pend.popleft()))
+        for i, q in enumerate(qs):
+            eids, edist = oracle_mod.search_exhaustive(rows, q, metric, k, None, keep if i % 3 == 0 else None)
+            assert np.array_equal(got[i][0], eids) and np.array_equal(got[i][1], edist), i
+        # ties flood the candidate list of an async query too (fallback inside wait)
+    rows2 = np.tile(rows[:1], (9000, 1))
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows2)
+        t = [idx.submit(qs[0], k), idx.submit(qs[1], k)]
+        for tk, q in zip(t, qs[:2]):
+            ids, dist = idx.wait(tk)
+            eids, edist = oracle_mod.search_exhaustive(rows2, q, metric, k)
+            assert np.array_equal(ids, eids) and np.array_equal(dist, edist)
+
+
+def test_concurrent_threads_share_one_handle(hip_lib, oracle_mod):
+    import threading
+
+    from tostore_amd import HipVectorIndex
+
+    d, n, k = 128, 40000, 20
+    rows = _mk(n, d, 91)
+    qs = _mk(32, d, 92)
+    errs = []
+    with HipVectorIndex(d, L2) as idx:
+        idx.append(0, rows)
+
+        def work(lo, hi):
+            try:
+                for i in range(lo, hi):
+                    ids, dist, cnt = idx.search(qs[i], k)
+                    eids, edist = oracle_mod.search_heap(rows, qs[i], L2, k)
+                    assert np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(i * 4, i * 4 + 4)) for i in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    assert not errs, errs

@@ -23,6 +23,7 @@ TSH_E_NO_DEVICE = -5
 TSH_E_OVERFLOW = -6
 TSH_E_IO = -7
 TSH_E_FORMAT = -8
+TSH_E_BUSY = -9
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 
@@ -60,6 +61,9 @@ SIGNATURES = {
     "tsh_index_dim": (c_i32, [p_void]),
     "tsh_index_metric": (c_i32, [p_void]),
     "tsh_search": (c_i32, [p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
+    "tsh_max_inflight": (c_i32, []),
+    "tsh_search_submit": (c_i32, [p_void, p_f32, c_i32, p_u8, p_i32]),
+    "tsh_search_wait": (c_i32, [p_void, c_i32, c_f64, p_i64, p_f64, p_i32]),
     "tsh_candidate_block_bytes": (c_i64, [c_i32]),
     "tsh_default_block_entries": (c_i32, [c_i32]),
     "tsh_search_shard": (c_i32, [p_void, p_f32, c_i32, c_i32, p_u8, c_i32, p_void, p_void]),

@@ -121,6 +121,30 @@ class HipVectorIndex:
                                          cnt.ctypes.data_as(_ffi.p_i32)))
         return ids[:, :kk], dist[:, :kk], cnt
 
+    # -- asynchronous single-query form (several queries in flight) -----------------
+    def submit(self, query, k: int, row_mask=None) -> tuple:
+        q = _f32c(query).reshape(-1)
+        if q.shape[0] != self.dim:
+            raise ValueError(f"query must have {self.dim} elements")
+        mp = None
+        if row_mask is not None:
+            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
+            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        t = ctypes.c_int32(-1)
+        _ffi.check(_ffi.lib().tsh_search_submit(self._h, q.ctypes.data_as(_ffi.p_f32), int(k), mp,
+                                                ctypes.byref(t)))
+        return (t.value, int(k))
+
+    def wait(self, ticket: tuple, distance_threshold: Optional[float] = None):
+        t, k = ticket
+        ids = np.empty(k, dtype=np.int64)
+        dist = np.empty(k, dtype=np.float64)
+        cnt = ctypes.c_int32(0)
+        thr = math.nan if distance_threshold is None else float(distance_threshold)
+        _ffi.check(_ffi.lib().tsh_search_wait(self._h, t, thr, ids.ctypes.data_as(_ffi.p_i64),
+                                              dist.ctypes.data_as(_ffi.p_f64), ctypes.byref(cnt)))
+        return ids[:cnt.value], dist[:cnt.value]
+
     def bench_scan(self, query, iters: int = 20, row_mask=None) -> float:
         q = _f32c(query)
         out = ctypes.c_double(0)

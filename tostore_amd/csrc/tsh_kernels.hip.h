@@ -110,7 +110,9 @@ __device__ __forceinline__ f32x4 ld16(const float *p) {
 
 struct ScanArgs {
   const float *rows;      // n x ld
-  const float *query;     // ld floats, zero padded past dim
+  const float *query;     // ld floats, zero padded past dim; NULL: the query rides in
+                          // the kernel-argument segment (ScanArgsQ::q), no H2D copy needed
+  float *query_out;       // nullable: workgroup 0 stores the query here for the rerank kernel
   const float *inv_norm;  // cosine: 1/|row| (0 for zero rows), else unused
   const uint64_t *live;   // masked variant: bit r of word t = row t*64+r present & not deleted
   const uint64_t *mask;   // masked variant, nullable: caller's keep mask, same layout
@@ -121,6 +123,15 @@ struct ScanArgs {
   int32_t d4;             // float4 per row (= ld/4)
   int32_t n_tiles;        // ceil(n/64)
 };
+
+// Kernel parameter block: the scan arguments plus up to 960 query floats inline,
+// 3936 bytes of the 4 KiB kernel-argument segment.
+constexpr int SCAN_Q_INLINE = 960;
+struct ScanArgsQ {
+  ScanArgs a;
+  float q[SCAN_Q_INLINE];
+};
+static_assert(sizeof(ScanArgsQ) <= 4096, "kernel arguments are limited to 4 KiB");
 
 // K1.  NCH >= ceil(d4/64) 16-byte chunks per lane per row.  FULL: d4 == NCH*64;
 // otherwise lanes past the row end re-read their chunk 0 (a cache hit) and the
@@ -138,8 +149,14 @@ struct ScanArgs {
   } while (0)
 
 template <int NCH, int METRIC, bool FULL, bool MASKED, int R, bool NT, int WAVES, int MINW>
-__global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgs a) {
+__global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   static_assert(R == 2 || R == 4, "R must give an even number of groups per 8-row batch");
+  const ScanArgs &a = aq.a;
+  const float *qsrc = a.query;
+  if (!qsrc) {
+    typedef const char __attribute__((address_space(4))) * karg_ptr;
+    qsrc = (const float *)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ScanArgsQ, q));
+  }
   constexpr int G = 8 / R;  // groups per batch
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -150,8 +167,14 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgs a) {
   f32x4 q[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    q[c] = *reinterpret_cast<const f32x4 *>(a.query + 4 * lane + (c < NCH - 1 ? c * 256 : tail_off));
+    q[c] = *reinterpret_cast<const f32x4 *>(qsrc + 4 * lane + (c < NCH - 1 ? c * 256 : tail_off));
     if (!FULL && c == NCH - 1 && !tail_ok) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (a.query_out && blockIdx.x == 0 && wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c < NCH - 1 || tail_ok)
+        *reinterpret_cast<f32x4 *>(a.query_out + 4 * lane + c * 256) = q[c];
   }
 
   for (int t = blockIdx.x * WAVES + wave; t < a.n_tiles; t += stride) {
@@ -283,7 +306,8 @@ constexpr uint32_t FLAG_LIST_OVERFLOW = 1u;
 struct SelectArgs {
   const uint32_t *gmin;
   const uint32_t *keys;
-  BlockHeader *hdr;
+  BlockHeader *hdr;       // device header (the rerank kernel reads its count)
+  BlockHeader *hdr_host;  // nullable: mirror in pinned host memory (zero-copy store)
   uint32_t *cand_rows;  // local row ids, capacity cand_cap
   int32_t n_tiles;
   int32_t k;
@@ -296,27 +320,43 @@ struct SelectArgs {
   int64_t shard_rows;
 };
 
-constexpr int SEL_THREADS = 1024;
-constexpr int SEL_LIST_CAP = 4096;  // LDS lists (keys of small tiles / tile ids)
+constexpr int SEL_THREADS = 1024;   // latency form: whole CU, tile minima in registers
+constexpr int SEL_THREADS_SMALL = 256;  // pipelined form: same CU footprint as one scan workgroup
+constexpr int SEL_VPT = 16;         // tile minima a thread keeps in registers (16384 tiles = 1M rows)
+constexpr int SEL_LIST_CAP = 4096;  // LDS lists (short list of tile minima / tile ids)
 
-// block-wide: smallest X with count(vals <= X) >= k, vals = VPT registers per
-// thread (pad with KEY_DEAD).  32 counting passes, no atomics on hot bins.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// ONE wave, no barriers: smallest X with count(v <= X) >= k over the wave's
+// VPT x 64 register values (pad with KEY_DEAD).  Bits above the highest bit in
+// which min and max differ are common to every value and are skipped.
 template <int VPT>
-__device__ uint32_t block_kth_bisect(const uint32_t (&v)[VPT], uint32_t k, uint32_t *s_cnt /*[2][16]*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t X = 0;
-  for (int bit = 31; bit >= 0; --bit) {
+__device__ uint32_t wave_kth_bisect(const uint32_t (&v)[VPT], uint32_t k) {
+  uint32_t lo = KEY_DEAD, hi = 0;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    lo = v[i] < lo ? v[i] : lo;
+    hi = v[i] > hi ? v[i] : hi;
+  }
+  lo = wave_min_u32(lo);
+  hi = wave_max_u32(hi);
+  uint32_t diff = lo ^ hi;
+  if (diff == 0) return lo;
+  int top = 31 - __builtin_clz(diff);  // highest differing bit
+  uint32_t X = top == 31 ? 0u : (lo >> (top + 1)) << (top + 1);
+  for (int bit = top; bit >= 0; --bit) {
     uint32_t T = X | ((1u << bit) - 1u);
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) c += __popcll(__ballot(v[i] <= T));
-    uint32_t *slot = s_cnt + (bit & 1) * 16;
-    if (lane == 0) slot[wave] = c;
-    __syncthreads();
-    uint32_t tot = 0;
-#pragma unroll
-    for (int w = 0; w < SEL_THREADS / 64; ++w) tot += slot[w];
-    if (tot < k) X |= (1u << bit);
+    for (int i = 0; i < VPT; ++i) c += (uint32_t)__popcll(__ballot(v[i] <= T));
+    if (c < k) X |= (1u << bit);
   }
   return X;
 }
@@ -339,103 +379,183 @@ __device__ __forceinline__ uint32_t band_of(uint32_t tau_key, float eps_rel, flo
   return f2key(f);
 }
 
-// K2
-__global__ void __launch_bounds__(SEL_THREADS) select_kernel(SelectArgs a) {
-  __shared__ uint32_t s_cnt[32];
+// K2.  One workgroup.  Each thread keeps its share of gmin[] in registers
+// (IN_REGS: n_tiles <= 16384) so global memory is read once.
+//  (a) per-thread minimum -> LDS; wave 0 bisects those 1024 values (or 256
+//      4-thread group minima when k <= 128) for U = their k-th smallest:
+//      k distinct threads hold a tile minimum <= U, so U >= k-th tile minimum
+//  (b) tile minima <= U -> short LDS list (about k(1 + k/2G) entries)
+//  (c) wave 0 bisects the short list: tau = exact k-th smallest tile minimum
+//  (d) band = tau widened by the f32 error model; tiles with minimum <= band
+//  (e) only those tiles' keys are re-read; keys <= band are the candidates
+template <int NT, bool IN_REGS>
+__global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
+  static_assert(NT == 1024 || NT == 256, "thread minima are bisected by one wave as 16 or 4 per lane");
+  constexpr int SEL_THREADS = NT;  // shadows the namespace constant inside this kernel
+  __shared__ uint32_t s_lm[SEL_THREADS];
   __shared__ uint32_t s_list[SEL_LIST_CAP];
-  __shared__ uint32_t s_n, s_tiles, s_cand, s_over;
+  __shared__ uint32_t s_n, s_tiles, s_cand, s_U, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.n_tiles;
+  const uint32_t k = (uint32_t)a.k;
   if (tid == 0) {
     s_n = 0;
     s_tiles = 0;
     s_cand = 0;
-    s_over = 0;
+    s_U = KEY_DEAD;
+    s_tau = KEY_NAN;
   }
-  __syncthreads();
-
-  uint32_t tau = KEY_NAN;  // default: every live row
-  const uint32_t k = (uint32_t)a.k;
-  if (!a.force_all && (uint32_t)M >= k && k <= SEL_THREADS) {
-    // (a) thread-local minima; the k-th smallest of them bounds the k-th
-    //     smallest tile minimum from above
-    uint32_t lm[1] = {KEY_DEAD};
-    for (int i = tid; i < M; i += SEL_THREADS) {
-      uint32_t g = a.gmin[i];
-      lm[0] = g < lm[0] ? g : lm[0];
-    }
-    uint32_t U = (M > SEL_LIST_CAP) ? block_kth_bisect<1>(lm, k, s_cnt) : KEY_DEAD;
-    __syncthreads();
-    // (b) tile minima <= U into LDS
-    for (int i = tid; i < M; i += SEL_THREADS) {
-      uint32_t g = a.gmin[i];
-      if (g <= U) {
-        uint32_t p = atomicAdd(&s_n, 1u);
-        if (p < SEL_LIST_CAP) s_list[p] = g;
-      }
-    }
-    __syncthreads();
-    uint32_t n = s_n;
-    if (n <= SEL_LIST_CAP) {
-      // (c) exact k-th smallest of the short list
-      uint32_t v[SEL_LIST_CAP / SEL_THREADS];
+  uint32_t g[SEL_VPT];
+  uint32_t lmin = KEY_DEAD;
+  if (IN_REGS) {
 #pragma unroll
-      for (int i = 0; i < SEL_LIST_CAP / SEL_THREADS; ++i) {
-        uint32_t p = tid + i * SEL_THREADS;
-        v[i] = p < n ? s_list[p] : KEY_DEAD;
-      }
-      tau = block_kth_bisect<SEL_LIST_CAP / SEL_THREADS>(v, k, s_cnt);
-      if (tau == KEY_DEAD) tau = KEY_NAN;  // fewer than k live tiles
+    for (int i = 0; i < SEL_VPT; ++i) {
+      int t = tid + i * SEL_THREADS;
+      g[i] = t < M ? a.gmin[t] : KEY_DEAD;
+      lmin = g[i] < lmin ? g[i] : lmin;
+    }
+  } else {
+    for (int t = tid; t < M; t += SEL_THREADS) {
+      uint32_t x = a.gmin[t];
+      lmin = x < lmin ? x : lmin;
+    }
+  }
+  const bool narrow = !a.force_all && (uint32_t)M >= k && k <= (uint32_t)SEL_THREADS;
+  const bool groups4 = NT == 1024 && k <= 128;  // 256 group minima are plenty for small k
+  if (narrow && M > SEL_LIST_CAP) {
+    uint32_t m = lmin;
+    if (groups4) {
+      uint32_t t1 = (uint32_t)__shfl_xor((int)m, 1);
+      m = t1 < m ? t1 : m;
+      uint32_t t2 = (uint32_t)__shfl_xor((int)m, 2);
+      m = t2 < m ? t2 : m;
+    }
+    s_lm[tid] = m;
+  }
+  __syncthreads();
+  if (narrow && M > SEL_LIST_CAP && wave == 0) {
+    uint32_t U;
+    if (groups4) {
+      uint32_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = s_lm[(lane + i * 64) * 4];
+      U = wave_kth_bisect<4>(v, k);
     } else {
-      tau = U;  // still a valid upper bound, just looser
-      if (tau == KEY_DEAD) tau = KEY_NAN;
+      uint32_t v[NT / 64];
+#pragma unroll
+      for (int i = 0; i < NT / 64; ++i) v[i] = s_lm[lane + i * 64];
+      U = wave_kth_bisect<NT / 64>(v, k);
+    }
+    if (lane == 0) s_U = U;
+  }
+  __syncthreads();
+  if (narrow) {
+    const uint32_t U = s_U;  // KEY_DEAD when the list holds everything (M <= cap)
+    if (IN_REGS) {
+#pragma unroll
+      for (int i = 0; i < SEL_VPT; ++i) {
+        if (tid + i * SEL_THREADS < M && g[i] <= U) {
+          uint32_t p = atomicAdd(&s_n, 1u);
+          if (p < SEL_LIST_CAP) s_list[p] = g[i];
+        }
+      }
+    } else {
+      for (int t = tid; t < M; t += SEL_THREADS) {
+        uint32_t x = a.gmin[t];
+        if (x <= U) {
+          uint32_t p = atomicAdd(&s_n, 1u);
+          if (p < SEL_LIST_CAP) s_list[p] = x;
+        }
+      }
     }
   }
   __syncthreads();
+  if (narrow && wave == 0) {
+    const uint32_t n = s_n;
+    uint32_t tau;
+    if (n > SEL_LIST_CAP) {
+      tau = s_U;  // ties flooded the list: U is still a valid (looser) bound
+    } else if (n <= 512) {
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (uint32_t)(lane + i * 64) < n ? s_list[lane + i * 64] : KEY_DEAD;
+      tau = wave_kth_bisect<8>(v, k);
+    } else {
+      uint32_t v[SEL_LIST_CAP / 64];
+#pragma unroll
+      for (int i = 0; i < SEL_LIST_CAP / 64; ++i)
+        v[i] = (uint32_t)(lane + i * 64) < n ? s_list[lane + i * 64] : KEY_DEAD;
+      tau = wave_kth_bisect<SEL_LIST_CAP / 64>(v, k);
+    }
+    if (tau == KEY_DEAD) tau = KEY_NAN;  // fewer than k live tiles: every live row
+    if (lane == 0) s_tau = tau;
+  }
+  __syncthreads();
+  const uint32_t tau = s_tau;
   const uint32_t band = a.force_all ? KEY_NAN : band_of(tau, a.eps_rel, a.delta_abs);
 
-  // (d) tiles whose minimum is inside the band
-  for (int i = tid; i < M; i += SEL_THREADS) {
-    uint32_t g = a.gmin[i];
-    if (g <= band) {  // KEY_DEAD > band always
-      uint32_t p = atomicAdd(&s_tiles, 1u);
-      if (p < SEL_LIST_CAP) s_list[p] = (uint32_t)i;
+  // (d) tiles whose minimum is inside the band (KEY_DEAD > band always)
+  if (IN_REGS) {
+#pragma unroll
+    for (int i = 0; i < SEL_VPT; ++i) {
+      if (g[i] <= band) {
+        uint32_t p = atomicAdd(&s_tiles, 1u);
+        if (p < SEL_LIST_CAP) s_list[p] = (uint32_t)(tid + i * SEL_THREADS);
+      }
+    }
+  } else {
+    for (int t = tid; t < M; t += SEL_THREADS) {
+      if (a.gmin[t] <= band) {
+        uint32_t p = atomicAdd(&s_tiles, 1u);
+        if (p < SEL_LIST_CAP) s_list[p] = (uint32_t)t;
+      }
     }
   }
   __syncthreads();
-  uint32_t nt = s_tiles;
-  bool over = nt > SEL_LIST_CAP;
+  const uint32_t nt = s_tiles;
+  const bool over = nt > SEL_LIST_CAP;
   if (!over) {
-    // (e) re-read only those tiles' keys; rows inside the band are candidates
-    for (uint32_t j = wave; j < nt; j += SEL_THREADS / 64) {
-      uint32_t tile = s_list[j];
-      uint32_t key = a.keys[(int64_t)tile * 64 + lane];
-      bool pass = key <= band;
-      uint64_t bm = __ballot(pass);
-      if (bm) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_cand, (uint32_t)__popcll(bm));
-        base = __shfl((int)base, 0);
-        if (pass) {
-          uint32_t p = base + __popcll(bm & ((1ull << lane) - 1ull));
-          if (p < (uint32_t)a.cand_cap) a.cand_rows[p] = tile * 64 + lane;
+    // (e) four tiles per wave per round so their (L2-resident) key loads overlap
+    constexpr int NW = SEL_THREADS / 64;
+    for (uint32_t j0 = wave * 4; j0 < nt; j0 += NW * 4) {
+      uint32_t tile[4], key[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        tile[u] = j0 + u < nt ? s_list[j0 + u] : 0xFFFFFFFFu;
+        key[u] = tile[u] != 0xFFFFFFFFu ? a.keys[(int64_t)tile[u] * 64 + lane] : KEY_DEAD;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool pass = key[u] <= band;
+        uint64_t bm = __ballot(pass);
+        if (bm) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&s_cand, (uint32_t)__popcll(bm));
+          base = (uint32_t)__shfl((int)base, 0);
+          if (pass) {
+            uint32_t p = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+            if (p < (uint32_t)a.cand_cap) a.cand_rows[p] = tile[u] * 64 + lane;
+          }
         }
       }
     }
   }
   __syncthreads();
   if (tid == 0) {
-    BlockHeader *h = a.hdr;
-    h->count = over ? 0u : s_cand;
-    h->tau_key = tau;
-    h->band_key = band;
-    h->tiles_hit = nt;
-    h->flags = (over || s_cand > (uint32_t)a.cand_cap) ? FLAG_LIST_OVERFLOW : 0u;
-    h->entries = (uint32_t)a.cand_cap;
-    h->k = (uint32_t)a.k;
-    h->metric = (uint32_t)a.metric;
-    h->row_base = a.row_base;
-    h->shard_rows = a.shard_rows;
+    BlockHeader hv;
+    hv.count = over ? 0u : s_cand;
+    hv.entries = (uint32_t)a.cand_cap;
+    hv.tau_key = tau;
+    hv.band_key = band;
+    hv.tiles_hit = nt;
+    hv.flags = (over || s_cand > (uint32_t)a.cand_cap) ? FLAG_LIST_OVERFLOW : 0u;
+    hv.k = (uint32_t)a.k;
+    hv.metric = (uint32_t)a.metric;
+    hv.row_base = a.row_base;
+    hv.shard_rows = a.shard_rows;
+    hv.pad[0] = hv.pad[1] = hv.pad[2] = hv.pad[3] = 0u;
+    *a.hdr = hv;
+    if (a.hdr_host) *a.hdr_host = hv;
   }
 }
 
@@ -481,15 +601,16 @@ constexpr int RR_CHUNK = 1024;
 
 __global__ void __launch_bounds__(64) rerank_kernel(RerankArgs a) {
 #pragma clang fp contract(off)
-  __shared__ double t0[RR_CHUNK];
-  __shared__ double t1[RR_CHUNK];
+  __shared__ __attribute__((aligned(16))) double t0[RR_CHUNK];
+  __shared__ __attribute__((aligned(16))) double t1[RR_CHUNK];
   const int lane = threadIdx.x;
   uint32_t count = *a.count_ptr;
   if (count > (uint32_t)a.cap) count = (uint32_t)a.cap;
+  const int chains = a.metric == METRIC_COS ? 2 : 1;  // lane 0: s0, lane 1: row norm
   for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
     uint32_t row = a.cand_rows[c];
     const float *rp = a.rows + (int64_t)row * a.ld;
-    double s0 = 0.0, s1 = 0.0;
+    double s = 0.0;
     for (int base = 0; base < a.dim; base += RR_CHUNK) {
       int m = a.dim - base < RR_CHUNK ? a.dim - base : RR_CHUNK;
       for (int i = lane; i < m; i += 64) {
@@ -503,18 +624,27 @@ __global__ void __launch_bounds__(64) rerank_kernel(RerankArgs a) {
         }
       }
       __syncthreads();
-      if (lane == 0) {
-        for (int i = 0; i < m; ++i) s0 = s0 + t0[i];
-      } else if (lane == 1 && a.metric == METRIC_COS) {
-        for (int i = 0; i < m; ++i) s1 = s1 + t1[i];
+      if (lane < chains) {
+        // strictly sequential adds; LDS reads are issued 32 elements ahead so
+        // only the add chain's own latency remains
+        const double *src = lane == 0 ? t0 : t1;
+        int i = 0;
+        for (; i + 32 <= m; i += 32) {
+          double x[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) x[u] = src[i + u];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) s = s + x[u];
+        }
+        for (; i < m; ++i) s = s + src[i];
       }
       __syncthreads();
     }
-    s1 = __shfl(s1, 1);
+    double s1 = __shfl(s, 1);
     if (lane == 0) {
       a.out[c].id = a.row_base + (int64_t)row;
-      a.out[c].s0 = s0;
-      a.out[c].s1 = s1;
+      a.out[c].s0 = s;
+      a.out[c].s1 = a.metric == METRIC_COS ? s1 : 0.0;
     }
   }
 }
@@ -535,17 +665,25 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
   const int lane = threadIdx.x & 63;
   int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // per-wave running statistics, published once at the end (one atomic per
+  // wave, not per row)
+  uint32_t w_norm = 0, w_abs = 0, w_bad = 0, w_tiny = 0;
   for (int64_t r = w; r < n; r += nw) {
     const float *rp = rows + (first + r) * ld;
     double s = 0.0;
     float mx = 0.f;
     bool bad = false;
-    for (int i = lane; i < dim; i += 64) {
-      float v = rp[i];
-      float av = fabsf(v);
-      if (!(av <= 3.0e38f)) bad = true;  // inf / nan
-      else mx = av > mx ? av : mx;
-      s += (double)v * (double)v;
+    // 16-byte loads over the padded row (pad elements are zero)
+    for (int c = lane; c < (int)(ld / 4); c += 64) {
+      f32x4 v4 = *reinterpret_cast<const f32x4 *>(rp + 4 * c);
+      float e[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float av = fabsf(e[u]);
+        if (!(av <= 3.0e38f)) bad = true;  // inf / nan
+        else mx = av > mx ? av : mx;
+        s += (double)e[u] * (double)e[u];
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -565,11 +703,17 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
       if (inv_norm) inv_norm[first + r] = inv;
       float nf = (float)nrm;
       if ((double)nf < nrm) nf = __uint_as_float(__float_as_uint(nf) + 1u);
-      if (!bad) atomicMax(&st->max_norm_bits, __float_as_uint(nf));
-      atomicMax(&st->max_abs_bits, __float_as_uint(mx));
-      if (bad) atomicAdd(&st->nonfinite_rows, 1u);
-      if (tiny) atomicAdd(&st->tiny_rows, 1u);
+      if (!bad && __float_as_uint(nf) > w_norm) w_norm = __float_as_uint(nf);
+      if (__float_as_uint(mx) > w_abs) w_abs = __float_as_uint(mx);
+      w_bad += bad ? 1u : 0u;
+      w_tiny += tiny ? 1u : 0u;
     }
+  }
+  if (lane == 0) {
+    if (w_norm) atomicMax(&st->max_norm_bits, w_norm);
+    if (w_abs) atomicMax(&st->max_abs_bits, w_abs);
+    if (w_bad) atomicAdd(&st->nonfinite_rows, w_bad);
+    if (w_tiny) atomicAdd(&st->tiny_rows, w_tiny);
   }
 }
 

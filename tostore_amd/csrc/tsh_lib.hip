@@ -58,8 +58,8 @@ int device_count_cached() {
   return n;
 }
 
-constexpr int QCHUNK = 32;            // queries enqueued per host sync
-constexpr int MAX_CTX = 4;            // concurrent searches per shard
+constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
+constexpr int PIPE_DEPTH = 4;         // queries a multi-query call keeps in flight
 constexpr int MAX_DIM_SCAN = 2048;    // register-resident query (NCH <= 8)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
 
@@ -159,13 +159,13 @@ template <int NCH, bool MASKED> struct ScanTune {
   static constexpr int MINW = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH == 6 ? 3 : 2)));
 };
 template <int NCH, int METRIC, bool FULL, bool MASKED>
-void launch_scan_t(const ScanArgs &a, int grid, hipStream_t s) {
+void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s) {
   using T = ScanTune<NCH, MASKED>;
   scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<grid, 256, 0, s>>>(a);
 }
 template <int NCH, int METRIC>
-void launch_scan_m(const ScanArgs &a, bool masked, int grid, hipStream_t s) {
-  bool full = a.d4 == NCH * 64;
+void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s) {
+  bool full = a.a.d4 == NCH * 64;
   if (full) {
     if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s);
     else launch_scan_t<NCH, METRIC, true, false>(a, grid, s);
@@ -175,13 +175,13 @@ void launch_scan_m(const ScanArgs &a, bool masked, int grid, hipStream_t s) {
   }
 }
 template <int NCH>
-void launch_scan_n(const ScanArgs &a, int metric, bool masked, int grid, hipStream_t s) {
+void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s) {
   if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s);
   else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s);
   else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s);
 }
-void launch_scan(const ScanArgs &a, int nch, int metric, bool masked, hipStream_t s) {
-  int grid = (a.n_tiles + 3) / 4;
+void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s) {
+  int grid = (a.a.n_tiles + 3) / 4;
   if (grid < 1) grid = 1;
   switch (nch) {
     case 1: launch_scan_n<1>(a, metric, masked, grid, s); break;
@@ -193,23 +193,59 @@ void launch_scan(const ScanArgs &a, int nch, int metric, bool masked, hipStream_
   }
 }
 
-// ---- per-search scratch ------------------------------------------------------
+// Reader/writer lock that may be released by a different thread than the one
+// that took it (an asynchronous search is submitted and waited independently).
+class RwLock {
+ public:
+  void lock_shared() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !writer_ && writers_waiting_ == 0; });
+    ++readers_;
+  }
+  void unlock_shared() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (--readers_ == 0) cv_.notify_all();
+  }
+  void lock() {
+    std::unique_lock<std::mutex> lk(m_);
+    ++writers_waiting_;
+    cv_.wait(lk, [&] { return !writer_ && readers_ == 0; });
+    --writers_waiting_;
+    writer_ = true;
+  }
+  void unlock() {
+    std::lock_guard<std::mutex> lk(m_);
+    writer_ = false;
+    cv_.notify_all();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int readers_ = 0, writers_waiting_ = 0;
+  bool writer_ = false;
+};
+
+// ---- per-search scratch: one context = one query in flight ---------------------
 struct Ctx {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // input upload, result copy, fallback path
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float *d_query = nullptr;  // QCHUNK x ld
-  float *h_query = nullptr;  // pinned
+  hipEvent_t ev_done = nullptr;  // recorded on the pipeline stream after a job's last kernel
+  uint8_t *h_block_dev = nullptr;  // device-side address of h_block (zero-copy result stores)
+  float *d_query = nullptr;  // ld floats
+  float *h_query = nullptr;  // pinned, ld floats
   uint64_t *d_mask = nullptr;
-  uint64_t *h_mask = nullptr;
+  uint64_t *h_mask = nullptr;  // pinned
   int64_t mask_words = 0;
+  uint64_t mask_epoch = 0;  // which caller mask the device copy holds
   uint32_t *d_keys = nullptr;
   uint32_t *d_gmin = nullptr;
   int64_t tiles_cap = 0;
-  uint8_t *d_blocks = nullptr;  // QCHUNK blocks of block_bytes
-  uint8_t *h_blocks = nullptr;  // pinned
-  uint32_t *d_cand = nullptr;   // QCHUNK x entries
+  uint8_t *d_block = nullptr;  // header + entries
+  uint8_t *h_block = nullptr;  // pinned
+  uint32_t *d_cand = nullptr;  // entries
   int64_t entries_cap = 0;
-  // fallback
+  // wide-band fallback
   uint32_t *d_big_rows = nullptr;
   BlockEntry *d_big_entries = nullptr;
   uint32_t *d_big_count = nullptr;
@@ -229,18 +265,25 @@ struct Shard {
   uint64_t *d_live = nullptr;
   IngestStats *d_stats = nullptr;
   uint32_t *d_tmp_u32 = nullptr;
-  int64_t live_rows = 0;   // present and not deleted
   int64_t deleted = 0;
-  bool all_live = true;    // every row in [0,rows) is present and not deleted
+  bool all_live = true;  // every row in [0,rows) is present and not deleted
   float max_norm = 0.f, max_abs = 0.f;
   uint32_t nonfinite_rows = 0, tiny_rows = 0;
   hipStream_t ingest_stream = nullptr;
+  // every query's scan -> select -> rerank runs on this one in-order stream,
+  // back to back; only the small input / result copies use the context streams.
+  // (Running a query's tail beside the next query's scan was measured 10-25x
+  // slower per tail: each dependent load queues behind the scan's loads.)
+  hipStream_t scan_stream = nullptr;
+  std::mutex scan_mu;
+  std::atomic<int> inflight{0};
 
-  std::shared_mutex mu;  // search: shared; append/delete: exclusive
+  RwLock mu;  // search: shared; append/delete: exclusive
   std::mutex ctx_mu;
   std::condition_variable ctx_cv;
   std::vector<std::unique_ptr<Ctx>> ctx_all;
   std::vector<Ctx *> ctx_free;
+  std::atomic<uint64_t> mask_epoch_src{1};
 
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   int64_t bytes = 0;
@@ -256,6 +299,7 @@ struct Shard {
 int shard_init(Shard *s) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamCreateWithFlags(&s->ingest_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&s->scan_stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
   HIPCHK(hipMalloc(&s->d_tmp_u32, 64));
@@ -317,10 +361,8 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
     HIPCHK(hipMemcpy2DAsync(dst, (size_t)s->ld * sizeof(float), src, (size_t)s->dim * sizeof(float),
                             (size_t)s->dim * sizeof(float), (size_t)n, kind, st));
   }
-  int blocks = (int)std::min<int64_t>((n + 3) / 4, 8192);
+  int blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);
   ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_stats);
-  // overwritten rows become live again; count them via the old bitmap is not
-  // needed: live_rows is recomputed from deleted/gaps bookkeeping below
   int lb = (int)std::min<int64_t>(((first + n - 1) / 64 - first / 64 + 1 + 255) / 256, 1024);
   live_range_kernel<<<lb, 256, 0, st>>>(s->d_live, first, n, 1);
   IngestStats hs;
@@ -341,14 +383,15 @@ void ctx_free_all(Ctx *c) {
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->ev_done) hipEventDestroy(c->ev_done);
   hipFree(c->d_query);
   hipHostFree(c->h_query);
   hipFree(c->d_mask);
   hipHostFree(c->h_mask);
   hipFree(c->d_keys);
   hipFree(c->d_gmin);
-  hipFree(c->d_blocks);
-  hipHostFree(c->h_blocks);
+  hipFree(c->d_block);
+  hipHostFree(c->h_block);
   hipFree(c->d_cand);
   hipFree(c->d_big_rows);
   hipFree(c->d_big_entries);
@@ -358,13 +401,16 @@ void ctx_free_all(Ctx *c) {
 int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
   HIPCHK(hipSetDevice(s->device));
   if (!c->stream) {
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
-    HIPCHK(hipMalloc(&c->d_query, (size_t)QCHUNK * s->ld * sizeof(float)));
-    HIPCHK(hipHostMalloc(&c->h_query, (size_t)QCHUNK * s->ld * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIPCHK(hipMalloc(&c->d_query, (size_t)s->ld * sizeof(float)));
+    HIPCHK(hipHostMalloc(&c->h_query, (size_t)s->ld * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipMalloc(&c->d_big_count, 64));
-    c->bytes += (int64_t)QCHUNK * s->ld * 4;
+    c->bytes += s->ld * 4;
   }
   int64_t tiles = s->cap / 64;
   if (tiles > c->tiles_cap) {
@@ -386,25 +432,27 @@ int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
     HIPCHK(hipHostMalloc(&c->h_mask, (size_t)tiles * 8, hipHostMallocDefault));
     c->bytes += (tiles - c->mask_words) * 8;
     c->mask_words = tiles;
+    c->mask_epoch = 0;
   }
   if (entries > c->entries_cap) {
-    hipFree(c->d_blocks);
-    hipHostFree(c->h_blocks);
+    hipFree(c->d_block);
+    hipHostFree(c->h_block);
     hipFree(c->d_cand);
-    c->d_blocks = nullptr;
-    c->h_blocks = nullptr;
+    c->d_block = nullptr;
+    c->h_block = nullptr;
     c->d_cand = nullptr;
     size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-    HIPCHK(hipMalloc(&c->d_blocks, bb * QCHUNK));
-    HIPCHK(hipHostMalloc(&c->h_blocks, bb * QCHUNK, hipHostMallocDefault));
-    HIPCHK(hipMalloc(&c->d_cand, (size_t)entries * QCHUNK * sizeof(uint32_t)));
-    c->bytes += (int64_t)(bb + 4 * (size_t)entries) * QCHUNK;
+    HIPCHK(hipMalloc(&c->d_block, bb));
+    HIPCHK(hipHostMalloc(&c->h_block, bb, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_block_dev), c->h_block, 0));
+    HIPCHK(hipMalloc(&c->d_cand, (size_t)entries * sizeof(uint32_t)));
+    c->bytes += (int64_t)(bb + 4 * (size_t)entries);
     c->entries_cap = entries;
   }
   return TSH_OK;
 }
 
-Ctx *ctx_acquire(Shard *s) {
+Ctx *ctx_acquire(Shard *s, bool block) {
   std::unique_lock<std::mutex> lk(s->ctx_mu);
   for (;;) {
     if (!s->ctx_free.empty()) {
@@ -416,6 +464,7 @@ Ctx *ctx_acquire(Shard *s) {
       s->ctx_all.emplace_back(new Ctx());
       return s->ctx_all.back().get();
     }
+    if (!block) return nullptr;
     s->ctx_cv.wait(lk);
   }
 }
@@ -426,12 +475,6 @@ void ctx_release(Shard *s, Ctx *c) {
   }
   s->ctx_cv.notify_one();
 }
-struct CtxLease {
-  Shard *s;
-  Ctx *c;
-  CtxLease(Shard *s_) : s(s_), c(ctx_acquire(s_)) {}
-  ~CtxLease() { ctx_release(s, c); }
-};
 
 // error band of the f32 ranking key (DESIGN.md "error model")
 struct Band {
@@ -445,14 +488,12 @@ Band compute_band(const Shard *s, const float *q) {
     return b;
   }
   double qn2 = 0;
-  float qmax = 0.f;
   for (int i = 0; i < s->dim; ++i) {
     float a = std::fabs(q[i]);
     if (!(a <= BIG_ABS)) {
       b.force_all = 1;  // inf / nan / huge query element
       return b;
     }
-    qmax = std::max(qmax, a);
     qn2 += (double)q[i] * (double)q[i];
   }
   double qn = std::sqrt(qn2) * (1.0 + 1e-6);
@@ -474,10 +515,11 @@ Band compute_band(const Shard *s, const float *q) {
   return b;
 }
 
-void fill_scan_args(const Shard *s, const Ctx *c, const float *d_query, bool masked, bool user_mask,
-                    ScanArgs *a) {
+void fill_scan_args(const Shard *s, const Ctx *c, bool masked, bool user_mask, ScanArgsQ *aq) {
+  ScanArgs *a = &aq->a;
   a->rows = s->d_rows;
-  a->query = d_query;
+  a->query = c->d_query;
+  a->query_out = nullptr;
   a->inv_norm = s->d_inv_norm;
   a->live = s->d_live;
   a->mask = (masked && user_mask) ? c->d_mask : nullptr;
@@ -489,7 +531,7 @@ void fill_scan_args(const Shard *s, const Ctx *c, const float *d_query, bool mas
   a->n_tiles = (int32_t)((s->rows + 63) / 64);
 }
 
-// slice the caller's GLOBAL keep mask into this shard's tile words (pinned)
+// slice the caller's GLOBAL keep mask into this shard's tile words
 void slice_mask(const Shard *s, const uint8_t *mask, uint64_t *out_words, int64_t n_words) {
   int64_t rows = s->rows;
   memset(out_words, 0, (size_t)n_words * 8);
@@ -509,20 +551,101 @@ void slice_mask(const Shard *s, const uint8_t *mask, uint64_t *out_words, int64_
   }
 }
 
-struct SearchOut {
-  // host mode: blocks copied to host; spill[q] holds the full list when a
-  // query's candidates exceeded `entries`
-  uint8_t *h_blocks = nullptr;  // nq blocks (caller memory)
-  std::vector<std::vector<BlockEntry>> *spill = nullptr;
-  // device mode
-  uint8_t *d_blocks = nullptr;
-  hipStream_t user_stream = nullptr;
+// One query in flight on one context.  Its three kernels (scan, select,
+// rerank) are enqueued back to back on the shard's single in-order pipeline
+// stream with NO copy and NO cross-stream dependency between them: the query
+// rides in the scan kernel's argument segment, the result block is stored
+// straight into pinned host memory, completion is one event.
+struct Job {
+  Ctx *c = nullptr;
+  int32_t k = 0, entries = 0;
+  bool masked = false, user_mask = false;
+  bool device_result = false;  // entries go to c->d_block (shard mode) instead of pinned host
+  bool counted = false;        // contributes to Shard::inflight
 };
 
-// Fallback for one query whose K2 list overflowed: whole-grid filter + rerank.
-// keys/gmin of THIS query must be in ctx scratch (caller re-runs K1).
-int run_fallback(Shard *s, Ctx *c, const float *d_query, uint32_t band_key, int32_t entries,
-                 uint8_t *d_block, std::vector<BlockEntry> *spill) {
+void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
+  if (n_tiles <= SEL_VPT * SEL_THREADS) select_kernel<SEL_THREADS, true><<<1, SEL_THREADS, 0, st>>>(se);
+  else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
+}
+
+// mask_words: this shard's slice of the caller mask (host), or NULL; epoch
+// identifies it so a context uploads it once per call
+int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
+                const uint64_t *mask_words, uint64_t epoch, bool device_result) {
+  Ctx *c = j->c;
+  int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
+  if (rc) return rc;
+  const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+  j->k = k;
+  j->entries = entries;
+  j->user_mask = mask_words != nullptr;
+  j->masked = j->user_mask || !s->all_live;
+  j->device_result = device_result;
+  const bool upload_mask = mask_words && c->mask_epoch != epoch;
+  if (upload_mask) {
+    memcpy(c->h_mask, mask_words, (size_t)n_tiles * 8);
+    c->mask_epoch = epoch;
+  }
+  static thread_local ScanArgsQ sa;  // 4 KiB: keep it off the stack of deep callers
+  fill_scan_args(s, c, j->masked, j->user_mask, &sa);
+  const bool inline_q = s->ld <= SCAN_Q_INLINE;
+  float *qdst = inline_q ? sa.q : c->h_query;
+  memcpy(qdst, query, (size_t)s->dim * sizeof(float));
+  for (int64_t i = s->dim; i < s->ld; ++i) qdst[i] = 0.f;
+  Band band = compute_band(s, qdst);
+  if (inline_q) {
+    sa.a.query = nullptr;        // read q[] from the kernel-argument segment ...
+    sa.a.query_out = c->d_query;  // ... and leave a device copy for the rerank kernel
+  }
+  SelectArgs se{};
+  se.gmin = c->d_gmin;
+  se.keys = c->d_keys;
+  se.hdr = reinterpret_cast<BlockHeader *>(c->d_block);
+  se.hdr_host = reinterpret_cast<BlockHeader *>(c->h_block_dev);
+  se.cand_rows = c->d_cand;
+  se.n_tiles = n_tiles;
+  se.k = k;
+  se.cand_cap = entries;
+  se.eps_rel = band.eps_rel;
+  se.delta_abs = band.delta_abs;
+  se.force_all = band.force_all;
+  se.metric = s->metric;
+  se.row_base = s->row_base;
+  se.shard_rows = s->rows;
+  RerankArgs ra{};
+  ra.rows = s->d_rows;
+  ra.query = c->d_query;
+  ra.cand_rows = c->d_cand;
+  ra.count_ptr = &se.hdr->count;
+  ra.out = reinterpret_cast<BlockEntry *>((device_result ? c->d_block : c->h_block_dev) + sizeof(BlockHeader));
+  ra.ld = s->ld;
+  ra.row_base = s->row_base;
+  ra.dim = s->dim;
+  ra.cap = entries;
+  ra.metric = s->metric;
+  s->inflight.fetch_add(1);
+  j->counted = true;
+  {
+    std::lock_guard<std::mutex> lk(s->scan_mu);
+    hipStream_t ps = s->scan_stream;
+    if (upload_mask)
+      HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
+    if (!inline_q)
+      HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
+    launch_scan(sa, s->nch, s->metric, j->masked, ps);
+    launch_select(se, n_tiles, ps);
+    rerank_kernel<<<std::min(entries, 1024), 64, 0, ps>>>(ra);
+    HIPCHK(hipEventRecord(c->ev_done, ps));
+  }
+  s->c_scans++;
+  return TSH_OK;
+}
+
+// Wide-band path for a query whose K2 list overflowed (ties / degenerate data):
+// whole-grid filter of this context's keys[] + f64 rerank of everything in the band.
+int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *spill) {
+  Ctx *c = j->c;
   hipStream_t st = c->stream;
   int64_t n_keys = ((s->rows + 63) / 64) * 64;
   if (s->cap > c->big_cap) {
@@ -542,9 +665,9 @@ int run_fallback(Shard *s, Ctx *c, const float *d_query, uint32_t band_key, int3
   uint32_t count = 0;
   HIPCHK(hipMemcpyAsync(&count, c->d_big_count, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  RerankArgs ra;
+  RerankArgs ra{};
   ra.rows = s->d_rows;
-  ra.query = d_query;
+  ra.query = c->d_query;
   ra.cand_rows = c->d_big_rows;
   ra.count_ptr = c->d_big_count;
   ra.out = c->d_big_entries;
@@ -557,18 +680,20 @@ int run_fallback(Shard *s, Ctx *c, const float *d_query, uint32_t band_key, int3
     int rgrid = (int)std::min<uint32_t>(count, 16384u);
     rerank_kernel<<<rgrid, 64, 0, st>>>(ra);
   }
-  // patch the block: header count/flags, and as many entries as fit
-  BlockHeader patch;
-  HIPCHK(hipMemcpyAsync(&patch, d_block, sizeof patch, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  patch.count = count;
-  patch.flags = count > (uint32_t)entries ? FLAG_LIST_OVERFLOW : 0u;
-  HIPCHK(hipMemcpyAsync(d_block, &patch, sizeof patch, hipMemcpyHostToDevice, st));
-  uint32_t fit = std::min<uint32_t>(count, (uint32_t)entries);
-  if (fit)
-    HIPCHK(hipMemcpyAsync(d_block + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
-                          hipMemcpyDeviceToDevice, st));
-  if (spill && count > (uint32_t)entries) {
+  BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_block);
+  h->count = count;
+  h->flags = count > (uint32_t)j->entries ? FLAG_LIST_OVERFLOW : 0u;
+  HIPCHK(hipMemcpyAsync(c->d_block, h, sizeof *h, hipMemcpyHostToDevice, st));
+  uint32_t fit = std::min<uint32_t>(count, (uint32_t)j->entries);
+  if (fit) {
+    if (j->device_result)
+      HIPCHK(hipMemcpyAsync(c->d_block + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
+                            hipMemcpyDeviceToDevice, st));
+    else
+      HIPCHK(hipMemcpyAsync(c->h_block + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
+                            hipMemcpyDeviceToHost, st));
+  }
+  if (spill && count > (uint32_t)j->entries) {
     spill->resize(count);
     HIPCHK(hipMemcpyAsync(spill->data(), c->d_big_entries, (size_t)count * sizeof(BlockEntry),
                           hipMemcpyDeviceToHost, st));
@@ -580,110 +705,119 @@ int run_fallback(Shard *s, Ctx *c, const float *d_query, uint32_t band_key, int3
   return TSH_OK;
 }
 
-// The single-query pipeline K1 -> K2 -> K4 for nq queries, one after another
-// on one stream.  Caller holds s->mu shared.
-int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const uint8_t *mask,
-                        int32_t entries, SearchOut *out) {
-  size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  CtxLease lease(s);
-  Ctx *c = lease.c;
-  bool masked = mask != nullptr || !s->all_live;
-  int rc = ctx_prepare(s, c, entries, mask != nullptr);
-  if (rc) return rc;
-  hipStream_t st = c->stream;
-  int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
-  if (mask) {
-    slice_mask(s, mask, c->h_mask, n_tiles);
-    HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+// Waits for a job; afterwards c->h_block / c->d_block hold the final block
+// (and *spill every candidate when they did not fit).
+int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill) {
+  Ctx *c = j->c;
+  if (j->counted) {
+    s->inflight.fetch_sub(1);
+    j->counted = false;
   }
-  for (int32_t q0 = 0; q0 < nq; q0 += QCHUNK) {
-    int32_t nc = std::min(QCHUNK, nq - q0);
-    Band bands[QCHUNK];
-    for (int32_t i = 0; i < nc; ++i) {
-      float *hq = c->h_query + (size_t)i * s->ld;
-      memcpy(hq, queries + (size_t)(q0 + i) * s->dim, (size_t)s->dim * sizeof(float));
-      for (int64_t j = s->dim; j < s->ld; ++j) hq[j] = 0.f;
-      bands[i] = compute_band(s, hq);
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipEventSynchronize(c->ev_done));
+  HIPCHK(hipGetLastError());
+  BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_block);
+  if (h->flags & FLAG_LIST_OVERFLOW) {
+    int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
+    if (rc) return rc;
+  } else {
+    s->c_cands += h->count;
+  }
+  s->c_searches++;
+  return TSH_OK;
+}
+
+struct SearchOut {
+  uint8_t *h_blocks = nullptr;  // host mode: nq blocks (caller memory)
+  std::vector<std::vector<BlockEntry>> *spill = nullptr;
+  uint8_t *d_blocks = nullptr;  // device mode
+  hipStream_t user_stream = nullptr;
+};
+
+// nq single-query searches, up to `depth` of them in flight on separate
+// contexts/streams so one query's select / rerank / copies hide behind the
+// next query's scan.  Caller holds s->mu shared.
+int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const uint8_t *mask,
+                        int32_t entries, SearchOut *out, int depth) {
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+  std::vector<uint64_t> mask_words;
+  uint64_t epoch = 0;
+  if (mask) {
+    mask_words.resize((size_t)n_tiles);
+    slice_mask(s, mask, mask_words.data(), n_tiles);
+    epoch = s->mask_epoch_src.fetch_add(1);
+  }
+  depth = std::max(1, std::min(depth, std::min(nq, MAX_CTX)));
+  std::vector<Job> jobs((size_t)depth);
+  int rc = TSH_OK;
+  int32_t submitted = 0, finished = 0;
+  auto release_all = [&]() {
+    for (auto &j : jobs)
+      if (j.c) {
+        if (j.counted) hipEventSynchronize(j.c->ev_done);
+        if (j.counted) s->inflight.fetch_sub(1);
+        j.counted = false;
+        ctx_release(s, j.c);
+        j.c = nullptr;
+      }
+  };
+  while (finished < nq) {
+    while (submitted < nq && submitted - finished < depth) {
+      Job &j = jobs[(size_t)(submitted % depth)];
+      j.c = ctx_acquire(s, true);
+      rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries,
+                       mask ? mask_words.data() : nullptr, epoch, out->d_blocks != nullptr);
+      if (rc) {
+        release_all();
+        return rc;
+      }
+      ++submitted;
     }
-    HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)nc * s->ld * sizeof(float),
-                          hipMemcpyHostToDevice, st));
-    for (int32_t i = 0; i < nc; ++i) {
-      const float *dq = c->d_query + (size_t)i * s->ld;
-      uint8_t *dblk = c->d_blocks + (size_t)i * bb;
-      ScanArgs sa;
-      fill_scan_args(s, c, dq, masked, mask != nullptr, &sa);
-      launch_scan(sa, s->nch, s->metric, masked, st);
-      SelectArgs se;
-      se.gmin = c->d_gmin;
-      se.keys = c->d_keys;
-      se.hdr = reinterpret_cast<BlockHeader *>(dblk);
-      se.cand_rows = c->d_cand + (size_t)i * entries;
-      se.n_tiles = n_tiles;
-      se.k = k;
-      se.cand_cap = entries;
-      se.eps_rel = bands[i].eps_rel;
-      se.delta_abs = bands[i].delta_abs;
-      se.force_all = bands[i].force_all;
-      se.metric = s->metric;
-      se.row_base = s->row_base;
-      se.shard_rows = s->rows;
-      select_kernel<<<1, SEL_THREADS, 0, st>>>(se);
-      RerankArgs ra;
-      ra.rows = s->d_rows;
-      ra.query = dq;
-      ra.cand_rows = se.cand_rows;
-      ra.count_ptr = &se.hdr->count;
-      ra.out = reinterpret_cast<BlockEntry *>(dblk + sizeof(BlockHeader));
-      ra.ld = s->ld;
-      ra.row_base = s->row_base;
-      ra.dim = s->dim;
-      ra.cap = entries;
-      ra.metric = s->metric;
-      rerank_kernel<<<std::min(entries, 1024), 64, 0, st>>>(ra);
+    Job &j = jobs[(size_t)(finished % depth)];
+    std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[(size_t)finished] : nullptr;
+    rc = job_finish(s, &j, sp);
+    if (rc) {
+      release_all();
+      return rc;
     }
-    s->c_scans += nc;
-    // headers first: overflow decisions need them on the host
-    HIPCHK(hipMemcpyAsync(c->h_blocks, c->d_blocks, bb * nc, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-    for (int32_t i = 0; i < nc; ++i) {
-      BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_blocks + (size_t)i * bb);
-      if (h->flags & FLAG_LIST_OVERFLOW) {
-        // re-run K1 for this query (scratch was reused), then the wide path
-        const float *dq = c->d_query + (size_t)i * s->ld;
-        uint8_t *dblk = c->d_blocks + (size_t)i * bb;
-        ScanArgs sa;
-        fill_scan_args(s, c, dq, masked, mask != nullptr, &sa);
-        launch_scan(sa, s->nch, s->metric, masked, st);
-        std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[q0 + i] : nullptr;
-        rc = run_fallback(s, c, dq, h->band_key, entries, dblk, sp);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->h_blocks + (size_t)i * bb, dblk, bb, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-      } else {
-        s->c_cands += h->count;
+    if (out->h_blocks) memcpy(out->h_blocks + (size_t)finished * bb, j.c->h_block, bb);
+    if (out->d_blocks) {
+      hipStream_t us = out->user_stream ? out->user_stream : j.c->stream;
+      hipError_t e = hipMemcpyAsync(out->d_blocks + (size_t)finished * bb, j.c->d_block, bb,
+                                    hipMemcpyDeviceToDevice, us);
+      if (e == hipSuccess) e = hipStreamSynchronize(us);  // the context is reused right away
+      if (e != hipSuccess) {
+        release_all();
+        return set_err(TSH_E_HIP, "block copy: %s", hipGetErrorString(e));
       }
     }
-    if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, c->h_blocks, bb * nc);
-    if (out->d_blocks) {
-      hipStream_t us = out->user_stream ? out->user_stream : st;
-      HIPCHK(hipMemcpyAsync(out->d_blocks + (size_t)q0 * bb, c->d_blocks, bb * nc,
-                            hipMemcpyDeviceToDevice, us));
-      HIPCHK(hipStreamSynchronize(us));  // scratch is reused by the next chunk
-    }
+    ctx_release(s, j.c);
+    j.c = nullptr;
+    ++finished;
   }
-  s->c_searches += nq;
   return TSH_OK;
 }
 
 }  // namespace
 
 // ============================================================================
+// an un-waited asynchronous search (tsh_search_submit): one job per shard; the
+// shards stay share-locked until the wait so appends cannot move the rows
+struct Ticket {
+  int32_t k = 0, entries = 0;
+  std::vector<float> query;
+  std::vector<Job> jobs;
+  std::vector<std::shared_lock<RwLock>> locks;
+};
+
 struct tsh_index {
   int dim = 0, metric = 0;
   int64_t rows_per_shard = 0;  // multi-device split (0: single shard)
   std::vector<std::unique_ptr<Shard>> shards;
   std::mutex mu;  // serialises append routing
+  std::mutex tk_mu;
+  std::vector<std::unique_ptr<Ticket>> tickets;
 };
 
 namespace {
@@ -711,6 +845,7 @@ void shard_destroy(Shard *s) {
   hipSetDevice(s->device);
   for (auto &c : s->ctx_all) ctx_free_all(c.get());
   if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
+  if (s->scan_stream) hipStreamDestroy(s->scan_stream);
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
   hipFree(s->d_live);
@@ -755,7 +890,7 @@ int index_append(tsh_index *idx, int64_t first, int64_t n, const float *rows, bo
       take = std::min(take, end - gid);
     }
     if (gid < s->row_base) return set_err(TSH_E_BAD_ARG, "row id %lld below shard base", (long long)gid);
-    std::unique_lock<std::shared_mutex> xl(s->mu);
+    std::unique_lock<RwLock> xl(s->mu);
     int rc = shard_append(s, gid - s->row_base, take, rows + (size_t)done * idx->dim, dev);
     if (rc) return rc;
     done += take;
@@ -836,7 +971,7 @@ int32_t tsh_index_create_shard(int32_t dim, int32_t metric, int64_t capacity_row
 int32_t tsh_index_destroy(tsh_index *idx) {
   if (!idx) return TSH_OK;
   for (auto &s : idx->shards) {
-    std::unique_lock<std::shared_mutex> xl(s->mu);
+    std::unique_lock<RwLock> xl(s->mu);
     shard_destroy(s.get());
   }
   delete idx;
@@ -858,7 +993,7 @@ int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n) {
   if (!ids) return set_err(TSH_E_BAD_ARG, "ids is NULL");
   for (auto &sp : idx->shards) {
     Shard *s = sp.get();
-    std::unique_lock<std::shared_mutex> xl(s->mu);
+    std::unique_lock<RwLock> xl(s->mu);
     if (s->rows == 0) continue;
     HIPCHK(hipSetDevice(s->device));
     int64_t *d_ids = nullptr;
@@ -885,7 +1020,7 @@ int64_t tsh_index_size(tsh_index *idx) {
   if (!idx) return 0;
   int64_t m = 0;
   for (auto &s : idx->shards) {
-    std::shared_lock<std::shared_mutex> sl(s->mu);
+    std::shared_lock<RwLock> sl(s->mu);
     if (s->rows > 0) m = std::max(m, s->row_base + s->rows);
   }
   return m;
@@ -923,7 +1058,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
 
   auto run = [&](size_t g) {
     Shard *s = idx->shards[g].get();
-    std::shared_lock<std::shared_mutex> sl(s->mu);
+    std::shared_lock<RwLock> sl(s->mu);
     if (s->rows == 0) return;
     active[g] = 1;
     blocks[g].resize(bb * (size_t)nq);
@@ -931,7 +1066,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     SearchOut so;
     so.h_blocks = blocks[g].data();
     so.spill = &spills[g];
-    rcs[g] = shard_search_blocks(s, queries, nq, k, row_mask, entries, &so);
+    rcs[g] = shard_search_blocks(s, queries, nq, k, row_mask, entries, &so, PIPE_DEPTH);
     if (rcs[g]) errs[g] = g_err;
   };
   if (ns == 1) {
@@ -965,13 +1100,119 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
   return TSH_OK;
 }
 
+// ---- asynchronous single-query searches ------------------------------------------
+int32_t tsh_max_inflight(void) { return MAX_CTX; }
+
+int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const uint8_t *row_mask,
+                          int32_t *out_ticket) {
+  if (!idx || !query || !out_ticket) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  if (k <= 0) return set_err(TSH_E_BAD_ARG, "k <= 0");
+  *out_ticket = -1;
+  std::unique_ptr<Ticket> t(new Ticket());
+  t->k = k;
+  t->entries = tsh_default_block_entries(k);
+  t->query.assign(query, query + idx->dim);
+  t->jobs.resize(idx->shards.size());
+  t->locks.resize(idx->shards.size());
+  int rc = TSH_OK;
+  for (size_t g = 0; g < idx->shards.size() && rc == TSH_OK; ++g) {
+    Shard *s = idx->shards[g].get();
+    t->locks[g] = std::shared_lock<RwLock>(s->mu);
+    if (s->rows == 0) continue;
+    Ctx *c = ctx_acquire(s, false);
+    if (!c) {
+      rc = set_err(TSH_E_BUSY, "more than %d searches in flight on this handle", MAX_CTX);
+      break;
+    }
+    t->jobs[g].c = c;
+    std::vector<uint64_t> words;
+    uint64_t epoch = 0;
+    if (row_mask) {
+      int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+      words.resize((size_t)n_tiles);
+      slice_mask(s, row_mask, words.data(), n_tiles);
+      epoch = s->mask_epoch_src.fetch_add(1);
+    }
+    rc = job_enqueue(s, &t->jobs[g], query, k, t->entries, row_mask ? words.data() : nullptr, epoch, false);
+  }
+  if (rc != TSH_OK) {
+    std::string keep = g_err;
+    for (size_t g = 0; g < idx->shards.size(); ++g)
+      if (t->jobs[g].c) {
+        if (t->jobs[g].counted) hipEventSynchronize(t->jobs[g].c->ev_done);
+        if (t->jobs[g].counted) idx->shards[g]->inflight.fetch_sub(1);
+        ctx_release(idx->shards[g].get(), t->jobs[g].c);
+      }
+    g_err = keep;
+    return rc;
+  }
+  std::lock_guard<std::mutex> lk(idx->tk_mu);
+  int slot = -1;
+  for (size_t i = 0; i < idx->tickets.size(); ++i)
+    if (!idx->tickets[i]) {
+      slot = (int)i;
+      break;
+    }
+  if (slot < 0) {
+    idx->tickets.emplace_back();
+    slot = (int)idx->tickets.size() - 1;
+  }
+  idx->tickets[(size_t)slot] = std::move(t);
+  *out_ticket = slot;
+  return TSH_OK;
+}
+
+int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double thr, int64_t *out_ids, double *out_dist,
+                        int32_t *out_count) {
+  if (!idx || !out_ids || !out_dist || !out_count) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  std::unique_ptr<Ticket> t;
+  {
+    std::lock_guard<std::mutex> lk(idx->tk_mu);
+    if (ticket < 0 || (size_t)ticket >= idx->tickets.size() || !idx->tickets[(size_t)ticket])
+      return set_err(TSH_E_BAD_ARG, "unknown ticket %d", ticket);
+    t = std::move(idx->tickets[(size_t)ticket]);
+  }
+  *out_count = 0;
+  int rc = TSH_OK;
+  std::vector<std::vector<BlockEntry>> spills(idx->shards.size());
+  std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
+  for (size_t g = 0; g < idx->shards.size(); ++g) {
+    Job &j = t->jobs[g];
+    if (!j.c) continue;
+    Shard *s = idx->shards[g].get();
+    if (rc == TSH_OK) {
+      rc = job_finish(s, &j, &spills[g]);
+    } else {
+      if (j.counted) hipEventSynchronize(j.c->ev_done);
+      if (j.counted) s->inflight.fetch_sub(1);
+      j.counted = false;
+    }
+    if (rc == TSH_OK) {
+      if (!spills[g].empty()) {
+        lists.push_back({spills[g].data(), (uint32_t)spills[g].size()});
+      } else {
+        const BlockHeader *h = reinterpret_cast<const BlockHeader *>(j.c->h_block);
+        lists.push_back({reinterpret_cast<const BlockEntry *>(j.c->h_block + sizeof(BlockHeader)),
+                         std::min(h->count, h->entries)});
+      }
+    }
+  }
+  if (rc == TSH_OK)
+    *out_count = finalize_query(idx->metric, idx->dim, t->query.data(), t->k, thr, lists, out_ids, out_dist);
+  std::string keep = g_err;
+  for (size_t g = 0; g < idx->shards.size(); ++g)
+    if (t->jobs[g].c) ctx_release(idx->shards[g].get(), t->jobs[g].c);
+  g_err = keep;
+  return rc;
+}
+
 int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                          const uint8_t *row_mask, int32_t entries, void *d_out_blocks, void *stream) {
   if (!idx || idx->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle");
   if (nq <= 0 || !queries || !d_out_blocks || k <= 0 || entries < 1)
     return set_err(TSH_E_BAD_ARG, "bad nq / k / entries / pointers");
   Shard *s = idx->shards[0].get();
-  std::shared_lock<std::shared_mutex> sl(s->mu);
+  std::shared_lock<RwLock> sl(s->mu);
   size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   if (s->rows == 0) {  // an empty shard contributes empty blocks
     HIPCHK(hipSetDevice(s->device));
@@ -989,7 +1230,7 @@ int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32
   SearchOut so;
   so.d_blocks = static_cast<uint8_t *>(d_out_blocks);
   so.user_stream = static_cast<hipStream_t>(stream);
-  return shard_search_blocks(s, queries, nq, k, row_mask, entries, &so);
+  return shard_search_blocks(s, queries, nq, k, row_mask, entries, &so, PIPE_DEPTH);
 }
 
 int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries, int32_t nq, int32_t k,
@@ -1036,7 +1277,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
   memset(out, 0, sizeof *out);
   for (auto &sp : idx->shards) {
     Shard *s = sp.get();
-    std::shared_lock<std::shared_mutex> sl(s->mu);
+    std::shared_lock<RwLock> sl(s->mu);
     if (s->rows > 0) out->rows = std::max(out->rows, s->row_base + s->rows);
     out->deleted_rows += s->deleted;
     out->searches = std::max<int64_t>(out->searches, s->c_searches.load());
@@ -1061,10 +1302,14 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   if (!idx || idx->shards.size() != 1 || !query || iters <= 0 || !out_avg_us)
     return set_err(TSH_E_BAD_ARG, "bad arguments");
   Shard *s = idx->shards[0].get();
-  std::shared_lock<std::shared_mutex> sl(s->mu);
+  std::shared_lock<RwLock> sl(s->mu);
   if (s->rows == 0) return set_err(TSH_E_BAD_ARG, "empty index");
-  CtxLease lease(s);
-  Ctx *c = lease.c;
+  Ctx *c = ctx_acquire(s, true);
+  struct Rel {
+    Shard *s;
+    Ctx *c;
+    ~Rel() { ctx_release(s, c); }
+  } rel{s, c};
   int rc = ctx_prepare(s, c, tsh_default_block_entries(100), row_mask != nullptr);
   if (rc) return rc;
   hipStream_t st = c->stream;
@@ -1073,12 +1318,13 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   if (row_mask) {
     slice_mask(s, row_mask, c->h_mask, n_tiles);
     HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+    c->mask_epoch = 0;
   }
   memcpy(c->h_query, query, (size_t)s->dim * sizeof(float));
   for (int64_t j = s->dim; j < s->ld; ++j) c->h_query[j] = 0.f;
   HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, st));
-  ScanArgs sa;
-  fill_scan_args(s, c, c->d_query, masked, row_mask != nullptr, &sa);
+  static thread_local ScanArgsQ sa;
+  fill_scan_args(s, c, masked, row_mask != nullptr, &sa);
   launch_scan(sa, s->nch, s->metric, masked, st);  // warm
   HIPCHK(hipEventRecord(c->ev0, st));
   for (int32_t i = 0; i < iters; ++i) launch_scan(sa, s->nch, s->metric, masked, st);

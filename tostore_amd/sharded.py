@@ -95,7 +95,7 @@ class ShardedSearcher:
             _ffi.check(L.tsh_search_shard(self.index._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), mp,
                                           entries, ctypes.c_void_p(mine.data_ptr()),
                                           ctypes.c_void_p(stream)))
-            if self.world > 1:
+            if self._dist.is_initialized():
                 self._dist.all_gather_into_tensor(allb, mine, group=self.group)
             else:
                 allb = mine
