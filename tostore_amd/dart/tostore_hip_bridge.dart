@@ -1,0 +1,219 @@
+// tostore_hip_bridge.dart -- the `dart:ffi` binding a ToStore maintainer adds as
+// lib/src/handler/hip_vector_backend.dart to route vectorSearch() through
+// libtostore_hip.so (include/tostore_hip.h).
+//
+// NOT compiled or tested in this repository: the build image has no Dart SDK.
+// It is a mechanical mapping of the C-ABI, written in the style of the
+// reference's only existing FFI user, lib/src/handler/system_ffi_helper.dart
+// (DynamicLibrary.open + lookupFunction, int32 status with 0 = success,
+// calloc/free in try/finally, every failure falls back to the Dart path).
+// The ctypes binding tostore_amd/_ffi.py exercises the same entry points with
+// the same argument meaning and IS tested (tests/test_abi.py, tests/test_gpu_*).
+
+import 'dart:ffi';
+import 'dart:typed_data';
+
+import 'package:ffi/ffi.dart';
+
+import '../core/ngh_graph_engine.dart' show NghSearchResult;
+import '../model/ngh_index_meta.dart';
+import '../model/table_schema.dart' show VectorDistanceMetric;
+import 'logger.dart';
+
+// ---- native signatures (include/tostore_hip.h) ---------------------------------
+typedef _AbiVersionC = Int32 Function();
+typedef _AbiVersionD = int Function();
+typedef _DeviceCountC = Int32 Function();
+typedef _DeviceCountD = int Function();
+typedef _LastErrorC = Int32 Function(Pointer<Utf8>, Int32);
+typedef _LastErrorD = int Function(Pointer<Utf8>, int);
+typedef _CreateC = Int32 Function(Int32, Int32, Int64, Int32, Pointer<Pointer<Void>>);
+typedef _CreateD = int Function(int, int, int, int, Pointer<Pointer<Void>>);
+typedef _DestroyC = Int32 Function(Pointer<Void>);
+typedef _DestroyD = int Function(Pointer<Void>);
+typedef _AppendC = Int32 Function(Pointer<Void>, Int64, Int64, Pointer<Float>);
+typedef _AppendD = int Function(Pointer<Void>, int, int, Pointer<Float>);
+typedef _SetDeletedC = Int32 Function(Pointer<Void>, Pointer<Int64>, Int64);
+typedef _SetDeletedD = int Function(Pointer<Void>, Pointer<Int64>, int);
+typedef _LoadRawvecC = Int32 Function(
+    Pointer<Void>, Pointer<Utf8>, Int32, Int32, Int64, Int64, Pointer<Int64>);
+typedef _LoadRawvecD = int Function(
+    Pointer<Void>, Pointer<Utf8>, int, int, int, int, Pointer<Int64>);
+typedef _SizeC = Int64 Function(Pointer<Void>);
+typedef _SizeD = int Function(Pointer<Void>);
+typedef _SearchC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, Double,
+    Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _SearchD = int Function(Pointer<Void>, Pointer<Float>, int, int, double,
+    Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+
+/// One device-resident copy of an NGH index's raw-vector column.
+///
+/// Lifetime: created lazily on the first vectorSearch / writeChanges of
+/// (tableName, indexName); dropped from clearCacheForTable / clearCacheForIndex /
+/// dispose (vector_index_manager.dart:1192-1216) and after reorderByLocality
+/// (:932-1159), which renumbers node ids.
+final class HipVectorBackend {
+  static DynamicLibrary? _lib;
+  static bool _probed = false;
+
+  static late final _AbiVersionD _abiVersion;
+  static late final _DeviceCountD _deviceCount;
+  static late final _LastErrorD _lastError;
+  static late final _CreateD _create;
+  static late final _DestroyD _destroy;
+  static late final _AppendD _append;
+  static late final _SetDeletedD _setDeleted;
+  static late final _LoadRawvecD _loadRawvec;
+  static late final _SizeD _size;
+  static late final _SearchD _search;
+
+  /// True when libtostore_hip.so is loadable, ABI-compatible and sees a GPU.
+  static bool get available {
+    if (_probed) return _lib != null;
+    _probed = true;
+    try {
+      final lib = DynamicLibrary.open('libtostore_hip.so');
+      _abiVersion = lib.lookupFunction<_AbiVersionC, _AbiVersionD>('tsh_abi_version');
+      _deviceCount = lib.lookupFunction<_DeviceCountC, _DeviceCountD>('tsh_device_count');
+      _lastError = lib.lookupFunction<_LastErrorC, _LastErrorD>('tsh_last_error');
+      _create = lib.lookupFunction<_CreateC, _CreateD>('tsh_index_create');
+      _destroy = lib.lookupFunction<_DestroyC, _DestroyD>('tsh_index_destroy');
+      _append = lib.lookupFunction<_AppendC, _AppendD>('tsh_index_append');
+      _setDeleted = lib.lookupFunction<_SetDeletedC, _SetDeletedD>('tsh_index_set_deleted');
+      _loadRawvec =
+          lib.lookupFunction<_LoadRawvecC, _LoadRawvecD>('tsh_index_load_rawvec_file');
+      _size = lib.lookupFunction<_SizeC, _SizeD>('tsh_index_size');
+      _search = lib.lookupFunction<_SearchC, _SearchD>('tsh_search');
+      if (_abiVersion() != 1 || _deviceCount() < 1) return false;
+      _lib = lib;
+      return true;
+    } catch (_) {
+      return false; // same catch-and-fall-back style as SystemFFIHelper
+    }
+  }
+
+  static String _errorText() {
+    final buf = calloc<Uint8>(512);
+    try {
+      _lastError(buf.cast<Utf8>(), 512);
+      return buf.cast<Utf8>().toDartString();
+    } finally {
+      calloc.free(buf);
+    }
+  }
+
+  Pointer<Void> _handle;
+  final int dimensions;
+  final VectorDistanceMetric metric;
+
+  HipVectorBackend._(this._handle, this.dimensions, this.metric);
+
+  /// metric index = enum order of VectorDistanceMetric (table_schema.dart:2511-2531).
+  static HipVectorBackend? tryCreate(NghIndexMeta meta, {int devices = 1}) {
+    if (!available) return null;
+    final out = calloc<Pointer<Void>>();
+    try {
+      final rc = _create(meta.dimensions, meta.distanceMetric.index,
+          meta.nextNodeId > 0 ? meta.nextNodeId : 0, devices, out);
+      if (rc != 0) {
+        Logger.warn('tsh_index_create failed ($rc): ${_errorText()}',
+            label: 'HipVectorBackend');
+        return null;
+      }
+      return HipVectorBackend._(out.value, meta.dimensions, meta.distanceMetric);
+    } finally {
+      calloc.free(out);
+    }
+  }
+
+  int get size => _size(_handle);
+
+  /// Feed from NghGraphEngine.insertBatch (ngh_graph_engine.dart:297-403): the
+  /// Float32Lists produced by prepareVectorBatchChunk, ids dense from `firstNodeId`.
+  bool append(int firstNodeId, List<Float32List> vectors) {
+    if (vectors.isEmpty) return true;
+    final n = vectors.length;
+    final buf = calloc<Float>(n * dimensions);
+    try {
+      final view = buf.asTypedList(n * dimensions);
+      for (var i = 0; i < n; i++) {
+        view.setRange(i * dimensions, (i + 1) * dimensions, vectors[i]);
+      }
+      final rc = _append(_handle, firstNodeId, n, buf);
+      if (rc != 0) Logger.warn('tsh_index_append failed ($rc): ${_errorText()}');
+      return rc == 0;
+    } finally {
+      calloc.free(buf);
+    }
+  }
+
+  /// Feed from NghGraphEngine.deleteBatch (ngh_graph_engine.dart:411-445).
+  bool setDeleted(List<int> nodeIds) {
+    if (nodeIds.isEmpty) return true;
+    final buf = calloc<Int64>(nodeIds.length);
+    try {
+      buf.asTypedList(nodeIds.length).setAll(0, nodeIds);
+      return _setDeleted(_handle, buf, nodeIds.length) == 0;
+    } finally {
+      calloc.free(buf);
+    }
+  }
+
+  /// Cold load of one rawvec partition file (path_manager.dart:318-324).
+  int loadRawVectorFile(String path, NghIndexMeta meta, int firstNodeId, int maxRows) {
+    final p = path.toNativeUtf8();
+    final out = calloc<Int64>();
+    try {
+      final rc = _loadRawvec(_handle, p, meta.nghPageSize, meta.precision.index,
+          firstNodeId, maxRows, out);
+      return rc == 0 ? out.value : -1;
+    } finally {
+      calloc.free(p);
+      calloc.free(out);
+    }
+  }
+
+  /// Drop-in for NghGraphEngine.search (ngh_graph_engine.dart:67-135).  `query`
+  /// is already _toFloat32'ed and (cosine) _normalizeFloat32'ed by the caller
+  /// (vector_index_manager.dart:514-520).  Returns null on any native failure so
+  /// the caller falls through to the original graph search.
+  List<NghSearchResult>? search(Float32List query, int topK,
+      {double? distanceThreshold, Uint8List? rowMask}) {
+    if (topK <= 0 || size == 0) return const [];
+    final q = calloc<Float>(dimensions);
+    final ids = calloc<Int64>(topK);
+    final dist = calloc<Double>(topK);
+    final cnt = calloc<Int32>();
+    Pointer<Uint8> mask = nullptr;
+    try {
+      q.asTypedList(dimensions).setAll(0, query);
+      if (rowMask != null) {
+        mask = calloc<Uint8>(rowMask.length);
+        mask.asTypedList(rowMask.length).setAll(0, rowMask);
+      }
+      final rc = _search(_handle, q, 1, topK, distanceThreshold ?? double.nan, mask,
+          ids, dist, cnt);
+      if (rc != 0) {
+        Logger.warn('tsh_search failed ($rc): ${_errorText()}', label: 'HipVectorBackend');
+        return null;
+      }
+      final n = cnt.value;
+      return [
+        for (var i = 0; i < n; i++) NghSearchResult(nodeId: ids[i], distance: dist[i])
+      ];
+    } finally {
+      calloc.free(q);
+      calloc.free(ids);
+      calloc.free(dist);
+      calloc.free(cnt);
+      if (mask != nullptr) calloc.free(mask);
+    }
+  }
+
+  void dispose() {
+    if (_handle != nullptr) {
+      _destroy(_handle);
+      _handle = nullptr;
+    }
+  }
+}
