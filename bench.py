@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--inflight", type=int, default=4,
                     help="independent single-query searches kept in flight (1 = strictly one at a time)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="queries per step through the batched matrix-core path (config C3: --batch 1024 "
+                         "--metric cosine); 0 = the headline single-query workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the N>1 code path (process group, all-gather, merge) even with one rank")
@@ -72,6 +75,50 @@ def make_queries(nq, d, metric):
         from tostore_amd import normalize_float32
         q = np.stack([normalize_float32(x) for x in q])
     return np.ascontiguousarray(q)
+
+
+def bench_batch(a, idx, host_rows, metric, world, rank):
+    """Config C3: one step = one call with `--batch` queries (matrix-core path).  Side
+    measurement, not the headline line; single GPU only."""
+    import torch
+
+    assert world == 1, "the batched benchmark is single-GPU"
+    n, d, k, nq = a.rows, a.dim, a.k, a.batch
+    steps, warm = max(1, min(a.steps, 20)), max(1, min(a.warmup, 3))
+    qs = make_queries(nq * 2, d, metric)
+    for i in range(warm):
+        idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ids, dist, cnt = idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gemm_us, flops = idx.bench_batch(qs[:nq], k, iters=3)
+    tf = flops / (gemm_us * 1e-6) / 1e12
+    out = {"metric": "kNN queries/sec, %dx%d f32 %s k=%d, %d-query batch (matrix-core path)" % (n, d, a.metric, k, nq),
+           "value": nq * steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+           "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "C3: %dx%d f32, %s, k=%d, %d-query batch" % (n, d, a.metric, k, nq)},
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                        "traffic": None, "kernel": "tsh::batch_score_kernel (sample + filtered passes)",
+                        "kernel_us": gemm_us, "algorithmic_flops_per_launch": flops}}
+    if host_rows is not None:
+        import oracle
+        m = 4
+        ok, hits = True, 0
+        for i in range(m):
+            j = ((steps - 1) % 2) * nq + i
+            eids, edist = oracle.search_heap_mt(host_rows, qs[j], metric, k)
+            hits += len(set(ids[i, :cnt[i]].tolist()) & set(eids.tolist()))
+            ok &= bool(np.array_equal(ids[i, :cnt[i]], eids) and np.array_equal(dist[i, :cnt[i]], edist))
+        out["recall_at_k"] = hits / (m * k)
+        out["ids_and_distances_bit_exact"] = ok
+    c = idx.counters()
+    out["counters"] = {k2: c[k2] for k2 in ("batch_launches", "scan_launches", "fallback_searches")}
+    idx.close()
+    print(json.dumps(out))
 
 
 def main():
@@ -114,6 +161,9 @@ def main():
         host_rows = corpus.cpu().numpy()  # for the CPU baseline / recall check only
     del corpus
     torch.cuda.empty_cache()
+
+    if a.batch > 0:
+        return bench_batch(a, idx, host_rows, metric, world, rank)
 
     nq_total = a.warmup + a.steps
     queries = make_queries(max(nq_total, 1), d, metric)

@@ -210,9 +210,18 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out);
  * HIP events on the library's own stream over `iters` launches of one query. */
 int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters,
                        const uint8_t *row_mask, double *out_avg_us);
-/* Same for one batched pass over nq queries. */
-int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_t iters,
-                        double *out_avg_us);
+/* One real batched search of nq queries, `iters` times: average device time of
+ * the two matrix-core passes (sample + filtered) that together score every row
+ * once, in microseconds (HIP events on the library's stream), and the
+ * algorithmic flop count 2*nq*rows*dim they performed. */
+int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_t k, int32_t iters,
+                        double *out_avg_gemm_us, double *out_flops);
+
+/* Tuning knobs (no reference counterpart).  TSH_OPT_BATCH_MIN_NQ: smallest nq
+ * for which tsh_search / tsh_search_shard use the batched matrix-core path
+ * (default 8; 0 = never).  Results are identical either way. */
+#define TSH_OPT_BATCH_MIN_NQ 1
+int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value);
 
 #ifdef __cplusplus
 }

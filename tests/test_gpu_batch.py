@@ -1,0 +1,122 @@
+"""GPU: the batched matrix-core path (nq >= 8 by default) against the oracle and
+against the single-query path.  Same bar: ids bit-exact, distances bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+L2, IP, COS = 0, 1, 2
+
+
+def _mk(n, d, seed, normalize=True, scale=None):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if normalize:
+        x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    if scale is not None:
+        x *= rng.uniform(scale[0], scale[1], size=(n, 1)).astype(np.float32)
+    return x
+
+
+def _queries(oracle, nq, d, seed, metric):
+    q = _mk(nq, d, seed)
+    return np.stack([oracle.normalize_f32(x) for x in q]) if metric == COS else q
+
+
+def _check_batch(oracle, idx, rows, qs, metric, k, thr=None, keep=None, tag=""):
+    ids, dist, cnt = idx.search(qs, k, thr, keep)
+    # the OpenMP oracle pays ~0.1 s of thread start-up per call on a 128-core box
+    ref = oracle.search_heap_mt if rows.size > 1e8 else oracle.search_heap
+    for i in range(len(qs)):
+        eids, edist = ref(rows, qs[i], metric, k, thr, keep)
+        n = int(cnt[i])
+        assert n == len(eids), f"{tag} q{i}: count {n} != {len(eids)}"
+        assert np.array_equal(ids[i, :n], eids), f"{tag} q{i}: ids differ"
+        assert np.array_equal(dist[i, :n], edist), f"{tag} q{i}: distances differ"
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("d,n,nq,k", [(128, 30000, 130, 10), (100, 20000, 9, 100), (768, 30000, 130, 100),
+                                      (36, 50000, 300, 37)])
+def test_batched_matches_oracle(hip_lib, oracle_mod, metric, d, n, nq, k):
+    from tostore_amd import HipVectorIndex
+
+    rows = _mk(n, d, 200 + d, scale=None if metric == COS else (0.5, 2.0))
+    qs = _queries(oracle_mod, nq, d, 300 + d, metric)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, tag=f"m{metric} d{d}")
+        c = idx.counters()
+        assert c["batch_launches"] >= 1 and c["scan_launches"] == 0, c  # the MFMA path answered all of them
+        # and the single-query path gives the same bytes
+        idx.set_batch_min_nq(0)
+        ids1, dist1, cnt1 = idx.search(qs[:12], k)
+        idx.set_batch_min_nq(8)
+        ids2, dist2, cnt2 = idx.search(qs[:12], k)
+        assert np.array_equal(ids1, ids2) and np.array_equal(dist1, dist2) and np.array_equal(cnt1, cnt2)
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_batched_mask_tombstones_threshold(hip_lib, oracle_mod, metric):
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq, k = 64, 25000, 40, 20
+    rows = _mk(n, d, 11, scale=None if metric == COS else (0.7, 1.5))
+    qs = _queries(oracle_mod, nq, d, 12, metric)
+    rng = np.random.default_rng(13)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        keepbits = rng.random(n) < 0.3
+        keep = np.packbits(keepbits, bitorder="little")
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, keep=keep, tag="mask")
+        dead = rng.choice(n, 3000, replace=False)
+        idx.set_deleted(dead)
+        alive = np.ones(n, bool)
+        alive[dead] = False
+        ids, dist, cnt = idx.search(qs, k)
+        for i in range(nq):
+            eids, edist = oracle_mod.search_exhaustive(rows, qs[i], metric, k, None, np.packbits(alive, bitorder="little"))
+            assert np.array_equal(ids[i, :cnt[i]], eids) and np.array_equal(dist[i, :cnt[i]], edist)
+        _, ed = oracle_mod.search_exhaustive(rows, qs[0], metric, k, None, np.packbits(alive & keepbits, bitorder="little"))
+        thr = float(ed[k // 2])
+        ids, dist, cnt = idx.search(qs, k, thr, keep)
+        for i in range(nq):
+            eids, edist = oracle_mod.search_exhaustive(rows, qs[i], metric, k, thr,
+                                                       np.packbits(alive & keepbits, bitorder="little"))
+            assert np.array_equal(ids[i, :cnt[i]], eids) and np.array_equal(dist[i, :cnt[i]], edist)
+        assert idx.counters()["batch_launches"] >= 3
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_batched_ties_fall_back_per_query(hip_lib, oracle_mod, metric):
+    """identical rows flood every candidate list: those queries are redone by the single-query path."""
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq, k = 32, 12000, 16, 50
+    rows = np.tile(_mk(3, d, 21), (n // 3, 1))
+    qs = _queries(oracle_mod, nq, d, 22, metric)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="ties")
+
+
+def test_batched_mixed_bad_query_and_small_index(hip_lib, oracle_mod):
+    from tostore_amd import HipVectorIndex
+
+    d, n = 48, 9000
+    rows = _mk(n, d, 31)
+    qs = _queries(oracle_mod, 20, d, 32, L2)
+    qs[3, 5] = np.inf  # outside the f32 error model: answered by the exact wide path
+    qs[7] = 0.0
+    with HipVectorIndex(d, L2) as idx:
+        idx.append(0, rows)
+        ids, dist, cnt = idx.search(qs, 10)
+        for i in range(20):
+            eids, edist = oracle_mod.search_exhaustive(rows, qs[i], L2, 10)
+            assert np.array_equal(ids[i, :cnt[i]], eids)
+            a, b = dist[i, :cnt[i]], edist
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    small = _mk(1000, d, 33)
+    with HipVectorIndex(d, L2) as idx:  # below 4096 rows the batch path is skipped
+        idx.append(0, small)
+        _check_batch(oracle_mod, idx, small, qs[:10][np.isfinite(qs[:10]).all(axis=1)], L2, 5, tag="small")
+        assert idx.counters()["batch_launches"] == 0

@@ -145,6 +145,18 @@ class HipVectorIndex:
                                               dist.ctypes.data_as(_ffi.p_f64), ctypes.byref(cnt)))
         return ids[:cnt.value], dist[:cnt.value]
 
+    def set_batch_min_nq(self, nq: int) -> None:
+        """nq at which search() switches to the matrix-core path (0 = never); results are identical."""
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 1, int(nq)))
+
+    def bench_batch(self, queries, k: int, iters: int = 3):
+        """(avg microseconds of the matrix-core passes, algorithmic flops) for one batch."""
+        q = _f32c(queries)
+        us, fl = ctypes.c_double(0), ctypes.c_double(0)
+        _ffi.check(_ffi.lib().tsh_bench_batch(self._h, q.ctypes.data_as(_ffi.p_f32), q.shape[0], int(k), iters,
+                                              ctypes.byref(us), ctypes.byref(fl)))
+        return us.value, fl.value
+
     def bench_scan(self, query, iters: int = 20, row_mask=None) -> float:
         q = _f32c(query)
         out = ctypes.c_double(0)

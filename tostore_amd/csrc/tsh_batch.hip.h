@@ -1,0 +1,437 @@
+// tsh_batch.hip.h -- batched-query path: Q (nq x d) against the resident rows
+// as a dense contraction on the FP32 matrix cores (v_mfma_f32_32x32x2_f32,
+// exact f32, 157 TF/s peak on MI355X), with the ranking-key transform and a
+// per-query threshold filter fused into the epilogue so the nq x n score
+// matrix never reaches HBM.
+//
+// Exactness comes from the same two-stage scheme as the single-query path:
+//   B0  score a SAMPLE of the rows densely (rows [0, n_sample)); per query the
+//       k-th smallest sample key is a proven upper bound tau_q on the k-th
+//       smallest key over ALL rows (the sample alone holds k rows <= tau_q)
+//   B1  score everything else with the filter key <= band(tau_q): about
+//       k * n / n_sample survivors per query, appended to per-query lists
+//   B2  per query: exact k-th smallest key of its list -> band -> candidates
+//   K4  the f64 rerank of tsh_kernels.hip.h, one (query, candidate) per wave
+// Keys: IP -dot; cosine -dot/|v|; L2 |q|^2 + |v|^2 - 2 dot.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsh_kernels.hip.h"
+
+namespace tsh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BT_M = 128;   // queries per workgroup tile
+constexpr int BT_N = 128;   // rows per workgroup tile
+constexpr int BT_K = 32;    // reduction chunk
+constexpr int BT_LD = 36;   // LDS row stride in floats: 144 B keeps ds_read_b128 conflict-free
+constexpr int BT_THREADS = 256;
+
+struct BatchArgs {
+  const float *Q;         // nq_pad x ld (rows past nq are zero)
+  const float *V;         // corpus rows, n x ld
+  const float *inv_norm;  // cosine
+  const float *sqnorm;    // L2: |v|^2
+  const float *qsq;       // L2: |q|^2 per query (nq_pad)
+  const float *thr;       // filter mode: per-query band (float, key space); nq_pad
+  const uint64_t *live;   // nullable: bit = row present & not deleted
+  const uint64_t *mask;   // nullable: caller keep mask
+  float *dense;           // dense mode: nq_pad x dense_ld keys of rows [row0,row1)
+  uint32_t *cand_key;     // filter mode: nq x cand_cap (float bits of the key)
+  uint32_t *cand_row;     // filter mode: nq x cand_cap
+  uint32_t *cand_cnt;     // filter mode: nq (may exceed cand_cap: overflow)
+  int64_t ld;
+  int64_t dense_ld;
+  int32_t row0, row1;     // rows scored by this launch
+  int32_t nq, nq_pad;     // nq_pad multiple of BT_M
+  int32_t kchunks;        // ceil(ld / BT_K); ld is padded with zeros to a multiple of 4
+  int32_t cand_cap;
+  int32_t q_tiles;        // nq_pad / BT_M
+  int32_t n_tiles;        // ceil((row1-row0) / BT_N)
+};
+
+// One workgroup = 128 queries x 128 rows; 4 waves as 2 x 2, each wave a
+// 64 x 64 patch = 2 x 2 MFMA blocks of 32 x 32.  Both operands are K-major in
+// memory; a lane stages float4s through registers into padded LDS, and reads
+// its fragments back as one ds_read_b128 per 4 MFMAs: lanes 0-31 own
+// k = 8t..8t+3, lanes 32-63 own k = 8t+4..8t+7 (the k order inside a chunk is
+// free as long as A and B agree).
+template <int METRIC, bool DENSE>
+__global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[2][BT_M][BT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BT_N][BT_LD];
+  __shared__ float s_thr[BT_M];
+  __shared__ float s_qsq[BT_M];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
+  // q_tiles consecutive workgroups that share one row tile (L2 reuse of V)
+  const int total = a.q_tiles * a.n_tiles;
+  int b = blockIdx.x;
+  int n_tile, q_tile;
+  {
+    const int xcd = b & 7, i = b >> 3;
+    const int per_round = 8 * a.q_tiles;
+    const int full_rounds = total / per_round;
+    if (b < full_rounds * per_round) {
+      q_tile = i % a.q_tiles;
+      n_tile = (i / a.q_tiles) * 8 + xcd;
+    } else {  // ragged tail: plain order
+      int r = b - full_rounds * per_round;
+      n_tile = full_rounds * 8 + r / a.q_tiles;
+      q_tile = r % a.q_tiles;
+    }
+  }
+  const int qbase = q_tile * BT_M;
+  const int nbase = a.row0 + n_tile * BT_N;
+
+  if (tid < BT_M) {
+    s_thr[tid] = DENSE ? 0.f : a.thr[qbase + tid];
+    s_qsq[tid] = METRIC == METRIC_L2 ? a.qsq[qbase + tid] : 0.f;
+  }
+
+  // staging map: thread -> (row r0 + 32 j, float4 column c4)
+  const int c4 = tid & 7, r0 = tid >> 3;
+  const float *qg[4], *vg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qg[j] = a.Q + (int64_t)(qbase + r0 + 32 * j) * a.ld + 4 * c4;
+    int vr = nbase + r0 + 32 * j;
+    if (vr >= a.row1) vr = a.row1 - 1;  // clamp: tail columns are discarded in the epilogue
+    vg[j] = a.V + (int64_t)vr * a.ld + 4 * c4;
+  }
+  const int kmax4 = (int)(a.ld / 4);  // float4s per row
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  auto gload = [&](int kc) {
+    const bool ok = kc * 8 + c4 < kmax4;  // ld need not be a multiple of BT_K
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = ok ? *reinterpret_cast<const f32x4 *>(qg[j] + kc * BT_K) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vg[j] + kc * BT_K))
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<f32x4 *>(&As[buf][r0 + 32 * j][4 * c4]) = ra[j];
+      *reinterpret_cast<f32x4 *>(&Bs[buf][r0 + 32 * j][4 * c4]) = rb[j];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
+  const int koff = 4 * (lane >> 5);
+  for (int kc = 0; kc < a.kchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < a.kchunks) gload(kc + 1);  // in flight while this chunk is multiplied
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const f32x4 *>(&As[buf][arow + 32 * i][8 * t + koff]);
+        fb[i] = *reinterpret_cast<const f32x4 *>(&Bs[buf][brow + 32 * i][8 * t + koff]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < a.kchunks) {
+      lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: key transform (+ filter) -----------------------------------------
+  // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = nbase + wn * 64 + j * 32 + (lane & 31);  // corpus row
+    const bool col_ok = col < a.row1;
+    float vin = 0.f, vsq = 0.f;
+    bool alive = col_ok;
+    if (col_ok) {
+      if (METRIC == METRIC_COS) vin = a.inv_norm[col];
+      if (METRIC == METRIC_L2) vsq = a.sqnorm[col];
+      if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
+      if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row in tile
+        const float dot = acc[i][j][r];
+        float key;
+        if (METRIC == METRIC_IP) key = -dot;
+        else if (METRIC == METRIC_COS) key = -(dot * vin);
+        else key = s_qsq[qi] + vsq - 2.f * dot;
+        if (DENSE) {
+          if (col_ok)
+            a.dense[(int64_t)(qbase + qi) * a.dense_ld + (col - a.row0)] = alive ? key : __builtin_nanf("");
+        } else {
+          const bool pass = alive && key <= s_thr[qi] && (qbase + qi) < a.nq;
+          if (pass) {
+            const int q = qbase + qi;
+            uint32_t p = atomicAdd(&a.cand_cnt[q], 1u);
+            if (p < (uint32_t)a.cand_cap) {
+              a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(key);
+              a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)col;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// block-wide exact k-th smallest (as an order-preserving u32 key) of `n` float
+// keys in global memory; NaN entries (dead rows) never count.  256 threads.
+// Same idea as K2: thread minima -> one wave bisects them -> short list of
+// everything <= that bound -> exact k-th.  Returns KEY_NAN when fewer than k
+// entries are finite (caller then keeps everything).
+constexpr int BS_THREADS = 256;
+constexpr int BS_LIST = 4096;
+
+struct KthScratch {
+  uint32_t lm[BS_THREADS];
+  uint32_t list[BS_LIST];
+  uint32_t n_list, U, tau;
+};
+
+__device__ __forceinline__ uint32_t fkey_or_dead(float f) { return f != f ? KEY_DEAD : f2key(f); }
+
+__device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    sc->n_list = 0;
+    sc->U = KEY_DEAD;
+    sc->tau = KEY_NAN;
+  }
+  uint32_t lmin = KEY_DEAD;
+  for (int i = tid; i < n; i += BS_THREADS) {
+    uint32_t x = fkey_or_dead(keys[i]);
+    lmin = x < lmin ? x : lmin;
+  }
+  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_THREADS && n > BS_LIST;
+  sc->lm[tid] = lmin;
+  __syncthreads();
+  if (narrow && wave == 0) {
+    uint32_t v[BS_THREADS / 64];
+#pragma unroll
+    for (int i = 0; i < BS_THREADS / 64; ++i) v[i] = sc->lm[lane + 64 * i];
+    uint32_t U = wave_kth_bisect<BS_THREADS / 64>(v, k);
+    if (lane == 0) sc->U = U;
+  }
+  __syncthreads();
+  const uint32_t U = sc->U;
+  for (int i = tid; i < n; i += BS_THREADS) {
+    uint32_t x = fkey_or_dead(keys[i]);
+    if (x <= U && x != KEY_DEAD) {
+      uint32_t p = atomicAdd(&sc->n_list, 1u);
+      if (p < BS_LIST) sc->list[p] = x;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const uint32_t m = sc->n_list;
+    uint32_t tau;
+    if (m < k) {
+      tau = KEY_NAN;  // fewer than k live entries
+    } else if (m > BS_LIST) {
+      tau = U == KEY_DEAD ? KEY_NAN : U;  // flooded by ties: U is a valid, looser bound
+    } else {
+      uint32_t v[BS_LIST / 64];
+#pragma unroll
+      for (int i = 0; i < BS_LIST / 64; ++i)
+        v[i] = (uint32_t)(lane + 64 * i) < m ? sc->list[lane + 64 * i] : KEY_DEAD;
+      tau = wave_kth_bisect<BS_LIST / 64>(v, k);
+    }
+    if (lane == 0) sc->tau = tau;
+  }
+  __syncthreads();
+  return sc->tau;
+}
+
+// absolute band of the batched (MFMA) key: band = tau + 2*delta, rounded up
+__device__ __forceinline__ float band_float(uint32_t tau_key, float delta2) {
+  uint32_t b = band_of(tau_key, 0.f, delta2);
+  if (b >= KEY_NAN) return __builtin_inff();
+  return key2f(b);
+}
+
+struct SampleSelArgs {
+  const float *dense;    // nq_pad x dense_ld
+  const float *delta2;   // per query: 2 * error bound of the key
+  float *thr;            // out: per-query filter threshold (key space)
+  uint32_t *cand_key, *cand_row, *cand_cnt;
+  int64_t dense_ld;
+  int32_t n_sample, k, cand_cap, row0;
+};
+
+// B0s: one workgroup per query.  thr[q] = band(k-th smallest sample key); the
+// sample rows at or below it open the query's candidate list.
+__global__ void __launch_bounds__(BS_THREADS) batch_sample_select_kernel(SampleSelArgs a) {
+  __shared__ KthScratch sc;
+  __shared__ uint32_t s_cnt;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const float *keys = a.dense + (int64_t)q * a.dense_ld;
+  uint32_t tau = block_kth_of_floats(keys, a.n_sample, (uint32_t)a.k, &sc);
+  float thr = band_float(tau, a.delta2[q]);
+  if (tid == 0) {
+    a.thr[q] = thr;
+    s_cnt = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < a.n_sample; i += BS_THREADS) {
+    float f = keys[i];
+    if (f <= thr) {  // NaN (dead) never passes
+      uint32_t p = atomicAdd(&s_cnt, 1u);
+      if (p < (uint32_t)a.cand_cap) {
+        a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(f);
+        a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)(a.row0 + i);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) a.cand_cnt[q] = s_cnt;
+}
+
+struct FinalSelArgs {
+  const uint32_t *cand_key, *cand_row, *cand_cnt;
+  const float *delta2;
+  uint8_t *blocks;       // nq blocks (BlockHeader + entries), device
+  uint32_t *final_rows;  // nq x entries
+  int64_t block_bytes;
+  int64_t row_base, shard_rows;
+  int32_t k, cand_cap, entries, metric;
+};
+
+// B2: one workgroup per query: exact k-th smallest key of the candidate list,
+// widened by the band; survivors are the rows the f64 rerank will score.
+__global__ void __launch_bounds__(BS_THREADS) batch_final_select_kernel(FinalSelArgs a) {
+  __shared__ KthScratch sc;
+  __shared__ uint32_t s_cnt;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t total = a.cand_cnt[q];
+  const bool over_in = total > (uint32_t)a.cand_cap;
+  const int n = (int)(over_in ? (uint32_t)a.cand_cap : total);
+  const float *keys = reinterpret_cast<const float *>(a.cand_key + (int64_t)q * a.cand_cap);
+  const uint32_t *rows = a.cand_row + (int64_t)q * a.cand_cap;
+  uint32_t tau = block_kth_of_floats(keys, n, (uint32_t)a.k, &sc);
+  float band = band_float(tau, a.delta2[q]);
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += BS_THREADS) {
+    if (keys[i] <= band) {
+      uint32_t p = atomicAdd(&s_cnt, 1u);
+      if (p < (uint32_t)a.entries) a.final_rows[(int64_t)q * a.entries + p] = rows[i];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    BlockHeader hv;
+    const bool over = over_in || s_cnt > (uint32_t)a.entries;
+    hv.count = over ? 0u : s_cnt;
+    hv.entries = (uint32_t)a.entries;
+    hv.tau_key = tau;
+    hv.band_key = f2key(band);
+    hv.tiles_hit = total;
+    hv.flags = over ? FLAG_LIST_OVERFLOW : 0u;
+    hv.k = (uint32_t)a.k;
+    hv.metric = (uint32_t)a.metric;
+    hv.row_base = a.row_base;
+    hv.shard_rows = a.shard_rows;
+    hv.pad[0] = hv.pad[1] = hv.pad[2] = hv.pad[3] = 0u;
+    *reinterpret_cast<BlockHeader *>(a.blocks + (int64_t)q * a.block_bytes) = hv;
+  }
+}
+
+// K4 over a batch: blockIdx.y = query, blockIdx.x strides over its candidates.
+// Identical arithmetic to rerank_kernel (tsh_kernels.hip.h).
+struct RerankBatchArgs {
+  const float *rows;
+  const float *Q;  // nq_pad x ld
+  const uint32_t *final_rows;  // nq x entries
+  uint8_t *blocks;
+  int64_t block_bytes;
+  int64_t ld, row_base;
+  int32_t dim, entries, metric;
+};
+
+__global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) double t0[RR_CHUNK];
+  __shared__ __attribute__((aligned(16))) double t1[RR_CHUNK];
+  const int lane = threadIdx.x, q = blockIdx.y;
+  uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
+  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
+  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
+  BlockEntry *out = reinterpret_cast<BlockEntry *>(blk + sizeof(BlockHeader));
+  const float *qp = a.Q + (int64_t)q * a.ld;
+  const int chains = a.metric == METRIC_COS ? 2 : 1;
+  for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+    uint32_t row = a.final_rows[(int64_t)q * a.entries + c];
+    const float *rp = a.rows + (int64_t)row * a.ld;
+    double s = 0.0;
+    for (int base = 0; base < a.dim; base += RR_CHUNK) {
+      int m = a.dim - base < RR_CHUNK ? a.dim - base : RR_CHUNK;
+      for (int i = lane; i < m; i += 64) {
+        double qv = (double)qp[base + i], bv = (double)rp[base + i];
+        if (a.metric == METRIC_L2) {
+          double diff = qv - bv;
+          t0[i] = diff * diff;
+        } else {
+          t0[i] = qv * bv;
+          if (a.metric == METRIC_COS) t1[i] = bv * bv;
+        }
+      }
+      __syncthreads();
+      if (lane < chains) {
+        const double *src = lane == 0 ? t0 : t1;
+        int i = 0;
+        for (; i + 32 <= m; i += 32) {
+          double x[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) x[u] = src[i + u];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) s = s + x[u];
+        }
+        for (; i < m; ++i) s = s + src[i];
+      }
+      __syncthreads();
+    }
+    double s1 = __shfl(s, 1);
+    if (lane == 0) {
+      out[c].id = a.row_base + (int64_t)row;
+      out[c].s0 = s;
+      out[c].s1 = a.metric == METRIC_COS ? s1 : 0.0;
+    }
+  }
+}
+
+}  // namespace tsh

@@ -661,7 +661,7 @@ struct IngestStats {
 
 __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t ld, int dim,
                                                      int64_t first, int64_t n, float *inv_norm,
-                                                     IngestStats *st) {
+                                                     float *sqnorm, IngestStats *st) {
   const int lane = threadIdx.x & 63;
   int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -701,6 +701,7 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
         else inv = (float)(1.0 / nrm);
       }
       if (inv_norm) inv_norm[first + r] = inv;
+      if (sqnorm) sqnorm[first + r] = (float)s;  // batched L2 key: |q|^2 + |v|^2 - 2 q.v
       float nf = (float)nrm;
       if ((double)nf < nrm) nf = __uint_as_float(__float_as_uint(nf) + 1u);
       if (!bad && __float_as_uint(nf) > w_norm) w_norm = __float_as_uint(nf);

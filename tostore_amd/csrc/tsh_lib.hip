@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/tostore_hip.h"
+#include "tsh_batch.hip.h"
 #include "tsh_kernels.hip.h"
 
 using namespace tsh;
@@ -262,6 +263,7 @@ struct Shard {
   int64_t cap = 0;       // allocated rows (multiple of 64)
   float *d_rows = nullptr;
   float *d_inv_norm = nullptr;
+  float *d_sqnorm = nullptr;  // |row|^2 (batched L2 key)
   uint64_t *d_live = nullptr;
   IngestStats *d_stats = nullptr;
   uint32_t *d_tmp_u32 = nullptr;
@@ -287,6 +289,7 @@ struct Shard {
 
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   int64_t bytes = 0;
+  struct BatchCtx *batch = nullptr;  // matrix-core path scratch (created with the shard)
 
   bool safe_mode() const {
     if (nonfinite_rows) return true;
@@ -311,14 +314,16 @@ int shard_reserve(Shard *s, int64_t want_rows) {
   int64_t ncap = std::max<int64_t>(round_up(want_rows, 64), 64);
   if (s->cap > 0) ncap = std::max<int64_t>(ncap, round_up(s->cap + s->cap / 2, 64));
   HIPCHK(hipSetDevice(s->device));
-  float *nrows = nullptr, *ninv = nullptr;
+  float *nrows = nullptr, *ninv = nullptr, *nsq = nullptr;
   uint64_t *nlive = nullptr;
   size_t row_bytes = (size_t)ncap * (size_t)s->ld * sizeof(float);
   HIPCHK(hipMalloc(&nrows, row_bytes));
   if (hipMalloc(&ninv, (size_t)ncap * sizeof(float)) != hipSuccess ||
+      hipMalloc(&nsq, (size_t)ncap * sizeof(float)) != hipSuccess ||
       hipMalloc(&nlive, (size_t)(ncap / 64) * sizeof(uint64_t)) != hipSuccess) {
     hipFree(nrows);
     if (ninv) hipFree(ninv);
+    if (nsq) hipFree(nsq);
     return set_err(TSH_E_OOM, "hipMalloc failed for %lld rows", (long long)ncap);
   }
   hipStream_t st = s->ingest_stream;
@@ -327,21 +332,25 @@ int shard_reserve(Shard *s, int64_t want_rows) {
     HIPCHK(hipMemcpyAsync(nrows, s->d_rows, old_bytes, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(ninv, s->d_inv_norm, (size_t)s->cap * sizeof(float),
                           hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(nsq, s->d_sqnorm, (size_t)s->cap * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(nlive, s->d_live, (size_t)(s->cap / 64) * sizeof(uint64_t),
                           hipMemcpyDeviceToDevice, st));
   }
   // rows past the old capacity read as zeros until written (tiles are whole)
   HIPCHK(hipMemsetAsync((char *)nrows + old_bytes, 0, row_bytes - old_bytes, st));
   HIPCHK(hipMemsetAsync(ninv + s->cap, 0, (size_t)(ncap - s->cap) * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(nsq + s->cap, 0, (size_t)(ncap - s->cap) * sizeof(float), st));
   HIPCHK(hipMemsetAsync(nlive + s->cap / 64, 0, (size_t)((ncap - s->cap) / 64) * sizeof(uint64_t), st));
   HIPCHK(hipStreamSynchronize(st));
   if (s->d_rows) hipFree(s->d_rows);
   if (s->d_inv_norm) hipFree(s->d_inv_norm);
+  if (s->d_sqnorm) hipFree(s->d_sqnorm);
   if (s->d_live) hipFree(s->d_live);
   s->d_rows = nrows;
   s->d_inv_norm = ninv;
+  s->d_sqnorm = nsq;
   s->d_live = nlive;
-  s->bytes += (int64_t)(row_bytes - old_bytes) + (ncap - s->cap) * 4 + (ncap - s->cap) / 8;
+  s->bytes += (int64_t)(row_bytes - old_bytes) + (ncap - s->cap) * 8 + (ncap - s->cap) / 8;
   s->cap = ncap;
   return TSH_OK;
 }
@@ -362,7 +371,7 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
                             (size_t)s->dim * sizeof(float), (size_t)n, kind, st));
   }
   int blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);
-  ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_stats);
+  ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_sqnorm, s->d_stats);
   int lb = (int)std::min<int64_t>(((first + n - 1) / 64 - first / 64 + 1 + 255) / 256, 1024);
   live_range_kernel<<<lb, 256, 0, st>>>(s->d_live, first, n, 1);
   IngestStats hs;
@@ -799,6 +808,291 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   return TSH_OK;
 }
 
+// ---- batched (matrix-core) path ---------------------------------------------------
+struct BatchCtx {
+  std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
+  float *d_Q = nullptr, *h_Q = nullptr;
+  float *d_qaux = nullptr, *h_qaux = nullptr;  // [qsq | delta2 | thr] x nq_pad
+  int64_t q_cap = 0, aux_cap = 0, cc_cap = 0;  // element capacities
+  float *d_dense = nullptr;
+  int64_t dense_cap = 0;  // floats
+  uint32_t *d_ck = nullptr, *d_cr = nullptr, *d_cc = nullptr;
+  int64_t cand_total = 0;  // nq * cand_cap capacity
+  uint8_t *d_blocks = nullptr, *h_blocks = nullptr;
+  uint32_t *d_final = nullptr;
+  int64_t blocks_cap = 0, final_cap = 0;
+  uint64_t *d_mask = nullptr, *h_mask = nullptr;
+  int64_t mask_words = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
+  int64_t bytes = 0;
+  double last_gemm_us = 0, last_flops = 0;
+};
+
+void batch_free(BatchCtx *b) {
+  hipFree(b->d_Q);
+  hipHostFree(b->h_Q);
+  hipFree(b->d_qaux);
+  hipHostFree(b->h_qaux);
+  hipFree(b->d_dense);
+  hipFree(b->d_ck);
+  hipFree(b->d_cr);
+  hipFree(b->d_cc);
+  hipFree(b->d_blocks);
+  hipHostFree(b->h_blocks);
+  hipFree(b->d_final);
+  hipFree(b->d_mask);
+  hipHostFree(b->h_mask);
+  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done})
+    if (e) hipEventDestroy(e);
+}
+
+template <typename T>
+int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
+  if (want <= *cap) return TSH_OK;
+  hipFree(*dev);
+  *dev = nullptr;
+  if (host) {
+    hipHostFree(*host);
+    *host = nullptr;
+  }
+  HIPCHK(hipMalloc(dev, (size_t)want * sizeof(T)));
+  if (host) HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
+  *bytes += (want - *cap) * (int64_t)sizeof(T);
+  *cap = want;
+  return TSH_OK;
+}
+
+template <int METRIC>
+void launch_batch_score(const BatchArgs &a, bool dense, hipStream_t st) {
+  int grid = a.q_tiles * a.n_tiles;
+  if (grid <= 0) return;
+  if (dense) batch_score_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
+  else batch_score_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
+}
+void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st) {
+  if (metric == TSH_METRIC_L2) launch_batch_score<METRIC_L2>(a, dense, st);
+  else if (metric == TSH_METRIC_IP) launch_batch_score<METRIC_IP>(a, dense, st);
+  else launch_batch_score<METRIC_COS>(a, dense, st);
+}
+
+// 2 * (error bound of the f32 MFMA key), absolute, per query
+bool batch_delta2(const Shard *s, const float *q, float *out_delta2, float *out_qsq) {
+  double qn2 = 0;
+  for (int i = 0; i < s->dim; ++i) {
+    float a = std::fabs(q[i]);
+    if (!(a <= BIG_ABS)) return false;
+    qn2 += (double)q[i] * (double)q[i];
+  }
+  const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
+  const double u2 = 1.1920928955078125e-07;        // 2^-23
+  const double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
+  double delta;
+  if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
+  else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07);
+  else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
+  delta += (double)s->dim * 7.5e-37;
+  double d2 = 2.0 * delta * 1.0001;
+  if (!(d2 < 1e30)) return false;
+  *out_delta2 = (float)d2;
+  if ((double)*out_delta2 < d2) *out_delta2 = std::nextafter(*out_delta2, INFINITY);
+  *out_qsq = (float)qn2;
+  return true;
+}
+
+// All nq queries in one pass over the rows on the matrix cores.  Queries the
+// error model cannot cover, or whose lists overflow (ties), are reported in
+// *redo and answered by the single-query path.  Caller holds s->mu shared.
+int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
+                       const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo) {
+  std::lock_guard<std::mutex> lk(b->mu);
+  HIPCHK(hipSetDevice(s->device));
+  const int64_t rows = s->rows, ld = s->ld;
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  const int32_t nq_pad = (int32_t)round_up(nq, BT_M);
+  int64_t n_sample = rows;
+  if (rows > 16384) n_sample = std::min<int64_t>(rows, std::max<int64_t>(round_up(rows / 32, BT_N), 8192));
+  if (n_sample < (int64_t)k * 4) n_sample = std::min<int64_t>(rows, round_up((int64_t)k * 4, BT_N));
+  const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
+  const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
+  if (!b->e0) {
+    for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
+    HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming));
+  }
+  int rc;
+  if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 3, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
+  {
+    int64_t want = (int64_t)nq * cand_cap, c1 = b->cand_total, c2 = b->cand_total;
+    if ((rc = regrow(&b->d_ck, (uint32_t **)nullptr, &c1, want, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_cr, (uint32_t **)nullptr, &c2, want, &b->bytes))) return rc;
+    b->cand_total = std::max(b->cand_total, want);
+    if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad, &b->bytes))) return rc;
+  }
+  if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
+  const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
+  if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
+
+  // ---- host prep: padded queries, per-query bands ------------------------------------
+  float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
+  std::vector<char> bad((size_t)nq, 0);
+  for (int32_t q = 0; q < nq_pad; ++q) {
+    float *dst = b->h_Q + (size_t)q * ld;
+    if (q < nq) {
+      memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
+      for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
+      if (!batch_delta2(s, dst, &h_d2[q], &h_qsq[q])) {
+        bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
+        memset(dst, 0, (size_t)ld * sizeof(float));
+        h_d2[q] = 0.f;
+        h_qsq[q] = 0.f;
+      }
+    } else {
+      memset(dst, 0, (size_t)ld * sizeof(float));
+      h_d2[q] = 0.f;
+      h_qsq[q] = 0.f;
+    }
+  }
+  if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
+
+  // ---- enqueue on the shard's pipeline stream ------------------------------------------
+  {
+    std::lock_guard<std::mutex> sl(s->scan_mu);
+    hipStream_t st = s->scan_stream;
+    HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
+    float *d_qsq = b->d_qaux, *d_d2 = b->d_qaux + nq_pad, *d_thr = b->d_qaux + 2 * (size_t)nq_pad;
+    BatchArgs a{};
+    a.Q = b->d_Q;
+    a.V = s->d_rows;
+    a.inv_norm = s->d_inv_norm;
+    a.sqnorm = s->d_sqnorm;
+    a.qsq = d_qsq;
+    a.thr = d_thr;
+    a.live = s->all_live ? nullptr : s->d_live;
+    a.mask = mask ? b->d_mask : nullptr;
+    a.dense = b->d_dense;
+    a.cand_key = b->d_ck;
+    a.cand_row = b->d_cr;
+    a.cand_cnt = b->d_cc;
+    a.ld = ld;
+    a.dense_ld = n_sample;
+    a.nq = nq;
+    a.nq_pad = nq_pad;
+    a.kchunks = (int32_t)((ld + BT_K - 1) / BT_K);
+    a.cand_cap = cand_cap;
+    a.q_tiles = nq_pad / BT_M;
+    // B0: dense keys of the sample rows
+    a.row0 = 0;
+    a.row1 = (int32_t)n_sample;
+    a.n_tiles = (int32_t)((n_sample + BT_N - 1) / BT_N);
+    HIPCHK(hipEventRecord(b->e0, st));
+    launch_batch_score_m(s->metric, a, true, st);
+    HIPCHK(hipEventRecord(b->e1, st));
+    // B0s: per-query threshold + the sample's own candidates
+    SampleSelArgs ss{};
+    ss.dense = b->d_dense;
+    ss.delta2 = d_d2;
+    ss.thr = d_thr;
+    ss.cand_key = b->d_ck;
+    ss.cand_row = b->d_cr;
+    ss.cand_cnt = b->d_cc;
+    ss.dense_ld = n_sample;
+    ss.n_sample = (int32_t)n_sample;
+    ss.k = k;
+    ss.cand_cap = cand_cap;
+    ss.row0 = 0;
+    batch_sample_select_kernel<<<nq, BS_THREADS, 0, st>>>(ss);
+    // B1: everything else, filtered
+    HIPCHK(hipEventRecord(b->e2, st));
+    if (rows > n_sample) {
+      a.row0 = (int32_t)n_sample;
+      a.row1 = (int32_t)rows;
+      a.n_tiles = (int32_t)((rows - n_sample + BT_N - 1) / BT_N);
+      launch_batch_score_m(s->metric, a, false, st);
+    }
+    HIPCHK(hipEventRecord(b->e3, st));
+    // B2 + rerank
+    FinalSelArgs fs{};
+    fs.cand_key = b->d_ck;
+    fs.cand_row = b->d_cr;
+    fs.cand_cnt = b->d_cc;
+    fs.delta2 = d_d2;
+    fs.blocks = b->d_blocks;
+    fs.final_rows = b->d_final;
+    fs.block_bytes = (int64_t)bb;
+    fs.row_base = s->row_base;
+    fs.shard_rows = rows;
+    fs.k = k;
+    fs.cand_cap = cand_cap;
+    fs.entries = entries;
+    fs.metric = s->metric;
+    batch_final_select_kernel<<<nq, BS_THREADS, 0, st>>>(fs);
+    RerankBatchArgs rb{};
+    rb.rows = s->d_rows;
+    rb.Q = b->d_Q;
+    rb.final_rows = b->d_final;
+    rb.blocks = b->d_blocks;
+    rb.block_bytes = (int64_t)bb;
+    rb.ld = ld;
+    rb.row_base = s->row_base;
+    rb.dim = s->dim;
+    rb.entries = entries;
+    rb.metric = s->metric;
+    rerank_batch_kernel<<<dim3((unsigned)std::min(entries, 160), (unsigned)nq), 64, 0, st>>>(rb);
+    HIPCHK(hipMemcpyAsync(b->h_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(b->e_done, st));
+  }
+  HIPCHK(hipEventSynchronize(b->e_done));
+  HIPCHK(hipGetLastError());
+  float ms0 = 0.f, ms1 = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
+  HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
+  b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
+  b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  s->c_batches++;
+  for (int32_t q = 0; q < nq; ++q) {
+    const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
+    if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) redo->push_back(q);
+    else s->c_cands += h->count;
+  }
+  s->c_searches += nq - (int64_t)redo->size();
+  if (out->h_blocks) memcpy(out->h_blocks, b->h_blocks, (size_t)nq * bb);
+  if (out->d_blocks) {
+    hipStream_t us = out->user_stream ? out->user_stream : s->scan_stream;
+    HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
+    HIPCHK(hipStreamSynchronize(us));
+  }
+  return TSH_OK;
+}
+
+// nq queries on one shard: matrix-core batch when it pays, single-query pipeline
+// otherwise and for whatever the batch hands back.
+int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
+                     const uint8_t *mask, int32_t entries, SearchOut *out) {
+  const bool use_batch = batch_min_nq > 0 && nq >= batch_min_nq && !s->safe_mode() && s->rows >= 4096 &&
+                         k <= 1024 && s->rows < 0x7FFFFF00ll;
+  if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
+  std::vector<int32_t> redo;
+  int rc = shard_search_batch(s, b, queries, nq, k, mask, entries, out, &redo);
+  if (rc) return rc;
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  for (int32_t q : redo) {
+    SearchOut one;
+    std::vector<std::vector<BlockEntry>> sp(1);
+    one.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q * bb : nullptr;
+    one.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr;
+    one.user_stream = out->user_stream;
+    one.spill = out->spill ? &sp : nullptr;
+    rc = shard_search_blocks(s, queries + (size_t)q * s->dim, 1, k, mask, entries, &one, 1);
+    if (rc) return rc;
+    if (out->spill) (*out->spill)[(size_t)q] = std::move(sp[0]);
+  }
+  return TSH_OK;
+}
+
 }  // namespace
 
 // ============================================================================
@@ -818,6 +1112,7 @@ struct tsh_index {
   std::mutex mu;  // serialises append routing
   std::mutex tk_mu;
   std::vector<std::unique_ptr<Ticket>> tickets;
+  std::atomic<int32_t> batch_min_nq{8};  // nq at which tsh_search switches to the matrix-core path
 };
 
 namespace {
@@ -833,6 +1128,7 @@ int make_shard(int dim, int metric, int device, int64_t row_base, int64_t cap_ro
   s->row_base = row_base;
   int rc = shard_init(s.get());
   if (rc) return rc;
+  s->batch = new BatchCtx();
   if (cap_rows > 0) {
     rc = shard_reserve(s.get(), cap_rows);
     if (rc) return rc;
@@ -844,10 +1140,16 @@ int make_shard(int dim, int metric, int device, int64_t row_base, int64_t cap_ro
 void shard_destroy(Shard *s) {
   hipSetDevice(s->device);
   for (auto &c : s->ctx_all) ctx_free_all(c.get());
+  if (s->batch) {
+    batch_free(s->batch);
+    delete s->batch;
+    s->batch = nullptr;
+  }
   if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
   if (s->scan_stream) hipStreamDestroy(s->scan_stream);
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
+  hipFree(s->d_sqnorm);
   hipFree(s->d_live);
   hipFree(s->d_stats);
   hipFree(s->d_tmp_u32);
@@ -1066,7 +1368,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     SearchOut so;
     so.h_blocks = blocks[g].data();
     so.spill = &spills[g];
-    rcs[g] = shard_search_blocks(s, queries, nq, k, row_mask, entries, &so, PIPE_DEPTH);
+    rcs[g] = shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
     if (rcs[g]) errs[g] = g_err;
   };
   if (ns == 1) {
@@ -1230,7 +1532,7 @@ int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32
   SearchOut so;
   so.d_blocks = static_cast<uint8_t *>(d_out_blocks);
   so.user_stream = static_cast<hipStream_t>(stream);
-  return shard_search_blocks(s, queries, nq, k, row_mask, entries, &so, PIPE_DEPTH);
+  return shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
 }
 
 int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries, int32_t nq, int32_t k,
@@ -1337,8 +1639,38 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   return TSH_OK;
 }
 
-int32_t tsh_bench_batch(tsh_index *, const float *, int32_t, int32_t, double *) {
-  return set_err(TSH_E_BAD_ARG, "batched path not built yet");
+int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
+  if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  if (option == TSH_OPT_BATCH_MIN_NQ) {
+    if (value < 0 || value > (1 << 20)) return set_err(TSH_E_BAD_ARG, "batch_min_nq out of range");
+    idx->batch_min_nq = (int32_t)value;
+    return TSH_OK;
+  }
+  return set_err(TSH_E_BAD_ARG, "unknown option %d", option);
+}
+
+int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_t k, int32_t iters,
+                        double *out_avg_gemm_us, double *out_flops) {
+  if (!idx || idx->shards.size() != 1 || !queries || nq <= 0 || k <= 0 || iters <= 0 || !out_avg_gemm_us)
+    return set_err(TSH_E_BAD_ARG, "bad arguments");
+  Shard *s = idx->shards[0].get();
+  std::shared_lock<RwLock> sl(s->mu);
+  if (s->rows == 0) return set_err(TSH_E_BAD_ARG, "empty index");
+  if (s->safe_mode()) return set_err(TSH_E_BAD_ARG, "index is in safe mode: no batched path");
+  int32_t entries = tsh_default_block_entries(k);
+  std::vector<uint8_t> blocks((size_t)tsh_candidate_block_bytes(entries) * (size_t)nq);
+  double acc = 0;
+  for (int32_t i = 0; i < iters; ++i) {
+    SearchOut so;
+    so.h_blocks = blocks.data();
+    std::vector<int32_t> redo;
+    int rc = shard_search_batch(s, s->batch, queries, nq, k, nullptr, entries, &so, &redo);
+    if (rc) return rc;
+    acc += s->batch->last_gemm_us;
+  }
+  *out_avg_gemm_us = acc / iters;
+  if (out_flops) *out_flops = s->batch->last_flops;
+  return TSH_OK;
 }
 
 }  // extern "C"
