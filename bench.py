@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--metric", default="l2", choices=["l2", "ip", "cosine"])
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent single-query searches kept in flight (1 = strictly one at a time)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--batch", type=int, default=0,
@@ -118,11 +118,26 @@ def bench_batch(a, idx, host_rows, metric, world, rank):
     c = idx.counters()
     out["counters"] = {k2: c[k2] for k2 in ("batch_launches", "scan_launches", "fallback_searches")}
     idx.close()
-    print(json.dumps(out))
+    return json.dumps(out)
 
 
 def main():
     a = parse()
+    # stdout must carry exactly ONE JSON line: park fd 1 on stderr while libraries
+    # (RCCL prints a version banner) run, and write the line to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run_bench(a)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+    if line is not None:
+        os.write(1, (line + "\n").encode())
+
+
+def run_bench(a):
     import torch
 
     from tostore_amd import HipVectorIndex, _ffi
@@ -168,6 +183,7 @@ def main():
     nq_total = a.warmup + a.steps
     queries = make_queries(max(nq_total, 1), d, metric)
     searcher = ShardedSearcher(idx) if dist is not None else None
+    idx.set_batch_min_nq(0)  # headline workload: every query scans the corpus on its own (no MFMA batching)
 
     def one(i):
         q = queries[i % len(queries)]
@@ -317,8 +333,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     idx.close()
-    if rank == 0:
-        print(json.dumps(out))
+    return json.dumps(out) if rank == 0 else None
 
 
 if __name__ == "__main__":

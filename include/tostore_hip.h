@@ -186,8 +186,9 @@ int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double distance_threshol
 int64_t tsh_candidate_block_bytes(int32_t entries);
 int32_t tsh_default_block_entries(int32_t k);
 /* d_out_blocks: device buffer of nq * tsh_candidate_block_bytes(entries) on the
- * handle's device.  stream: hipStream_t to order the final device-to-device
- * copy on (NULL = library stream, synchronised before return).
+ * handle's device; the kernels store the blocks into it directly and the call
+ * returns after they completed (host-synchronised), so any stream may read it
+ * next.  stream: reserved (pass NULL or the consumer's hipStream_t).
  * row_mask is GLOBAL (bit = global row id). */
 int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                          const uint8_t *row_mask, int32_t entries, void *d_out_blocks,

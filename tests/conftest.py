@@ -23,6 +23,14 @@ def oracle_mod():
 @pytest.fixture(scope="session")
 def hip_lib():
     """The product library; GPU tests fail loudly when it is missing or sees no device."""
+    # torch bundles its own ROCm runtime: when both live in one process torch must
+    # initialise first, or its HSA copy finds the device already claimed
+    try:
+        import torch
+
+        torch.cuda.is_available() and torch.cuda.init()
+    except ImportError:
+        pass
     from tostore_amd import _ffi
 
     L = _ffi.lib()

@@ -160,7 +160,10 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   constexpr int G = 8 / R;  // groups per batch
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int stride = gridDim.x * WAVES;
+  // WAVES bounds the workgroup size; small shards are launched with one wave
+  // per workgroup so the dispatcher can balance tiles across CUs
+  const int wpb = __builtin_amdgcn_readfirstlane((int)blockDim.x >> 6);
+  const int stride = gridDim.x * wpb;
   const bool tail_ok = FULL || (NCH - 1) * 64 + lane < a.d4;
   const int tail_off = tail_ok ? (NCH - 1) * 256 : 0;
 
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
         *reinterpret_cast<f32x4 *>(a.query_out + 4 * lane + c * 256) = q[c];
   }
 
-  for (int t = blockIdx.x * WAVES + wave; t < a.n_tiles; t += stride) {
+  for (int t = blockIdx.x * wpb + wave; t < a.n_tiles; t += stride) {
     const float *tbase = a.rows + (int64_t)t * 64 * a.ld + 4 * lane;
     uint64_t bits = ~0ull;
     int cnt = 64;

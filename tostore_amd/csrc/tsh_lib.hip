@@ -60,7 +60,7 @@ int device_count_cached() {
 }
 
 constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
-constexpr int PIPE_DEPTH = 4;         // queries a multi-query call keeps in flight
+constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
 constexpr int MAX_DIM_SCAN = 2048;    // register-resident query (NCH <= 8)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
 
@@ -162,7 +162,9 @@ template <int NCH, bool MASKED> struct ScanTune {
 template <int NCH, int METRIC, bool FULL, bool MASKED>
 void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s) {
   using T = ScanTune<NCH, MASKED>;
-  scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<grid, 256, 0, s>>>(a);
+  // grid > 0: 4-wave workgroups; grid < 0: -grid one-wave workgroups (small shards)
+  if (grid > 0) scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<grid, 256, 0, s>>>(a);
+  else scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<-grid, 64, 0, s>>>(a);
 }
 template <int NCH, int METRIC>
 void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s) {
@@ -184,6 +186,9 @@ void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStr
 void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s) {
   int grid = (a.a.n_tiles + 3) / 4;
   if (grid < 1) grid = 1;
+  // fewer than ~6 four-wave workgroups per CU: tile counts per CU differ by tens of
+  // percent; one tile per workgroup lets the dispatcher even them out
+  if (a.a.n_tiles < 6 * 4 * 256) grid = -std::max(1, (int)a.a.n_tiles);
   switch (nch) {
     case 1: launch_scan_n<1>(a, metric, masked, grid, s); break;
     case 2: launch_scan_n<2>(a, metric, masked, grid, s); break;
@@ -231,7 +236,8 @@ class RwLock {
 struct Ctx {
   hipStream_t stream = nullptr;  // input upload, result copy, fallback path
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t ev_done = nullptr;  // recorded on the pipeline stream after a job's last kernel
+  hipEvent_t ev_done = nullptr;  // recorded after a job's last kernel
+  hipEvent_t ev_scanned = nullptr;  // scan stream -> tail stream hand-off
   uint8_t *h_block_dev = nullptr;  // device-side address of h_block (zero-copy result stores)
   float *d_query = nullptr;  // ld floats
   float *h_query = nullptr;  // pinned, ld floats
@@ -277,6 +283,11 @@ struct Shard {
   // (Running a query's tail beside the next query's scan was measured 10-25x
   // slower per tail: each dependent load queues behind the scan's loads.)
   hipStream_t scan_stream = nullptr;
+  // When several queries are in flight, a query's select + rerank run here, on
+  // CUs the scan stream's CU mask leaves free (2 per XCD), so they overlap the
+  // next query's scan without queueing behind its loads on the same CU.
+  hipStream_t tail_stream = nullptr;
+  bool cu_split = false;
   std::mutex scan_mu;
   std::atomic<int> inflight{0};
 
@@ -302,7 +313,30 @@ struct Shard {
 int shard_init(Shard *s) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipStreamCreateWithFlags(&s->ingest_stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&s->scan_stream, hipStreamNonBlocking));
+  {
+    // CU mask bit i = CU slot i/8 of XCD i%8 on MI355X (measured, tools/cumask_probe.hip):
+    // bits 0..15 = two CUs of every XCD, reserved for the tails.
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, s->device));
+    const char *env = getenv("TSH_NO_CU_SPLIT");
+    int cus = prop.multiProcessorCount;
+    if (!(env && env[0] == '1') && cus >= 64 && cus % 32 == 0) {
+      std::vector<uint32_t> scan_mask((size_t)cus / 32, 0xFFFFFFFFu), tail_mask((size_t)cus / 32, 0u);
+      scan_mask[0] = 0xFFFF0000u;
+      tail_mask[0] = 0x0000FFFFu;
+      if (hipExtStreamCreateWithCUMask(&s->scan_stream, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&s->tail_stream, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
+        s->cu_split = true;
+      } else {
+        if (s->scan_stream) hipStreamDestroy(s->scan_stream);
+  if (s->tail_stream) hipStreamDestroy(s->tail_stream);
+        if (s->tail_stream) hipStreamDestroy(s->tail_stream);
+        s->scan_stream = s->tail_stream = nullptr;
+        (void)hipGetLastError();
+      }
+    }
+    if (!s->cu_split) HIPCHK(hipStreamCreateWithFlags(&s->scan_stream, hipStreamNonBlocking));
+  }
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
   HIPCHK(hipMalloc(&s->d_tmp_u32, 64));
@@ -393,6 +427,7 @@ void ctx_free_all(Ctx *c) {
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->ev_done) hipEventDestroy(c->ev_done);
+  if (c->ev_scanned) hipEventDestroy(c->ev_scanned);
   hipFree(c->d_query);
   hipHostFree(c->h_query);
   hipFree(c->d_mask);
@@ -416,6 +451,7 @@ int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_scanned, hipEventDisableTiming));
     HIPCHK(hipMalloc(&c->d_query, (size_t)s->ld * sizeof(float)));
     HIPCHK(hipHostMalloc(&c->h_query, (size_t)s->ld * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipMalloc(&c->d_big_count, 64));
@@ -569,8 +605,8 @@ struct Job {
   Ctx *c = nullptr;
   int32_t k = 0, entries = 0;
   bool masked = false, user_mask = false;
-  bool device_result = false;  // entries go to c->d_block (shard mode) instead of pinned host
-  bool counted = false;        // contributes to Shard::inflight
+  uint8_t *dev_target = nullptr;  // shard mode: caller's device block (header + entries land there)
+  bool counted = false;           // contributes to Shard::inflight
 };
 
 void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
@@ -581,7 +617,7 @@ void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
 // mask_words: this shard's slice of the caller mask (host), or NULL; epoch
 // identifies it so a context uploads it once per call
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
-                const uint64_t *mask_words, uint64_t epoch, bool device_result) {
+                const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target) {
   Ctx *c = j->c;
   int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
   if (rc) return rc;
@@ -590,7 +626,8 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   j->entries = entries;
   j->user_mask = mask_words != nullptr;
   j->masked = j->user_mask || !s->all_live;
-  j->device_result = device_result;
+  j->dev_target = dev_target;
+  uint8_t *dev_block = dev_target ? dev_target : c->d_block;  // where the device header lives
   const bool upload_mask = mask_words && c->mask_epoch != epoch;
   if (upload_mask) {
     memcpy(c->h_mask, mask_words, (size_t)n_tiles * 8);
@@ -610,7 +647,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   SelectArgs se{};
   se.gmin = c->d_gmin;
   se.keys = c->d_keys;
-  se.hdr = reinterpret_cast<BlockHeader *>(c->d_block);
+  se.hdr = reinterpret_cast<BlockHeader *>(dev_block);
   se.hdr_host = reinterpret_cast<BlockHeader *>(c->h_block_dev);
   se.cand_rows = c->d_cand;
   se.n_tiles = n_tiles;
@@ -627,13 +664,15 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   ra.query = c->d_query;
   ra.cand_rows = c->d_cand;
   ra.count_ptr = &se.hdr->count;
-  ra.out = reinterpret_cast<BlockEntry *>((device_result ? c->d_block : c->h_block_dev) + sizeof(BlockHeader));
+  ra.out = reinterpret_cast<BlockEntry *>((dev_target ? dev_target : c->h_block_dev) + sizeof(BlockHeader));
   ra.ld = s->ld;
   ra.row_base = s->row_base;
   ra.dim = s->dim;
   ra.cap = entries;
   ra.metric = s->metric;
-  s->inflight.fetch_add(1);
+  // with other queries already in flight the tail moves to the reserved CUs;
+  // a lone query keeps everything in order on one stream (no hand-off latency)
+  const bool overlap = s->inflight.fetch_add(1) > 0 && s->cu_split;
   j->counted = true;
   {
     std::lock_guard<std::mutex> lk(s->scan_mu);
@@ -643,9 +682,15 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     if (!inline_q)
       HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
     launch_scan(sa, s->nch, s->metric, j->masked, ps);
-    launch_select(se, n_tiles, ps);
-    rerank_kernel<<<std::min(entries, 1024), 64, 0, ps>>>(ra);
-    HIPCHK(hipEventRecord(c->ev_done, ps));
+    hipStream_t ts = ps;
+    if (overlap) {
+      ts = s->tail_stream;
+      HIPCHK(hipEventRecord(c->ev_scanned, ps));
+      HIPCHK(hipStreamWaitEvent(ts, c->ev_scanned, 0));
+    }
+    launch_select(se, n_tiles, ts);
+    rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
+    HIPCHK(hipEventRecord(c->ev_done, ts));
   }
   s->c_scans++;
   return TSH_OK;
@@ -692,11 +737,11 @@ int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *s
   BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_block);
   h->count = count;
   h->flags = count > (uint32_t)j->entries ? FLAG_LIST_OVERFLOW : 0u;
-  HIPCHK(hipMemcpyAsync(c->d_block, h, sizeof *h, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j->dev_target ? j->dev_target : c->d_block, h, sizeof *h, hipMemcpyHostToDevice, st));
   uint32_t fit = std::min<uint32_t>(count, (uint32_t)j->entries);
   if (fit) {
-    if (j->device_result)
-      HIPCHK(hipMemcpyAsync(c->d_block + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
+    if (j->dev_target)
+      HIPCHK(hipMemcpyAsync(j->dev_target + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
                             hipMemcpyDeviceToDevice, st));
     else
       HIPCHK(hipMemcpyAsync(c->h_block + sizeof(BlockHeader), c->d_big_entries, (size_t)fit * sizeof(BlockEntry),
@@ -776,7 +821,8 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
       Job &j = jobs[(size_t)(submitted % depth)];
       j.c = ctx_acquire(s, true);
       rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries,
-                       mask ? mask_words.data() : nullptr, epoch, out->d_blocks != nullptr);
+                       mask ? mask_words.data() : nullptr, epoch,
+                       out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr);
       if (rc) {
         release_all();
         return rc;
@@ -791,16 +837,6 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
       return rc;
     }
     if (out->h_blocks) memcpy(out->h_blocks + (size_t)finished * bb, j.c->h_block, bb);
-    if (out->d_blocks) {
-      hipStream_t us = out->user_stream ? out->user_stream : j.c->stream;
-      hipError_t e = hipMemcpyAsync(out->d_blocks + (size_t)finished * bb, j.c->d_block, bb,
-                                    hipMemcpyDeviceToDevice, us);
-      if (e == hipSuccess) e = hipStreamSynchronize(us);  // the context is reused right away
-      if (e != hipSuccess) {
-        release_all();
-        return set_err(TSH_E_HIP, "block copy: %s", hipGetErrorString(e));
-      }
-    }
     ctx_release(s, j.c);
     j.c = nullptr;
     ++finished;
@@ -1147,6 +1183,7 @@ void shard_destroy(Shard *s) {
   }
   if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
   if (s->scan_stream) hipStreamDestroy(s->scan_stream);
+  if (s->tail_stream) hipStreamDestroy(s->tail_stream);
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
   hipFree(s->d_sqnorm);
@@ -1435,7 +1472,7 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
       slice_mask(s, row_mask, words.data(), n_tiles);
       epoch = s->mask_epoch_src.fetch_add(1);
     }
-    rc = job_enqueue(s, &t->jobs[g], query, k, t->entries, row_mask ? words.data() : nullptr, epoch, false);
+    rc = job_enqueue(s, &t->jobs[g], query, k, t->entries, row_mask ? words.data() : nullptr, epoch, nullptr);
   }
   if (rc != TSH_OK) {
     std::string keep = g_err;
