@@ -199,10 +199,10 @@ def run_bench(a):
             for i in range(count):
                 one(first + i)
         elif searcher is not None:
-            # N > 1: groups of `inflight` queries share one all-gather + one merge call
-            for g0 in range(0, count, a.inflight):
-                ids = [(first + g0 + j) % len(queries) for j in range(min(a.inflight, count - g0))]
-                searcher.search(queries[ids], k)
+            # N > 1: groups of `inflight` queries share one all-gather + one merge call, and the
+            # next group's shard scans run while this group is exchanged and merged
+            sel = [(first + j) % len(queries) for j in range(count)]
+            searcher.search_many(queries[sel], k, group=max(16, a.inflight))
         else:
             from collections import deque
             pend = deque()
@@ -289,7 +289,8 @@ def run_bench(a):
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: %dx%d f32, %s, k=%d, single query per step" % (n, d, a.metric, k),
-                       "rows": n, "dim": d, "k": k, "metric": a.metric, "queries_in_flight": a.inflight,
+                       "rows": n, "dim": d, "k": k, "metric": a.metric,
+                       "queries_in_flight": a.inflight if searcher is None else max(16, a.inflight),
                        "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -65,7 +65,9 @@ struct Variant {
 
 template <int NCH, int METRIC, bool FULL, bool MASKED, int R, bool NT, int WAVES, int MINW>
 void launch_v(const ScanArgs &a, int grid, hipStream_t s) {
-  scan_kernel<NCH, METRIC, FULL, MASKED, R, NT, WAVES, MINW><<<grid, WAVES * 64, 0, s>>>(a);
+  static ScanArgsQ aq;  // query passed by pointer here (a.query != NULL), q[] unused
+  aq.a = a;
+  scan_kernel<NCH, METRIC, FULL, MASKED, R, NT, WAVES, MINW><<<grid, WAVES * 64, 0, s>>>(aq);
 }
 
 #define V(NCH, R, NT, WAVES, MINW)                                                        \
@@ -103,7 +105,7 @@ int main(int argc, char **argv) {
   CK(hipMemset(live, 0xFF, cap / 64 * 8));
   CK(hipDeviceSynchronize());
   ScanArgs a;
-  a.rows = rows; a.query = query; a.inv_norm = inv; a.live = live; a.mask = nullptr;
+  a.rows = rows; a.query = query; a.query_out = nullptr; a.inv_norm = inv; a.live = live; a.mask = nullptr;
   a.keys = keys; a.gmin = gmin; a.ld = d; a.n = (int64_t)n; a.d4 = d / 4;
   a.n_tiles = (int)((n + 63) / 64);
   double bytes = (double)n * d * 4;

@@ -66,16 +66,83 @@ class ShardedSearcher:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._bufs = {}
 
-    def _buffers(self, nq: int, entries: int):
-        key = (nq, entries)
+    def _buffers(self, nq: int, entries: int, slot: int = 0):
+        key = (nq, entries, slot)
         if key not in self._bufs:
             t = self._torch
             bb = _ffi.lib().tsh_candidate_block_bytes(entries)
             mine = t.empty(nq * bb, dtype=t.uint8, device="cuda")
             allb = t.empty(self.world * nq * bb, dtype=t.uint8, device="cuda")
             host = t.empty(self.world * nq * bb, dtype=t.uint8, pin_memory=True)
-            self._bufs = {key: (mine, allb, host)}  # keep one shape resident
+            if len(self._bufs) > 8:
+                self._bufs.clear()
+            self._bufs[key] = (mine, allb, host)
         return self._bufs[key]
+
+    def _scan(self, q: np.ndarray, k: int, mp, entries: int, slot: int):
+        """This rank's shard: candidate blocks for the queries of one group, left in device memory."""
+        mine, _, _ = self._buffers(q.shape[0], entries, slot)
+        _ffi.check(_ffi.lib().tsh_search_shard(self.index._h, q.ctypes.data_as(_ffi.p_f32), q.shape[0], int(k), mp,
+                                               entries, ctypes.c_void_p(mine.data_ptr()), None))
+
+    def _exchange_merge(self, q: np.ndarray, k: int, thr, entries: int, slot: int):
+        t = self._torch
+        mine, allb, host = self._buffers(q.shape[0], entries, slot)
+        if self._dist.is_initialized():
+            self._dist.all_gather_into_tensor(allb, mine, group=self.group)
+        else:
+            allb = mine
+        host[: allb.numel()].copy_(allb, non_blocking=True)
+        t.cuda.current_stream().synchronize()
+        return merge_candidate_blocks(self.index.metric, self.index.dim, q, k, thr, host[: allb.numel()].numpy(),
+                                      self.world, entries)
+
+    def search_many(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None,
+                    group: int = 8):
+        """A stream of independent queries in groups: while the main thread all-gathers and merges
+        group g (collectives stay on one thread, in one order on every rank), a helper thread already
+        runs group g+1's shard scans (ctypes releases the GIL).  Same results as search()."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, kk = q.shape[0], max(int(k), 0)
+        ids = np.full((nq, kk), -1, dtype=np.int64)
+        dist = np.full((nq, kk), np.nan, dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        entries = _ffi.lib().tsh_default_block_entries(int(k))
+        mp = None
+        if row_mask is not None:
+            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
+            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        spans = [(s, min(nq, s + group)) for s in range(0, nq, group)]
+        if not spans:
+            return ids, dist, cnt
+        dev = self._torch.cuda.current_device()
+
+        def scan(span, slot):
+            self._torch.cuda.set_device(dev)  # the helper thread starts on device 0 otherwise
+            self._scan(q[span[0]:span[1]], k, mp, entries, slot)
+
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            fut = ex.submit(scan, spans[0], 0)
+            for g, (lo, hi) in enumerate(spans):
+                fut.result()
+                if g + 1 < len(spans):
+                    fut = ex.submit(scan, spans[g + 1], (g + 1) % 2)
+                try:
+                    i, d, c = self._exchange_merge(q[lo:hi], k, distance_threshold, entries, g % 2)
+                except _ffi.TshError as e:
+                    if e.code != _ffi.TSH_E_OVERFLOW:
+                        raise
+                    if g + 1 < len(spans):
+                        fut.result()  # keep the helper idle while this group is redone
+                    i, d, c = self.search(q[lo:hi], k, distance_threshold, row_mask)  # ties: bigger blocks
+                    if g + 1 < len(spans):
+                        fut = ex.submit(scan, spans[g + 1], (g + 1) % 2)
+                ids[lo:hi], dist[lo:hi], cnt[lo:hi] = i, d, c
+        return ids, dist, cnt
 
     def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
         t = self._torch
