@@ -68,6 +68,10 @@ typedef struct tsh_counters {
   int32_t safe_mode;         /* !=0: corpus values outside the f32 error model; every
                                 search re-ranks all rows in f64 (exact, slow) */
   int32_t device_id;
+  /* scan-kernel device time sampled with HIP events on the stream the kernel runs
+   * on, inside real searches (every 4th query): sum of microseconds / samples */
+  double scan_us_sum;
+  int64_t scan_us_samples;
 } tsh_counters;
 
 int32_t tsh_abi_version(void);

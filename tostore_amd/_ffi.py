@@ -42,6 +42,7 @@ class TshCounters(ctypes.Structure):
         ("scan_launches", c_i64), ("batch_launches", c_i64),
         ("fallback_searches", c_i64), ("candidates_total", c_i64),
         ("bytes_resident", c_i64), ("safe_mode", c_i32), ("device_id", c_i32),
+        ("scan_us_sum", c_f64), ("scan_us_samples", c_i64),
     ]
 
 

@@ -299,6 +299,8 @@ struct Shard {
   std::atomic<uint64_t> mask_epoch_src{1};
 
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
+  double scan_us_sum = 0;  // guarded by ctx_mu
+  int64_t scan_us_samples = 0;
   int64_t bytes = 0;
   struct BatchCtx *batch = nullptr;  // matrix-core path scratch (created with the shard)
 
@@ -606,6 +608,7 @@ struct Job {
   int32_t k = 0, entries = 0;
   bool masked = false, user_mask = false;
   uint8_t *dev_target = nullptr;  // shard mode: caller's device block (header + entries land there)
+  bool timed = false;             // ev0/ev1 bracket this job's scan kernel
   bool counted = false;           // contributes to Shard::inflight
 };
 
@@ -681,7 +684,10 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
     if (!inline_q)
       HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
+    j->timed = (s->c_scans.load() & 3) == 0;  // sample every 4th scan with timing events
+    if (j->timed) HIPCHK(hipEventRecord(c->ev0, ps));
     launch_scan(sa, s->nch, s->metric, j->masked, ps);
+    if (j->timed) HIPCHK(hipEventRecord(c->ev1, ps));
     hipStream_t ts = ps;
     if (overlap) {
       ts = s->tail_stream;
@@ -770,6 +776,15 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill) {
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipEventSynchronize(c->ev_done));
   HIPCHK(hipGetLastError());
+  if (j->timed) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
+      std::lock_guard<std::mutex> lk(s->ctx_mu);
+      s->scan_us_sum += (double)ms * 1e3;
+      s->scan_us_samples++;
+    }
+    j->timed = false;
+  }
   BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_block);
   if (h->flags & FLAG_LIST_OVERFLOW) {
     int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
@@ -1628,6 +1643,8 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     {
       std::lock_guard<std::mutex> lk(s->ctx_mu);
       for (auto &c : s->ctx_all) b += c->bytes;
+      out->scan_us_sum += s->scan_us_sum;
+      out->scan_us_samples += s->scan_us_samples;
     }
     out->bytes_resident += b;
     if (s->safe_mode()) out->safe_mode = 1;
