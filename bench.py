@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0,
                     help="queries per step through the batched matrix-core path (config C3: --batch 1024 "
                          "--metric cosine); 0 = the headline single-query workload")
+    ap.add_argument("--mask-keep", type=float, default=0.0,
+                    help="config C5: Bernoulli row mask keeping this fraction of the rows (0 = no mask)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the N>1 code path (process group, all-gather, merge) even with one rank")
@@ -185,11 +187,16 @@ def run_bench(a):
     searcher = ShardedSearcher(idx) if dist is not None else None
     idx.set_batch_min_nq(0)  # headline workload: every query scans the corpus on its own (no MFMA batching)
 
+    row_mask = None
+    if a.mask_keep > 0:  # C5: WHERE pre-filter as a device-side row bitmask (seed 20260614)
+        keepbits = np.random.Generator(np.random.Philox(20260614)).random(n) < a.mask_keep
+        row_mask = np.packbits(keepbits, bitorder="little")
+
     def one(i):
         q = queries[i % len(queries)]
         if searcher is not None:
-            return searcher.search(q, k)
-        return idx.search(q, k)
+            return searcher.search(q, k, None, row_mask)
+        return idx.search(q, k, None, row_mask)
 
     def run(first, count):
         """`count` single-query searches, `--inflight` of them in flight.  Each query still
@@ -202,14 +209,14 @@ def run_bench(a):
             # N > 1: groups of `inflight` queries share one all-gather + one merge call, and the
             # next group's shard scans run while this group is exchanged and merged
             sel = [(first + j) % len(queries) for j in range(count)]
-            searcher.search_many(queries[sel], k, group=max(16, a.inflight))
+            searcher.search_many(queries[sel], k, None, row_mask, group=max(16, a.inflight))
         else:
             from collections import deque
             pend = deque()
             for i in range(count):
                 if len(pend) == a.inflight:
                     idx.wait(pend.popleft())
-                pend.append(idx.submit(queries[(first + i) % len(queries)], k))
+                pend.append(idx.submit(queries[(first + i) % len(queries)], k, row_mask))
             while pend:
                 idx.wait(pend.popleft())
 
@@ -243,8 +250,11 @@ def run_bench(a):
     # around real scan launches on its pipeline stream, during the timed region above
     ns = c1["scan_us_samples"] - c0["scan_us_samples"]
     scan_us = (c1["scan_us_sum"] - c0["scan_us_sum"]) / ns if ns > 0 else float("nan")
-    scan_alone_us = idx.bench_scan(queries[0], iters=50) if hi > lo else float("nan")
+    scan_alone_us = idx.bench_scan(queries[0], iters=50, row_mask=row_mask) if hi > lo else float("nan")
     shard_bytes = float(hi - lo) * d * 4  # algorithmic: every stored f32 read once
+    if row_mask is not None:  # C5: only kept rows are read, plus the mask itself
+        kept = int(np.unpackbits(row_mask, bitorder="little")[lo:hi].sum())
+        shard_bytes = float(kept) * d * 4 + (hi - lo) / 8
     if dist is not None:
         tt = torch.tensor([scan_us], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -256,12 +266,12 @@ def run_bench(a):
         import oracle
 
         t1 = time.perf_counter()
-        oracle.search_heap(host_rows, queries[0], metric, k)
+        oracle.search_heap(host_rows, queries[0], metric, k, None, row_mask)
         per_q = time.perf_counter() - t1
         budget = a.cpu_seconds if world == 1 else min(a.cpu_seconds, 4.0)
         n_cpu = int(max(2, min(32, budget / max(per_q, 1e-3))))
         t1 = time.perf_counter()
-        ref = [oracle.search_heap(host_rows, queries[i], metric, k) for i in range(n_cpu)]
+        ref = [oracle.search_heap(host_rows, queries[i], metric, k, None, row_mask) for i in range(n_cpu)]
         cpu_elapsed = time.perf_counter() - t1
     if dist is not None:
         tt = torch.tensor([n_cpu], dtype=torch.int64, device=dev)
@@ -294,7 +304,7 @@ def run_bench(a):
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: %dx%d f32, %s, k=%d, single query per step" % (n, d, a.metric, k),
-                       "rows": n, "dim": d, "k": k, "metric": a.metric,
+                       "rows": n, "dim": d, "k": k, "metric": a.metric, "mask_keep": a.mask_keep or None,
                        "queries_in_flight": a.inflight if searcher is None else max(16, a.inflight),
                        "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world
                        if world > 1 else "single GPU"},
@@ -326,7 +336,7 @@ def run_bench(a):
                     t1 = time.perf_counter()
                     m = max(2, min(n_cpu, 8))
                     for i in range(m):
-                        oracle.search_heap_mt(host_rows, queries[i], metric, k)
+                        oracle.search_heap_mt(host_rows, queries[i], metric, k, None, row_mask)
                     out["cpu_baseline_mt"] = {"value": m / (time.perf_counter() - t1), "unit": "queries/s",
                                               "cores": thr, "kind": "port", "sample": "%d queries, OpenMP" % m}
                 except Exception:

@@ -348,3 +348,29 @@ def test_concurrent_threads_share_one_handle(hip_lib, oracle_mod):
         for t in th:
             t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_more_than_16384_tiles(hip_lib, oracle_mod, metric):
+    """> 1,048,576 rows: the select kernel walks gmin[] in memory instead of registers."""
+    from tostore_amd import HipVectorIndex
+
+    d, n = 8, 1_200_000
+    rows = _mk(n, d, 101, scale=(0.5, 2.0))
+    rows[700_000:700_050] = rows[5]  # ties far apart
+    with HipVectorIndex(d, metric, capacity_rows=n) as idx:
+        idx.append(0, rows[:600_000])
+        idx.append(600_000, rows[600_000:])
+        idx.set_batch_min_nq(0)
+        for qi in range(2):
+            q = _prep_query(oracle_mod, _mk(1, d, 102 + qi)[0], metric)
+            for k in (10, 100, 300):
+                ids, dist, cnt = idx.search(q, k)
+                eids, edist = oracle_mod.search_heap_mt(rows, q, metric, k)
+                assert cnt[0] == k and np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
+        qs = np.stack([_prep_query(oracle_mod, x, metric) for x in _mk(12, d, 110)])
+        idx.set_batch_min_nq(8)  # and the matrix-core path over the same index
+        ids, dist, cnt = idx.search(qs, 20)
+        for i in range(12):
+            eids, edist = oracle_mod.search_heap_mt(rows, qs[i], metric, 20)
+            assert np.array_equal(ids[i], eids) and np.array_equal(dist[i], edist)

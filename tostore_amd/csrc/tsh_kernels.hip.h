@@ -323,8 +323,7 @@ struct SelectArgs {
   int64_t shard_rows;
 };
 
-constexpr int SEL_THREADS = 1024;   // latency form: whole CU, tile minima in registers
-constexpr int SEL_THREADS_SMALL = 256;  // pipelined form: same CU footprint as one scan workgroup
+constexpr int SEL_THREADS = 1024;   // one whole CU; tile minima stay in registers
 constexpr int SEL_VPT = 16;         // tile minima a thread keeps in registers (16384 tiles = 1M rows)
 constexpr int SEL_LIST_CAP = 4096;  // LDS lists (short list of tile minima / tile ids)
 

@@ -141,10 +141,30 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
   return (int32_t)r;
 }
 
+// run fn(q) for q in [0,n) on a few host threads (per-query finalisation of a batch)
+template <typename F>
+void parallel_for(int32_t n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 1, 16);
+  nt = std::min(nt, n / 64);  // below 64 queries per thread it is not worth a thread
+  if (nt <= 1) {
+    for (int32_t q = 0; q < n; ++q) fn(q);
+    return;
+  }
+  std::atomic<int32_t> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&] {
+      for (;;) {
+        int32_t q0 = next.fetch_add(16);
+        if (q0 >= n) return;
+        for (int32_t q = q0; q < std::min(n, q0 + 16); ++q) fn(q);
+      }
+    });
+  for (auto &t : th) t.join();
+}
+
 // ---- kernel dispatch ---------------------------------------------------------
-struct ScanCfg {
-  int nch;
-};
 inline int pick_nch(int d4) {
   int need = (d4 + 63) / 64;
   static const int opts[] = {1, 2, 3, 4, 6, 8};
@@ -1435,7 +1455,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
       g_err = errs[g];
       return rcs[g];
     }
-  for (int32_t q = 0; q < nq; ++q) {
+  parallel_for(nq, [&](int32_t q) {
     std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
     for (size_t g = 0; g < ns; ++g) {
       if (!active[g]) continue;
@@ -1450,7 +1470,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     }
     out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, lists,
                                   out_ids + (size_t)q * k, out_dist + (size_t)q * k);
-  }
+  });
   return TSH_OK;
 }
 
@@ -1613,7 +1633,7 @@ int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries, 
     if (needed_entries) *needed_entries = (int32_t)round_up(need, 64);
     return set_err(TSH_E_OVERFLOW, "a candidate block needs %u entries (have %d)", need, entries);
   }
-  for (int32_t q = 0; q < nq; ++q) {
+  parallel_for(nq, [&](int32_t q) {
     std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
     for (int32_t b = 0; b < n_blocks; ++b) {
       const uint8_t *p = base + ((size_t)b * nq + q) * bb;
@@ -1622,7 +1642,7 @@ int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries, 
     }
     out_count[q] = finalize_query(metric, dim, queries + (size_t)q * dim, k, thr, lists,
                                   out_ids + (size_t)q * k, out_dist + (size_t)q * k);
-  }
+  });
   return TSH_OK;
 }
 
