@@ -120,3 +120,18 @@ def test_batched_mixed_bad_query_and_small_index(hip_lib, oracle_mod):
         idx.append(0, small)
         _check_batch(oracle_mod, idx, small, qs[:10][np.isfinite(qs[:10]).all(axis=1)], L2, 5, tag="small")
         assert idx.counters()["batch_launches"] == 0
+
+
+@pytest.mark.parametrize("k", [300, 1000])
+def test_batched_large_k(hip_lib, oracle_mod, k):
+    """k above the thread count of the per-query select kernels (group minima, 4 per thread)."""
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq = 32, 60000, 12
+    rows = _mk(n, d, 41)
+    qs = _queries(oracle_mod, nq, d, 42, COS)
+    with HipVectorIndex(d, COS) as idx:
+        idx.append(0, rows)
+        _check_batch(oracle_mod, idx, rows, qs, COS, k, tag=f"k{k}")
+        c = idx.counters()
+        assert c["batch_launches"] >= 1 and c["scan_launches"] == 0, c

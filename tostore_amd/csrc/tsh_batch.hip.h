@@ -63,8 +63,8 @@ template <int METRIC, bool DENSE>
 __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a) {
   __shared__ __attribute__((aligned(16))) float As[2][BT_M][BT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BT_N][BT_LD];
-  __shared__ float s_thr[BT_M];
-  __shared__ float s_qsq[BT_M];
+  __shared__ __attribute__((aligned(16))) float s_thr[BT_M];
+  __shared__ __attribute__((aligned(16))) float s_qsq[BT_M];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
   const int nbase = a.row0 + n_tile * BT_N;
 
   if (tid < BT_M) {
-    s_thr[tid] = DENSE ? 0.f : a.thr[qbase + tid];
+    s_thr[tid] = (DENSE || qbase + tid >= a.nq) ? -__builtin_inff() : a.thr[qbase + tid];
     s_qsq[tid] = METRIC == METRIC_L2 ? a.qsq[qbase + tid] : 0.f;
   }
 
@@ -165,39 +165,61 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
   }
 
   // ---- epilogue: key transform (+ filter) -----------------------------------------
-  // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+  // for a fixed reg >> 2 the four rows are consecutive, so a lane's 16 per-row
+  // values (threshold, |q|^2) are four float4 reads.
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = nbase + wn * 64 + j * 32 + (lane & 31);  // corpus row
-    const bool col_ok = col < a.row1;
-    float vin = 0.f, vsq = 0.f;
-    bool alive = col_ok;
-    if (col_ok) {
-      if (METRIC == METRIC_COS) vin = a.inv_norm[col];
-      if (METRIC == METRIC_L2) vsq = a.sqnorm[col];
-      if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
-      if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = wm * 64 + i * 32 + 4 * (lane >> 5);  // tile row of reg 0
+    f32x4 th[4], qq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      th[g] = *reinterpret_cast<const f32x4 *>(&s_thr[rbase + 8 * g]);
+      if (METRIC == METRIC_L2) qq[g] = *reinterpret_cast<const f32x4 *>(&s_qsq[rbase + 8 * g]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      const int col = nbase + wn * 64 + j * 32 + (lane & 31);  // corpus row
+      const bool col_ok = col < a.row1;
+      float vin = 0.f, vsq = 0.f;
+      bool alive = col_ok;
+      if (col_ok) {
+        if (METRIC == METRIC_COS) vin = a.inv_norm[col];
+        if (METRIC == METRIC_L2) vsq = a.sqnorm[col];
+        if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
+        if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+      }
+      float key[16];
+      uint32_t pass = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int qi = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row in tile
         const float dot = acc[i][j][r];
-        float key;
-        if (METRIC == METRIC_IP) key = -dot;
-        else if (METRIC == METRIC_COS) key = -(dot * vin);
-        else key = s_qsq[qi] + vsq - 2.f * dot;
-        if (DENSE) {
-          if (col_ok)
-            a.dense[(int64_t)(qbase + qi) * a.dense_ld + (col - a.row0)] = alive ? key : __builtin_nanf("");
-        } else {
-          const bool pass = alive && key <= s_thr[qi] && (qbase + qi) < a.nq;
-          if (pass) {
-            const int q = qbase + qi;
+        if (METRIC == METRIC_IP) key[r] = -dot;
+        else if (METRIC == METRIC_COS) key[r] = -(dot * vin);
+        else key[r] = qq[r >> 2][r & 3] + vsq - 2.f * dot;
+        if (!DENSE) pass |= (key[r] <= th[r >> 2][r & 3]) ? (1u << r) : 0u;
+      }
+      if (DENSE) {
+        if (col_ok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qi = rbase + (r & 3) + 8 * (r >> 2);
+            a.dense[(int64_t)(qbase + qi) * a.dense_ld + (col - a.row0)] = alive ? key[r] : __builtin_nanf("");
+          }
+        }
+      } else {
+        if (!alive) pass = 0;
+        while (pass) {  // rare: about k * n / n_sample survivors per query over the whole pass
+          const int r = __builtin_ctz(pass);
+          pass &= pass - 1;
+          const int q = qbase + rbase + (r & 3) + 8 * (r >> 2);
+          if (q < a.nq) {
+            float kv = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) kv = u == r ? key[u] : kv;  // register select, no scratch
             uint32_t p = atomicAdd(&a.cand_cnt[q], 1u);
             if (p < (uint32_t)a.cand_cap) {
-              a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(key);
+              a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(kv);
               a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)col;
             }
           }
@@ -206,7 +228,6 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
     }
   }
 }
-
 
 // ---------------------------------------------------------------------------
 // block-wide exact k-th smallest (as an order-preserving u32 key) of `n` float
@@ -217,8 +238,10 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
 constexpr int BS_THREADS = 256;
 constexpr int BS_LIST = 4096;
 
+constexpr int BS_GROUPS = 4 * BS_THREADS;  // group minima per workgroup: supports k <= 1024
+
 struct KthScratch {
-  uint32_t lm[BS_THREADS];
+  uint32_t lm[BS_GROUPS];
   uint32_t list[BS_LIST];
   uint32_t n_list, U, tau;
 };
@@ -232,19 +255,28 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
     sc->U = KEY_DEAD;
     sc->tau = KEY_NAN;
   }
-  uint32_t lmin = KEY_DEAD;
-  for (int i = tid; i < n; i += BS_THREADS) {
-    uint32_t x = fkey_or_dead(keys[i]);
-    lmin = x < lmin ? x : lmin;
+  // 1024 strided groups (4 per thread): k distinct groups hold an entry <= the k-th
+  // smallest group minimum, so that minimum bounds the k-th smallest entry
+  uint32_t lmin[4] = {KEY_DEAD, KEY_DEAD, KEY_DEAD, KEY_DEAD};
+  for (int base = 0; base < n; base += BS_GROUPS) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = base + u * BS_THREADS + tid;
+      if (i < n) {
+        uint32_t x = fkey_or_dead(keys[i]);
+        lmin[u] = x < lmin[u] ? x : lmin[u];
+      }
+    }
   }
-  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_THREADS && n > BS_LIST;
-  sc->lm[tid] = lmin;
+  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_GROUPS && n > BS_LIST;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) sc->lm[u * BS_THREADS + tid] = lmin[u];
   __syncthreads();
   if (narrow && wave == 0) {
-    uint32_t v[BS_THREADS / 64];
+    uint32_t v[BS_GROUPS / 64];
 #pragma unroll
-    for (int i = 0; i < BS_THREADS / 64; ++i) v[i] = sc->lm[lane + 64 * i];
-    uint32_t U = wave_kth_bisect<BS_THREADS / 64>(v, k);
+    for (int i = 0; i < BS_GROUPS / 64; ++i) v[i] = sc->lm[lane + 64 * i];
+    uint32_t U = wave_kth_bisect<BS_GROUPS / 64>(v, k);
     if (lane == 0) sc->U = U;
   }
   __syncthreads();

@@ -946,6 +946,14 @@ void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_
   else launch_batch_score<METRIC_COS>(a, dense, st);
 }
 
+int64_t batch_sample_rows(int64_t rows, int32_t k) {
+  if (rows <= 16384) return rows;
+  int64_t n = std::max<int64_t>(rows / 32, (int64_t)k * rows / 3000);
+  n = std::max<int64_t>(round_up(n, BT_N), 8192);
+  n = std::max<int64_t>(n, round_up((int64_t)k * 4, BT_N));
+  return std::min(n, rows);
+}
+
 // 2 * (error bound of the f32 MFMA key), absolute, per query
 bool batch_delta2(const Shard *s, const float *q, float *out_delta2, float *out_qsq) {
   double qn2 = 0;
@@ -980,9 +988,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int64_t rows = s->rows, ld = s->ld;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   const int32_t nq_pad = (int32_t)round_up(nq, BT_M);
-  int64_t n_sample = rows;
-  if (rows > 16384) n_sample = std::min<int64_t>(rows, std::max<int64_t>(round_up(rows / 32, BT_N), 8192));
-  if (n_sample < (int64_t)k * 4) n_sample = std::min<int64_t>(rows, round_up((int64_t)k * 4, BT_N));
+  // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
+  // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
+  const int64_t n_sample = batch_sample_rows(rows, k);
   const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
@@ -1147,9 +1155,22 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
                          k <= 1024 && s->rows < 0x7FFFFF00ll;
   if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
   std::vector<int32_t> redo;
-  int rc = shard_search_batch(s, b, queries, nq, k, mask, entries, out, &redo);
-  if (rc) return rc;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  // the dense sample matrix (nq_pad x n_sample floats) is kept under 8 GB per call
+  const int64_t per_q = batch_sample_rows(s->rows, k) * 4;
+  const int32_t chunk = (int32_t)std::max<int64_t>(BT_M, (int64_t)(8e9 / (double)per_q) / BT_M * BT_M);
+  for (int32_t q0 = 0; q0 < nq; q0 += chunk) {
+    const int32_t nc = std::min(chunk, nq - q0);
+    SearchOut part;
+    part.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q0 * bb : nullptr;
+    part.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q0 * bb : nullptr;
+    part.user_stream = out->user_stream;
+    std::vector<int32_t> r;
+    int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);
+    if (rc) return rc;
+    for (int32_t q : r) redo.push_back(q0 + q);
+  }
+  int rc = TSH_OK;
   for (int32_t q : redo) {
     SearchOut one;
     std::vector<std::vector<BlockEntry>> sp(1);
