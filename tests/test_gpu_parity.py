@@ -374,3 +374,22 @@ def test_more_than_16384_tiles(hip_lib, oracle_mod, metric):
         for i in range(12):
             eids, edist = oracle_mod.search_heap_mt(rows, qs[i], metric, 20)
             assert np.array_equal(ids[i], eids) and np.array_equal(dist[i], edist)
+
+
+@pytest.mark.parametrize("k", [513, 1000, 1024, 1500])
+def test_large_k_single_query(hip_lib, oracle_mod, k):
+    """k above 512 uses 2048 tile-minimum groups in the select kernel; above 1024 every live row
+    is a candidate (wide path) -- always exact."""
+    from tostore_amd import HipVectorIndex
+
+    d, n = 16, 300_000  # 4688 tiles: more than the select kernel's short list holds
+    rows = _mk(n, d, 121)
+    q = _mk(1, d, 122)[0]
+    with HipVectorIndex(d, L2, capacity_rows=n) as idx:
+        idx.append(0, rows)
+        idx.set_batch_min_nq(0)
+        ids, dist, cnt = idx.search(q, k)
+        eids, edist = oracle_mod.search_heap_mt(rows, q, L2, k)
+        assert cnt[0] == k and np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
+        if k <= 1024:
+            assert idx.counters()["fallback_searches"] == 0

@@ -238,7 +238,8 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
 constexpr int BS_THREADS = 256;
 constexpr int BS_LIST = 4096;
 
-constexpr int BS_GROUPS = 4 * BS_THREADS;  // group minima per workgroup: supports k <= 1024
+constexpr int BS_GPT = 8;                    // group minima per thread
+constexpr int BS_GROUPS = BS_GPT * BS_THREADS;  // 2048 groups: the bound stays tight up to k = 1024
 
 struct KthScratch {
   uint32_t lm[BS_GROUPS];
@@ -255,12 +256,15 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
     sc->U = KEY_DEAD;
     sc->tau = KEY_NAN;
   }
-  // 1024 strided groups (4 per thread): k distinct groups hold an entry <= the k-th
-  // smallest group minimum, so that minimum bounds the k-th smallest entry
-  uint32_t lmin[4] = {KEY_DEAD, KEY_DEAD, KEY_DEAD, KEY_DEAD};
+  // 2048 strided groups (8 per thread): k distinct groups hold an entry <= the k-th
+  // smallest group minimum, so that minimum bounds the k-th smallest entry; about
+  // G ln(G / (G - k)) entries lie at or below it (1420 at k = 1024)
+  uint32_t lmin[BS_GPT];
+#pragma unroll
+  for (int u = 0; u < BS_GPT; ++u) lmin[u] = KEY_DEAD;
   for (int base = 0; base < n; base += BS_GROUPS) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < BS_GPT; ++u) {
       int i = base + u * BS_THREADS + tid;
       if (i < n) {
         uint32_t x = fkey_or_dead(keys[i]);
@@ -268,9 +272,9 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
       }
     }
   }
-  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_GROUPS && n > BS_LIST;
+  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_GROUPS / 2 && n > BS_LIST;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) sc->lm[u * BS_THREADS + tid] = lmin[u];
+  for (int u = 0; u < BS_GPT; ++u) sc->lm[u * BS_THREADS + tid] = lmin[u];
   __syncthreads();
   if (narrow && wave == 0) {
     uint32_t v[BS_GROUPS / 64];

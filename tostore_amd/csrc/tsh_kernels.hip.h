@@ -394,7 +394,7 @@ template <int NT, bool IN_REGS>
 __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
   static_assert(NT == 1024 || NT == 256, "thread minima are bisected by one wave as 16 or 4 per lane");
   constexpr int SEL_THREADS = NT;  // shadows the namespace constant inside this kernel
-  __shared__ uint32_t s_lm[SEL_THREADS];
+  __shared__ uint32_t s_lm[2 * SEL_THREADS];
   __shared__ uint32_t s_list[SEL_LIST_CAP];
   __shared__ uint32_t s_n, s_tiles, s_cand, s_U, s_tau;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -408,22 +408,28 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
     s_tau = KEY_NAN;
   }
   uint32_t g[SEL_VPT];
-  uint32_t lmin = KEY_DEAD;
+  uint32_t lmin = KEY_DEAD, lodd = KEY_DEAD;  // lodd: minimum over this thread's odd-numbered elements
   if (IN_REGS) {
 #pragma unroll
     for (int i = 0; i < SEL_VPT; ++i) {
       int t = tid + i * SEL_THREADS;
       g[i] = t < M ? a.gmin[t] : KEY_DEAD;
       lmin = g[i] < lmin ? g[i] : lmin;
+      if (i & 1) lodd = g[i] < lodd ? g[i] : lodd;
     }
   } else {
-    for (int t = tid; t < M; t += SEL_THREADS) {
+    int it = 0;
+    for (int t = tid; t < M; t += SEL_THREADS, ++it) {
       uint32_t x = a.gmin[t];
       lmin = x < lmin ? x : lmin;
+      if (it & 1) lodd = x < lodd ? x : lodd;
     }
   }
   const bool narrow = !a.force_all && (uint32_t)M >= k && k <= (uint32_t)SEL_THREADS;
   const bool groups4 = NT == 1024 && k <= 128;  // 256 group minima are plenty for small k
+  // above k = 512 the k-th of 1024 thread minima gets loose (G ln(G/(G-k)) entries below
+  // it): split every thread into its even and odd elements, 2048 groups
+  const bool groups2k = k > 512;
   if (narrow && M > SEL_LIST_CAP) {
     uint32_t m = lmin;
     if (groups4) {
@@ -433,11 +439,32 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
       m = t2 < m ? t2 : m;
     }
     s_lm[tid] = m;
+    if (groups2k) {  // even-element minimum and odd-element minimum as separate groups
+      uint32_t leven = KEY_DEAD;
+      if (IN_REGS) {
+#pragma unroll
+        for (int i = 0; i < SEL_VPT; i += 2) leven = g[i] < leven ? g[i] : leven;
+      } else {
+        int it = 0;
+        for (int t = tid; t < M; t += SEL_THREADS, ++it)
+          if (!(it & 1)) {
+            uint32_t x = a.gmin[t];
+            leven = x < leven ? x : leven;
+          }
+      }
+      s_lm[tid] = leven;
+      s_lm[SEL_THREADS + tid] = lodd;
+    }
   }
   __syncthreads();
   if (narrow && M > SEL_LIST_CAP && wave == 0) {
     uint32_t U;
-    if (groups4) {
+    if (groups2k) {
+      uint32_t v[2 * NT / 64];
+#pragma unroll
+      for (int i = 0; i < 2 * NT / 64; ++i) v[i] = s_lm[lane + i * 64];
+      U = wave_kth_bisect<2 * NT / 64>(v, k);
+    } else if (groups4) {
       uint32_t v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = s_lm[(lane + i * 64) * 4];
