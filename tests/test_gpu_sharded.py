@@ -82,3 +82,41 @@ def test_truncated_block_asks_every_rank_to_retry(hip_lib, oracle_mod):
         blk = _shard_blocks(torch, s, q[None], k, e.value.needed_entries).cpu().numpy()
         ids, dist, cnt = merge_candidate_blocks(L2, d, q, k, None, blk, 1, e.value.needed_entries)
         assert ids[0].tolist() == list(range(1000, 1000 + k))  # ties -> lowest global ids
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_in_process_multi_shard_handle(hip_lib, oracle_mod, metric, monkeypatch):
+    """tsh_index_create(n_devices=3): the one-process deployment shape (a Dart server with several
+    GPUs).  TSH_SHARDS_SHARE_DEVICES=1 lets the three shards share this box's single GPU."""
+    from tostore_amd import HipVectorIndex
+
+    monkeypatch.setenv("TSH_SHARDS_SHARE_DEVICES", "1")
+    rng = np.random.default_rng(9)
+    n, d, k = 10_000, 40, 25
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((10, d)).astype(np.float32)
+    if metric == COS:
+        qs = np.stack([oracle_mod.normalize_f32(q) for q in qs])
+    with HipVectorIndex(d, metric, capacity_rows=n, n_devices=3) as idx:
+        idx.append(0, rows[:3000])       # inside shard 0
+        idx.append(3000, rows[3000:7777])  # straddles shard 0 -> 1 -> 2 boundaries (3392 rows per shard)
+        idx.append(7777, rows[7777:])
+        assert idx.size == n
+        dead = rng.choice(n, 700, replace=False)
+        idx.set_deleted(dead)
+        alive = np.ones(n, bool)
+        alive[dead] = False
+        keep = np.packbits(rng.random(n) < 0.7, bitorder="little")
+        both = np.packbits(alive & np.unpackbits(keep, bitorder="little")[:n].astype(bool), bitorder="little")
+        for nq in (1, 10):
+            ids, dist, cnt = idx.search(qs[:nq], k, None, keep)
+            for i in range(nq):
+                eids, edist = oracle_mod.search_exhaustive(rows, qs[i], metric, k, None, both)
+                assert cnt[i] == len(eids) and np.array_equal(ids[i, :cnt[i]], eids)
+                assert np.array_equal(dist[i, :cnt[i]], edist)
+        t = idx.submit(qs[0], k)  # asynchronous form over all shards
+        ids, dist = idx.wait(t)
+        eids, edist = oracle_mod.search_exhaustive(rows, qs[0], metric, k, None, np.packbits(alive, bitorder="little"))
+        assert np.array_equal(ids, eids) and np.array_equal(dist, edist)
+        c = idx.counters()
+        assert c["rows"] == n and c["deleted_rows"] == 700

@@ -1314,7 +1314,12 @@ int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows, int
                          tsh_index **out) {
   int rc = check_create_args(dim, metric, capacity_rows, out);
   if (rc) return rc;
-  if (n_devices < 1 || n_devices > device_count_cached())
+  // TSH_SHARDS_SHARE_DEVICES=1 (testing hook): shards of a multi-device handle may share a
+  // physical device (shard g on device g % count), so the multi-shard code path -- append
+  // routing, one host thread per shard, host merge -- can be exercised on a one-GPU box
+  const char *share_env = getenv("TSH_SHARDS_SHARE_DEVICES");
+  const bool share = share_env && share_env[0] == '1';
+  if (n_devices < 1 || (!share && n_devices > device_count_cached()) || n_devices > 64)
     return set_err(TSH_E_BAD_ARG, "n_devices %d outside [1,%d]", n_devices, device_count_cached());
   std::unique_ptr<tsh_index> idx(new tsh_index());
   idx->dim = dim;
@@ -1332,7 +1337,8 @@ int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows, int
     idx->rows_per_shard = round_up((capacity_rows + n_devices - 1) / n_devices, 64);
     for (int g = 0; g < n_devices; ++g) {
       std::unique_ptr<Shard> s;
-      rc = make_shard(dim, metric, g, (int64_t)g * idx->rows_per_shard, idx->rows_per_shard, &s);
+      rc = make_shard(dim, metric, g % device_count_cached(), (int64_t)g * idx->rows_per_shard,
+                      idx->rows_per_shard, &s);
       if (rc) {
         for (auto &p : idx->shards) shard_destroy(p.get());
         return rc;
