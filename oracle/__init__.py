@@ -29,7 +29,9 @@ def build(force: bool = False) -> None:
     src = os.path.join(_HERE, "vs_oracle.c")
     if (not force and os.path.exists(so)
             and os.path.getmtime(so) >= os.path.getmtime(src)
-            and os.path.exists(os.path.join(_HERE, "libvs_oracle_mt.so"))):
+            and os.path.exists(os.path.join(_HERE, "libvs_oracle_mt.so"))
+            and os.path.getmtime(os.path.join(_HERE, "libvs_oracle_mt.so"))
+            >= os.path.getmtime(os.path.join(_HERE, "vs_oracle_mt.c"))):
         return
     subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
                    stdout=subprocess.DEVNULL)
@@ -98,6 +100,9 @@ def lib_mt() -> ctypes.CDLL:
                                          _c_f32p, _c_i64, ctypes.c_double, _c_u8p,
                                          ctypes.c_int, _c_i64p, _c_f64p]
         L.vso_search_heap_mt.restype = _c_i64
+        L.vso_search_heap_many_mt.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int, _c_f32p, _c_i64, _c_i64,
+                                              ctypes.c_double, _c_u8p, ctypes.c_int, _c_i64p, _c_f64p, _c_i64p]
+        L.vso_search_heap_many_mt.restype = _c_i64
         _lib_mt = L
     return _lib_mt
 
@@ -183,6 +188,26 @@ def search_heap(rows, query, metric: int, k: int, threshold=None, keep=None):
 def search_heap_mt(rows, query, metric: int, k: int, threshold=None, keep=None, threads=0):
     return _search(lib_mt().vso_search_heap_mt, rows, query, metric, k, threshold, keep,
                    int(threads))
+
+
+def search_heap_many_mt(rows, queries, metric: int, k: int, threshold=None, keep=None, threads=0):
+    """Exact top-k of many queries (OpenMP over query groups); returns (ids[nq,k], dist[nq,k], count[nq])."""
+    rows, queries = _f32(rows), _f32(queries)
+    n, d = rows.shape
+    nq = queries.shape[0]
+    ids = np.full((nq, max(k, 1)), -1, dtype=np.int64)
+    dist = np.full((nq, max(k, 1)), np.nan, dtype=np.float64)
+    cnt = np.zeros(nq, dtype=np.int64)
+    thr = math.nan if threshold is None else float(threshold)
+    kp = None
+    if keep is not None:
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        kp = _p(keep, _c_u8p)
+    rc = lib_mt().vso_search_heap_many_mt(_p(rows, _c_f32p), n, d, metric, _p(queries, _c_f32p), nq, int(k), thr, kp,
+                                          int(threads), _p(ids, _c_i64p), _p(dist, _c_f64p), _p(cnt, _c_i64p))
+    if rc != 0:
+        raise MemoryError("oracle allocation failed")
+    return ids[:, :k], dist[:, :k], cnt
 
 
 def mt_max_threads() -> int:

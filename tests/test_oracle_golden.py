@@ -108,6 +108,15 @@ def test_two_restatements_agree(oracle_mod):
             c = oracle_mod.search_heap_mt(rows, q, metric, 33, threads=3)
             assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1]))
             assert np.array_equal(a[0], c[0]) and np.array_equal(_bits(a[1]), _bits(c[1]))
+        # the many-query OpenMP variant (recall checks over >= 1000 queries) is the same arithmetic
+        qs = rng.standard_normal((9, d)).astype(np.float32)
+        keep = np.packbits(rng.random(400) < 0.5, bitorder="little")
+        for metric in (L2, IP, COS):
+            ids, dist, cnt = oracle_mod.search_heap_many_mt(rows, qs, metric, 21, None, keep, threads=3)
+            for i in range(9):
+                e_ids, e_dist = oracle_mod.search_exhaustive(rows, qs[i], metric, 21, None, keep)
+                assert cnt[i] == len(e_ids) and np.array_equal(ids[i, :cnt[i]], e_ids)
+                assert np.array_equal(_bits(dist[i, :cnt[i]]), _bits(e_dist))
 
 
 def test_properties_on_all_distances(oracle_mod):
