@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--recall-queries", type=int, default=1000,
                     help="N=1: queries whose GPU answer is compared with the exhaustive CPU oracle (all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets several ranks share one GPU in tests)")
+    ap.add_argument("--ranks-share-gpu", action="store_true", help="testing: every rank uses cuda:0")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the N>1 code path (process group, all-gather, merge) even with one rank")
     return ap.parse_args()
@@ -161,6 +164,8 @@ def run_bench(a):
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if a.ranks_share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -169,8 +174,12 @@ def run_bench(a):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    ctl = dev if a.backend == "nccl" else torch.device("cpu")  # where small control tensors live
     n, d, k = a.rows, a.dim, a.k
     assert _ffi.lib().tsh_device_count() >= 1, "libtostore_hip.so sees no device"
 
@@ -179,6 +188,7 @@ def run_bench(a):
     per = (n + world - 1) // world
     lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
     idx = HipVectorIndex(d, metric, capacity_rows=hi - lo, shard_device=local_rank, row_base=lo)
+    torch.cuda.synchronize()  # the library copies on its own stream: the producer must be done
     if hi > lo:
         idx.append_device(lo, hi - lo, corpus[lo:hi].data_ptr())
     torch.cuda.synchronize()
@@ -247,7 +257,7 @@ def run_bench(a):
     elapsed = time.perf_counter() - t0
     c1 = idx.counters()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -269,7 +279,7 @@ def run_bench(a):
         kept = int(np.unpackbits(row_mask, bitorder="little")[lo:hi].sum())
         shard_bytes = float(kept) * d * 4 + (hi - lo) / 8
     if dist is not None:
-        tt = torch.tensor([scan_us], dtype=torch.float64, device=dev)
+        tt = torch.tensor([scan_us], dtype=torch.float64, device=ctl)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         scan_us = float(tt.item())
 
@@ -287,7 +297,7 @@ def run_bench(a):
         ref = [oracle.search_heap(host_rows, queries[i], metric, k, None, row_mask) for i in range(n_cpu)]
         cpu_elapsed = time.perf_counter() - t1
     if dist is not None:
-        tt = torch.tensor([n_cpu], dtype=torch.int64, device=dev)
+        tt = torch.tensor([n_cpu], dtype=torch.int64, device=ctl)
         dist.broadcast(tt, src=0)
         n_cpu = int(tt.item())
     got = [one(i) for i in range(n_cpu)]

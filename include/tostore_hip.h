@@ -112,7 +112,8 @@ int32_t tsh_index_destroy(tsh_index *idx);
 int32_t tsh_index_append(tsh_index *idx, int64_t first_row_id, int64_t n_rows,
                          const float *rows);
 /* Same, from a device pointer on the handle's device (bulk loaders that
- * already hold the column in HBM). */
+ * already hold the column in HBM).  The copy runs on a library stream: the
+ * caller must have synchronised whatever produced d_rows before the call. */
 int32_t tsh_index_append_device(tsh_index *idx, int64_t first_row_id, int64_t n_rows,
                                 const void *d_rows);
 

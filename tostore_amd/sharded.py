@@ -88,6 +88,12 @@ class ShardedSearcher:
     def _exchange_merge(self, q: np.ndarray, k: int, thr, entries: int, slot: int):
         t = self._torch
         mine, allb, host = self._buffers(q.shape[0], entries, slot)
+        if self._dist.is_initialized() and self._dist.get_backend(self.group) == "gloo":
+            # test setups (several ranks on one GPU): exchange through host memory
+            mine_h = mine.cpu()
+            self._dist.all_gather_into_tensor(host, mine_h, group=self.group)
+            return merge_candidate_blocks(self.index.metric, self.index.dim, q, k, thr, host.numpy(),
+                                          self.world, entries)
         if self._dist.is_initialized():
             self._dist.all_gather_into_tensor(allb, mine, group=self.group)
         else:
@@ -157,20 +163,9 @@ class ShardedSearcher:
             row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
             mp = row_mask.ctypes.data_as(_ffi.p_u8)
         for _attempt in range(3):
-            mine, allb, host = self._buffers(nq, entries)
-            stream = t.cuda.current_stream().cuda_stream
-            _ffi.check(L.tsh_search_shard(self.index._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), mp,
-                                          entries, ctypes.c_void_p(mine.data_ptr()),
-                                          ctypes.c_void_p(stream)))
-            if self._dist.is_initialized():
-                self._dist.all_gather_into_tensor(allb, mine, group=self.group)
-            else:
-                allb = mine
-            host[: allb.numel()].copy_(allb, non_blocking=True)
-            t.cuda.current_stream().synchronize()
+            self._scan(q, k, mp, entries, 0)
             try:
-                return merge_candidate_blocks(self.index.metric, self.index.dim, q, k, distance_threshold,
-                                              host[: allb.numel()].numpy(), self.world, entries)
+                return self._exchange_merge(q, k, distance_threshold, entries, 0)
             except _ffi.TshError as e:
                 if e.code != _ffi.TSH_E_OVERFLOW:
                     raise
