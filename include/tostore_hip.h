@@ -144,6 +144,19 @@ int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t pag
                                    int32_t precision, int64_t first_row_id, int64_t max_rows,
                                    int64_t *out_rows);
 
+/* Write-path helper: PQ-encode resident rows
+ * [first_row_id, first_row_id + n_rows) against a trained codebook -- the
+ * arithmetic of batchPqEncode (lib/src/core/compute_tasks.dart:2292-2326) ==
+ * VectorQuantizer.encode (core/vector_quantizer.dart:357-368,461-483): per
+ * sub-space the FIRST centroid with the smallest f64-accumulated squared
+ * distance.  codebook: host, float32, layout centroids[(m*K + k)*subDim + d]
+ * (vector_quantizer.dart:15), subDim = dim / subspaces; out_codes: host,
+ * n_rows x subspaces bytes (one NghPqCodePage entry each, ngh_page.dart:232-300).
+ * Codes are bit-exact with the reference; training (k-means++ seeded by Dart's
+ * Random(42)) is not reproduced here. */
+int32_t tsh_index_pq_encode(tsh_index *idx, int64_t first_row_id, int64_t n_rows, const float *codebook,
+                            int32_t subspaces, int32_t centroids, uint8_t *out_codes);
+
 int64_t tsh_index_size(tsh_index *idx); /* next row id (rows incl. tombstones) */
 int32_t tsh_index_dim(tsh_index *idx);
 int32_t tsh_index_metric(tsh_index *idx);

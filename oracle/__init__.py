@@ -70,6 +70,9 @@ def lib() -> ctypes.CDLL:
         L.vso_all_distances.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int,
                                         _c_f32p, _c_f64p]
         L.vso_all_distances.restype = None
+        L.vso_pq_encode.argtypes = [_c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32p, _c_i64, ctypes.c_int,
+                                    _c_u8p]
+        L.vso_pq_encode.restype = None
         L.vso_crc32.argtypes = [_c_u8p, ctypes.c_size_t]
         L.vso_crc32.restype = ctypes.c_uint32
         L.vso_vectors_per_raw_page.argtypes = [ctypes.c_int] * 3
@@ -212,6 +215,15 @@ def search_heap_many_mt(rows, queries, metric: int, k: int, threshold=None, keep
 
 def mt_max_threads() -> int:
     return lib_mt().vso_mt_max_threads()
+
+
+def pq_encode(codebook, subspaces: int, centroids: int, sub_dim: int, vectors) -> np.ndarray:
+    cb, v = _f32(codebook).reshape(-1), _f32(vectors)
+    assert cb.shape[0] == subspaces * centroids * sub_dim and v.shape[1] >= subspaces * sub_dim
+    codes = np.empty((v.shape[0], subspaces), dtype=np.uint8)
+    lib().vso_pq_encode(_p(cb, _c_f32p), subspaces, centroids, sub_dim, _p(v, _c_f32p), v.shape[0], v.shape[1],
+                        _p(codes, _c_u8p))
+    return codes
 
 
 def crc32(data: bytes) -> int:

@@ -156,6 +156,28 @@ def distance_to_score(distance: float, metric: int) -> float:
     return s
 
 
+def pq_encode(codebook, subspaces: int, centroids: int, sub_dim: int, vectors) -> np.ndarray:
+    """N4. ref: core/compute_tasks.dart:2292-2326 (f64 accumulation over the sub-space, first minimum)."""
+    cb = np.asarray(codebook, np.float32).reshape(subspaces, centroids, sub_dim).astype(np.float64)
+    v = np.asarray(vectors, np.float32).astype(np.float64)
+    codes = np.zeros((v.shape[0], subspaces), np.uint8)
+    with np.errstate(all="ignore"):
+        for m in range(subspaces):
+            sub = v[:, m * sub_dim:(m + 1) * sub_dim]
+            dist = np.zeros((v.shape[0], centroids))
+            for dd in range(sub_dim):  # sequential accumulation, one rounding per multiply and add
+                diff = sub[:, dd:dd + 1] - cb[m, :, dd][None, :]
+                dist = dist + diff * diff
+            best = np.full(v.shape[0], np.inf)
+            idx = np.zeros(v.shape[0], np.int64)
+            for c in range(centroids):  # strict `<`: ties and NaN keep the lower index
+                lt = dist[:, c] < best
+                best = np.where(lt, dist[:, c], best)
+                idx = np.where(lt, c, idx)
+            codes[:, m] = idx.astype(np.uint8)
+    return codes
+
+
 # ---- A7 page framing ------------------------------------------------------
 def crc32(data: bytes) -> int:
     """ref: core/btree_page.dart:61-89 (IEEE CRC-32; same as zlib.crc32)."""

@@ -249,6 +249,34 @@ int64_t vso_search_heap(const float *rows, int64_t n, int d, int metric,
   return m;
 }
 
+/* ---- N4: ref: core/compute_tasks.dart:2292-2326 ------------------------------ */
+void vso_pq_encode(const float *codebook, int subspaces, int centroids, int sub_dim,
+                   const float *vectors, int64_t n, int dim, uint8_t *codes) {
+  int64_t v;
+  for (v = 0; v < n; v++) {
+    const float *vec = vectors + v * (int64_t)dim;
+    int m;
+    for (m = 0; m < subspaces; m++) {
+      int sub_start = m * sub_dim, best_idx = 0, c, d;
+      double best = INFINITY;
+      const float *cb = codebook + (int64_t)m * centroids * sub_dim;
+      for (c = 0; c < centroids; c++) {
+        double dist = 0;
+        const float *cc = cb + (int64_t)c * sub_dim;
+        for (d = 0; d < sub_dim; d++) {
+          double diff = (double)vec[sub_start + d] - (double)cc[d];
+          dist += diff * diff;
+        }
+        if (dist < best) {
+          best = dist;
+          best_idx = c;
+        }
+      }
+      codes[v * subspaces + m] = (uint8_t)best_idx; /* code[m] = bestIdx into a Uint8List */
+    }
+  }
+}
+
 /* ---- A7: CRC32.  ref: core/btree_page.dart:61-89 ------------------------ */
 uint32_t vso_crc32(const uint8_t *data, size_t len) {
   static uint32_t table[256];

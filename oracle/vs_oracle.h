@@ -79,6 +79,16 @@ int64_t vso_search_heap(const float *rows, int64_t n, int d, int metric,
 void vso_all_distances(const float *rows, int64_t n, int d, int metric,
                        const float *query, double *out_dist);
 
+/* N4 (write path): batch PQ encode.  ref: core/compute_tasks.dart:2292-2326
+ * (batchPqEncode) == core/vector_quantizer.dart:357-368,461-483 (encode /
+ * _nearestCentroid): per vector and sub-space m, the index of the first
+ * centroid with the smallest f64-accumulated squared distance (strict `<`, so
+ * ties and NaN keep the lower index).  codebook layout :15
+ * centroids[(m*K + k)*subDim + d]; vectors n x dim with dim >= subspaces*subDim;
+ * codes n x subspaces. */
+void vso_pq_encode(const float *codebook, int subspaces, int centroids, int sub_dim,
+                   const float *vectors, int64_t n, int dim, uint8_t *codes);
+
 /* A7  page framing.  ref: core/btree_page.dart:61-89 (CRC32 IEEE, reflected,
  * poly 0xEDB88320), :132-234 (20-byte 'TPG2' header) */
 uint32_t vso_crc32(const uint8_t *data, size_t len);

@@ -87,6 +87,18 @@ class HipVectorIndex:
                                                          first_row_id, max_rows, ctypes.byref(out)))
         return out.value
 
+    def pq_encode(self, first_row_id: int, n_rows: int, codebook, subspaces: int, centroids: int = 256) -> np.ndarray:
+        """PQ codes (n_rows x subspaces, uint8) of resident rows; mirrors batchPqEncode
+        (/root/reference/lib/src/core/compute_tasks.dart:2292-2326)."""
+        cb = _f32c(codebook).reshape(-1)
+        sub_dim = self.dim // subspaces
+        if cb.shape[0] != subspaces * centroids * sub_dim:
+            raise ValueError("codebook must hold subspaces*centroids*(dim//subspaces) floats")
+        codes = np.empty((n_rows, subspaces), dtype=np.uint8)
+        _ffi.check(_ffi.lib().tsh_index_pq_encode(self._h, first_row_id, n_rows, cb.ctypes.data_as(_ffi.p_f32),
+                                                  subspaces, centroids, codes.ctypes.data_as(_ffi.p_u8)))
+        return codes
+
     @property
     def size(self) -> int:
         return _ffi.lib().tsh_index_size(self._h)

@@ -25,6 +25,7 @@
 #include "../../include/tostore_hip.h"
 #include "tsh_batch.hip.h"
 #include "tsh_kernels.hip.h"
+#include "tsh_pq.hip.h"
 
 using namespace tsh;
 
@@ -1907,4 +1908,62 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
   fclose(f);
   if (out_rows) *out_rows = loaded;
   return rc;
+}
+
+// ---- N4: batch PQ encode of resident rows -------------------------------------------
+extern "C" int32_t tsh_index_pq_encode(tsh_index *idx, int64_t first_row_id, int64_t n_rows, const float *codebook,
+                                       int32_t subspaces, int32_t centroids, uint8_t *out_codes) {
+  if (!idx || !codebook || !out_codes) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  if (n_rows < 0 || first_row_id < 0) return set_err(TSH_E_BAD_ARG, "negative row range");
+  if (subspaces < 1 || subspaces > idx->dim || centroids < 1 || centroids > 256)
+    return set_err(TSH_E_BAD_ARG, "subspaces %d / centroids %d out of range", subspaces, centroids);
+  const int32_t sub_dim = idx->dim / subspaces;  // PqCodebook: dimensions = subspaces * subDimensions
+  if (sub_dim < 1 || sub_dim > 64) return set_err(TSH_E_BAD_ARG, "sub-space width %d outside [1,64]", sub_dim);
+  if (n_rows == 0) return TSH_OK;
+  const size_t cb_elems = (size_t)subspaces * centroids * sub_dim;
+  std::vector<double> cb64(cb_elems);
+  for (size_t i = 0; i < cb_elems; ++i) cb64[i] = (double)codebook[i];  // exact widening
+  int64_t done = 0;
+  while (done < n_rows) {
+    const int64_t gid = first_row_id + done;
+    Shard *s = shard_for_row(idx, gid);
+    std::shared_lock<RwLock> sl(s->mu);
+    const int64_t local = gid - s->row_base;
+    if (local < 0 || local >= s->rows)
+      return set_err(TSH_E_BAD_ARG, "row %lld is not resident", (long long)gid);
+    const int64_t take = std::min(n_rows - done, s->rows - local);
+    HIPCHK(hipSetDevice(s->device));
+    double *d_cb = nullptr;
+    uint8_t *d_codes = nullptr;
+    HIPCHK(hipMalloc(&d_cb, cb_elems * sizeof(double)));
+    hipError_t e = hipMalloc(&d_codes, (size_t)take * subspaces);
+    hipStream_t st = s->ingest_stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cb, cb64.data(), cb_elems * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      PqEncodeArgs a{};
+      a.rows = s->d_rows;
+      a.codebook = d_cb;
+      a.codes = d_codes;
+      a.ld = s->ld;
+      a.first = local;
+      a.n = take;
+      a.subspaces = subspaces;
+      a.centroids = centroids;
+      a.sub_dim = sub_dim;
+      const unsigned grid = (unsigned)((take + 255) / 256);
+      if (sub_dim == 8) pq_encode_kernel<8><<<grid, 256, 0, st>>>(a);
+      else if (sub_dim == 4) pq_encode_kernel<4><<<grid, 256, 0, st>>>(a);
+      else if (sub_dim == 16) pq_encode_kernel<16><<<grid, 256, 0, st>>>(a);
+      else pq_encode_kernel<0><<<grid, 256, 0, st>>>(a);
+      e = hipMemcpyAsync(out_codes + (size_t)done * subspaces, d_codes, (size_t)take * subspaces,
+                         hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    hipFree(d_cb);
+    if (d_codes) hipFree(d_codes);
+    if (e != hipSuccess) return set_err(TSH_E_HIP, "pq_encode: %s", hipGetErrorString(e));
+    done += take;
+  }
+  return TSH_OK;
 }
