@@ -26,8 +26,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BT_M = 128;   // queries per workgroup tile
 constexpr int BT_N = 128;   // rows per workgroup tile
-constexpr int BT_K = 32;    // reduction chunk
-constexpr int BT_LD = 36;   // LDS row stride in floats: 144 B keeps ds_read_b128 conflict-free
+constexpr int BT_K = 32;    // default reduction chunk (template parameter BK of the kernel)
+// LDS row stride in floats for a chunk of BK: BK + 4 (144 B / 80 B rows keep ds_read_b128 conflict-free)
+constexpr int bt_ld(int bk) { return bk + 4; }
 constexpr int BT_THREADS = 256;
 
 struct BatchArgs {
@@ -47,7 +48,7 @@ struct BatchArgs {
   int64_t dense_ld;
   int32_t row0, row1;     // rows scored by this launch
   int32_t nq, nq_pad;     // nq_pad multiple of BT_M
-  int32_t kchunks;        // ceil(ld / BT_K); ld is padded with zeros to a multiple of 4
+  int32_t kchunks;        // ceil(ld / BK); ld is padded with zeros to a multiple of 4
   int32_t cand_cap;
   int32_t q_tiles;        // nq_pad / BT_M
   int32_t n_tiles;        // ceil((row1-row0) / BT_N)
@@ -59,8 +60,12 @@ struct BatchArgs {
 // its fragments back as one ds_read_b128 per 4 MFMAs: lanes 0-31 own
 // k = 8t..8t+3, lanes 32-63 own k = 8t+4..8t+7 (the k order inside a chunk is
 // free as long as A and B agree).
-template <int METRIC, bool DENSE>
-__global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a) {
+template <int METRIC, bool DENSE, int BK = BT_K>
+__global__ void __launch_bounds__(BT_THREADS, BK == 32 ? 2 : 3) batch_score_kernel(BatchArgs a) {
+  constexpr int BT_LD = bt_ld(BK);
+  constexpr int C4 = BK / 4;             // float4 columns per chunk row
+  constexpr int RPP = BT_THREADS / C4;   // rows staged per pass
+  constexpr int NJ = BT_M / RPP;         // passes per operand
   __shared__ __attribute__((aligned(16))) float As[2][BT_M][BT_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BT_N][BT_LD];
   __shared__ __attribute__((aligned(16))) float s_thr[BT_M];
@@ -96,13 +101,13 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
     s_qsq[tid] = METRIC == METRIC_L2 ? a.qsq[qbase + tid] : 0.f;
   }
 
-  // staging map: thread -> (row r0 + 32 j, float4 column c4)
-  const int c4 = tid & 7, r0 = tid >> 3;
-  const float *qg[4], *vg[4];
+  // staging map: thread -> (row r0 + RPP j, float4 column c4)
+  const int c4 = tid % C4, r0 = tid / C4;
+  const float *qg[NJ], *vg[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    qg[j] = a.Q + (int64_t)(qbase + r0 + 32 * j) * a.ld + 4 * c4;
-    int vr = nbase + r0 + 32 * j;
+  for (int j = 0; j < NJ; ++j) {
+    qg[j] = a.Q + (int64_t)(qbase + r0 + RPP * j) * a.ld + 4 * c4;
+    int vr = nbase + r0 + RPP * j;
     if (vr >= a.row1) vr = a.row1 - 1;  // clamp: tail columns are discarded in the epilogue
     vg[j] = a.V + (int64_t)vr * a.ld + 4 * c4;
   }
@@ -116,21 +121,21 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[NJ], rb[NJ];
   auto gload = [&](int kc) {
-    const bool ok = kc * 8 + c4 < kmax4;  // ld need not be a multiple of BT_K
+    const bool ok = kc * C4 + c4 < kmax4;  // ld need not be a multiple of BK
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = ok ? *reinterpret_cast<const f32x4 *>(qg[j] + kc * BT_K) : f32x4{0.f, 0.f, 0.f, 0.f};
-      rb[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vg[j] + kc * BT_K))
+    for (int j = 0; j < NJ; ++j) {
+      ra[j] = ok ? *reinterpret_cast<const f32x4 *>(qg[j] + kc * BK) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vg[j] + kc * BK))
                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<f32x4 *>(&As[buf][r0 + 32 * j][4 * c4]) = ra[j];
-      *reinterpret_cast<f32x4 *>(&Bs[buf][r0 + 32 * j][4 * c4]) = rb[j];
+    for (int j = 0; j < NJ; ++j) {
+      *reinterpret_cast<f32x4 *>(&As[buf][r0 + RPP * j][4 * c4]) = ra[j];
+      *reinterpret_cast<f32x4 *>(&Bs[buf][r0 + RPP * j][4 * c4]) = rb[j];
     }
   };
 
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(BT_THREADS, 2) batch_score_kernel(BatchArgs a)
     const int buf = kc & 1;
     if (kc + 1 < a.kchunks) gload(kc + 1);  // in flight while this chunk is multiplied
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < BK / 8; ++t) {
       f32x4 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {

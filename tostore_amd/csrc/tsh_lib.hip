@@ -309,6 +309,7 @@ struct Shard {
   // next query's scan without queueing behind its loads on the same CU.
   hipStream_t tail_stream = nullptr;
   bool cu_split = false;
+  hipStream_t batch_stream = nullptr;  // matrix-core batches: compute-bound, so all CUs (no mask)
   std::mutex scan_mu;
   std::atomic<int> inflight{0};
 
@@ -353,12 +354,15 @@ int shard_init(Shard *s) {
       } else {
         if (s->scan_stream) hipStreamDestroy(s->scan_stream);
   if (s->tail_stream) hipStreamDestroy(s->tail_stream);
+  if (s->batch_stream) hipStreamDestroy(s->batch_stream);
         if (s->tail_stream) hipStreamDestroy(s->tail_stream);
+  if (s->batch_stream) hipStreamDestroy(s->batch_stream);
         s->scan_stream = s->tail_stream = nullptr;
         (void)hipGetLastError();
       }
     }
     if (!s->cu_split) HIPCHK(hipStreamCreateWithFlags(&s->scan_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->batch_stream, hipStreamNonBlocking));
   }
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
@@ -1036,10 +1040,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
 
-  // ---- enqueue on the shard's pipeline stream ------------------------------------------
+  // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
   {
-    std::lock_guard<std::mutex> sl(s->scan_mu);
-    hipStream_t st = s->scan_stream;
+    hipStream_t st = s->batch_stream;
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
@@ -1141,7 +1144,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   s->c_searches += nq - (int64_t)redo->size();
   if (out->h_blocks) memcpy(out->h_blocks, b->h_blocks, (size_t)nq * bb);
   if (out->d_blocks) {
-    hipStream_t us = out->user_stream ? out->user_stream : s->scan_stream;
+    hipStream_t us = out->user_stream ? out->user_stream : s->batch_stream;
     HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
     HIPCHK(hipStreamSynchronize(us));
   }
@@ -1241,6 +1244,7 @@ void shard_destroy(Shard *s) {
   if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
   if (s->scan_stream) hipStreamDestroy(s->scan_stream);
   if (s->tail_stream) hipStreamDestroy(s->tail_stream);
+  if (s->batch_stream) hipStreamDestroy(s->batch_stream);
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
   hipFree(s->d_sqnorm);
