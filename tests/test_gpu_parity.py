@@ -184,10 +184,10 @@ def test_threshold_is_strict(hip_lib, oracle_mod, metric):
 
 
 @pytest.mark.parametrize("metric", METRICS)
-def test_mask_and_tombstones(hip_lib, oracle_mod, metric):
+@pytest.mark.parametrize("d", [96, 128, 64, 32])  # 128/64/32: the packed narrow-row scan, masked variant
+def test_mask_and_tombstones(hip_lib, oracle_mod, metric, d):
     from tostore_amd import HipVectorIndex
 
-    d = 96
     n = 7000  # not a multiple of 64
     rows = _mk(n, d, 41)
     rng = np.random.default_rng(42)

@@ -281,6 +281,88 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   }
 }
 
+// K1 for narrow rows (ld = 128 / 64 / 32 floats): one 1 KiB wave load covers
+// 2 / 4 / 8 whole rows, so every lane stays busy.  A "virtual row" is the 256
+// floats of one wave load; the butterfly is the same as above but stops before
+// its last SPLIT exchange steps, which leaves each of the virtual row's real rows
+// in its own group of 64 >> SPLIT lanes.  Masked tiles are not compacted here
+// (rows are tiny): a tile is skipped only when none of its 64 rows is live.
+template <int SPLIT, int METRIC, bool MASKED, bool NT>
+__global__ void __launch_bounds__(256, 4) scan_packed_kernel(ScanArgsQ aq) {
+  static_assert(SPLIT >= 1 && SPLIT <= 3, "2, 4 or 8 rows per wave load");
+  constexpr int LPR = 64 >> SPLIT;           // lanes per real row
+  constexpr int NB = 8 >> SPLIT;             // batches of 8 virtual rows per 64-row tile
+  const ScanArgs &a = aq.a;
+  const float *qsrc = a.query;
+  if (!qsrc) {
+    typedef const char __attribute__((address_space(4))) * karg_ptr;
+    qsrc = (const float *)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ScanArgsQ, q));
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = __builtin_amdgcn_readfirstlane((int)blockDim.x >> 6);
+  const int stride = gridDim.x * wpb;
+  const f32x4 q = *reinterpret_cast<const f32x4 *>(qsrc + 4 * (lane & (LPR - 1)));
+  if (a.query_out && blockIdx.x == 0 && wave == 0 && lane < LPR)
+    *reinterpret_cast<f32x4 *>(a.query_out + 4 * lane) = q;
+  // real row (within the tile) whose key this lane ends up holding
+  const int my_b = (lane >> 3) & (NB - 1);
+  const int rr = (((my_b * 8) + (lane & 7)) << SPLIT) | (lane >> (6 - SPLIT));
+
+  for (int t = blockIdx.x * wpb + wave; t < a.n_tiles; t += stride) {
+    const float *tbase = a.rows + (int64_t)t * 64 * a.ld + 4 * lane;
+    uint64_t bits = ~0ull;
+    if (MASKED) {
+      uint64_t w = a.live[t];
+      if (a.mask) w &= a.mask[t];
+      uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)w);
+      uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
+      bits = ((uint64_t)hi << 32) | lo;
+      if (bits == 0) {
+        a.keys[(int64_t)t * 64 + lane] = KEY_DEAD;
+        if (lane == 0) a.gmin[t] = KEY_DEAD;
+        continue;
+      }
+    }
+    f32x4 v[2][8];
+    auto load_batch = [&](int buf, int b) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[buf][j] = ld16<NT>(tbase + (b * 8 + j) * 256);
+    };
+    float val = 0.f;
+    load_batch(0, 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) load_batch((b + 1) & 1, b + 1);
+      TSH_FENCE();
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float sacc = accum4<METRIC>(0.f, q, v[b & 1][j]);
+        asm volatile("" : "+v"(sacc)::"memory");
+        acc[j] = sacc;
+      }
+      float o = treduce8<0>(acc, lane);
+      if (LPR >= 16) o += __shfl_xor(o, 8);
+      if (LPR >= 32) o += __shfl_xor(o, 16);
+      if (my_b == b) val = o;
+      TSH_FENCE();
+    }
+    const int64_t row = (int64_t)t * 64 + rr;
+    const bool alive = MASKED ? ((bits >> rr) & 1ull) != 0 : row < a.n;
+    if (METRIC == METRIC_IP) {
+      val = -val;
+    } else if (METRIC == METRIC_COS) {
+      float inv = alive ? a.inv_norm[row] : 0.f;
+      val = -(val * inv);
+    }
+    uint32_t key = alive ? f2key(val) : KEY_DEAD;
+    a.keys[row] = key;
+    uint32_t m = wave_min_u32(key);
+    if (lane == 0) a.gmin[t] = m;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // candidate block written by K2/K3/K4 and shipped to the host (and all-gathered
 // between ranks): 64-byte header + entries x {int64 id, f64 s0, f64 s1}

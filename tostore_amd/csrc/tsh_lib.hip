@@ -204,9 +204,30 @@ void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStr
   else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s);
   else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s);
 }
+template <int SPLIT>
+void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s) {
+#define TSH_PK(M, MK) scan_packed_kernel<SPLIT, M, MK, true><<<grid, threads, 0, s>>>(a)
+  if (metric == TSH_METRIC_L2) { if (masked) TSH_PK(METRIC_L2, true); else TSH_PK(METRIC_L2, false); }
+  else if (metric == TSH_METRIC_IP) { if (masked) TSH_PK(METRIC_IP, true); else TSH_PK(METRIC_IP, false); }
+  else { if (masked) TSH_PK(METRIC_COS, true); else TSH_PK(METRIC_COS, false); }
+#undef TSH_PK
+}
+
 void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s) {
   int grid = (a.a.n_tiles + 3) / 4;
   if (grid < 1) grid = 1;
+  if (a.a.ld == 128 || a.a.ld == 64 || a.a.ld == 32) {
+    // narrow rows: several whole rows per 1 KiB wave load (scan_packed_kernel)
+    int threads = 256;
+    if (a.a.n_tiles < 6 * 4 * 256) {
+      grid = std::max(1, (int)a.a.n_tiles);
+      threads = 64;
+    }
+    if (a.a.ld == 128) launch_packed<1>(a, metric, masked, grid, threads, s);
+    else if (a.a.ld == 64) launch_packed<2>(a, metric, masked, grid, threads, s);
+    else launch_packed<3>(a, metric, masked, grid, threads, s);
+    return;
+  }
   // fewer than ~6 four-wave workgroups per CU: tile counts per CU differ by tens of
   // percent; one tile per workgroup lets the dispatcher even them out
   if (a.a.n_tiles < 6 * 4 * 256) grid = -std::max(1, (int)a.a.n_tiles);
