@@ -1,0 +1,70 @@
+"""GPU: seeded fuzz over shapes the hand-written cases may miss -- random row counts (not multiples
+of 64), dimensions 1..300 (every scan-kernel variant incl. tails and the packed narrow-row
+kernels), k, metrics, masks, tombstones, thresholds, duplicate rows, chunked appends, both the
+single-query and the batched path.  Every answer must equal the oracle bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _one_case(oracle, rng, case):
+    from tostore_amd import HipVectorIndex
+
+    d = int(rng.choice([1, 2, 3, 4, 5, 8, 13, 16, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256,
+                        257, 300]))
+    n = int(rng.integers(1, 9000)) if rng.random() < 0.8 else int(rng.integers(9000, 40000))
+    metric = int(rng.integers(0, 3))
+    k = int(rng.choice([1, 2, 7, 10, 33, 100, 257, n, n + 3]))
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    if rng.random() < 0.3:
+        rows *= rng.uniform(0.01, 50.0, size=(n, 1)).astype(np.float32)
+    if rng.random() < 0.3 and n > 10:  # duplicate rows -> ties broken by id
+        src = rng.integers(0, n, size=max(1, n // 20))
+        dst = rng.integers(0, n, size=len(src))
+        rows[dst] = rows[src]
+    if rng.random() < 0.15:
+        rows[rng.integers(0, n)] = 0.0
+    nq = int(rng.choice([1, 1, 2, 9, 20]))
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    if rng.random() < 0.2:
+        qs[0] = rows[rng.integers(0, n)]  # exact hit
+    if metric == 2:
+        qs = np.stack([oracle.normalize_f32(q) for q in qs])
+    keep = None
+    if rng.random() < 0.4:
+        keep = np.packbits(rng.random(n) < rng.choice([0.02, 0.5, 0.95]), bitorder="little")
+    alive = np.ones(n, bool)
+    with HipVectorIndex(d, metric) as idx:
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            if hi > lo:
+                idx.append(lo, rows[lo:hi])
+        if rng.random() < 0.4 and n > 3:
+            dead = rng.choice(n, size=int(rng.integers(1, max(2, n // 3))), replace=False)
+            idx.set_deleted(dead)
+            alive[dead] = False
+        eff = alive if keep is None else alive & np.unpackbits(keep, bitorder="little")[:n].astype(bool)
+        eff_mask = np.packbits(eff, bitorder="little")
+        thr = None
+        if rng.random() < 0.3:
+            _, ed = oracle.search_exhaustive(rows, qs[0], metric, min(k, 50), None, eff_mask)
+            if len(ed):
+                thr = float(ed[len(ed) // 2])
+        if rng.random() < 0.5:
+            idx.set_batch_min_nq(0)
+        ids, dist, cnt = idx.search(qs, k, thr, keep)
+        for i in range(nq):
+            eids, edist = oracle.search_exhaustive(rows, qs[i], metric, k, thr, eff_mask)
+            tag = f"case {case}: n={n} d={d} metric={metric} k={k} nq={nq} mask={keep is not None} thr={thr}"
+            assert cnt[i] == len(eids), tag
+            assert np.array_equal(ids[i, :cnt[i]], eids), tag
+            a, b = dist[i, :cnt[i]], edist
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), tag
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz(hip_lib, oracle_mod, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(40):
+        _one_case(oracle_mod, rng, f"{seed}/{case}")
