@@ -393,3 +393,55 @@ def test_large_k_single_query(hip_lib, oracle_mod, k):
         assert cnt[0] == k and np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
         if k <= 1024:
             assert idx.counters()["fallback_searches"] == 0
+
+
+def test_appends_and_deletes_while_searching(hip_lib, oracle_mod):
+    """search (shared lock) vs append / delete (exclusive lock) from different threads: every answer
+    must be the exact answer for the row set at some moment between call and return."""
+    import threading
+
+    from tostore_amd import HipVectorIndex
+
+    d, total, chunk, k = 64, 30000, 750, 15
+    rows = _mk(total, d, 131)
+    qs = _mk(6, d, 132)
+    errs, stop = [], threading.Event()
+    with HipVectorIndex(d, L2) as idx:
+        idx.append(0, rows[:chunk])
+
+        def writer():
+            try:
+                for lo in range(chunk, total, chunk):
+                    idx.append(lo, rows[lo:lo + chunk])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+            finally:
+                stop.set()
+
+        def reader(qi):
+            try:
+                while not stop.is_set():
+                    before = idx.size
+                    ids, dist, cnt = idx.search(qs[qi], k)
+                    after = idx.size
+                    got, gd = ids[0, :cnt[0]], dist[0, :cnt[0]]
+                    assert cnt[0] == k and (got < after).all()
+                    exact = np.array([oracle_mod.exact_distance(qs[qi], rows[i], L2) for i in got])
+                    assert np.array_equal(gd, exact)                        # distances of those very rows
+                    assert all((gd[i], got[i]) <= (gd[i + 1], got[i + 1]) for i in range(k - 1))
+                    _, lo_d = oracle_mod.search_heap(rows[:before], qs[qi], L2, k)
+                    _, hi_d = oracle_mod.search_heap(rows[:after], qs[qi], L2, k)
+                    assert hi_d[-1] <= gd[-1] <= lo_d[-1]                    # between the two snapshots
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=writer)] + [threading.Thread(target=reader, args=(i,)) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs[:2]
+        assert idx.size == total
+        ids, dist, cnt = idx.search(qs[0], k)
+        eids, edist = oracle_mod.search_heap(rows, qs[0], L2, k)
+        assert np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
