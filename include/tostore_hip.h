@@ -152,10 +152,23 @@ int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t pag
  * distance.  codebook: host, float32, layout centroids[(m*K + k)*subDim + d]
  * (vector_quantizer.dart:15), subDim = dim / subspaces; out_codes: host,
  * n_rows x subspaces bytes (one NghPqCodePage entry each, ngh_page.dart:232-300).
- * Codes are bit-exact with the reference; training (k-means++ seeded by Dart's
- * Random(42)) is not reproduced here. */
+ * Codes are bit-exact with the reference. */
 int32_t tsh_index_pq_encode(tsh_index *idx, int64_t first_row_id, int64_t n_rows, const float *codebook,
                             int32_t subspaces, int32_t centroids, uint8_t *out_codes);
+
+/* Write-path helper (N4): train a PQ codebook the way the index manager's isolate
+ * tasks do -- one trainPqSubspace per sub-space (lib/src/core/compute_tasks.dart:
+ * 2135-2266, dispatched from core/vector_index_manager.dart:740-850 when >= 100
+ * samples were collected; `iterations` is 10 there and centroids = min(256, n)).
+ * samples: host, n x dim float32 (already _toFloat32'd, cosine rows normalised);
+ * init_index: host, subspaces x centroids sample indices -- the values the
+ * reference draws with Random(42 + subspaceIndex).nextInt(n), which stay on the
+ * Dart side; out_codebook: host, layout centroids[(m*K + k)*subDim + d]
+ * (vector_quantizer.dart:15).  Given the same init_index the codebook is
+ * bit-identical to the reference's (mixed f32/f64 arithmetic restated, see
+ * tsh_pq.hip.h).  Stateless: runs on `device`, needs no index handle. */
+int32_t tsh_pq_train(int32_t device, const float *samples, int64_t n, int32_t dim, int32_t subspaces,
+                     int32_t centroids, int32_t iterations, const int32_t *init_index, float *out_codebook);
 
 int64_t tsh_index_size(tsh_index *idx); /* next row id (rows incl. tombstones) */
 int32_t tsh_index_dim(tsh_index *idx);

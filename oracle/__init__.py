@@ -73,6 +73,9 @@ def lib() -> ctypes.CDLL:
         L.vso_pq_encode.argtypes = [_c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f32p, _c_i64, ctypes.c_int,
                                     _c_u8p]
         L.vso_pq_encode.restype = None
+        L.vso_pq_train_subspace.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_int32), _c_f32p]
+        L.vso_pq_train_subspace.restype = None
         L.vso_crc32.argtypes = [_c_u8p, ctypes.c_size_t]
         L.vso_crc32.restype = ctypes.c_uint32
         L.vso_vectors_per_raw_page.argtypes = [ctypes.c_int] * 3
@@ -224,6 +227,21 @@ def pq_encode(codebook, subspaces: int, centroids: int, sub_dim: int, vectors) -
     lib().vso_pq_encode(_p(cb, _c_f32p), subspaces, centroids, sub_dim, _p(v, _c_f32p), v.shape[0], v.shape[1],
                         _p(codes, _c_u8p))
     return codes
+
+
+def pq_train(samples, subspaces: int, k: int, iterations: int, init_index) -> np.ndarray:
+    """Codebook (subspaces x k x subDim) trained like the reference's isolate tasks, one
+    trainPqSubspace per sub-space, from caller-supplied initial sample indices (subspaces x k)."""
+    s = _f32(samples)
+    n, dim = s.shape
+    sd = dim // subspaces
+    init = np.ascontiguousarray(init_index, dtype=np.int32).reshape(subspaces, k)
+    out = np.empty((subspaces, k, sd), dtype=np.float32)
+    for m in range(subspaces):
+        sub = np.ascontiguousarray(s[:, m * sd:(m + 1) * sd])
+        lib().vso_pq_train_subspace(_p(sub, _c_f32p), n, sd, k, iterations,
+                                    init[m].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _p(out[m], _c_f32p))
+    return out
 
 
 def crc32(data: bytes) -> int:

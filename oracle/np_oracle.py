@@ -178,6 +178,57 @@ def pq_encode(codebook, subspaces: int, centroids: int, sub_dim: int, vectors) -
     return codes
 
 
+def pq_train_subspace(data, k: int, iterations: int, init_index) -> np.ndarray:
+    """N4. ref: core/compute_tasks.dart:2135-2266, arithmetic widths as in the Dart text
+    (Float32List stores round to f32; `double` temporaries are f64)."""
+    data = np.asarray(data, np.float32)
+    n, sd = data.shape
+    f32, f64 = np.float32, np.float64
+    cent = data[np.asarray(init_index, np.int64)].copy()
+    simd = sd % 4 == 0
+    d64 = data.astype(f64)
+    with np.errstate(all="ignore"):
+        for _ in range(iterations):
+            norm = np.zeros(k, f64)
+            for d in range(sd):
+                v = cent[:, d].astype(f64)
+                norm = norm + v * v
+            norms = (norm * 0.5).astype(f32)
+            dot = np.zeros((n, k), f64)
+            if simd:
+                for d in range(0, sd, 4):
+                    r = [(data[:, d + u:d + u + 1] * cent[:, d + u][None, :]).astype(f32).astype(f64) for u in range(4)]
+                    dot = dot + (((r[0] + r[1]) + r[2]) + r[3])
+            else:
+                c64 = cent.astype(f64)
+                for d in range(sd):
+                    dot = dot + d64[:, d:d + 1] * c64[:, d][None, :]
+            score = dot - norms.astype(f64)[None, :]
+            best = np.full(n, -np.inf)
+            assign = np.zeros(n, np.int64)
+            for c in range(k):
+                gt = score[:, c] > best
+                best = np.where(gt, score[:, c], best)
+                assign = np.where(gt, c, assign)
+            sums = np.zeros((k, sd), f32)
+            counts = np.zeros(k, np.int64)
+            for i in range(n):  # Float32List += : one f32 rounding per add, in sample order
+                c = assign[i]
+                counts[c] += 1
+                sums[c] = (sums[c].astype(f64) + d64[i]).astype(f32)
+            changed = False
+            for c in range(k):
+                if counts[c] == 0:
+                    continue
+                new = sums[c].astype(f64) * (1.0 / counts[c])
+                if (np.abs(cent[c].astype(f64) - new) > 1e-4).any():
+                    changed = True
+                cent[c] = new.astype(f32)
+            if not changed:
+                break
+    return cent
+
+
 # ---- A7 page framing ------------------------------------------------------
 def crc32(data: bytes) -> int:
     """ref: core/btree_page.dart:61-89 (IEEE CRC-32; same as zlib.crc32)."""

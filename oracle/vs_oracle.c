@@ -277,6 +277,77 @@ void vso_pq_encode(const float *codebook, int subspaces, int centroids, int sub_
   }
 }
 
+/* ---- N4: ref: core/compute_tasks.dart:2135-2266 (trainPqSubspace) ------------ */
+void vso_pq_train_subspace(const float *data, int64_t n, int sub_dim, int k, int iterations,
+                           const int32_t *init_index, float *centroids) {
+  int32_t *assign = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  int32_t *counts = (int32_t *)malloc((size_t)k * sizeof(int32_t));
+  float *sums = (float *)malloc((size_t)k * sub_dim * sizeof(float));
+  float *norms = (float *)malloc((size_t)k * sizeof(float));
+  int use_simd = (sub_dim % 4 == 0), iter, c, d;
+  int64_t i;
+  for (c = 0; c < k; c++) /* :2144-2151 */
+    for (d = 0; d < sub_dim; d++) centroids[c * sub_dim + d] = data[(int64_t)init_index[c] * sub_dim + d];
+  for (iter = 0; iter < iterations; iter++) {
+    int changed = 0;
+    for (c = 0; c < k; c++) { /* :2166-2174 */
+      double norm = 0;
+      for (d = 0; d < sub_dim; d++) {
+        double val = (double)centroids[c * sub_dim + d];
+        norm += val * val;
+      }
+      norms[c] = (float)(norm * 0.5);
+    }
+    for (i = 0; i < n; i++) { /* :2183-2233 */
+      double best = -INFINITY;
+      int best_idx = 0;
+      for (c = 0; c < k; c++) {
+        double dot = 0, score;
+        if (use_simd) {
+          for (d = 0; d < sub_dim; d += 4) { /* Float32x4 multiply: four f32 products */
+            float rx = data[i * sub_dim + d] * centroids[c * sub_dim + d];
+            float ry = data[i * sub_dim + d + 1] * centroids[c * sub_dim + d + 1];
+            float rz = data[i * sub_dim + d + 2] * centroids[c * sub_dim + d + 2];
+            float rw = data[i * sub_dim + d + 3] * centroids[c * sub_dim + d + 3];
+            dot += (((double)rx + (double)ry) + (double)rz) + (double)rw;
+          }
+        } else {
+          for (d = 0; d < sub_dim; d++) dot += (double)data[i * sub_dim + d] * (double)centroids[c * sub_dim + d];
+        }
+        score = dot - (double)norms[c];
+        if (score > best) {
+          best = score;
+          best_idx = c;
+        }
+      }
+      assign[i] = best_idx;
+    }
+    memset(sums, 0, (size_t)k * sub_dim * sizeof(float)); /* :2236-2248 */
+    memset(counts, 0, (size_t)k * sizeof(int32_t));
+    for (i = 0; i < n; i++) {
+      c = assign[i];
+      counts[c]++;
+      for (d = 0; d < sub_dim; d++)
+        sums[c * sub_dim + d] = (float)((double)sums[c * sub_dim + d] + (double)data[i * sub_dim + d]);
+    }
+    for (c = 0; c < k; c++) { /* :2250-2261 */
+      double inv;
+      if (counts[c] == 0) continue;
+      inv = 1.0 / (double)counts[c];
+      for (d = 0; d < sub_dim; d++) {
+        double new_val = (double)sums[c * sub_dim + d] * inv;
+        if (fabs((double)centroids[c * sub_dim + d] - new_val) > 1e-4) changed = 1;
+        centroids[c * sub_dim + d] = (float)new_val;
+      }
+    }
+    if (!changed) break; /* :2262 */
+  }
+  free(assign);
+  free(counts);
+  free(sums);
+  free(norms);
+}
+
 /* ---- A7: CRC32.  ref: core/btree_page.dart:61-89 ------------------------ */
 uint32_t vso_crc32(const uint8_t *data, size_t len) {
   static uint32_t table[256];

@@ -89,6 +89,19 @@ void vso_all_distances(const float *rows, int64_t n, int d, int metric,
 void vso_pq_encode(const float *codebook, int subspaces, int centroids, int sub_dim,
                    const float *vectors, int64_t n, int dim, uint8_t *codes);
 
+/* N4: PQ codebook training for ONE sub-space, given the k sample indices the
+ * reference draws with Random(42 + subspaceIndex).nextInt(n) (Dart PRNG, not
+ * restated: the caller supplies them).  ref: core/compute_tasks.dart:2135-2266
+ * (trainPqSubspace).  Mixed arithmetic restated exactly: centroid norms f64
+ * accumulate -> *0.5 -> f32; assignment maximises dot - norm with, when
+ * subDim % 4 == 0, Float32x4 products (f32 multiply) summed ((x+y)+z)+w in f64,
+ * else f64 products; update accumulates sums in a Float32List (f32 rounding per
+ * add, sample order), divides by count in f64, stores f32; stops after the
+ * update of the first iteration in which no coordinate moved by > 1e-4.
+ * sub_samples n x sub_dim; init_index k; out_centroids k x sub_dim. */
+void vso_pq_train_subspace(const float *sub_samples, int64_t n, int sub_dim, int k, int iterations,
+                           const int32_t *init_index, float *out_centroids);
+
 /* A7  page framing.  ref: core/btree_page.dart:61-89 (CRC32 IEEE, reflected,
  * poly 0xEDB88320), :132-234 (20-byte 'TPG2' header) */
 uint32_t vso_crc32(const uint8_t *data, size_t len);

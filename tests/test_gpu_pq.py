@@ -63,3 +63,79 @@ def test_pq_encode_rate(hip_lib, oracle_mod):
         print(f"\npq_encode {n}x{dim} M={M}: {dt * 1e3:.1f} ms = {n / dt / 1e6:.2f} M vectors/s")
         sample = rng.choice(n, 300, replace=False)
         assert np.array_equal(got[sample], oracle_mod.pq_encode(cb, M, 256, 8, rows[sample]))
+
+
+def _clustered(rng, n, dim, spread=3.0):
+    centres = rng.standard_normal((17, dim)) * spread
+    return (centres[rng.integers(0, 17, n)] + rng.standard_normal((n, dim))).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,dim,subspaces,k", [
+    (2500, 64, 8, 256),    # subDim 8: Float32x4 path, the manager's maxSamples
+    (1200, 128, 8, 256),   # subDim 16
+    (900, 48, 12, 256),    # subDim 4
+    (700, 96, 8, 128),     # subDim 12: generic width, Float32x4 path
+    (600, 100, 10, 64),    # subDim 10: scalar path (f64 products)
+    (500, 36, 12, 256),    # subDim 3: scalar path
+    (150, 32, 4, 150),     # k = min(256, n) = n: every sample may seed a centroid
+])
+def test_pq_train_bit_exact(hip_lib, oracle_mod, n, dim, subspaces, k):
+    """Codebook == the oracle's restatement of trainPqSubspace (/root/reference/lib/src/core/
+    compute_tasks.dart:2135-2266) bit for bit, from the same initial sample indices."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(n + dim)
+    samples = _clustered(rng, n, dim)
+    init = rng.integers(0, n, size=(subspaces, k)).astype(np.int32)  # duplicates allowed, as with nextInt
+    got = HipVectorIndex.pq_train(samples, subspaces, init, centroids=k, iterations=10)
+    want = oracle_mod.pq_train(samples, subspaces, k, 10, init)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_pq_train_early_stop_and_edge_values(hip_lib, oracle_mod):
+    """Sub-spaces converge at different iterations (device-side flags); NaN/inf samples; 0 iterations."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(11)
+    n, dim, M, k = 400, 32, 4, 16
+    samples = _clustered(rng, n, dim)
+    samples[:, 0:8] = np.repeat(rng.standard_normal((4, 8)).astype(np.float32), 100, axis=0)  # 4 exact points: stops at once
+    samples[7, 9] = np.nan
+    samples[8, 17] = np.inf
+    init = rng.integers(0, n, size=(M, k)).astype(np.int32)
+    for iters in (0, 1, 3, 10, 25):
+        got = HipVectorIndex.pq_train(samples, M, init, centroids=k, iterations=iters)
+        want = oracle_mod.pq_train(samples, M, k, iters, init)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), iters
+
+
+def test_pq_train_then_encode_pipeline(hip_lib, oracle_mod):
+    """train -> encode on the GPU == train -> encode in the oracle (the reference's write path for a new index)."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(5)
+    n, dim, M = 4000, 64, 8
+    rows = _clustered(rng, n, dim)
+    samples = rows[rng.choice(n, 2500, replace=False)]
+    init = rng.integers(0, 2500, size=(M, 256)).astype(np.int32)
+    t = time.perf_counter()
+    cb = HipVectorIndex.pq_train(samples, M, init)
+    dt = time.perf_counter() - t
+    print(f"\npq_train 2500x{dim} M={M}: {dt * 1e3:.1f} ms")
+    with HipVectorIndex(dim, 0) as idx:
+        idx.append(0, rows)
+        codes = idx.pq_encode(0, n, cb, M)
+    cb_o = oracle_mod.pq_train(samples, M, 256, 10, init)
+    assert np.array_equal(codes, oracle_mod.pq_encode(cb_o, M, 256, 8, rows))
+
+
+def test_pq_train_bad_args(hip_lib):
+    from tostore_amd import HipVectorIndex
+    from tostore_amd._ffi import TshError as TostoreHipError
+
+    s = np.zeros((10, 16), np.float32)
+    with pytest.raises(TostoreHipError):
+        HipVectorIndex.pq_train(s, 2, np.full((2, 4), 10, np.int32), centroids=4)  # index == n
+    with pytest.raises(TostoreHipError):
+        HipVectorIndex.pq_train(s, 2, np.zeros((2, 300), np.int32), centroids=300)

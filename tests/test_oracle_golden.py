@@ -191,3 +191,17 @@ def test_rawvec_page_format(oracle_mod):
     assert oracle_mod.rawvec_locate(0, 5, 1024) == (0, 1, 0)
     assert oracle_mod.rawvec_locate(5 * 1024 - 1, 5, 1024) == (0, 1024, 4)
     assert oracle_mod.rawvec_locate(5 * 1024, 5, 1024) == (1, 1, 0)
+
+
+@pytest.mark.parametrize("n,sd,k", [(300, 8, 64), (250, 6, 32), (200, 4, 200), (120, 3, 16)])
+def test_pq_train_restatements_agree(oracle_mod, n, sd, k):
+    """N4 training: C and NumPy restatements of trainPqSubspace, written separately, agree bit for bit."""
+    from oracle import np_oracle as npo
+
+    rng = np.random.default_rng(n)
+    data = (rng.standard_normal((n, sd)) + rng.integers(0, 5, (n, 1)) * 2.5).astype(np.float32)
+    init = rng.integers(0, n, size=k).astype(np.int32)
+    for iters in (1, 10):
+        a = oracle_mod.pq_train(data, 1, k, iters, init)[0]
+        b = npo.pq_train_subspace(data, k, iters, init)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -58,6 +58,7 @@ SIGNATURES = {
     "tsh_index_append_device": (c_i32, [p_void, c_i64, c_i64, p_void]),
     "tsh_index_set_deleted": (c_i32, [p_void, p_i64, c_i64]),
     "tsh_index_load_rawvec_file": (c_i32, [p_void, ctypes.c_char_p, c_i32, c_i32, c_i64, c_i64, p_i64]),
+    "tsh_pq_train": (c_i32, [c_i32, p_f32, c_i64, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), p_f32]),
     "tsh_index_pq_encode": (c_i32, [p_void, c_i64, c_i64, p_f32, c_i32, c_i32, p_u8]),
     "tsh_index_size": (c_i64, [p_void]),
     "tsh_index_dim": (c_i32, [p_void]),

@@ -99,6 +99,25 @@ class HipVectorIndex:
                                                   subspaces, centroids, codes.ctypes.data_as(_ffi.p_u8)))
         return codes
 
+    @staticmethod
+    def pq_train(samples, subspaces: int, init_index, centroids: int = 256, iterations: int = 10,
+                 device: int = 0) -> np.ndarray:
+        """Codebook (subspaces x centroids x subDim, float32) from host samples; mirrors the per-sub-space
+        trainPqSubspace tasks (/root/reference/lib/src/core/compute_tasks.dart:2135-2266) given the
+        initial sample indices the reference draws from Random(42 + m)."""
+        s = _f32c(samples)
+        if s.ndim != 2:
+            raise ValueError("samples must be n x dim")
+        n, dim = s.shape
+        init = np.ascontiguousarray(init_index, dtype=np.int32)
+        if init.size != subspaces * centroids:
+            raise ValueError("init_index must hold subspaces*centroids indices")
+        out = np.empty((subspaces, centroids, dim // subspaces), dtype=np.float32)
+        _ffi.check(_ffi.lib().tsh_pq_train(device, s.ctypes.data_as(_ffi.p_f32), n, dim, subspaces, centroids,
+                                           iterations, init.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                           out.ctypes.data_as(_ffi.p_f32)))
+        return out
+
     @property
     def size(self) -> int:
         return _ffi.lib().tsh_index_size(self._h)

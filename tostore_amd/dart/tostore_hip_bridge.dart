@@ -11,11 +11,13 @@
 // the same argument meaning and IS tested (tests/test_abi.py, tests/test_gpu_*).
 
 import 'dart:ffi';
+import 'dart:math' show Random;
 import 'dart:typed_data';
 
 import 'package:ffi/ffi.dart';
 
 import '../core/ngh_graph_engine.dart' show NghSearchResult;
+import '../core/vector_quantizer.dart' show PqCodebook;
 import '../model/ngh_index_meta.dart';
 import '../model/table_schema.dart' show VectorDistanceMetric;
 import 'logger.dart';
@@ -45,6 +47,14 @@ typedef _SearchC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, D
     Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
 typedef _SearchD = int Function(Pointer<Void>, Pointer<Float>, int, int, double,
     Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _PqEncodeC = Int32 Function(
+    Pointer<Void>, Int64, Int64, Pointer<Float>, Int32, Int32, Pointer<Uint8>);
+typedef _PqEncodeD = int Function(
+    Pointer<Void>, int, int, Pointer<Float>, int, int, Pointer<Uint8>);
+typedef _PqTrainC = Int32 Function(Int32, Pointer<Float>, Int64, Int32, Int32, Int32, Int32,
+    Pointer<Int32>, Pointer<Float>);
+typedef _PqTrainD = int Function(int, Pointer<Float>, int, int, int, int, int,
+    Pointer<Int32>, Pointer<Float>);
 
 /// One device-resident copy of an NGH index's raw-vector column.
 ///
@@ -66,6 +76,8 @@ final class HipVectorBackend {
   static late final _LoadRawvecD _loadRawvec;
   static late final _SizeD _size;
   static late final _SearchD _search;
+  static late final _PqEncodeD _pqEncode;
+  static late final _PqTrainD _pqTrain;
 
   /// True when libtostore_hip.so is loadable, ABI-compatible and sees a GPU.
   static bool get available {
@@ -84,6 +96,8 @@ final class HipVectorBackend {
           lib.lookupFunction<_LoadRawvecC, _LoadRawvecD>('tsh_index_load_rawvec_file');
       _size = lib.lookupFunction<_SizeC, _SizeD>('tsh_index_size');
       _search = lib.lookupFunction<_SearchC, _SearchD>('tsh_search');
+      _pqEncode = lib.lookupFunction<_PqEncodeC, _PqEncodeD>('tsh_index_pq_encode');
+      _pqTrain = lib.lookupFunction<_PqTrainC, _PqTrainD>('tsh_pq_train');
       if (_abiVersion() != 1 || _deviceCount() < 1) return false;
       _lib = lib;
       return true;
@@ -127,6 +141,64 @@ final class HipVectorBackend {
   }
 
   int get size => _size(_handle);
+
+  /// Replaces the trainPqSubspace isolate fan-out of _ensurePqCodebook
+  /// (vector_index_manager.dart:740-850): same codebook, bit for bit, because the
+  /// seeds are drawn here exactly as compute_tasks.dart:2144-2151 draws them.
+  static Float32List? trainCodebook(List<Float32List> samples, int dimensions, int subspaces,
+      {int iterations = 10}) {
+    if (!available || samples.length < 100) return null; // small sets keep VectorQuantizer.train
+    final n = samples.length;
+    final k = n < 256 ? n : 256;
+    final subDim = dimensions ~/ subspaces;
+    final pSamples = calloc<Float>(n * dimensions);
+    final pInit = calloc<Int32>(subspaces * k);
+    final pOut = calloc<Float>(subspaces * k * subDim);
+    try {
+      final flat = pSamples.asTypedList(n * dimensions);
+      for (int i = 0; i < n; i++) {
+        flat.setRange(i * dimensions, (i + 1) * dimensions, samples[i]);
+      }
+      final init = pInit.asTypedList(subspaces * k);
+      for (int m = 0; m < subspaces; m++) {
+        final random = Random(42 + m);
+        for (int c = 0; c < k; c++) {
+          init[m * k + c] = random.nextInt(n);
+        }
+      }
+      final rc = _pqTrain(0, pSamples, n, dimensions, subspaces, k, iterations, pInit, pOut);
+      if (rc != 0) {
+        Logger.warn('tsh_pq_train failed ($rc): ${_errorText()}', label: 'HipVectorBackend');
+        return null;
+      }
+      return Float32List.fromList(pOut.asTypedList(subspaces * k * subDim));
+    } finally {
+      calloc.free(pSamples);
+      calloc.free(pInit);
+      calloc.free(pOut);
+    }
+  }
+
+  /// Replaces batchPqEncode (compute_tasks.dart:2292-2326) for rows that are already
+  /// resident: n x subspaces code bytes for node ids [firstNodeId, firstNodeId + n).
+  Uint8List? pqEncode(int firstNodeId, int n, PqCodebook codebook) {
+    final pCb = calloc<Float>(codebook.data.length);
+    final pOut = calloc<Uint8>(n * codebook.subspaces);
+    try {
+      pCb.asTypedList(codebook.data.length).setAll(0, codebook.data);
+      final rc = _pqEncode(_handle, firstNodeId, n, pCb, codebook.subspaces,
+          codebook.centroids, pOut);
+      if (rc != 0) {
+        Logger.warn('tsh_index_pq_encode failed ($rc): ${_errorText()}',
+            label: 'HipVectorBackend');
+        return null;
+      }
+      return Uint8List.fromList(pOut.asTypedList(n * codebook.subspaces));
+    } finally {
+      calloc.free(pCb);
+      calloc.free(pOut);
+    }
+  }
 
   /// Feed from NghGraphEngine.insertBatch (ngh_graph_engine.dart:297-403): the
   /// Float32Lists produced by prepareVectorBatchChunk, ids dense from `firstNodeId`.
