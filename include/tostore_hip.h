@@ -144,6 +144,42 @@ int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t pag
                                    int32_t precision, int64_t first_row_id, int64_t max_rows,
                                    int64_t *out_rows);
 
+/* What tsh_index_open_ngh found: the NghIndexMeta fields it used
+ * (lib/src/model/ngh_index_meta.dart:359-408) and what it loaded. */
+typedef struct tsh_ngh_info {
+  int32_t dimensions;
+  int32_t metric;    /* 0 l2, 1 innerProduct, 2 cosine */
+  int32_t precision; /* 0 float64, 1 float32, 2 int8 (VectorPrecision order) */
+  int32_t page_size;
+  int32_t max_degree;
+  int32_t reserved;
+  int64_t next_node_id;
+  int64_t total_vectors; /* meta.json's own count of live vectors */
+  int64_t deleted_count; /* meta.json's own count of tombstones */
+  int64_t max_partition_file_size;
+  int64_t rows_loaded; /* node ids now resident (absent files/pages load as zero vectors) */
+  int64_t tombstones;  /* node ids whose graph slot carries NghNodeFlags.deleted */
+  int64_t files_read;
+} tsh_ngh_info;
+
+/* Cold start from an index directory written by the reference, without Dart
+ * (SURVEY.md section 8f, N1): `<index>/ngh` as laid out by
+ * lib/src/core/path_manager.dart:275-324.  Reads meta.json (jsonEncode of
+ * NghIndexMeta.toJson, vector_index_manager.dart:623-634) for dimensions,
+ * metric, precision, nextNodeId, page and partition-file sizes; creates the
+ * handle; loads every raw-vector partition rawvec/dir_{p / max_entries_per_dir}/
+ * p{p}.ngh with the addressing of ngh_index_meta.dart:480-490; then walks the
+ * graph partitions and tombstones every node whose slot flags carry
+ * NghNodeFlags.deleted (ngh_page.dart:105-108,198-213).  A missing file or a
+ * page past the end of a file reads as an empty page exactly as in the
+ * reference (zero vectors / no flags); a page with a bad frame or CRC is
+ * TSH_E_FORMAT (the reference throws there, btree_page.dart:215-233).
+ * max_entries_per_dir <= 0 selects the reference default of 500
+ * (handler/common.dart:43).  Encrypted vector pages are not supported
+ * (EncryptionConfig.encryptVectorIndex must be off).  info may be NULL. */
+int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices, tsh_index **out,
+                           tsh_ngh_info *info);
+
 /* Write-path helper: PQ-encode resident rows
  * [first_row_id, first_row_id + n_rows) against a trained codebook -- the
  * arithmetic of batchPqEncode (lib/src/core/compute_tasks.dart:2292-2326) ==

@@ -205,3 +205,25 @@ def test_pq_train_restatements_agree(oracle_mod, n, sd, k):
         a = oracle_mod.pq_train(data, 1, k, iters, init)[0]
         b = npo.pq_train_subspace(data, k, iters, init)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_ngh_directory_writer_reader_round_trip(oracle_mod, tmp_path):
+    """N1 fixtures: the directory writer restatement (oracle/ngh_dir.py) and the reader restatement agree,
+    across partition files and dir_N buckets, for every stored precision."""
+    from oracle import ngh_dir
+
+    rng = np.random.default_rng(9)
+    v = (rng.standard_normal((1200, 96)) * 0.5).astype(np.float32)
+    for precision in (1, 0, 2):
+        root = tmp_path / f"ngh{precision}"
+        meta = ngh_dir.write_ngh_dir(str(root), v, metric=1, precision=precision, max_partition_file_size=16384 * 4,
+                                     deleted=[0, 7, 1199], max_entries_per_dir=2)
+        assert precision == 2 or (root / "rawvec" / "dir_1" / "p2.ngh").exists()
+        m2, vec, dead = ngh_dir.read_ngh_dir(str(root), 2)
+        assert m2 == meta and np.flatnonzero(dead).tolist() == [0, 7, 1199]
+        if precision != 2:
+            assert np.array_equal(vec, v)
+        else:  # int8 pages: clamp to [-1,1], *127 rounded half away from zero, read back as /127
+            c = np.clip(v.astype(np.float64), -1, 1) * 127
+            q = np.where(c < 0, -np.floor(-c + 0.5), np.floor(c + 0.5))
+            assert np.array_equal(vec, (q / 127.0).astype(np.float32))

@@ -46,6 +46,15 @@ class TshCounters(ctypes.Structure):
     ]
 
 
+class TshNghInfo(ctypes.Structure):
+    _fields_ = [
+        ("dimensions", c_i32), ("metric", c_i32), ("precision", c_i32), ("page_size", c_i32),
+        ("max_degree", c_i32), ("reserved", c_i32), ("next_node_id", c_i64), ("total_vectors", c_i64),
+        ("deleted_count", c_i64), ("max_partition_file_size", c_i64), ("rows_loaded", c_i64),
+        ("tombstones", c_i64), ("files_read", c_i64),
+    ]
+
+
 # every symbol include/tostore_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "tsh_abi_version": (c_i32, []),
@@ -58,6 +67,7 @@ SIGNATURES = {
     "tsh_index_append_device": (c_i32, [p_void, c_i64, c_i64, p_void]),
     "tsh_index_set_deleted": (c_i32, [p_void, p_i64, c_i64]),
     "tsh_index_load_rawvec_file": (c_i32, [p_void, ctypes.c_char_p, c_i32, c_i32, c_i64, c_i64, p_i64]),
+    "tsh_index_open_ngh": (c_i32, [ctypes.c_char_p, c_i32, c_i32, ctypes.POINTER(p_void), ctypes.POINTER(TshNghInfo)]),
     "tsh_pq_train": (c_i32, [c_i32, p_f32, c_i64, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), p_f32]),
     "tsh_index_pq_encode": (c_i32, [p_void, c_i64, c_i64, p_f32, c_i32, c_i32, p_u8]),
     "tsh_index_size": (c_i64, [p_void]),

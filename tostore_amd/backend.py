@@ -46,6 +46,18 @@ class HipVectorIndex:
                                                 ctypes.byref(self._h)))
         self.dim, self.metric, self.row_base = dim, metric, row_base
 
+    @classmethod
+    def open_ngh(cls, ngh_dir: str, max_entries_per_dir: int = 500, n_devices: int = 1):
+        """Cold start from `<index>/ngh` (meta.json + rawvec + graph tombstones) as the reference lays it
+        out (/root/reference/lib/src/core/path_manager.dart:275-324).  Returns (index, info dict)."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        info = _ffi.TshNghInfo()
+        _ffi.check(_ffi.lib().tsh_index_open_ngh(str(ngh_dir).encode(), max_entries_per_dir, n_devices,
+                                                 ctypes.byref(self._h), ctypes.byref(info)))
+        self.dim, self.metric, self.row_base = info.dimensions, info.metric, 0
+        return self, {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
+
     # -- lifetime -----------------------------------------------------------
     def close(self) -> None:
         if self._h:

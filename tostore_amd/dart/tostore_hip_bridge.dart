@@ -47,6 +47,10 @@ typedef _SearchC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, D
     Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
 typedef _SearchD = int Function(Pointer<Void>, Pointer<Float>, int, int, double,
     Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _OpenNghC = Int32 Function(
+    Pointer<Utf8>, Int32, Int32, Pointer<Pointer<Void>>, Pointer<Void>);
+typedef _OpenNghD = int Function(
+    Pointer<Utf8>, int, int, Pointer<Pointer<Void>>, Pointer<Void>);
 typedef _PqEncodeC = Int32 Function(
     Pointer<Void>, Int64, Int64, Pointer<Float>, Int32, Int32, Pointer<Uint8>);
 typedef _PqEncodeD = int Function(
@@ -76,6 +80,7 @@ final class HipVectorBackend {
   static late final _LoadRawvecD _loadRawvec;
   static late final _SizeD _size;
   static late final _SearchD _search;
+  static late final _OpenNghD _openNgh;
   static late final _PqEncodeD _pqEncode;
   static late final _PqTrainD _pqTrain;
 
@@ -96,6 +101,7 @@ final class HipVectorBackend {
           lib.lookupFunction<_LoadRawvecC, _LoadRawvecD>('tsh_index_load_rawvec_file');
       _size = lib.lookupFunction<_SizeC, _SizeD>('tsh_index_size');
       _search = lib.lookupFunction<_SearchC, _SearchD>('tsh_search');
+      _openNgh = lib.lookupFunction<_OpenNghC, _OpenNghD>('tsh_index_open_ngh');
       _pqEncode = lib.lookupFunction<_PqEncodeC, _PqEncodeD>('tsh_index_pq_encode');
       _pqTrain = lib.lookupFunction<_PqTrainC, _PqTrainD>('tsh_pq_train');
       if (_abiVersion() != 1 || _deviceCount() < 1) return false;
@@ -136,6 +142,27 @@ final class HipVectorBackend {
       }
       return HipVectorBackend._(out.value, meta.dimensions, meta.distanceMetric);
     } finally {
+      calloc.free(out);
+    }
+  }
+
+  /// Cold start straight from `<index>/ngh` (path_manager.dart:275-278): the library reads
+  /// meta.json, every rawvec partition and the graph slots' deleted flags itself.
+  static HipVectorBackend? tryOpen(String nghDir, NghIndexMeta meta, int maxEntriesPerDir,
+      {int devices = 1}) {
+    if (!available) return null;
+    final out = calloc<Pointer<Void>>();
+    final p = nghDir.toNativeUtf8();
+    try {
+      final rc = _openNgh(p, maxEntriesPerDir, devices, out, nullptr);
+      if (rc != 0) {
+        Logger.warn('tsh_index_open_ngh failed ($rc): ${_errorText()}',
+            label: 'HipVectorBackend');
+        return null;
+      }
+      return HipVectorBackend._(out.value, meta.dimensions, meta.distanceMetric);
+    } finally {
+      calloc.free(p);
       calloc.free(out);
     }
   }
