@@ -50,7 +50,9 @@ def parse():
                     help="queries per step through the batched matrix-core path (config C3: --batch 1024 "
                          "--metric cosine); 0 = the headline single-query workload")
     ap.add_argument("--mask-keep", type=float, default=0.0,
-                    help="config C5: Bernoulli row mask keeping this fraction of the rows (0 = no mask)")
+                    help="config C5: row mask keeping this fraction of the rows (0 = no mask)")
+    ap.add_argument("--mask-kind", choices=["bernoulli", "range"], default="bernoulli",
+                    help="C5 mask shape: i.i.d. Bernoulli(keep) per row, or one contiguous id range of keep*rows rows")
     ap.add_argument("--recall-queries", type=int, default=1000,
                     help="N=1: queries whose GPU answer is compared with the exhaustive CPU oracle (all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,7 +210,12 @@ def run_bench(a):
 
     row_mask = None
     if a.mask_keep > 0:  # C5: WHERE pre-filter as a device-side row bitmask (seed 20260614)
-        keepbits = np.random.Generator(np.random.Philox(20260614)).random(n) < a.mask_keep
+        if a.mask_kind == "range":  # e.g. WHERE id BETWEEN ...: one contiguous run of node ids
+            keepbits = np.zeros(n, bool)
+            start = int(np.random.Generator(np.random.Philox(20260614)).integers(0, max(1, n - int(n * a.mask_keep))))
+            keepbits[start:start + int(n * a.mask_keep)] = True
+        else:
+            keepbits = np.random.Generator(np.random.Philox(20260614)).random(n) < a.mask_keep
         row_mask = np.packbits(keepbits, bitorder="little")
 
     def one(i):
@@ -328,6 +335,7 @@ def run_bench(a):
             "data": "synthetic",
             "config": {"workload": "C2: %dx%d f32, %s, k=%d, single query per step" % (n, d, a.metric, k),
                        "rows": n, "dim": d, "k": k, "metric": a.metric, "mask_keep": a.mask_keep or None,
+                       "mask_kind": a.mask_kind if a.mask_keep else None,
                        "queries_in_flight": 8,
                        "queries_per_call": (a.group or 1) if searcher is None else max(32, a.inflight),
                        "note": "every query scans the whole corpus on its own (HBM-bound kernel, no matrix-core "

@@ -445,3 +445,49 @@ def test_appends_and_deletes_while_searching(hip_lib, oracle_mod):
         ids, dist, cnt = idx.search(qs[0], k)
         eids, edist = oracle_mod.search_heap(rows, qs[0], L2, k)
         assert np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("keep_frac", [0.5, 0.05, 0.004])
+def test_contiguous_range_mask_needs_no_fallback(hip_lib, oracle_mod, metric, keep_frac):
+    """C5 with a contiguous id range (WHERE id BETWEEN ...): few live tiles make the tile-minimum bound loose;
+    the select kernel's exact-tau refinement must keep the candidate list short (no wide-band fallback)."""
+    from tostore_amd import HipVectorIndex
+
+    n, d, k = 120_000, 96, 100
+    rows = _mk(n, d, 77, normalize=(metric == COS))
+    rng = np.random.default_rng(int(keep_frac * 1000) + metric)
+    keep = np.zeros(n, bool)
+    m = int(n * keep_frac)
+    start = int(rng.integers(0, n - m))
+    keep[start:start + m] = True
+    bits = np.packbits(keep, bitorder="little")
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        before = idx.counters()["fallback_searches"]
+        for s in range(4):
+            q = _prep_query(oracle_mod, rng.standard_normal(d).astype(np.float32), metric)
+            _check(oracle_mod, idx, rows, q, metric, k, keep=bits, tag=f"range{keep_frac}")
+        assert idx.counters()["fallback_searches"] == before
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_rows_inserted_by_topic_need_no_fallback(hip_lib, oracle_mod, metric):
+    """Neighbours of a query sit in consecutive rows (documents inserted topic by topic): thousands of keys are
+    below the k-th smallest tile minimum; refinement finds the exact k-th key instead of overflowing."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(5 + metric)
+    n_topics, per, d, k = 150, 800, 64, 100
+    centres = rng.standard_normal((n_topics, d)).astype(np.float32) * 4
+    rows = (np.repeat(centres, per, axis=0) + 0.3 * rng.standard_normal((n_topics * per, d))).astype(np.float32)
+    if metric == COS:
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        before = idx.counters()["fallback_searches"]
+        for t in (0, 71, 149):
+            q = _prep_query(oracle_mod, (centres[t] + 0.1 * rng.standard_normal(d)).astype(np.float32), metric)
+            for kk in (10, k, 700):
+                _check(oracle_mod, idx, rows, q, metric, kk, tag=f"topic{t}")
+        assert idx.counters()["fallback_searches"] == before

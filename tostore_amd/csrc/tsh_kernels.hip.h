@@ -180,7 +180,10 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
         *reinterpret_cast<f32x4 *>(a.query_out + 4 * lane + c * 256) = q[c];
   }
 
-  for (int t = blockIdx.x * wpb + wave; t < a.n_tiles; t += stride) {
+  // masked scans hand consecutive tiles to different WORKGROUPS: a contiguous id-range
+  // filter leaves one run of live tiles, which would otherwise land on a few CUs
+  for (int t = MASKED ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * wpb + wave; t < a.n_tiles;
+       t += stride) {
     const float *tbase = a.rows + (int64_t)t * 64 * a.ld + 4 * lane;
     uint64_t bits = ~0ull;
     int cnt = 64;
@@ -192,8 +195,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
       bits = ((uint64_t)hi << 32) | lo;
       cnt = __popcll(bits);
       if (cnt == 0) {
-        a.keys[(int64_t)t * 64 + lane] = KEY_DEAD;
-        if (lane == 0) a.gmin[t] = KEY_DEAD;
+        if (lane == 0) a.gmin[t] = KEY_DEAD;  // keys[] of a dead tile stay stale: every reader checks gmin first
         continue;
       }
     }
@@ -309,7 +311,10 @@ __global__ void __launch_bounds__(256, 4) scan_packed_kernel(ScanArgsQ aq) {
   const int my_b = (lane >> 3) & (NB - 1);
   const int rr = (((my_b * 8) + (lane & 7)) << SPLIT) | (lane >> (6 - SPLIT));
 
-  for (int t = blockIdx.x * wpb + wave; t < a.n_tiles; t += stride) {
+  // masked scans hand consecutive tiles to different WORKGROUPS: a contiguous id-range
+  // filter leaves one run of live tiles, which would otherwise land on a few CUs
+  for (int t = MASKED ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * wpb + wave; t < a.n_tiles;
+       t += stride) {
     const float *tbase = a.rows + (int64_t)t * 64 * a.ld + 4 * lane;
     uint64_t bits = ~0ull;
     if (MASKED) {
@@ -319,8 +324,7 @@ __global__ void __launch_bounds__(256, 4) scan_packed_kernel(ScanArgsQ aq) {
       uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
       bits = ((uint64_t)hi << 32) | lo;
       if (bits == 0) {
-        a.keys[(int64_t)t * 64 + lane] = KEY_DEAD;
-        if (lane == 0) a.gmin[t] = KEY_DEAD;
+        if (lane == 0) a.gmin[t] = KEY_DEAD;  // keys[] of a dead tile stay stale: every reader checks gmin first
         continue;
       }
     }
@@ -387,6 +391,7 @@ struct BlockEntry {
 };
 static_assert(sizeof(BlockEntry) == 24, "entry is 24 bytes");
 constexpr uint32_t FLAG_LIST_OVERFLOW = 1u;
+constexpr uint32_t FLAG_TAU_REFINED = 2u;  // informational: select step (f) ran
 
 struct SelectArgs {
   const uint32_t *gmin;
@@ -625,9 +630,9 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
   __syncthreads();
   const uint32_t nt = s_tiles;
   const bool over = nt > SEL_LIST_CAP;
-  if (!over) {
-    // (e) four tiles per wave per round so their (L2-resident) key loads overlap
-    constexpr int NW = SEL_THREADS / 64;
+  constexpr int NW = SEL_THREADS / 64;
+  // (e) four tiles per wave per round so their (L2-resident) key loads overlap
+  auto emit = [&](uint32_t bnd) {
     for (uint32_t j0 = wave * 4; j0 < nt; j0 += NW * 4) {
       uint32_t tile[4], key[4];
 #pragma unroll
@@ -637,7 +642,7 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        bool pass = key[u] <= band;
+        bool pass = key[u] <= bnd;
         uint64_t bm = __ballot(pass);
         if (bm) {
           uint32_t base = 0;
@@ -650,16 +655,85 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
         }
       }
     }
-  }
+  };
+  if (!over) emit(band);
   __syncthreads();
+  uint32_t tau_out = tau, band_out = band;
+  const uint32_t first_count = s_cand;
+  // (f) The k-th smallest TILE MINIMUM is a loose bound when the best rows sit together in a
+  // few tiles (rows inserted by topic, a contiguous-range filter, ...): far more than k keys
+  // are then <= band and the list overflows.  Every key <= tau lives in a hit tile, and there
+  // are at least k of them, so the k-th smallest key over the hit tiles IS the exact k-th
+  // smallest key of the shard: bisect for it (block-wide counts; keys in registers when the
+  // hit tiles fit, otherwise re-read from L2) and emit again with the tight band.
+  // (tau == KEY_NAN, fewer than k live tiles, is covered too: more than cand_cap >= k live keys exist)
+  if (!over && !a.force_all && first_count > (uint32_t)a.cand_cap) {
+    __shared__ uint32_t s_cnt[3], s_lo;
+    constexpr int RV = 16;  // tiles a wave keeps in registers
+    const bool in_regs = nt <= (uint32_t)(NW * RV);
+    uint32_t kr[RV];
+    uint32_t lo = KEY_DEAD;
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < RV; ++i) {
+        uint32_t j = (uint32_t)(wave + i * NW);
+        kr[i] = j < nt ? a.keys[(int64_t)s_list[j] * 64 + lane] : KEY_DEAD;
+        lo = kr[i] < lo ? kr[i] : lo;
+      }
+    } else {
+      for (uint32_t j = wave; j < nt; j += NW) {
+        uint32_t x = a.keys[(int64_t)s_list[j] * 64 + lane];
+        lo = x < lo ? x : lo;
+      }
+    }
+    if (tid == 0) {
+      s_lo = KEY_DEAD;
+      s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+    }
+    __syncthreads();  // every thread has read first_count by now
+    if (tid == 0) s_cand = 0;
+    lo = wave_min_u32(lo);
+    if (lane == 0) atomicMin(&s_lo, lo);
+    __syncthreads();
+    lo = s_lo;
+    uint32_t X = lo;
+    const uint32_t diff = lo ^ tau;  // lo <= answer <= tau
+    if (diff) {
+      const int top = 31 - __builtin_clz(diff);
+      X = top == 31 ? 0u : (lo >> (top + 1)) << (top + 1);
+      int slot = 0;
+      for (int bit = top; bit >= 0; --bit) {
+        const uint32_t T = X | ((1u << bit) - 1u);
+        uint32_t c = 0;
+        if (in_regs) {
+#pragma unroll
+          for (int i = 0; i < RV; ++i) c += (uint32_t)__popcll(__ballot(kr[i] <= T));
+        } else {
+          for (uint32_t j = wave; j < nt; j += NW)
+            c += (uint32_t)__popcll(__ballot(a.keys[(int64_t)s_list[j] * 64 + lane] <= T));
+        }
+        if (lane == 0) atomicAdd(&s_cnt[slot], c);
+        const int nxt = slot == 2 ? 0 : slot + 1;
+        if (tid == 0) s_cnt[nxt] = 0;  // nobody touches the next slot before the barrier below
+        __syncthreads();
+        if (s_cnt[slot] < k) X |= (1u << bit);
+        slot = nxt;
+      }
+    }
+    tau_out = X;
+    band_out = band_of(X, a.eps_rel, a.delta_abs);
+    emit(band_out);
+    __syncthreads();
+  }
   if (tid == 0) {
     BlockHeader hv;
     hv.count = over ? 0u : s_cand;
     hv.entries = (uint32_t)a.cand_cap;
-    hv.tau_key = tau;
-    hv.band_key = band;
+    hv.tau_key = tau_out;
+    hv.band_key = band_out;
     hv.tiles_hit = nt;
     hv.flags = (over || s_cand > (uint32_t)a.cand_cap) ? FLAG_LIST_OVERFLOW : 0u;
+    if (tau_out != tau) hv.flags |= FLAG_TAU_REFINED;
     hv.k = (uint32_t)a.k;
     hv.metric = (uint32_t)a.metric;
     hv.row_base = a.row_base;
@@ -671,14 +745,14 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
 }
 
 // K3: whole-grid filter (fallback).  count accumulates in *out_count.
-__global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, int64_t n_keys,
+__global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
                                                      uint32_t band, uint32_t *out_rows,
                                                      uint32_t *out_count, uint32_t cap) {
   const int lane = threadIdx.x & 63;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t n_round = (n_keys + 63) & ~(int64_t)63;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-    bool pass = i < n_keys && keys[i] <= band;
+    bool pass = i < n_keys && gmin[i >> 6] != KEY_DEAD && keys[i] <= band;  // a wave covers one tile
     uint64_t bm = __ballot(pass);
     if (bm) {
       uint32_t base = 0;

@@ -770,7 +770,7 @@ int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *s
   }
   HIPCHK(hipMemsetAsync(c->d_big_count, 0, 4, st));
   int fgrid = (int)std::min<int64_t>((n_keys + 255) / 256, 4096);
-  filter_kernel<<<fgrid, 256, 0, st>>>(c->d_keys, n_keys, band_key, c->d_big_rows, c->d_big_count,
+  filter_kernel<<<fgrid, 256, 0, st>>>(c->d_keys, c->d_gmin, n_keys, band_key, c->d_big_rows, c->d_big_count,
                                       (uint32_t)c->big_cap);
   uint32_t count = 0;
   HIPCHK(hipMemcpyAsync(&count, c->d_big_count, 4, hipMemcpyDeviceToHost, st));
