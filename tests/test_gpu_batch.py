@@ -5,6 +5,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 L2, IP, COS = 0, 1, 2
+METRICS = [L2, IP, COS]
 
 
 def _mk(n, d, seed, normalize=True, scale=None):
@@ -37,12 +38,14 @@ def _check_batch(oracle, idx, rows, qs, metric, k, thr=None, keep=None, tag=""):
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 @pytest.mark.parametrize("d,n,nq,k", [(128, 30000, 130, 10), (100, 20000, 9, 100), (768, 30000, 130, 100),
                                       (36, 50000, 300, 37)])
-def test_batched_matches_oracle(hip_lib, oracle_mod, metric, d, n, nq, k):
+@pytest.mark.parametrize("kernel", [1, 0])  # 1 = bf16x3 split MFMA (default), 0 = f32 MFMA
+def test_batched_matches_oracle(hip_lib, oracle_mod, metric, d, n, nq, k, kernel):
     from tostore_amd import HipVectorIndex
 
     rows = _mk(n, d, 200 + d, scale=None if metric == COS else (0.5, 2.0))
     qs = _queries(oracle_mod, nq, d, 300 + d, metric)
     with HipVectorIndex(d, metric) as idx:
+        idx.set_batch_kernel(kernel)
         idx.append(0, rows)
         _check_batch(oracle_mod, idx, rows, qs, metric, k, tag=f"m{metric} d{d}")
         c = idx.counters()
@@ -56,7 +59,8 @@ def test_batched_matches_oracle(hip_lib, oracle_mod, metric, d, n, nq, k):
 
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
-def test_batched_mask_tombstones_threshold(hip_lib, oracle_mod, metric):
+@pytest.mark.parametrize("kernel", [1, 0])
+def test_batched_mask_tombstones_threshold(hip_lib, oracle_mod, metric, kernel):
     from tostore_amd import HipVectorIndex
 
     d, n, nq, k = 64, 25000, 40, 20
@@ -64,6 +68,7 @@ def test_batched_mask_tombstones_threshold(hip_lib, oracle_mod, metric):
     qs = _queries(oracle_mod, nq, d, 12, metric)
     rng = np.random.default_rng(13)
     with HipVectorIndex(d, metric) as idx:
+        idx.set_batch_kernel(kernel)
         idx.append(0, rows)
         keepbits = rng.random(n) < 0.3
         keep = np.packbits(keepbits, bitorder="little")
@@ -135,3 +140,43 @@ def test_batched_large_k(hip_lib, oracle_mod, k):
         _check_batch(oracle_mod, idx, rows, qs, COS, k, tag=f"k{k}")
         c = idx.counters()
         assert c["batch_launches"] >= 1 and c["scan_launches"] == 0, c
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_bf16_planes_follow_appends_overwrites_and_growth(hip_lib, oracle_mod, metric):
+    """The bf16 (hi, lo) copy of the rows is built by the first batched search and must track later appends,
+    overwrites of existing ids and reallocation of the row store."""
+    from tostore_amd import HipVectorIndex
+
+    d, nq, k = 96, 32, 30
+    rows = _mk(30_000, d, 21, normalize=(metric == COS))
+    qs = _queries(oracle_mod, nq, d, 22, metric)
+    with HipVectorIndex(d, metric) as idx:  # capacity grows on demand
+        idx.append(0, rows[:6000])
+        _check_batch(oracle_mod, idx, rows[:6000], qs, metric, k, tag="first")
+        idx.append(6000, rows[6000:9000])                     # append inside / past the capacity
+        _check_batch(oracle_mod, idx, rows[:9000], qs, metric, k, tag="appended")
+        rows[100:164] = rows[20_000:20_064]                   # overwrite existing ids
+        idx.append(100, rows[100:164])
+        _check_batch(oracle_mod, idx, rows[:9000], qs, metric, k, tag="overwritten")
+        idx.append(9000, rows[9000:])                         # forces a reallocation of the row store
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="grown")
+        idx.set_batch_kernel(0)
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="f32 kernel")
+        assert idx.counters()["scan_launches"] == 0
+
+
+def test_bf16x3_wide_dynamic_range(hip_lib, oracle_mod):
+    """Rows whose components span many binades (hi + lo must carry each element's own exponent)."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(8)
+    n, d, nq = 12_000, 200, 24
+    rows = (rng.standard_normal((n, d)) * np.exp2(rng.integers(-40, 20, (n, 1)))).astype(np.float32)
+    rows[:, ::7] *= np.float32(2.0 ** -30)
+    qs = (rng.standard_normal((nq, d)) * np.exp2(rng.integers(-10, 10, (nq, 1)))).astype(np.float32)
+    for metric in METRICS:
+        qm = np.stack([oracle_mod.normalize_f32(x) for x in qs]) if metric == COS else qs
+        with HipVectorIndex(d, metric) as idx:
+            idx.append(0, rows)
+            _check_batch(oracle_mod, idx, rows, qm, metric, 25, tag=f"range m{metric}")

@@ -192,6 +192,10 @@ class HipVectorIndex:
         """nq at which search() switches to the matrix-core path (0 = never); results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 1, int(nq)))
 
+    def set_batch_kernel(self, kind: int) -> None:
+        """1 (default): bf16x3 matrix-core keys; 0: f32 MFMA keys.  Results are identical."""
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 2, int(kind)))
+
     def bench_batch(self, queries, k: int, iters: int = 3):
         """(avg microseconds of the matrix-core passes, algorithmic flops) for one batch."""
         q = _f32c(queries)

@@ -23,6 +23,7 @@
 namespace tsh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BT_M = 128;   // queries per workgroup tile
 constexpr int BT_N = 128;   // rows per workgroup tile
@@ -52,7 +53,98 @@ struct BatchArgs {
   int32_t cand_cap;
   int32_t q_tiles;        // nq_pad / BT_M
   int32_t n_tiles;        // ceil((row1-row0) / BT_N)
+  // bf16x3 variant: operands pre-split into bf16 (hi, lo) planes, see split_rows_kernel
+  const u32x4 *Qs;        // nq_pad x hchunks x 128 B
+  const u32x4 *Vs;        // n x hchunks x 128 B
+  int32_t hchunks;        // ceil(dim / 32)
 };
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
+// q_tiles consecutive workgroups that share one row tile (L2 reuse of V)
+__device__ __forceinline__ void batch_tile_of(const BatchArgs &a, int b, int *q_tile, int *n_tile) {
+  const int total = a.q_tiles * a.n_tiles;
+  const int xcd = b & 7, i = b >> 3;
+  const int per_round = 8 * a.q_tiles;
+  const int full_rounds = total / per_round;
+  if (b < full_rounds * per_round) {
+    *q_tile = i % a.q_tiles;
+    *n_tile = (i / a.q_tiles) * 8 + xcd;
+  } else {  // ragged tail: plain order
+    int r = b - full_rounds * per_round;
+    *n_tile = full_rounds * 8 + r / a.q_tiles;
+    *q_tile = r % a.q_tiles;
+  }
+}
+
+// Epilogue shared by the f32 and the bf16x3 kernels: key transform (+ filter) of a wave's
+// 64 x 64 patch held as 2 x 2 MFMA 32x32 accumulators.
+template <int METRIC, bool DENSE>
+__device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)[2][2], const float *s_thr,
+                                               const float *s_qsq, int qbase, int nbase, int wm, int wn, int lane) {
+  // ---- epilogue: key transform (+ filter) -----------------------------------------
+  // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+  // for a fixed reg >> 2 the four rows are consecutive, so a lane's 16 per-row
+  // values (threshold, |q|^2) are four float4 reads.
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = wm * 64 + i * 32 + 4 * (lane >> 5);  // tile row of reg 0
+    f32x4 th[4], qq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      th[g] = *reinterpret_cast<const f32x4 *>(&s_thr[rbase + 8 * g]);
+      if (METRIC == METRIC_L2) qq[g] = *reinterpret_cast<const f32x4 *>(&s_qsq[rbase + 8 * g]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = nbase + wn * 64 + j * 32 + (lane & 31);  // corpus row
+      const bool col_ok = col < a.row1;
+      float vin = 0.f, vsq = 0.f;
+      bool alive = col_ok;
+      if (col_ok) {
+        if (METRIC == METRIC_COS) vin = a.inv_norm[col];
+        if (METRIC == METRIC_L2) vsq = a.sqnorm[col];
+        if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
+        if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+      }
+      float key[16];
+      uint32_t pass = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dot = acc[i][j][r];
+        if (METRIC == METRIC_IP) key[r] = -dot;
+        else if (METRIC == METRIC_COS) key[r] = -(dot * vin);
+        else key[r] = qq[r >> 2][r & 3] + vsq - 2.f * dot;
+        if (!DENSE) pass |= (key[r] <= th[r >> 2][r & 3]) ? (1u << r) : 0u;
+      }
+      if (DENSE) {
+        if (col_ok) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qi = rbase + (r & 3) + 8 * (r >> 2);
+            a.dense[(int64_t)(qbase + qi) * a.dense_ld + (col - a.row0)] = alive ? key[r] : __builtin_nanf("");
+          }
+        }
+      } else {
+        if (!alive) pass = 0;
+        while (pass) {  // rare: about k * n / n_sample survivors per query over the whole pass
+          const int r = __builtin_ctz(pass);
+          pass &= pass - 1;
+          const int q = qbase + rbase + (r & 3) + 8 * (r >> 2);
+          if (q < a.nq) {
+            float kv = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) kv = u == r ? key[u] : kv;  // register select, no scratch
+            uint32_t p = atomicAdd(&a.cand_cnt[q], 1u);
+            if (p < (uint32_t)a.cand_cap) {
+              a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(kv);
+              a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)col;
+            }
+          }
+        }
+      }
+    }
+  }
+}
 
 // One workgroup = 128 queries x 128 rows; 4 waves as 2 x 2, each wave a
 // 64 x 64 patch = 2 x 2 MFMA blocks of 32 x 32.  Both operands are K-major in
@@ -75,24 +167,8 @@ __global__ void __launch_bounds__(BT_THREADS, BK == 32 ? 2 : 3) batch_score_kern
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
-  // q_tiles consecutive workgroups that share one row tile (L2 reuse of V)
-  const int total = a.q_tiles * a.n_tiles;
-  int b = blockIdx.x;
   int n_tile, q_tile;
-  {
-    const int xcd = b & 7, i = b >> 3;
-    const int per_round = 8 * a.q_tiles;
-    const int full_rounds = total / per_round;
-    if (b < full_rounds * per_round) {
-      q_tile = i % a.q_tiles;
-      n_tile = (i / a.q_tiles) * 8 + xcd;
-    } else {  // ragged tail: plain order
-      int r = b - full_rounds * per_round;
-      n_tile = full_rounds * 8 + r / a.q_tiles;
-      q_tile = r % a.q_tiles;
-    }
-  }
+  batch_tile_of(a, blockIdx.x, &q_tile, &n_tile);
   const int qbase = q_tile * BT_M;
   const int nbase = a.row0 + n_tile * BT_N;
 
@@ -169,69 +245,166 @@ __global__ void __launch_bounds__(BT_THREADS, BK == 32 ? 2 : 3) batch_score_kern
     }
   }
 
-  // ---- epilogue: key transform (+ filter) -----------------------------------------
-  // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
-  // for a fixed reg >> 2 the four rows are consecutive, so a lane's 16 per-row
-  // values (threshold, |q|^2) are four float4 reads.
+  batch_epilogue<METRIC, DENSE>(a, acc, s_thr, s_qsq, qbase, nbase, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------
+// bf16x3 variant.  x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|:
+//   q.x ~= qh.xh + qh.xl + ql.xh      (three bf16 MFMAs; products exact in f32)
+// misses ql.xl + q.r_x + r_q.x <= 3.1 * 2^-18 |q||x| per element, which is an eighth of the
+// f32 accumulation bound the band already carries -- the keys are a
+// pre-filter, the f64 rerank decides.  v_mfma_f32_32x32x16_bf16 runs 16x the rate of the f32
+// MFMA, so three of them per k are 5.3x faster than the f32 kernel at the same tile shape.
+//
+// Operand layout ("split planes"): per row, per chunk of 32 k-values, 128 bytes:
+//   [ hi(k0..k0+31) : 64 B ][ lo(k0..k0+31) : 64 B ],  rows zero-padded to whole chunks
+// i.e. 4 B per element like the f32 rows, one full cache line per (row, chunk).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {  // finite inputs (|x| <= 1e15 outside safe mode)
+  uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+struct SplitArgs {
+  const float *rows;  // n x ld f32
+  u32x4 *out;         // n x hchunks x 8 pieces of 16 B
+  int64_t ld;
+  int64_t first, n;   // rows [first, first + n)
+  int32_t dim, hchunks;
+};
+
+// one thread = 8 consecutive k of one row: a 16-B hi piece and a 16-B lo piece
+__global__ void __launch_bounds__(256) split_rows_kernel(SplitArgs a) {
+  const int64_t per_row = (int64_t)a.hchunks * 4;
+  const int64_t total = a.n * per_row, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = a.first + i / per_row;
+    const int p = (int)(i % per_row), kc = p >> 2, c = p & 3;
+    const int k0 = kc * 32 + c * 8;
+    const float *src = a.rows + row * a.ld + k0;
+    uint32_t hi[4], lo[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rbase = wm * 64 + i * 32 + 4 * (lane >> 5);  // tile row of reg 0
-    f32x4 th[4], qq[4];
+    for (int e = 0; e < 4; ++e) {
+      uint32_t h2[2], l2[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      th[g] = *reinterpret_cast<const f32x4 *>(&s_thr[rbase + 8 * g]);
-      if (METRIC == METRIC_L2) qq[g] = *reinterpret_cast<const f32x4 *>(&s_qsq[rbase + 8 * g]);
+      for (int u = 0; u < 2; ++u) {
+        const int k = k0 + 2 * e + u;
+        const float x = k < a.dim ? src[2 * e + u] : 0.f;
+        const uint32_t hb = bf16_rne_bits(x);
+        const float rest = x - __uint_as_float(hb << 16);  // exact in f32
+        h2[u] = hb;
+        l2[u] = bf16_rne_bits(rest);
+      }
+      hi[e] = h2[0] | (h2[1] << 16);
+      lo[e] = l2[0] | (l2[1] << 16);
     }
+    u32x4 *dst = a.out + (row * a.hchunks + kc) * 8;
+    dst[c] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    dst[4 + c] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+  }
+}
+
+// Same tile shape as the f32 kernel: 128 queries x 128 rows per workgroup, 4 waves 2 x 2,
+// 64 x 64 per wave.  LDS holds [stage][plane][row][4 pieces of 16 B] without padding; piece c
+// of row r sits at c ^ ((r >> 2) & 3), which makes the 16-lane groups of ds_read_b128
+// (MI355X_MICROARCH.md, LDS table) hit 16 distinct 16-B bank quads.  64 KB per workgroup:
+// two workgroups per CU.  A lane's fragment for the k16 slab s is piece 2s + (lane >> 5).
+template <int METRIC, bool DENSE>
+__global__ void __launch_bounds__(BT_THREADS, 2) batch_score_bf16x3_kernel(BatchArgs a) {
+  __shared__ u32x4 As[2][2][BT_M][4];
+  __shared__ u32x4 Bs[2][2][BT_N][4];
+  __shared__ __attribute__((aligned(16))) float s_thr[BT_M];
+  __shared__ __attribute__((aligned(16))) float s_qsq[BT_M];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int n_tile, q_tile;
+  batch_tile_of(a, blockIdx.x, &q_tile, &n_tile);
+  const int qbase = q_tile * BT_M;
+  const int nbase = a.row0 + n_tile * BT_N;
+  if (tid < BT_M) {
+    s_thr[tid] = (DENSE || qbase + tid >= a.nq) ? -__builtin_inff() : a.thr[qbase + tid];
+    s_qsq[tid] = METRIC == METRIC_L2 ? a.qsq[qbase + tid] : 0.f;
+  }
+
+  // staging: piece p = tid + 256 j of the tile's 128 rows x 8 pieces (4 hi, 4 lo);
+  // 8 consecutive threads fetch one row's 128-byte line
+  const u32x4 *qg[4], *vg[4];
+  int st_row[4], st_plane[4], st_col[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = nbase + wn * 64 + j * 32 + (lane & 31);  // corpus row
-      const bool col_ok = col < a.row1;
-      float vin = 0.f, vsq = 0.f;
-      bool alive = col_ok;
-      if (col_ok) {
-        if (METRIC == METRIC_COS) vin = a.inv_norm[col];
-        if (METRIC == METRIC_L2) vsq = a.sqnorm[col];
-        if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
-        if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+  for (int j = 0; j < 4; ++j) {
+    const int p = tid + BT_THREADS * j, r = p >> 3, c8 = p & 7;
+    st_row[j] = r;
+    st_plane[j] = c8 >> 2;
+    st_col[j] = (c8 & 3) ^ ((r >> 2) & 3);
+    qg[j] = a.Qs + (int64_t)(qbase + r) * a.hchunks * 8 + c8;
+    int vr = nbase + r;
+    if (vr >= a.row1) vr = a.row1 - 1;  // clamp: tail columns are discarded in the epilogue
+    vg[j] = a.Vs + (int64_t)vr * a.hchunks * 8 + c8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = qg[j][kc * 8];
+      rb[j] = __builtin_nontemporal_load(vg[j] + kc * 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      As[buf][st_plane[j]][st_row[j]][st_col[j]] = ra[j];
+      Bs[buf][st_plane[j]][st_row[j]][st_col[j]] = rb[j];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
+  const int half = lane >> 5;
+  // (row >> 2) & 3 is the same for row and row + 32
+  const int asw = (arow >> 2) & 3, bsw = (brow >> 2) & 3;
+  for (int kc = 0; kc < a.hchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < a.hchunks) gload(kc + 1);  // in flight while this chunk is multiplied
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int pc = 2 * s2 + half;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, As[buf][0][arow + 32 * i][pc ^ asw]);
+        al[i] = __builtin_bit_cast(bf16x8, As[buf][1][arow + 32 * i][pc ^ asw]);
+        bh[i] = __builtin_bit_cast(bf16x8, Bs[buf][0][brow + 32 * i][pc ^ bsw]);
+        bl[i] = __builtin_bit_cast(bf16x8, Bs[buf][1][brow + 32 * i][pc ^ bsw]);
       }
-      float key[16];
-      uint32_t pass = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float dot = acc[i][j][r];
-        if (METRIC == METRIC_IP) key[r] = -dot;
-        else if (METRIC == METRIC_COS) key[r] = -(dot * vin);
-        else key[r] = qq[r >> 2][r & 3] + vsq - 2.f * dot;
-        if (!DENSE) pass |= (key[r] <= th[r >> 2][r & 3]) ? (1u << r) : 0u;
-      }
-      if (DENSE) {
-        if (col_ok) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int qi = rbase + (r & 3) + 8 * (r >> 2);
-            a.dense[(int64_t)(qbase + qi) * a.dense_ld + (col - a.row0)] = alive ? key[r] : __builtin_nanf("");
-          }
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-      } else {
-        if (!alive) pass = 0;
-        while (pass) {  // rare: about k * n / n_sample survivors per query over the whole pass
-          const int r = __builtin_ctz(pass);
-          pass &= pass - 1;
-          const int q = qbase + rbase + (r & 3) + 8 * (r >> 2);
-          if (q < a.nq) {
-            float kv = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) kv = u == r ? key[u] : kv;  // register select, no scratch
-            uint32_t p = atomicAdd(&a.cand_cnt[q], 1u);
-            if (p < (uint32_t)a.cand_cap) {
-              a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(kv);
-              a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)col;
-            }
-          }
-        }
-      }
+    }
+    if (kc + 1 < a.hchunks) {
+      lstore(buf ^ 1);
+      __syncthreads();
     }
   }
+  batch_epilogue<METRIC, DENSE>(a, acc, s_thr, s_qsq, qbase, nbase, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------

@@ -350,6 +350,13 @@ struct Shard {
   int64_t scan_us_samples = 0;
   int64_t bytes = 0;
   struct BatchCtx *batch = nullptr;  // matrix-core path scratch (created with the shard)
+  // bf16 (hi, lo) planes of the rows for the bf16x3 batch kernel; built lazily by the first
+  // batch search, kept current from split_valid (guarded by batch->mu under a shared s->mu;
+  // appends lower split_valid under the exclusive lock)
+  u32x4 *d_split = nullptr;
+  int64_t split_cap = 0;    // rows allocated
+  int64_t split_valid = 0;  // rows [0, split_valid) are converted
+  int batch_kernel = 1;     // TSH_OPT_BATCH_KERNEL: 0 f32 MFMA, 1 bf16x3
 
   bool safe_mode() const {
     if (nonfinite_rows) return true;
@@ -471,6 +478,7 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
   s->tiny_rows = hs.tiny_rows;
   if (first > s->rows) s->all_live = false;  // gap of absent rows
   if (first + n > s->rows) s->rows = first + n;
+  s->split_valid = std::min(s->split_valid, first);  // overwritten / new rows need re-splitting
   return TSH_OK;
 }
 
@@ -913,6 +921,8 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
 struct BatchCtx {
   std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
   float *d_Q = nullptr, *h_Q = nullptr;
+  u32x4 *d_Qs = nullptr;  // bf16 planes of the padded queries
+  int64_t qs_cap = 0;     // in u32x4 units
   float *d_qaux = nullptr, *h_qaux = nullptr;  // [qsq | delta2 | thr] x nq_pad
   int64_t q_cap = 0, aux_cap = 0, cc_cap = 0;  // element capacities
   float *d_dense = nullptr;
@@ -931,6 +941,7 @@ struct BatchCtx {
 
 void batch_free(BatchCtx *b) {
   hipFree(b->d_Q);
+  hipFree(b->d_Qs);
   hipHostFree(b->h_Q);
   hipFree(b->d_qaux);
   hipHostFree(b->h_qaux);
@@ -970,7 +981,20 @@ void launch_batch_score(const BatchArgs &a, bool dense, hipStream_t st) {
   if (dense) batch_score_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
   else batch_score_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
 }
+template <int METRIC>
+void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
+  int grid = a.q_tiles * a.n_tiles;
+  if (grid <= 0) return;
+  if (dense) batch_score_bf16x3_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
+  else batch_score_bf16x3_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
+}
 void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st) {
+  if (a.Vs) {
+    if (metric == TSH_METRIC_L2) launch_batch_score_bf16<METRIC_L2>(a, dense, st);
+    else if (metric == TSH_METRIC_IP) launch_batch_score_bf16<METRIC_IP>(a, dense, st);
+    else launch_batch_score_bf16<METRIC_COS>(a, dense, st);
+    return;
+  }
   if (metric == TSH_METRIC_L2) launch_batch_score<METRIC_L2>(a, dense, st);
   else if (metric == TSH_METRIC_IP) launch_batch_score<METRIC_IP>(a, dense, st);
   else launch_batch_score<METRIC_COS>(a, dense, st);
@@ -985,7 +1009,7 @@ int64_t batch_sample_rows(int64_t rows, int32_t k) {
 }
 
 // 2 * (error bound of the f32 MFMA key), absolute, per query
-bool batch_delta2(const Shard *s, const float *q, float *out_delta2, float *out_qsq) {
+bool batch_delta2(const Shard *s, const float *q, bool bf16x3, float *out_delta2, float *out_qsq) {
   double qn2 = 0;
   for (int i = 0; i < s->dim; ++i) {
     float a = std::fabs(q[i]);
@@ -994,7 +1018,13 @@ bool batch_delta2(const Shard *s, const float *q, float *out_delta2, float *out_
   }
   const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
   const double u2 = 1.1920928955078125e-07;        // 2^-23
-  const double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
+  double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
+  if (bf16x3) {
+    // three partial products per k accumulate in f32 (chain of 3 ld terms, each product exact),
+    // and hi + lo drops 3.1 * 2^-18 |q_i||v_i| per element (tsh_batch.hip.h, bf16x3 variant)
+    const double hld = (double)round_up(s->dim, 32);
+    gam = (3.0 * hld + 8.0) * u2 * (1.0 + 0.00391) + 3.1 * 3.814697265625e-06;
+  }
   double delta;
   if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
   else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07);
@@ -1043,6 +1073,23 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
   if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
 
+  // ---- bf16x3 kernel: keep the (hi, lo) planes of the rows current -----------------------
+  const bool use_bf16 = s->batch_kernel == 1;
+  const int32_t hchunks = (int32_t)((s->dim + 31) / 32);
+  if (use_bf16) {
+    if (s->split_cap < s->cap) {  // first use, or the row store grew: (re)allocate, convert everything
+      if (s->d_split) hipFree(s->d_split);
+      s->d_split = nullptr;
+      s->bytes -= s->split_cap * hchunks * 128;
+      s->split_cap = 0;
+      s->split_valid = 0;
+      HIPCHK(hipMalloc(&s->d_split, (size_t)s->cap * hchunks * 128));
+      s->split_cap = s->cap;
+      s->bytes += s->split_cap * hchunks * 128;
+    }
+    if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, (int64_t)nq_pad * hchunks * 8, &b->bytes))) return rc;
+  }
+
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
   std::vector<char> bad((size_t)nq, 0);
@@ -1051,7 +1098,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if (q < nq) {
       memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
       for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
-      if (!batch_delta2(s, dst, &h_d2[q], &h_qsq[q])) {
+      if (!batch_delta2(s, dst, use_bf16, &h_d2[q], &h_qsq[q])) {
         bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
         memset(dst, 0, (size_t)ld * sizeof(float));
         h_d2[q] = 0.f;
@@ -1073,6 +1120,28 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
     float *d_qsq = b->d_qaux, *d_d2 = b->d_qaux + nq_pad, *d_thr = b->d_qaux + 2 * (size_t)nq_pad;
     BatchArgs a{};
+    if (use_bf16) {
+      auto split = [&](const float *src, int64_t first, int64_t n, u32x4 *dst) {
+        SplitArgs sa{};
+        sa.rows = src;
+        sa.out = dst;
+        sa.ld = ld;
+        sa.first = first;
+        sa.n = n;
+        sa.dim = s->dim;
+        sa.hchunks = hchunks;
+        const int64_t total = n * hchunks * 4;
+        split_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(sa);
+      };
+      if (s->split_valid < rows) {
+        split(s->d_rows, s->split_valid, rows - s->split_valid, s->d_split);
+        s->split_valid = rows;
+      }
+      split(b->d_Q, 0, nq_pad, b->d_Qs);
+      a.Qs = b->d_Qs;
+      a.Vs = s->d_split;
+      a.hchunks = hchunks;
+    }
     a.Q = b->d_Q;
     a.V = s->d_rows;
     a.inv_norm = s->d_inv_norm;
@@ -1274,6 +1343,7 @@ void shard_destroy(Shard *s) {
   hipFree(s->d_inv_norm);
   hipFree(s->d_sqnorm);
   hipFree(s->d_live);
+  hipFree(s->d_split);
   hipFree(s->d_stats);
   hipFree(s->d_tmp_u32);
 }
@@ -1775,6 +1845,14 @@ int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
   if (option == TSH_OPT_BATCH_MIN_NQ) {
     if (value < 0 || value > (1 << 20)) return set_err(TSH_E_BAD_ARG, "batch_min_nq out of range");
     idx->batch_min_nq = (int32_t)value;
+    return TSH_OK;
+  }
+  if (option == TSH_OPT_BATCH_KERNEL) {
+    if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "batch kernel must be 0 (f32 MFMA) or 1 (bf16x3)");
+    for (auto &sh : idx->shards) {
+      std::unique_lock<RwLock> xl(sh->mu);
+      sh->batch_kernel = (int)value;
+    }
     return TSH_OK;
   }
   return set_err(TSH_E_BAD_ARG, "unknown option %d", option);
