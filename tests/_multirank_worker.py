@@ -32,6 +32,7 @@ for mode in ("search", "search_many"):
         ok &= bool(np.array_equal(ids[i, :cnt[i]], e) and np.array_equal(dd[i, :cnt[i]], ed))
         if not ok and rank == 0 and i == 0:
             print("got", ids[0], "want", e, flush=True)
-    print("rank", rank, mode, "ok" if ok else "MISMATCH", "size", idx.size, "lo", lo, flush=True)
+    # one write() per line: the ranks share the parent's pipe and print() would interleave words
+    os.write(1, ("rank %d %s %s size %d lo %d\n" % (rank, mode, "ok" if ok else "MISMATCH", idx.size, lo)).encode())
 dist.barrier()
 dist.destroy_process_group()

@@ -597,54 +597,63 @@ struct RerankBatchArgs {
   int32_t dim, entries, metric;
 };
 
+// One wave = up to 64 candidates of ONE query, one candidate per lane.  The exact sums must
+// add their terms strictly in dimension order -- a serial chain per candidate -- so 64 chains
+// run side by side and nothing crosses lanes: each lane streams its own row (16 B at a time,
+// 8 loads in flight, the next 32 dimensions prefetched while the current ones are added) and
+// the query values are wave-uniform (scalar loads).
+constexpr int RB_CH = 32;  // dimensions per step
+
 __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
 #pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) double t0[RR_CHUNK];
-  __shared__ __attribute__((aligned(16))) double t1[RR_CHUNK];
   const int lane = threadIdx.x, q = blockIdx.y;
   uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
   uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
   if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
+  const uint32_t c0 = blockIdx.x * 64u;
+  if (c0 >= count) return;
+  const bool mine = c0 + lane < count;
   BlockEntry *out = reinterpret_cast<BlockEntry *>(blk + sizeof(BlockHeader));
-  const float *qp = a.Q + (int64_t)q * a.ld;
-  const int chains = a.metric == METRIC_COS ? 2 : 1;
-  for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
-    uint32_t row = a.final_rows[(int64_t)q * a.entries + c];
-    const float *rp = a.rows + (int64_t)row * a.ld;
-    double s = 0.0;
-    for (int base = 0; base < a.dim; base += RR_CHUNK) {
-      int m = a.dim - base < RR_CHUNK ? a.dim - base : RR_CHUNK;
-      for (int i = lane; i < m; i += 64) {
-        double qv = (double)qp[base + i], bv = (double)rp[base + i];
-        if (a.metric == METRIC_L2) {
-          double diff = qv - bv;
-          t0[i] = diff * diff;
-        } else {
-          t0[i] = qv * bv;
-          if (a.metric == METRIC_COS) t1[i] = bv * bv;
+  const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;
+  const uint32_t row = mine ? a.final_rows[(int64_t)q * a.entries + c0 + lane] : 0u;
+  const float *__restrict__ rp = a.rows + (int64_t)row * a.ld;
+  const bool cosine = a.metric == METRIC_COS, l2 = a.metric == METRIC_L2;
+  const int ld = (int)a.ld;  // multiple of 4; rows and queries are zero beyond dim
+  double s0 = 0.0, s1 = 0.0;
+  f32x4 cur[RB_CH / 4], nxt[RB_CH / 4];
+  auto fetch = [&](f32x4 (&dst)[RB_CH / 4], int base) {
+#pragma unroll
+    for (int j = 0; j < RB_CH / 4; ++j)
+      dst[j] = base + 4 * j < ld ? *reinterpret_cast<const f32x4 *>(rp + base + 4 * j)  // through L1: a lane's 8
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};                          // loads share one 128-B line
+  };
+  fetch(cur, 0);
+  for (int base = 0; base < a.dim; base += RB_CH) {
+    if (base + RB_CH < a.dim) fetch(nxt, base + RB_CH);
+    const int m = a.dim - base < RB_CH ? a.dim - base : RB_CH;  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < RB_CH / 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * j + e;
+        if (i < m) {
+          const double qd = (double)qp[base + i], bd = (double)cur[j][e];
+          if (l2) {
+            const double diff = qd - bd;
+            s0 = s0 + diff * diff;
+          } else {
+            s0 = s0 + qd * bd;
+            if (cosine) s1 = s1 + bd * bd;
+          }
         }
       }
-      __syncthreads();
-      if (lane < chains) {
-        const double *src = lane == 0 ? t0 : t1;
-        int i = 0;
-        for (; i + 32 <= m; i += 32) {
-          double x[32];
 #pragma unroll
-          for (int u = 0; u < 32; ++u) x[u] = src[i + u];
-#pragma unroll
-          for (int u = 0; u < 32; ++u) s = s + x[u];
-        }
-        for (; i < m; ++i) s = s + src[i];
-      }
-      __syncthreads();
-    }
-    double s1 = __shfl(s, 1);
-    if (lane == 0) {
-      out[c].id = a.row_base + (int64_t)row;
-      out[c].s0 = s;
-      out[c].s1 = a.metric == METRIC_COS ? s1 : 0.0;
-    }
+    for (int j = 0; j < RB_CH / 4; ++j) cur[j] = nxt[j];
+  }
+  if (mine) {
+    out[c0 + lane].id = a.row_base + (int64_t)row;
+    out[c0 + lane].s0 = s0;
+    out[c0 + lane].s1 = cosine ? s1 : 0.0;
   }
 }
 

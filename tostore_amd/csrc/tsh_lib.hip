@@ -15,7 +15,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cctype>
+#include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -146,27 +148,82 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
   return (int32_t)r;
 }
 
-// run fn(q) for q in [0,n) on a few host threads (per-query finalisation of a batch)
+// run fn(q) for q in [0,n) on a few host threads (per-query preparation / finalisation of a
+// batch).  The workers are created once and parked on a condition variable: spawning threads
+// per call costs more than the work itself (about 30 us per thread on a 128-core host).
+class HostPool {
+ public:
+  static HostPool &get() {
+    static HostPool *p = new HostPool();  // never destroyed: workers may outlive static teardown
+    return *p;
+  }
+  // false when the pool is busy with another caller's job (the caller then runs inline)
+  bool run(int32_t n, const std::function<void(int32_t)> &fn) {
+    std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
+    if (!own.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      n_ = n;
+      next_.store(0);
+      pending_ = (int)workers_.size();
+      ++gen_;
+    }
+    cv_.notify_all();
+    chunks();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+    return true;
+  }
+  int threads() const { return (int)workers_.size() + 1; }
+
+ private:
+  HostPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, 15);
+    for (int i = 0; i < nt; ++i) {
+      workers_.emplace_back([this] { loop(); });
+      workers_.back().detach();
+    }
+  }
+  void chunks() {
+    for (;;) {
+      int32_t q0 = next_.fetch_add(8);
+      if (q0 >= n_) return;
+      for (int32_t q = q0; q < std::min(n_, q0 + 8); ++q) (*fn_)(q);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+      }
+      chunks();
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex owner_, m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int32_t)> *fn_ = nullptr;
+  int32_t n_ = 0;
+  std::atomic<int32_t> next_{0};
+  int pending_ = 0;
+  uint64_t gen_ = 0;
+};
+
 template <typename F>
 void parallel_for(int32_t n, F fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<unsigned>(hw ? hw : 1, 16);
-  nt = std::min(nt, n / 64);  // below 64 queries per thread it is not worth a thread
-  if (nt <= 1) {
-    for (int32_t q = 0; q < n; ++q) fn(q);
-    return;
+  if (n >= 64) {
+    std::function<void(int32_t)> f = fn;
+    if (HostPool::get().run(n, f)) return;
   }
-  std::atomic<int32_t> next{0};
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&] {
-      for (;;) {
-        int32_t q0 = next.fetch_add(16);
-        if (q0 >= n) return;
-        for (int32_t q = q0; q < std::min(n, q0 + 16); ++q) fn(q);
-      }
-    });
-  for (auto &t : th) t.join();
+  for (int32_t q = 0; q < n; ++q) fn(q);
 }
 
 // ---- kernel dispatch ---------------------------------------------------------
@@ -1038,12 +1095,21 @@ bool batch_delta2(const Shard *s, const float *q, bool bf16x3, float *out_delta2
   return true;
 }
 
+inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool trace_batch() {
+  static const bool on = getenv("TSH_TRACE_BATCH") != nullptr;
+  return on;
+}
+
 // All nq queries in one pass over the rows on the matrix cores.  Queries the
 // error model cannot cover, or whose lists overflow (ties), are reported in
 // *redo and answered by the single-query path.  Caller holds s->mu shared.
 int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
                        const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo) {
   std::lock_guard<std::mutex> lk(b->mu);
+  const double t_in = now_us();
   HIPCHK(hipSetDevice(s->device));
   const int64_t rows = s->rows, ld = s->ld;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
@@ -1093,7 +1159,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
   std::vector<char> bad((size_t)nq, 0);
-  for (int32_t q = 0; q < nq_pad; ++q) {
+  parallel_for(nq_pad, [&](int32_t q) {
     float *dst = b->h_Q + (size_t)q * ld;
     if (q < nq) {
       memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
@@ -1109,9 +1175,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       h_d2[q] = 0.f;
       h_qsq[q] = 0.f;
     }
-  }
+  });
   if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
 
+  const double t_prep = now_us();
   // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
   {
     hipStream_t st = s->batch_stream;
@@ -1218,12 +1285,14 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     rb.dim = s->dim;
     rb.entries = entries;
     rb.metric = s->metric;
-    rerank_batch_kernel<<<dim3((unsigned)std::min(entries, 160), (unsigned)nq), 64, 0, st>>>(rb);
+    rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)nq), 64, 0, st>>>(rb);
     HIPCHK(hipMemcpyAsync(b->h_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(b->e_done, st));
   }
+  const double t_enq = now_us();
   HIPCHK(hipEventSynchronize(b->e_done));
   HIPCHK(hipGetLastError());
+  const double t_gpu = now_us();
   float ms0 = 0.f, ms1 = 0.f;
   HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
   HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
@@ -1242,6 +1311,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
     HIPCHK(hipStreamSynchronize(us));
   }
+  if (trace_batch())
+    fprintf(stderr, "[tsh batch] nq=%d prep %.0f us, enqueue %.0f us, gpu wait %.0f us, post %.0f us (gemm %.0f us)\n", nq,
+            t_prep - t_in, t_enq - t_prep, t_gpu - t_enq, now_us() - t_gpu, b->last_gemm_us);
   return TSH_OK;
 }
 
@@ -1548,10 +1620,11 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
   if (k <= 0) return TSH_OK;  // reference: topK <= 0 yields an empty list
   if (!out_ids || !out_dist) return set_err(TSH_E_BAD_ARG, "out_ids / out_dist is NULL");
 
+  const double t_in = now_us();
   size_t ns = idx->shards.size();
   int32_t entries = tsh_default_block_entries(k);
   size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  std::vector<std::vector<uint8_t>> blocks(ns);
+  std::vector<std::unique_ptr<uint8_t[]>> blocks(ns);  // uninitialised: every block is written whole
   std::vector<std::vector<std::vector<BlockEntry>>> spills(ns);
   std::vector<int> rcs(ns, TSH_OK);
   std::vector<std::string> errs(ns);
@@ -1562,10 +1635,10 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     std::shared_lock<RwLock> sl(s->mu);
     if (s->rows == 0) return;
     active[g] = 1;
-    blocks[g].resize(bb * (size_t)nq);
+    blocks[g].reset(new uint8_t[bb * (size_t)nq]);
     spills[g].resize((size_t)nq);
     SearchOut so;
-    so.h_blocks = blocks[g].data();
+    so.h_blocks = blocks[g].get();
     so.spill = &spills[g];
     rcs[g] = shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
     if (rcs[g]) errs[g] = g_err;
@@ -1582,6 +1655,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
       g_err = errs[g];
       return rcs[g];
     }
+  const double t_shards = now_us();
   parallel_for(nq, [&](int32_t q) {
     std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
     for (size_t g = 0; g < ns; ++g) {
@@ -1589,7 +1663,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
       if (!spills[g][(size_t)q].empty()) {
         lists.push_back({spills[g][(size_t)q].data(), (uint32_t)spills[g][(size_t)q].size()});
       } else {
-        const uint8_t *b = blocks[g].data() + (size_t)q * bb;
+        const uint8_t *b = blocks[g].get() + (size_t)q * bb;
         const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b);
         lists.push_back({reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)),
                          std::min(h->count, h->entries)});
@@ -1598,6 +1672,8 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, lists,
                                   out_ids + (size_t)q * k, out_dist + (size_t)q * k);
   });
+  if (trace_batch() && nq >= 64)
+    fprintf(stderr, "[tsh search] nq=%d shards %.0f us, finalize %.0f us\n", nq, t_shards - t_in, now_us() - t_shards);
   return TSH_OK;
 }
 
