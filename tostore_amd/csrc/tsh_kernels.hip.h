@@ -413,6 +413,7 @@ struct SelectArgs {
 constexpr int SEL_THREADS = 1024;   // one whole CU; tile minima stay in registers
 constexpr int SEL_VPT = 16;         // tile minima a thread keeps in registers (16384 tiles = 1M rows)
 constexpr int SEL_LIST_CAP = 4096;  // LDS lists (short list of tile minima / tile ids)
+constexpr int SEL_PREFILTER_MIN = 512;  // above this many tiles, bound the list by the thread-minima bisect first
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
   // above k = 512 the k-th of 1024 thread minima gets loose (G ln(G/(G-k)) entries below
   // it): split every thread into its even and odd elements, 2048 groups
   const bool groups2k = k > 512;
-  if (narrow && M > SEL_LIST_CAP) {
+  if (narrow && M > SEL_PREFILTER_MIN) {
     uint32_t m = lmin;
     if (groups4) {
       uint32_t t1 = (uint32_t)__shfl_xor((int)m, 1);
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
     }
   }
   __syncthreads();
-  if (narrow && M > SEL_LIST_CAP && wave == 0) {
+  if (narrow && M > SEL_PREFILTER_MIN && wave == 0) {
     uint32_t U;
     if (groups2k) {
       uint32_t v[2 * NT / 64];
@@ -566,7 +567,7 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
   }
   __syncthreads();
   if (narrow) {
-    const uint32_t U = s_U;  // KEY_DEAD when the list holds everything (M <= cap)
+    const uint32_t U = s_U;  // KEY_DEAD when the list holds everything (M <= SEL_PREFILTER_MIN)
     if (IN_REGS) {
 #pragma unroll
       for (int i = 0; i < SEL_VPT; ++i) {

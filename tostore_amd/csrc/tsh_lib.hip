@@ -7,6 +7,7 @@
 // kernels in tsh_kernels.hip.h.  No CPU fallback exists: without a device every
 // compute entry returns TSH_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -68,6 +69,8 @@ int device_count_cached() {
 
 constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
 constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
+constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgroups, two scan streams
+constexpr int SUBMIT_THREADS = 3;     // host threads that submit a multi-query call's searches
 constexpr int MAX_DIM_SCAN = 2048;    // register-resident query (NCH <= 8)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
 
@@ -241,64 +244,80 @@ template <int NCH, bool MASKED> struct ScanTune {
   static constexpr int R = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 2 : 4) : 2);
   static constexpr int MINW = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH == 6 ? 3 : 2)));
 };
+// Events that ride on the scan's own dispatch packet (hipExtLaunchKernel): a separate
+// hipEventRecord is a barrier packet of its own, and two or three of those between
+// consecutive scans were most of the gap between them.
+struct LaunchEv {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+#define TSH_LAUNCH(KERN, GRID, BLOCK, ST, EV, ARG)                                                       \
+  do {                                                                                                  \
+    if ((EV).start || (EV).stop)                                                                        \
+      hipExtLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), 0, ST, (EV).start,   \
+                            (EV).stop, 0, ARG);                                                         \
+    else                                                                                                \
+      KERN<<<(GRID), (BLOCK), 0, ST>>>(ARG);                                                            \
+  } while (0)
+
 template <int NCH, int METRIC, bool FULL, bool MASKED>
-void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s) {
+void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s, const LaunchEv &ev) {
   using T = ScanTune<NCH, MASKED>;
   // grid > 0: 4-wave workgroups; grid < 0: -grid one-wave workgroups (small shards)
-  if (grid > 0) scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<grid, 256, 0, s>>>(a);
-  else scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW><<<-grid, 64, 0, s>>>(a);
+  if (grid > 0) TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), grid, 256, s, ev, a);
+  else TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), -grid, 64, s, ev, a);
 }
 template <int NCH, int METRIC>
-void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s) {
+void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
   bool full = a.a.d4 == NCH * 64;
   if (full) {
-    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s);
-    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s);
+    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s, ev);
+    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s, ev);
   } else {
-    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s);
-    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s);
+    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s, ev);
+    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s, ev);
   }
 }
 template <int NCH>
-void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s) {
-  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s);
-  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s);
-  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s);
+void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
+  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s, ev);
+  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s, ev);
+  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s, ev);
 }
 template <int SPLIT>
-void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s) {
-#define TSH_PK(M, MK) scan_packed_kernel<SPLIT, M, MK, true><<<grid, threads, 0, s>>>(a)
+void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s,
+                   const LaunchEv &ev) {
+#define TSH_PK(M, MK) TSH_LAUNCH((scan_packed_kernel<SPLIT, M, MK, true>), grid, threads, s, ev, a)
   if (metric == TSH_METRIC_L2) { if (masked) TSH_PK(METRIC_L2, true); else TSH_PK(METRIC_L2, false); }
   else if (metric == TSH_METRIC_IP) { if (masked) TSH_PK(METRIC_IP, true); else TSH_PK(METRIC_IP, false); }
   else { if (masked) TSH_PK(METRIC_COS, true); else TSH_PK(METRIC_COS, false); }
 #undef TSH_PK
 }
 
-void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s) {
+void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev = LaunchEv()) {
   int grid = (a.a.n_tiles + 3) / 4;
   if (grid < 1) grid = 1;
   if (a.a.ld == 128 || a.a.ld == 64 || a.a.ld == 32) {
     // narrow rows: several whole rows per 1 KiB wave load (scan_packed_kernel)
     int threads = 256;
-    if (a.a.n_tiles < 6 * 4 * 256) {
+    if (a.a.n_tiles < SMALL_SHARD_TILES) {
       grid = std::max(1, (int)a.a.n_tiles);
       threads = 64;
     }
-    if (a.a.ld == 128) launch_packed<1>(a, metric, masked, grid, threads, s);
-    else if (a.a.ld == 64) launch_packed<2>(a, metric, masked, grid, threads, s);
-    else launch_packed<3>(a, metric, masked, grid, threads, s);
+    if (a.a.ld == 128) launch_packed<1>(a, metric, masked, grid, threads, s, ev);
+    else if (a.a.ld == 64) launch_packed<2>(a, metric, masked, grid, threads, s, ev);
+    else launch_packed<3>(a, metric, masked, grid, threads, s, ev);
     return;
   }
   // fewer than ~6 four-wave workgroups per CU: tile counts per CU differ by tens of
   // percent; one tile per workgroup lets the dispatcher even them out
-  if (a.a.n_tiles < 6 * 4 * 256) grid = -std::max(1, (int)a.a.n_tiles);
+  if (a.a.n_tiles < SMALL_SHARD_TILES) grid = -std::max(1, (int)a.a.n_tiles);
   switch (nch) {
-    case 1: launch_scan_n<1>(a, metric, masked, grid, s); break;
-    case 2: launch_scan_n<2>(a, metric, masked, grid, s); break;
-    case 3: launch_scan_n<3>(a, metric, masked, grid, s); break;
-    case 4: launch_scan_n<4>(a, metric, masked, grid, s); break;
-    case 6: launch_scan_n<6>(a, metric, masked, grid, s); break;
-    default: launch_scan_n<8>(a, metric, masked, grid, s); break;
+    case 1: launch_scan_n<1>(a, metric, masked, grid, s, ev); break;
+    case 2: launch_scan_n<2>(a, metric, masked, grid, s, ev); break;
+    case 3: launch_scan_n<3>(a, metric, masked, grid, s, ev); break;
+    case 4: launch_scan_n<4>(a, metric, masked, grid, s, ev); break;
+    case 6: launch_scan_n<6>(a, metric, masked, grid, s, ev); break;
+    default: launch_scan_n<8>(a, metric, masked, grid, s, ev); break;
   }
 }
 
@@ -386,6 +405,9 @@ struct Shard {
   // (Running a query's tail beside the next query's scan was measured 10-25x
   // slower per tail: each dependent load queues behind the scan's loads.)
   hipStream_t scan_stream = nullptr;
+  // small shards alternate their scans between two streams (see job_enqueue)
+  hipStream_t scan_stream2 = nullptr;
+  uint64_t scan_seq = 0;  // guarded by scan_mu
   // When several queries are in flight, a query's select + rerank run here, on
   // CUs the scan stream's CU mask leaves free (2 per XCD), so they overlap the
   // next query's scan without queueing behind its loads on the same CU.
@@ -438,15 +460,14 @@ int shard_init(Shard *s) {
       scan_mask[0] = 0xFFFF0000u;
       tail_mask[0] = 0x0000FFFFu;
       if (hipExtStreamCreateWithCUMask(&s->scan_stream, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&s->scan_stream2, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
           hipExtStreamCreateWithCUMask(&s->tail_stream, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
         s->cu_split = true;
       } else {
         if (s->scan_stream) hipStreamDestroy(s->scan_stream);
-  if (s->tail_stream) hipStreamDestroy(s->tail_stream);
-  if (s->batch_stream) hipStreamDestroy(s->batch_stream);
+        if (s->scan_stream2) hipStreamDestroy(s->scan_stream2);
         if (s->tail_stream) hipStreamDestroy(s->tail_stream);
-  if (s->batch_stream) hipStreamDestroy(s->batch_stream);
-        s->scan_stream = s->tail_stream = nullptr;
+        s->scan_stream = s->scan_stream2 = s->tail_stream = nullptr;
         (void)hipGetLastError();
       }
     }
@@ -795,19 +816,34 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   {
     std::lock_guard<std::mutex> lk(s->scan_mu);
     hipStream_t ps = s->scan_stream;
+    {
+      // Between two scans on one in-order stream the GPU idles for about 13 us (drain, write-back,
+      // ramp-up).  That is 3 % of a 1 M-row scan but 20 % of a 125 k-row one (a shard of an 8-GPU
+      // index), so small shards alternate between two streams and the next scan's workgroups fill
+      // in as the previous one drains (+12 % queries/s at 125 k and 250 k rows).  The two scans
+      // then run side by side, so each one's own duration roughly doubles; large shards keep one
+      // stream, where a scan's duration is its HBM time.  TSH_SCAN_STREAMS=1 / 2 forces either.
+      static const int forced = getenv("TSH_SCAN_STREAMS") ? atoi(getenv("TSH_SCAN_STREAMS")) : 0;
+      const bool two = forced == 2 || (forced != 1 && n_tiles < SMALL_SHARD_TILES);
+      if (overlap && two && s->scan_stream2 && (s->scan_seq++ & 1)) ps = s->scan_stream2;
+    }
     if (upload_mask)
       HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
     if (!inline_q)
       HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
     j->timed = (s->c_scans.load() & 3) == 0;  // sample every 4th scan with timing events
-    if (j->timed) HIPCHK(hipEventRecord(c->ev0, ps));
-    launch_scan(sa, s->nch, s->metric, j->masked, ps);
-    if (j->timed) HIPCHK(hipEventRecord(c->ev1, ps));
+    LaunchEv ev;  // start / stop ride on the scan's own packet: no barrier packets between scans
+    if (j->timed) {
+      ev.start = c->ev0;
+      ev.stop = c->ev1;
+    } else if (overlap) {
+      ev.stop = c->ev_scanned;
+    }
+    launch_scan(sa, s->nch, s->metric, j->masked, ps, ev);
     hipStream_t ts = ps;
     if (overlap) {
       ts = s->tail_stream;
-      HIPCHK(hipEventRecord(c->ev_scanned, ps));
-      HIPCHK(hipStreamWaitEvent(ts, c->ev_scanned, 0));
+      HIPCHK(hipStreamWaitEvent(ts, ev.stop, 0));
     }
     launch_select(se, n_tiles, ts);
     rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
@@ -918,24 +954,16 @@ struct SearchOut {
   hipStream_t user_stream = nullptr;
 };
 
-// nq single-query searches, up to `depth` of them in flight on separate
-// contexts/streams so one query's select / rerank / copies hide behind the
-// next query's scan.  Caller holds s->mu shared.
-int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const uint8_t *mask,
-                        int32_t entries, SearchOut *out, int depth) {
+// One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
+// `depth` of them in flight on separate contexts so one query's select / rerank / copies hide
+// behind the next query's scan.
+int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, int32_t k, const uint64_t *mask_words,
+                       uint64_t epoch, int32_t entries, SearchOut *out, int depth) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
-  std::vector<uint64_t> mask_words;
-  uint64_t epoch = 0;
-  if (mask) {
-    mask_words.resize((size_t)n_tiles);
-    slice_mask(s, mask, mask_words.data(), n_tiles);
-    epoch = s->mask_epoch_src.fetch_add(1);
-  }
-  depth = std::max(1, std::min(depth, std::min(nq, MAX_CTX)));
+  depth = std::max(1, std::min(depth, std::min(q1 - q0, MAX_CTX)));
   std::vector<Job> jobs((size_t)depth);
   int rc = TSH_OK;
-  int32_t submitted = 0, finished = 0;
+  int32_t submitted = q0, finished = q0;
   auto release_all = [&]() {
     for (auto &j : jobs)
       if (j.c) {
@@ -946,12 +974,15 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
         j.c = nullptr;
       }
   };
-  while (finished < nq) {
-    while (submitted < nq && submitted - finished < depth) {
-      Job &j = jobs[(size_t)(submitted % depth)];
-      j.c = ctx_acquire(s, true);
-      rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries,
-                       mask ? mask_words.data() : nullptr, epoch,
+  while (finished < q1) {
+    while (submitted < q1 && submitted - finished < depth) {
+      // wait for a context only while holding none: callers that each hold some and wait for
+      // more would deadlock on the shard's fixed pool
+      Ctx *c = ctx_acquire(s, submitted == finished);
+      if (!c) break;
+      Job &j = jobs[(size_t)((submitted - q0) % depth)];
+      j.c = c;
+      rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries, mask_words, epoch,
                        out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr);
       if (rc) {
         release_all();
@@ -959,7 +990,7 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
       }
       ++submitted;
     }
-    Job &j = jobs[(size_t)(finished % depth)];
+    Job &j = jobs[(size_t)((finished - q0) % depth)];
     std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[(size_t)finished] : nullptr;
     rc = job_finish(s, &j, sp);
     if (rc) {
@@ -971,6 +1002,43 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
     j.c = nullptr;
     ++finished;
   }
+  return TSH_OK;
+}
+
+// nq single-query searches.  Each query costs the host about seven runtime calls (three
+// launches, events, a wait); on a small shard (a row range of a multi-GPU index) that is
+// longer than the scan itself, so larger calls are submitted from a few threads at once.
+// Caller holds s->mu shared.
+int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const uint8_t *mask,
+                        int32_t entries, SearchOut *out, int depth) {
+  const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+  std::vector<uint64_t> mask_words;
+  uint64_t epoch = 0;
+  if (mask) {
+    mask_words.resize((size_t)n_tiles);
+    slice_mask(s, mask, mask_words.data(), n_tiles);
+    epoch = s->mask_epoch_src.fetch_add(1);
+  }
+  const uint64_t *mw = mask ? mask_words.data() : nullptr;
+  const int T = std::min(SUBMIT_THREADS, nq / 8);
+  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth);
+  std::vector<int> rcs((size_t)T, TSH_OK);
+  std::vector<std::string> errs((size_t)T);
+  const int per_depth = std::max(2, depth / T);
+  auto run = [&](int t) {
+    const int32_t q0 = (int32_t)((int64_t)nq * t / T), q1 = (int32_t)((int64_t)nq * (t + 1) / T);
+    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth);
+    if (rcs[(size_t)t]) errs[(size_t)t] = g_err;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(run, t);
+  run(0);
+  for (auto &x : th) x.join();
+  for (int t = 0; t < T; ++t)
+    if (rcs[(size_t)t]) {
+      g_err = errs[(size_t)t];
+      return rcs[(size_t)t];
+    }
   return TSH_OK;
 }
 
@@ -1409,6 +1477,7 @@ void shard_destroy(Shard *s) {
   }
   if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
   if (s->scan_stream) hipStreamDestroy(s->scan_stream);
+  if (s->scan_stream2) hipStreamDestroy(s->scan_stream2);
   if (s->tail_stream) hipStreamDestroy(s->tail_stream);
   if (s->batch_stream) hipStreamDestroy(s->batch_stream);
   hipFree(s->d_rows);
