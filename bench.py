@@ -157,13 +157,13 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    try:
-        line = run_bench(a)
-    finally:
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
+    # fd 1 stays parked on stderr until the process exits: RCCL's banner sits in C stdio's buffer
+    # and is only flushed at exit, i.e. after the JSON line
+    line = run_bench(a)
+    sys.stdout.flush()
     if line is not None:
-        os.write(1, (line + "\n").encode())
+        os.write(real_stdout, (line + "\n").encode())
+    os.close(real_stdout)
 
 
 def run_bench(a):
@@ -245,10 +245,10 @@ def run_bench(a):
             for i in range(count):
                 one(first + i)
         elif searcher is not None:
-            # N > 1: groups of `inflight` queries share one all-gather + one merge call, and the
+            # N > 1: groups of `--group` queries share one all-gather + one merge call, and the
             # next group's shard scans run while this group is exchanged and merged
             sel = [(first + j) % len(queries) for j in range(count)]
-            searcher.search_many(queries[sel], k, None, row_mask, group=max(32, a.inflight))
+            searcher.search_many(queries[sel], k, None, row_mask, group=max(a.group or 64, a.inflight))
         elif a.group > 0:
             for g0 in range(0, count, a.group):
                 sel = [(first + g0 + j) % len(queries) for j in range(min(a.group, count - g0))]
@@ -350,7 +350,7 @@ def run_bench(a):
                        "rows": n, "dim": d, "k": k, "metric": a.metric, "mask_keep": a.mask_keep or None,
                        "mask_kind": a.mask_kind if a.mask_keep else None,
                        "queries_in_flight": 8,
-                       "queries_per_call": (a.group or 1) if searcher is None else max(32, a.inflight),
+                       "queries_per_call": (a.group or 1) if searcher is None else max(a.group or 64, a.inflight),
                        "note": "every query scans the whole corpus on its own (HBM-bound kernel, no matrix-core "
                                "batching); independent queries are handed over in groups and pipelined",
                        "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world

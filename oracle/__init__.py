@@ -10,6 +10,7 @@ import ctypes
 import math
 import os
 import subprocess
+from typing import Optional
 
 import numpy as np
 
@@ -31,7 +32,10 @@ def build(force: bool = False) -> None:
             and os.path.getmtime(so) >= os.path.getmtime(src)
             and os.path.exists(os.path.join(_HERE, "libvs_oracle_mt.so"))
             and os.path.getmtime(os.path.join(_HERE, "libvs_oracle_mt.so"))
-            >= os.path.getmtime(os.path.join(_HERE, "vs_oracle_mt.c"))):
+            >= os.path.getmtime(os.path.join(_HERE, "vs_oracle_mt.c"))
+            and os.path.exists(os.path.join(_HERE, "libngh_ann.so"))
+            and os.path.getmtime(os.path.join(_HERE, "libngh_ann.so"))
+            >= os.path.getmtime(os.path.join(_HERE, "ngh_ann.c"))):
         return
     subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
                    stdout=subprocess.DEVNULL)
@@ -290,3 +294,92 @@ def rawvec_locate(node_id: int, vectors_per_page: int, pages_per_partition: int)
     lib().vso_rawvec_locate(node_id, vectors_per_page, pages_per_partition,
                             ctypes.byref(part), ctypes.byref(page), ctypes.byref(slot))
     return part.value, page.value, slot.value
+
+
+# ---- N3: the reference's own ANN path, restated (oracle/ngh_ann.c) ------------------------------
+_lib_ann = None
+
+
+def _ann():
+    global _lib_ann
+    if _lib_ann is None:
+        build()
+        L = ctypes.CDLL(os.path.join(_HERE, "libngh_ann.so"))
+        L.vso_ann_create.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double, _c_f32p]
+        L.vso_ann_create.restype = ctypes.c_void_p
+        L.vso_ann_destroy.argtypes = [ctypes.c_void_p]
+        L.vso_ann_destroy.restype = None
+        L.vso_ann_insert_batch.argtypes = [ctypes.c_void_p, _c_f32p, _c_i64]
+        L.vso_ann_insert_batch.restype = None
+        L.vso_ann_search.argtypes = [ctypes.c_void_p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                     _c_i64p, _c_f64p]
+        L.vso_ann_search.restype = _c_i64
+        L.vso_ann_size.argtypes = [ctypes.c_void_p]
+        L.vso_ann_size.restype = _c_i64
+        L.vso_ann_counters.argtypes = [ctypes.c_void_p, _c_i64p, _c_i64p, ctypes.c_int]
+        L.vso_ann_counters.restype = None
+        L.vso_ann_mean_degree.argtypes = [ctypes.c_void_p]
+        L.vso_ann_mean_degree.restype = ctypes.c_double
+        _lib_ann = L
+    return _lib_ann
+
+
+class NghAnnIndex:
+    """The reference's index as it builds and searches it (NghGraphEngine + VectorQuantizer), restated on
+    the CPU for context numbers only.  `first_batch` plays the first writeChanges call: its first <= 2500
+    rows train the codebook (trainPqSubspace per sub-space, seeds from `seed` because Dart's PRNG is not
+    reproducible here).  ref: core/vector_index_manager.dart:300-420,725-850, core/ngh_graph_engine.dart."""
+
+    def __init__(self, dim: int, metric: int, first_batch, *, subspaces: Optional[int] = None, max_degree: int = 64,
+                 ef_search: int = 64, ef_construction: int = 128, prune_alpha: float = 1.2, seed: int = 42):
+        fb = _f32(first_batch)
+        self.dim, self.metric = dim, metric
+        self.subspaces = subspaces or min(max(dim // 8, 8), 128)  # NghIndexMeta.autoPqSubspaces
+        samples = fb[:2500]
+        n = samples.shape[0]
+        if n < 100:
+            raise ValueError("the restated path covers the >= 100-sample training branch only")
+        self.centroids = min(256, n)
+        rng = np.random.default_rng(seed)
+        init = rng.integers(0, n, size=(self.subspaces, self.centroids)).astype(np.int32)
+        self.codebook = pq_train(samples, self.subspaces, self.centroids, 10, init)
+        cb = np.ascontiguousarray(self.codebook.reshape(-1), dtype=np.float32)
+        self._h = _ann().vso_ann_create(dim, metric, self.subspaces, self.centroids, max_degree, ef_search,
+                                        ef_construction, prune_alpha, _p(cb, _c_f32p))
+        self.insert_batch(fb)
+
+    def insert_batch(self, vectors) -> None:
+        v = _f32(vectors)
+        _ann().vso_ann_insert_batch(self._h, _p(v, _c_f32p), v.shape[0])
+
+    def search(self, query, k: int, ef_search: int = -1, threshold=None):
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        ids = np.empty(max(k, 1), np.int64)
+        dist = np.empty(max(k, 1), np.float64)
+        n = _ann().vso_ann_search(self._h, _p(q, _c_f32p), k, ef_search, (math.nan if threshold is None else float(threshold)), _p(ids, _c_i64p),
+                                  _p(dist, _c_f64p))
+        return ids[:n].copy(), dist[:n].copy()
+
+    def counters(self, reset: bool = True):
+        a, h = ctypes.c_int64(), ctypes.c_int64()
+        _ann().vso_ann_counters(self._h, ctypes.byref(a), ctypes.byref(h), 1 if reset else 0)
+        return {"adc_evaluations": a.value, "hops": h.value}
+
+    @property
+    def size(self) -> int:
+        return _ann().vso_ann_size(self._h)
+
+    @property
+    def mean_degree(self) -> float:
+        return _ann().vso_ann_mean_degree(self._h)
+
+    def close(self) -> None:
+        if self._h:
+            _ann().vso_ann_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
