@@ -70,7 +70,7 @@ int device_count_cached() {
 constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
 constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
 constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgroups, two scan streams
-constexpr int SUBMIT_THREADS = 3;     // host threads that submit a multi-query call's searches
+constexpr int SUBMIT_THREADS = 1;     // host threads that submit a multi-query call (more did not help: the pipeline is GPU-bound)
 constexpr int MAX_DIM_SCAN = 2048;    // register-resident query (NCH <= 8)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
 
