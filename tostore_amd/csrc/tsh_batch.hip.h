@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "tsh_kernels.hip.h"
 
 namespace tsh {
@@ -57,6 +59,7 @@ struct BatchArgs {
   const u32x4 *Qs;        // nq_pad x hchunks x 128 B
   const u32x4 *Vs;        // n x hchunks x 128 B
   int32_t hchunks;        // ceil(dim / 32)
+  int32_t tile_m;         // workgroup tile (queries = rows): 128 or 256 (host-side dispatch only)
 };
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
@@ -80,14 +83,14 @@ __device__ __forceinline__ void batch_tile_of(const BatchArgs &a, int b, int *q_
 // 64 x 64 patch held as 2 x 2 MFMA 32x32 accumulators.
 template <int METRIC, bool DENSE>
 __device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)[2][2], const float *s_thr,
-                                               const float *s_qsq, int qbase, int nbase, int wm, int wn, int lane) {
+                                               const float *s_qsq, int qbase, int nbase, int prow, int pcol, int lane) {
   // ---- epilogue: key transform (+ filter) -----------------------------------------
   // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
   // for a fixed reg >> 2 the four rows are consecutive, so a lane's 16 per-row
   // values (threshold, |q|^2) are four float4 reads.
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int rbase = wm * 64 + i * 32 + 4 * (lane >> 5);  // tile row of reg 0
+    const int rbase = prow + i * 32 + 4 * (lane >> 5);  // tile row of reg 0
     f32x4 th[4], qq[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -96,7 +99,7 @@ __device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = nbase + wn * 64 + j * 32 + (lane & 31);  // corpus row
+      const int col = nbase + pcol + j * 32 + (lane & 31);  // corpus row
       const bool col_ok = col < a.row1;
       float vin = 0.f, vsq = 0.f;
       bool alive = col_ok;
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(BT_THREADS, BK == 32 ? 2 : 3) batch_score_kern
     }
   }
 
-  batch_epilogue<METRIC, DENSE>(a, acc, s_thr, s_qsq, qbase, nbase, wm, wn, lane);
+  batch_epilogue<METRIC, DENSE>(a, acc, s_thr, s_qsq, qbase, nbase, wm * 64, wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -305,106 +308,165 @@ __global__ void __launch_bounds__(256) split_rows_kernel(SplitArgs a) {
   }
 }
 
-// Same tile shape as the f32 kernel: 128 queries x 128 rows per workgroup, 4 waves 2 x 2,
-// 64 x 64 per wave.  LDS holds [stage][plane][row][4 pieces of 16 B] without padding; piece c
-// of row r sits at c ^ ((r >> 2) & 3), which makes the 16-lane groups of ds_read_b128
-// (MI355X_MICROARCH.md, LDS table) hit 16 distinct 16-B bank quads.  64 KB per workgroup:
-// two workgroups per CU.  A lane's fragment for the k16 slab s is piece 2s + (lane >> 5).
-template <int METRIC, bool DENSE>
-__global__ void __launch_bounds__(BT_THREADS, 2) batch_score_bf16x3_kernel(BatchArgs a) {
-  __shared__ u32x4 As[2][2][BT_M][4];
-  __shared__ u32x4 Bs[2][2][BT_N][4];
-  __shared__ __attribute__((aligned(16))) float s_thr[BT_M];
-  __shared__ __attribute__((aligned(16))) float s_qsq[BT_M];
+// Tile shapes (TM queries x TN rows per workgroup, each wave a PM x 64 patch of 32 x 32 MFMA blocks):
+//   small  128 x 128, PM = 64, 4 waves, two workgroups per CU  -- batches of up to 128 queries
+//   big    256 x 256, PM = 128, 8 waves, one workgroup per CU  -- everything larger
+// Measured on the small tile (1 M x 768, 1024 queries): operand traffic alone (no MFMA) 3.3 ms, MFMA +
+// LDS reads alone 3.0 ms, together 4.65 ms.  The big tile moves half the bytes per flop (L2 -> LDS) and
+// reads 25 % fewer LDS bytes per MFMA.
+// LDS holds [stage][row][8 pieces of 16 B] (hi pieces 0-3, lo pieces 4-7 of a row's 128-byte line) without
+// padding; piece p of row r sits at p ^ ((r >> 1) & 7): the eight lanes that store one row fill its 128
+// bytes (all 32 banks once), and the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table) hit
+// 16 distinct 16-B bank quads.  A lane's fragment for the k16 slab s is piece 2s + (lane >> 5) of the hi
+// or lo half.  Global loads run NSETS - 1 ... NSETS chunks ahead of the multiply in NSETS register sets.
+template <int TM, int TN, int PM>
+struct HbTile {
+  static constexpr int WM = TM / PM, WN = TN / 64, WAVES = WM * WN, THREADS = 64 * WAVES;
+  static constexpr int NA = TM * 8 / THREADS, NB = TN * 8 / THREADS;  // 16-B pieces a thread stages per chunk
+  static constexpr int MI = PM / 32;                                  // MFMA block rows per wave
+  static constexpr int NSETS = PM == 64 ? 2 : 1;
+  static constexpr int MIN_WG = PM == 64 ? 2 : 1;
+};
+
+template <int METRIC, bool DENSE, int TM = 128, int TN = 128, int PM = 64, int DBG = 0>
+__global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN, PM>::MIN_WG))
+    batch_score_bf16x3_kernel(BatchArgs a) {
+  using T = HbTile<TM, TN, PM>;
+  constexpr int THREADS = T::THREADS, NA = T::NA, NB = T::NB, MI = T::MI, NSETS = T::NSETS;
+  __shared__ u32x4 As[2][TM][8];
+  __shared__ u32x4 Bs[2][TN][8];
+  __shared__ __attribute__((aligned(16))) float s_thr[TM];
+  __shared__ __attribute__((aligned(16))) float s_qsq[TM];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / T::WN, wn = wave % T::WN;
   int n_tile, q_tile;
   batch_tile_of(a, blockIdx.x, &q_tile, &n_tile);
-  const int qbase = q_tile * BT_M;
-  const int nbase = a.row0 + n_tile * BT_N;
-  if (tid < BT_M) {
-    s_thr[tid] = (DENSE || qbase + tid >= a.nq) ? -__builtin_inff() : a.thr[qbase + tid];
-    s_qsq[tid] = METRIC == METRIC_L2 ? a.qsq[qbase + tid] : 0.f;
+  const int qbase = q_tile * TM;
+  const int nbase = a.row0 + n_tile * TN;
+  for (int t = tid; t < TM; t += THREADS) {
+    s_thr[t] = (DENSE || qbase + t >= a.nq) ? -__builtin_inff() : a.thr[qbase + t];
+    s_qsq[t] = METRIC == METRIC_L2 ? a.qsq[qbase + t] : 0.f;
   }
 
-  // staging: piece p = tid + 256 j of the tile's 128 rows x 8 pieces (4 hi, 4 lo);
+  // staging: piece p = tid + THREADS j of an operand tile's rows x 8 pieces (4 hi, 4 lo);
   // 8 consecutive threads fetch one row's 128-byte line
-  const u32x4 *qg[4], *vg[4];
-  int st_row[4], st_plane[4], st_col[4];
+  const u32x4 *qg[NA], *vg[NB];
+  int sa_row[NA], sa_col[NA], sb_row[NB], sb_col[NB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int p = tid + BT_THREADS * j, r = p >> 3, c8 = p & 7;
-    st_row[j] = r;
-    st_plane[j] = c8 >> 2;
-    st_col[j] = (c8 & 3) ^ ((r >> 2) & 3);
+  for (int j = 0; j < NA; ++j) {
+    const int p = tid + THREADS * j, r = p >> 3, c8 = p & 7;
+    sa_row[j] = r;
+    sa_col[j] = c8 ^ ((r >> 1) & 7);
     qg[j] = a.Qs + (int64_t)(qbase + r) * a.hchunks * 8 + c8;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int p = tid + THREADS * j, r = p >> 3, c8 = p & 7;
+    sb_row[j] = r;
+    sb_col[j] = c8 ^ ((r >> 1) & 7);
     int vr = nbase + r;
     if (vr >= a.row1) vr = a.row1 - 1;  // clamp: tail columns are discarded in the epilogue
     vg[j] = a.Vs + (int64_t)vr * a.hchunks * 8 + c8;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int kc) {
+  u32x4 ra[NSETS][NA], rb[NSETS][NB];
+  auto gload = [&](auto SET, int kc) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = qg[j][kc * 8];
-      rb[j] = __builtin_nontemporal_load(vg[j] + kc * 8);
-    }
-  };
-  auto lstore = [&](int buf) {
+    for (int j = 0; j < NA; ++j) ra[S][j] = qg[j][kc * 8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      As[buf][st_plane[j]][st_row[j]][st_col[j]] = ra[j];
-      Bs[buf][st_plane[j]][st_row[j]][st_col[j]] = rb[j];
-    }
+    for (int j = 0; j < NB; ++j) rb[S][j] = __builtin_nontemporal_load(vg[j] + kc * 8);
   };
+  auto lstore = [&](auto SET, int buf) {
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) As[buf][sa_row[j]][sa_col[j]] = ra[S][j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) Bs[buf][sb_row[j]][sb_col[j]] = rb[S][j];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSETS - 1>;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
+  const int arow = wm * PM + (lane & 31), brow = wn * 64 + (lane & 31);
   const int half = lane >> 5;
-  // (row >> 2) & 3 is the same for row and row + 32
-  const int asw = (arow >> 2) & 3, bsw = (brow >> 2) & 3;
-  for (int kc = 0; kc < a.hchunks; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < a.hchunks) gload(kc + 1);  // in flight while this chunk is multiplied
+  // (row >> 1) & 7 is the same for row and row + 32
+  const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int pc = 2 * s2 + half;
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, As[buf][0][arow + 32 * i][pc ^ asw]);
-        al[i] = __builtin_bit_cast(bf16x8, As[buf][1][arow + 32 * i][pc ^ asw]);
-        bh[i] = __builtin_bit_cast(bf16x8, Bs[buf][0][brow + 32 * i][pc ^ bsw]);
-        bl[i] = __builtin_bit_cast(bf16x8, Bs[buf][1][brow + 32 * i][pc ^ bsw]);
+      for (int i = 0; i < MI; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, As[buf][arow + 32 * i][pc ^ asw]);
+        al[i] = __builtin_bit_cast(bf16x8, As[buf][arow + 32 * i][(4 + pc) ^ asw]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = __builtin_bit_cast(bf16x8, Bs[buf][brow + 32 * j][pc ^ bsw]);
+        bl[j] = __builtin_bit_cast(bf16x8, Bs[buf][brow + 32 * j][(4 + pc) ^ bsw]);
+      }
+      // product type outermost: MFMAs into the same accumulator are 2 MI issues apart
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     }
-    if (kc + 1 < a.hchunks) {
-      lstore(buf ^ 1);
-      __syncthreads();
+  };
+  const int nk = a.hchunks;
+  if (NSETS == 2) {
+    // one step: chunk kc is in LDS stage kc & 1, chunk kc + 1 in flight in the OTHER register set
+    auto step = [&](auto CUR, auto NXT, int kc) {
+      if (DBG != 2 && kc + 2 < nk) gload(CUR, kc + 2);  // set CUR held chunk kc, already stored to LDS
+      if (DBG != 1) multiply(kc & 1);
+      if (kc + 1 < nk) {
+        if (DBG != 2) lstore(NXT, (kc + 1) & 1);
+        __syncthreads();
+      }
+    };
+    gload(S0{}, 0);
+    lstore(S0{}, 0);
+    if (nk > 1) gload(S1{}, 1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+      step(S0{}, S1{}, kc);
+      if (kc + 1 < nk) step(S1{}, S0{}, kc + 1);
+    }
+  } else {
+    gload(S0{}, 0);
+    lstore(S0{}, 0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      if (DBG != 2 && kc + 1 < nk) gload(S0{}, kc + 1);  // in flight while this chunk is multiplied
+      if (DBG != 1) multiply(kc & 1);
+      if (kc + 1 < nk) {
+        if (DBG != 2) lstore(S0{}, (kc + 1) & 1);
+        __syncthreads();
+      }
     }
   }
-  batch_epilogue<METRIC, DENSE>(a, acc, s_thr, s_qsq, qbase, nbase, wm, wn, lane);
+#pragma unroll
+  for (int h = 0; h < MI / 2; ++h)
+    batch_epilogue<METRIC, DENSE>(a, reinterpret_cast<f32x16(&)[2][2]>(acc[2 * h]), s_thr, s_qsq, qbase, nbase,
+                                  wm * PM + 64 * h, wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------

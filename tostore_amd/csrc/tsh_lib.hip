@@ -1110,6 +1110,11 @@ template <int METRIC>
 void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
   int grid = a.q_tiles * a.n_tiles;
   if (grid <= 0) return;
+  if (a.tile_m == 256) {  // 256 x 256 tiles, 8 waves (batches of more than 128 queries)
+    if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128><<<grid, 512, 0, st>>>(a);
+    else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128><<<grid, 512, 0, st>>>(a);
+    return;
+  }
   if (dense) batch_score_bf16x3_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
   else batch_score_bf16x3_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
 }
@@ -1128,8 +1133,8 @@ void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_
 int64_t batch_sample_rows(int64_t rows, int32_t k) {
   if (rows <= 16384) return rows;
   int64_t n = std::max<int64_t>(rows / 32, (int64_t)k * rows / 3000);
-  n = std::max<int64_t>(round_up(n, BT_N), 8192);
-  n = std::max<int64_t>(n, round_up((int64_t)k * 4, BT_N));
+  n = std::max<int64_t>(round_up(n, 256), 8192);  // whole row tiles of either tile shape
+  n = std::max<int64_t>(n, round_up((int64_t)k * 4, 256));
   return std::min(n, rows);
 }
 
@@ -1181,7 +1186,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   HIPCHK(hipSetDevice(s->device));
   const int64_t rows = s->rows, ld = s->ld;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  const int32_t nq_pad = (int32_t)round_up(nq, BT_M);
+  // bf16x3 kernel: 256 x 256 tiles for batches of more than 128 queries, 128 x 128 otherwise
+  const int32_t tile = (s->batch_kernel == 1 && nq > 128) ? 256 : 128;
+  const int32_t nq_pad = (int32_t)round_up(nq, tile);
   // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
   const int64_t n_sample = batch_sample_rows(rows, k);
@@ -1295,11 +1302,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.nq_pad = nq_pad;
     a.kchunks = (int32_t)((ld + BT_K - 1) / BT_K);
     a.cand_cap = cand_cap;
-    a.q_tiles = nq_pad / BT_M;
+    a.tile_m = tile;
+    a.q_tiles = nq_pad / tile;
     // B0: dense keys of the sample rows
     a.row0 = 0;
     a.row1 = (int32_t)n_sample;
-    a.n_tiles = (int32_t)((n_sample + BT_N - 1) / BT_N);
+    a.n_tiles = (int32_t)((n_sample + tile - 1) / tile);
     HIPCHK(hipEventRecord(b->e0, st));
     launch_batch_score_m(s->metric, a, true, st);
     HIPCHK(hipEventRecord(b->e1, st));
@@ -1322,7 +1330,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if (rows > n_sample) {
       a.row0 = (int32_t)n_sample;
       a.row1 = (int32_t)rows;
-      a.n_tiles = (int32_t)((rows - n_sample + BT_N - 1) / BT_N);
+      a.n_tiles = (int32_t)((rows - n_sample + tile - 1) / tile);
       launch_batch_score_m(s->metric, a, false, st);
     }
     HIPCHK(hipEventRecord(b->e3, st));
@@ -1396,7 +1404,7 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   // the dense sample matrix (nq_pad x n_sample floats) is kept under 8 GB per call
   const int64_t per_q = batch_sample_rows(s->rows, k) * 4;
-  const int32_t chunk = (int32_t)std::max<int64_t>(BT_M, (int64_t)(8e9 / (double)per_q) / BT_M * BT_M);
+  const int32_t chunk = (int32_t)std::max<int64_t>(256, (int64_t)(8e9 / (double)per_q) / 256 * 256);
   for (int32_t q0 = 0; q0 < nq; q0 += chunk) {
     const int32_t nc = std::min(chunk, nq - q0);
     SearchOut part;
