@@ -2040,18 +2040,32 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
 // ---- rawvec partition file loader -------------
 namespace {
 
-uint32_t crc32_ieee(const uint8_t *p, size_t n) {  // core/btree_page.dart:61-89
-  static uint32_t table[256];
+// IEEE CRC-32 (core/btree_page.dart:61-89: the reference's byte-at-a-time table loop), computed
+// eight bytes per step (slicing-by-8) -- same polynomial, same result
+uint32_t crc32_ieee(const uint8_t *p, size_t n) {
+  static uint32_t table[8][256];
   static std::once_flag once;
   std::call_once(once, [] {
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-      table[i] = c;
+      table[0][i] = c;
     }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
   });
   uint32_t c = 0xFFFFFFFFu;
-  for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+        table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  for (size_t i = 0; i < n; ++i) c = table[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;
 }
 inline uint32_t rd16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
@@ -2082,6 +2096,11 @@ PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int 
   if ((int)dims != dim) return PAGE_ERROR;  // not this index's column
   int take = (int)std::min<uint32_t>(vc, (uint32_t)vpp);
   const uint8_t *d = pl + 8;
+  if (prec == 1) {  // little-endian f32 on a little-endian host: the per-element getFloat32 loop is a copy
+    memcpy(out, d, (size_t)take * dim * sizeof(float));
+    *vcount = take;
+    return PAGE_OK;
+  }
   for (int v = 0; v < take; ++v)
     for (int i = 0; i < dim; ++i) {  // getVectorAsFloat32, ngh_page.dart:364-391
       const uint8_t *e = d + ((size_t)v * dim + i) * bpe;
@@ -2122,13 +2141,29 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
   if (!f) return set_err(TSH_E_IO, "cannot open %s", path);
   int64_t n_pages = (max_rows + vpp - 1) / vpp;  // data pages needed to cover the ids
   const int BATCH = std::max(1, (int)((32 << 20) / ((int64_t)vpp * dim * 4)));
-  std::vector<uint8_t> raw((size_t)page_size);
+  // one read per block of BATCH pages, pages decoded (CRC + copy / widen) in parallel on the host pool
+  std::vector<uint8_t> raw((size_t)BATCH * (size_t)page_size);
   std::vector<float> rows((size_t)BATCH * vpp * dim);
+  std::vector<int> kinds((size_t)BATCH), counts((size_t)BATCH);
   int64_t loaded = 0;
   int rc = TSH_OK;
   for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
     int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
-    std::fill(rows.begin(), rows.begin() + (size_t)nb * vpp * dim, 0.f);
+    size_t got_total = 0;
+    if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // pageNo 0 is the partition meta page
+      got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
+    parallel_for((int32_t)nb, [&](int32_t b) {
+      const size_t off = (size_t)b * (size_t)page_size;
+      const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
+      float *dst = rows.data() + (size_t)b * vpp * dim;
+      int vc = 0;
+      PageKind k = decode_rawvec_page(raw.data() + off, got, page_size, dim, vpp, dst, &vc);
+      if (k != PAGE_OK) vc = k == PAGE_EMPTY ? vpp : 0;
+      if (k != PAGE_OK || vc < vpp)  // empty pages and slots past vectorCount read as zero vectors
+        std::fill(dst + (k == PAGE_OK ? (size_t)vc * dim : 0), dst + (size_t)vpp * dim, 0.f);
+      kinds[(size_t)b] = (int)k;
+      counts[(size_t)b] = vc;
+    });
     // runs of consecutive present rows inside the batch are appended together
     int64_t run_start = -1, run_len = 0;
     auto flush = [&]() {
@@ -2141,18 +2176,14 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
       run_len = 0;
     };
     for (int64_t b = 0; b < nb && rc == TSH_OK; ++b) {
-      int64_t page_no = 1 + p0 + b;  // pageNo 0 is the partition meta page
-      size_t got = 0;
-      if (fseeko(f, (off_t)page_no * page_size, SEEK_SET) == 0) got = fread(raw.data(), 1, (size_t)page_size, f);
-      int vc = 0;
-      PageKind k = decode_rawvec_page(raw.data(), got, page_size, dim, vpp, rows.data() + (size_t)b * vpp * dim, &vc);
-      if (k == PAGE_ERROR) {
+      if (kinds[(size_t)b] == (int)PAGE_ERROR) {
         flush();
-        if (rc == TSH_OK) rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path, (long long)page_no);
+        if (rc == TSH_OK)
+          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path, (long long)(1 + p0 + b));
         break;
       }
       int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
-      int64_t lim = std::min<int64_t>(vc, max_rows - base);
+      int64_t lim = std::min<int64_t>(counts[(size_t)b], max_rows - base);
       if (lim <= 0) continue;
       if (run_len > 0 && run_start + run_len == b * vpp) {
         run_len += lim;
@@ -2376,7 +2407,10 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
   int64_t tombstones = 0;
   if (rc == TSH_OK && npg > 0) {
     const int64_t ids_per_part = ppp * npg;
-    std::vector<uint8_t> raw((size_t)page_size);
+    const int64_t BLOCK = std::max<int64_t>(64, (32 << 20) / page_size);  // pages per read
+    std::vector<uint8_t> raw((size_t)BLOCK * (size_t)page_size);
+    std::vector<std::vector<int64_t>> found((size_t)BLOCK);  // per page, filled in parallel
+    std::vector<char> bad_page((size_t)BLOCK);
     std::vector<int64_t> dead;
     for (int64_t part = 0; rc == TSH_OK && part * ids_per_part < next_id; ++part) {
       const std::string path = ngh_partition_path(dir, "graph", part, max_entries_per_dir);
@@ -2385,29 +2419,44 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
       ++files;
       const int64_t first = part * ids_per_part;
       const int64_t n_pages = (std::min(ids_per_part, next_id - first) + npg - 1) / npg;
-      fseeko(f, (off_t)page_size, SEEK_SET);  // page 0 is the partition meta page
-      for (int64_t pg = 0; pg < n_pages; ++pg) {
-        const size_t got = fread(raw.data(), 1, (size_t)page_size, f);
-        uint32_t plen = 0;
-        int type = 0;
-        bool bad = false;
-        const uint8_t *pl = page_payload(raw.data(), got, &plen, &type, &bad);
-        if (bad) {
-          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path.c_str(), (long long)(pg + 1));
-          break;
-        }
-        if (got < (size_t)page_size && got == 0) break;  // past the end of the file: empty pages from here on
-        // NghGraphPage.tryDecodePayload, ngh_page.dart:193-222 (null -> empty page)
-        if (!pl || plen < 4) continue;
-        const uint32_t slot_count = rd16(pl), deg = rd16(pl + 2);
-        if (deg == 0) continue;
-        const uint64_t ss = 2 + (uint64_t)deg * 4;
-        if ((uint64_t)plen < 4 + slot_count * ss) continue;
-        const int64_t base = first + pg * npg;
-        for (uint32_t sl = 0; sl < slot_count && (int64_t)sl < npg; ++sl) {
-          const int64_t id = base + sl;
-          if (id >= next_id) break;
-          if (pl[4 + sl * ss] & 0x01) dead.push_back(id);
+      for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BLOCK) {
+        const int64_t nb = std::min(BLOCK, n_pages - p0);
+        size_t got_total = 0;
+        if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // page 0 is the partition meta page
+          got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
+        if (got_total == 0) break;  // past the end of the file: empty pages from here on
+        parallel_for((int32_t)nb, [&](int32_t b) {
+          found[(size_t)b].clear();
+          bad_page[(size_t)b] = 0;
+          const size_t off = (size_t)b * (size_t)page_size;
+          const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
+          uint32_t plen = 0;
+          int type = 0;
+          bool bad = false;
+          const uint8_t *pl = page_payload(raw.data() + off, got, &plen, &type, &bad);
+          if (bad) {
+            bad_page[(size_t)b] = 1;
+            return;
+          }
+          // NghGraphPage.tryDecodePayload, ngh_page.dart:193-222 (null -> empty page)
+          if (!pl || plen < 4) return;
+          const uint32_t slot_count = rd16(pl), deg = rd16(pl + 2);
+          if (deg == 0) return;
+          const uint64_t ss = 2 + (uint64_t)deg * 4;
+          if ((uint64_t)plen < 4 + slot_count * ss) return;
+          const int64_t base = first + (p0 + b) * npg;
+          for (uint32_t sl = 0; sl < slot_count && (int64_t)sl < npg; ++sl) {
+            const int64_t id = base + sl;
+            if (id >= next_id) break;
+            if (pl[4 + sl * ss] & 0x01) found[(size_t)b].push_back(id);
+          }
+        });
+        for (int64_t b = 0; b < nb; ++b) {
+          if (bad_page[(size_t)b]) {
+            rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path.c_str(), (long long)(1 + p0 + b));
+            break;
+          }
+          dead.insert(dead.end(), found[(size_t)b].begin(), found[(size_t)b].end());
         }
       }
       fclose(f);
