@@ -68,3 +68,59 @@ def test_fuzz(hip_lib, oracle_mod, seed):
     rng = np.random.default_rng(1000 + seed)
     for case in range(40):
         _one_case(oracle_mod, rng, f"{seed}/{case}")
+
+
+def _batch_case(oracle, rng, case):
+    """The batched path specifically: batches on both sides of the 128-query tile switch, both key kernels,
+    row widths around the 32-dimension chunk of the bf16 planes, masks and tombstones."""
+    from tostore_amd import HipVectorIndex
+
+    d = int(rng.choice([5, 31, 32, 33, 64, 96, 100, 129, 200, 256, 300, 384]))
+    n = int(rng.integers(4096, 30000))
+    metric = int(rng.integers(0, 3))
+    k = int(rng.choice([1, 10, 64, 100, 300]))
+    nq = int(rng.choice([9, 100, 128, 129, 257, 300]))
+    kernel = int(rng.integers(0, 2))
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    if rng.random() < 0.4:
+        rows *= rng.uniform(0.05, 20.0, size=(n, 1)).astype(np.float32)
+    if rng.random() < 0.3:
+        src = rng.integers(0, n, size=n // 50)
+        rows[rng.integers(0, n, size=len(src))] = rows[src]
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    qs[0] = rows[rng.integers(0, n)]
+    if metric == 2:
+        qs = np.stack([oracle.normalize_f32(q) for q in qs])
+    keep = None
+    if rng.random() < 0.4:
+        keep = np.packbits(rng.random(n) < rng.choice([0.1, 0.6]), bitorder="little")
+    alive = np.ones(n, bool)
+    with HipVectorIndex(d, metric) as idx:
+        idx.set_batch_kernel(kernel)
+        half = int(rng.integers(1, n))
+        idx.append(0, rows[:half])
+        if rng.random() < 0.5:
+            idx.search(qs[:16], k)  # builds the bf16 planes early: the second append must extend them
+        idx.append(half, rows[half:])
+        if rng.random() < 0.4:
+            dead = rng.choice(n, size=int(rng.integers(1, n // 4)), replace=False)
+            idx.set_deleted(dead)
+            alive[dead] = False
+        eff = alive if keep is None else alive & np.unpackbits(keep, bitorder="little")[:n].astype(bool)
+        eff_mask = np.packbits(eff, bitorder="little")
+        before = idx.counters()["batch_launches"]
+        ids, dist, cnt = idx.search(qs, k, None, keep)
+        assert idx.counters()["batch_launches"] > before
+        eids, edist, ecnt = oracle.search_heap_many_mt(rows, qs, metric, k, None, eff_mask)
+        tag = f"batch case {case}: n={n} d={d} metric={metric} k={k} nq={nq} kernel={kernel} mask={keep is not None}"
+        assert np.array_equal(cnt, ecnt), tag
+        for i in range(nq):
+            assert np.array_equal(ids[i, :cnt[i]], eids[i, :cnt[i]]), tag + f" q{i}"
+            assert np.array_equal(dist[i, :cnt[i]], edist[i, :cnt[i]]), tag + f" q{i}"
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_batched(hip_lib, oracle_mod, seed):
+    rng = np.random.default_rng(7000 + seed)
+    for case in range(12):
+        _batch_case(oracle_mod, rng, f"{seed}/{case}")
