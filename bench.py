@@ -237,6 +237,11 @@ def run_bench(a):
             return searcher.search(q, k, None, row_mask)
         return idx.search(q, k, None, row_mask)
 
+    def sharded_group(count):
+        # N > 1: up to --group queries per all-gather / merge; short runs use smaller groups so that
+        # at least four of them pipeline (scan of group g+1 behind the exchange of group g)
+        return max(16, min(a.group or 64, count // 4))
+
     def run(first, count):
         """`count` single-query searches, `--inflight` of them in flight.  Each query still
         streams the whole (shard of the) corpus on its own; only the select / re-rank /
@@ -248,7 +253,7 @@ def run_bench(a):
             # N > 1: groups of `--group` queries share one all-gather + one merge call, and the
             # next group's shard scans run while this group is exchanged and merged
             sel = [(first + j) % len(queries) for j in range(count)]
-            searcher.search_many(queries[sel], k, None, row_mask, group=max(a.group or 64, a.inflight))
+            searcher.search_many(queries[sel], k, None, row_mask, group=sharded_group(count))
         elif a.group > 0:
             for g0 in range(0, count, a.group):
                 sel = [(first + g0 + j) % len(queries) for j in range(min(a.group, count - g0))]
@@ -350,7 +355,7 @@ def run_bench(a):
                        "rows": n, "dim": d, "k": k, "metric": a.metric, "mask_keep": a.mask_keep or None,
                        "mask_kind": a.mask_kind if a.mask_keep else None,
                        "queries_in_flight": 8,
-                       "queries_per_call": (a.group or 1) if searcher is None else max(a.group or 64, a.inflight),
+                       "queries_per_call": (a.group or 1) if searcher is None else sharded_group(a.steps),
                        "note": "every query scans the whole corpus on its own (HBM-bound kernel, no matrix-core "
                                "batching); independent queries are handed over in groups and pipelined",
                        "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world
