@@ -67,17 +67,22 @@ class ShardedSearcher:
         self._bufs = {}
 
     def _buffers(self, nq: int, entries: int, slot: int = 0):
-        key = (nq, entries, slot)
-        if key not in self._bufs:
-            t = self._torch
-            bb = _ffi.lib().tsh_candidate_block_bytes(entries)
-            mine = t.empty(nq * bb, dtype=t.uint8, device="cuda")
-            allb = t.empty(self.world * nq * bb, dtype=t.uint8, device="cuda")
-            host = t.empty(self.world * nq * bb, dtype=t.uint8, pin_memory=True)
+        """(mine, all, host) byte buffers for nq blocks per rank: views of per-(entries, slot) buffers that only
+        grow, so a short last group does not allocate (pinned allocations cost about a millisecond)."""
+        t = self._torch
+        bb = _ffi.lib().tsh_candidate_block_bytes(entries)
+        key = (entries, slot)
+        cur = self._bufs.get(key)
+        if cur is None or cur[0] < nq:
+            cap = max(nq, 64, 0 if cur is None else cur[0])
             if len(self._bufs) > 8:
                 self._bufs.clear()
-            self._bufs[key] = (mine, allb, host)
-        return self._bufs[key]
+            cur = (cap, t.empty(cap * bb, dtype=t.uint8, device="cuda"),
+                   t.empty(self.world * cap * bb, dtype=t.uint8, device="cuda"),
+                   t.empty(self.world * cap * bb, dtype=t.uint8, pin_memory=True))
+            self._bufs[key] = cur
+        _, mine, allb, host = cur
+        return mine[: nq * bb], allb[: self.world * nq * bb], host[: self.world * nq * bb]
 
     def _scan(self, q: np.ndarray, k: int, mp, entries: int, slot: int):
         """This rank's shard: candidate blocks for the queries of one group, left in device memory."""
