@@ -51,8 +51,9 @@ def parse():
                          "--metric cosine); 0 = the headline single-query workload")
     ap.add_argument("--mask-keep", type=float, default=0.0,
                     help="config C5: row mask keeping this fraction of the rows (0 = no mask)")
-    ap.add_argument("--batch-kernel", type=int, choices=[0, 1], default=1,
-                    help="C3: 1 = bf16x3 split matrix-core keys (default), 0 = f32 MFMA keys; results are identical")
+    ap.add_argument("--batch-kernel", type=int, choices=[0, 1, 2, 3], default=3,
+                    help="C3 pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 fp16, 3 auto = the library default (fp16 for cosine, "
+                         "bf16x3 otherwise); results are identical")
     ap.add_argument("--mask-kind", choices=["bernoulli", "range"], default="bernoulli",
                     help="C5 mask shape: i.i.d. Bernoulli(keep) per row, or one contiguous id range of keep*rows rows")
     ap.add_argument("--recall-queries", type=int, default=1000,
@@ -105,6 +106,8 @@ def bench_batch(a, idx, host_rows, metric, world, rank):
     steps, warm = max(1, min(a.steps, 20)), max(1, min(a.warmup, 3))
     qs = make_queries(nq * 2, d, metric)
     idx.set_batch_kernel(a.batch_kernel)
+    if a.batch_kernel == 3:
+        a.batch_kernel = 2 if metric == 2 else 1  # what auto resolves to, for the report below
     for i in range(warm):
         idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)
     torch.cuda.synchronize()
@@ -118,14 +121,19 @@ def bench_batch(a, idx, host_rows, metric, world, rank):
     out = {"metric": "kNN queries/sec, %dx%d f32 %s k=%d, %d-query batch (matrix-core path)" % (n, d, a.metric, k, nq),
            "value": nq * steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm,
            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f32" if a.batch_kernel == 0 else "f32 as bf16 hi+lo (3 bf16 MFMAs per product), f64 rerank",
+           "dtype": {0: "f32", 1: "f32 as bf16 hi+lo (3 bf16 MFMAs per product), f64 rerank",
+                     2: "fp16 pre-filter keys (1 f16 MFMA per product), f64 rerank"}[a.batch_kernel],
            "data": "synthetic",
            "config": {"workload": "C3: %dx%d f32, %s, k=%d, %d-query batch" % (n, d, a.metric, k, nq),
-                      "batch_kernel": "f32 MFMA" if a.batch_kernel == 0 else "bf16x3"}}
+                      "batch_kernel": {0: "f32 MFMA", 1: "bf16x3", 2: "f16"}[a.batch_kernel]}}
     if a.batch_kernel == 0:
         out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                            "traffic": None, "kernel": "tsh::batch_score_kernel (sample + filtered passes)",
                            "kernel_us": gemm_us, "algorithmic_flops_per_launch": flops}
+    elif a.batch_kernel == 2:
+        out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                           "traffic": None, "kernel": "tsh::batch_score_bf16x3_kernel<MODE=f16> (sample + filtered passes)",
+                           "kernel_us": gemm_us, "algorithmic_flops_per_launch": flops, "vs_f32_mfma_peak": tf / 157.3}
     else:  # three bf16 MFMAs per algorithmic multiply-add: the ceiling for ALGORITHMIC flops is 2500 / 3
         out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 2500.0 / 3, "unit": "TFLOP/s",
                            "frac": tf / (2500.0 / 3), "traffic": None,
@@ -146,6 +154,7 @@ def bench_batch(a, idx, host_rows, metric, world, rank):
         out["ids_and_distances_bit_exact"] = ok
     c = idx.counters()
     out["counters"] = {k2: c[k2] for k2 in ("batch_launches", "scan_launches", "fallback_searches")}
+    out["counters"]["candidates_per_query"] = c["candidates_total"] / max(c["searches"], 1)
     idx.close()
     return json.dumps(out)
 

@@ -289,12 +289,19 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
  * for which tsh_search / tsh_search_shard use the batched matrix-core path
  * (default 8; 0 = never).  Results are identical either way. */
 #define TSH_OPT_BATCH_MIN_NQ 1
-/* TSH_OPT_BATCH_KERNEL: how the batched path forms its f32 pre-filter keys.
- * 1 (default): each f32 operand split into bf16 hi + lo, three bf16 MFMAs per
- * product (error 3.1 * 2^-18 |q||v| on top of the f32 accumulation bound; costs
- * a second copy of the rows, 4 B per element, built on the first batched search);
- * 0: f32 MFMA on the rows as stored.  The band each variant adds to its keys
- * covers its error, and the f64 rerank decides: results are identical either way. */
+/* TSH_OPT_BATCH_KERNEL: how the batched path forms its pre-filter keys (the f64
+ * rerank decides, and each variant's band covers its own error, so results are
+ * identical whichever runs):
+ *   0  f32 MFMA on the rows as stored;
+ *   1  bf16x3: each f32 operand split into bf16 hi + lo, three bf16 MFMAs per
+ *      product (error 3.1 * 2^-18 |q||v| on top of the f32 accumulation bound);
+ *      costs a second copy of the rows, 4 B per element;
+ *   2  f16: operands rounded to fp16 after an exact power-of-two scaling (cosine
+ *      rows normalised first), one f16 MFMA per product (error 2^-10 |q||v|);
+ *      costs a copy of 2 B per element;
+ *   3  (default) auto: f16 for cosine indexes, whose keys are scale-free, bf16x3
+ *      for inner-product and L2 indexes, whose bands scale with the largest row.
+ * The copy is built by the first batched search and kept current across appends. */
 #define TSH_OPT_BATCH_KERNEL 2
 int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value);
 

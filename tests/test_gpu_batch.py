@@ -38,7 +38,7 @@ def _check_batch(oracle, idx, rows, qs, metric, k, thr=None, keep=None, tag=""):
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 @pytest.mark.parametrize("d,n,nq,k", [(128, 30000, 130, 10), (100, 20000, 9, 100), (768, 30000, 130, 100),
                                       (36, 50000, 300, 37)])
-@pytest.mark.parametrize("kernel", [1, 0])  # 1 = bf16x3 split MFMA (default), 0 = f32 MFMA
+@pytest.mark.parametrize("kernel", [1, 0, 2])  # 1 = bf16x3 split MFMA (default), 0 = f32 MFMA, 2 = f16
 def test_batched_matches_oracle(hip_lib, oracle_mod, metric, d, n, nq, k, kernel):
     from tostore_amd import HipVectorIndex
 
@@ -59,7 +59,7 @@ def test_batched_matches_oracle(hip_lib, oracle_mod, metric, d, n, nq, k, kernel
 
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
-@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("kernel", [1, 0, 2])
 def test_batched_mask_tombstones_threshold(hip_lib, oracle_mod, metric, kernel):
     from tostore_amd import HipVectorIndex
 
@@ -163,6 +163,10 @@ def test_bf16_planes_follow_appends_overwrites_and_growth(hip_lib, oracle_mod, m
         _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="grown")
         idx.set_batch_kernel(0)
         _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="f32 kernel")
+        idx.set_batch_kernel(2)                               # planes rebuilt in the other format
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="f16 kernel")
+        idx.append(30_000, rows[:500] * np.float32(40.0))     # larger magnitudes: the f16 scale must follow
+        _check_batch(oracle_mod, idx, np.concatenate([rows, rows[:500] * np.float32(40.0)]), qs, metric, k, tag="f16 rescale")
         assert idx.counters()["scan_launches"] == 0
 
 
@@ -177,6 +181,8 @@ def test_bf16x3_wide_dynamic_range(hip_lib, oracle_mod):
     qs = (rng.standard_normal((nq, d)) * np.exp2(rng.integers(-10, 10, (nq, 1)))).astype(np.float32)
     for metric in METRICS:
         qm = np.stack([oracle_mod.normalize_f32(x) for x in qs]) if metric == COS else qs
-        with HipVectorIndex(d, metric) as idx:
-            idx.append(0, rows)
-            _check_batch(oracle_mod, idx, rows, qm, metric, 25, tag=f"range m{metric}")
+        for kernel in (1, 2):  # f16: rows far below the largest magnitude and small queries must stay exact
+            with HipVectorIndex(d, metric) as idx:
+                idx.set_batch_kernel(kernel)
+                idx.append(0, rows)
+                _check_batch(oracle_mod, idx, rows, qm, metric, 25, tag=f"range m{metric} kernel{kernel}")

@@ -80,7 +80,7 @@ def _batch_case(oracle, rng, case):
     metric = int(rng.integers(0, 3))
     k = int(rng.choice([1, 10, 64, 100, 300]))
     nq = int(rng.choice([9, 100, 128, 129, 257, 300]))
-    kernel = int(rng.integers(0, 2))
+    kernel = int(rng.integers(0, 3))
     rows = rng.standard_normal((n, d)).astype(np.float32)
     if rng.random() < 0.4:
         rows *= rng.uniform(0.05, 20.0, size=(n, 1)).astype(np.float32)

@@ -193,7 +193,8 @@ class HipVectorIndex:
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 1, int(nq)))
 
     def set_batch_kernel(self, kind: int) -> None:
-        """1 (default): bf16x3 matrix-core keys; 0: f32 MFMA keys.  Results are identical."""
+        """Batched pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (default: f16 for cosine, bf16x3
+        otherwise).  Results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 2, int(kind)))
 
     def bench_batch(self, queries, k: int, iters: int = 3):

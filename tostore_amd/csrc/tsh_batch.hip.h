@@ -60,6 +60,7 @@ struct BatchArgs {
   const u32x4 *Vs;        // n x hchunks x 128 B
   int32_t hchunks;        // ceil(dim / 32)
   int32_t tile_m;         // workgroup tile (queries = rows): 128 or 256 (host-side dispatch only)
+  float dot_scale;        // f16 variant: 2^-(eq + ev), undoes the power-of-two operand scales (0 = unused)
 };
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
@@ -81,7 +82,7 @@ __device__ __forceinline__ void batch_tile_of(const BatchArgs &a, int b, int *q_
 
 // Epilogue shared by the f32 and the bf16x3 kernels: key transform (+ filter) of a wave's
 // 64 x 64 patch held as 2 x 2 MFMA 32x32 accumulators.
-template <int METRIC, bool DENSE>
+template <int METRIC, bool DENSE, bool SCALED = false>
 __device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)[2][2], const float *s_thr,
                                                const float *s_qsq, int qbase, int nbase, int prow, int pcol, int lane) {
   // ---- epilogue: key transform (+ filter) -----------------------------------------
@@ -104,7 +105,7 @@ __device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)
       float vin = 0.f, vsq = 0.f;
       bool alive = col_ok;
       if (col_ok) {
-        if (METRIC == METRIC_COS) vin = a.inv_norm[col];
+        if (METRIC == METRIC_COS) vin = a.inv_norm ? a.inv_norm[col] : 1.f;  // f16 planes hold unit rows
         if (METRIC == METRIC_L2) vsq = a.sqnorm[col];
         if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
         if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)
       uint32_t pass = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float dot = acc[i][j][r];
+        const float dot = SCALED ? acc[i][j][r] * a.dot_scale : acc[i][j][r];  // power of two: exact
         if (METRIC == METRIC_IP) key[r] = -dot;
         else if (METRIC == METRIC_COS) key[r] = -(dot * vin);
         else key[r] = qq[r >> 2][r & 3] + vsq - 2.f * dot;
@@ -308,6 +309,40 @@ __global__ void __launch_bounds__(256) split_rows_kernel(SplitArgs a) {
   }
 }
 
+// f16 variant (TSH_OPT_BATCH_KERNEL = 2): ONE v_mfma_f32_32x32x16_f16 per product on operands rounded
+// to fp16 (11-bit significand: 2^-11 per operand, products exact in f32).  Operand layout: per row, per
+// chunk of 64 k-values, 128 bytes of fp16 -- 2 B per element.  Values are scaled by a power of two
+// (exact) so the largest magnitude sits at 2^13..2^14, far from fp16's 65504 and with 27 binades above
+// its subnormal step; cosine rows are stored normalised (x * inv_norm), so their key is -dot itself.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct HalfArgs {
+  const float *rows;      // n x ld f32
+  const float *inv_norm;  // nullable: multiply each row by its 1/|row| first (cosine corpus)
+  u32x4 *out;             // n x hchunks x 8 pieces of 16 B
+  int64_t ld;
+  int64_t first, n;
+  int32_t dim, hchunks;   // hchunks = ceil(dim / 64)
+  float scale;            // power of two
+};
+
+// one thread = 8 consecutive k of one row = one 16-B piece
+__global__ void __launch_bounds__(256) half_rows_kernel(HalfArgs a) {
+  const int64_t per_row = (int64_t)a.hchunks * 8;
+  const int64_t total = a.n * per_row, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = a.first + i / per_row;
+    const int p = (int)(i % per_row);
+    const int k0 = p * 8;
+    const float *src = a.rows + row * a.ld + k0;
+    const float mul = a.inv_norm ? a.inv_norm[row] * a.scale : a.scale;
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)(k0 + e < a.dim ? src[e] * mul : 0.f);  // round to nearest even
+    a.out[row * per_row + p] = __builtin_bit_cast(u32x4, h);
+  }
+}
+
 // Tile shapes (TM queries x TN rows per workgroup, each wave a PM x 64 patch of 32 x 32 MFMA blocks):
 //   small  128 x 128, PM = 64, 4 waves, two workgroups per CU  -- batches of up to 128 queries
 //   big    256 x 256, PM = 128, 8 waves, one workgroup per CU  -- everything larger
@@ -328,7 +363,9 @@ struct HbTile {
   static constexpr int MIN_WG = PM == 64 ? 2 : 1;
 };
 
-template <int METRIC, bool DENSE, int TM = 128, int TN = 128, int PM = 64, int DBG = 0>
+// MODE 0: bf16x3 (chunk = 32 k: 4 hi + 4 lo pieces, three MFMAs per block and slab of 16 k);
+// MODE 1: f16 (chunk = 64 k: 8 pieces, one MFMA per block and slab).
+template <int METRIC, bool DENSE, int TM = 128, int TN = 128, int PM = 64, int DBG = 0, int MODE = 0>
 __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN, PM>::MIN_WG))
     batch_score_bf16x3_kernel(BatchArgs a) {
   using T = HbTile<TM, TN, PM>;
@@ -402,6 +439,22 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
   // (row >> 1) & 7 is the same for row and row + 32
   const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;
   auto multiply = [&](int buf) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int pc = 2 * s4 + half;
+        f16x8 fa[MI], fb[2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = __builtin_bit_cast(f16x8, As[buf][arow + 32 * i][pc ^ asw]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(f16x8, Bs[buf][brow + 32 * j][pc ^ bsw]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int pc = 2 * s2 + half;
@@ -465,8 +518,8 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
   }
 #pragma unroll
   for (int h = 0; h < MI / 2; ++h)
-    batch_epilogue<METRIC, DENSE>(a, reinterpret_cast<f32x16(&)[2][2]>(acc[2 * h]), s_thr, s_qsq, qbase, nbase,
-                                  wm * PM + 64 * h, wn * 64, lane);
+    batch_epilogue<METRIC, DENSE, MODE == 1>(a, reinterpret_cast<f32x16(&)[2][2]>(acc[2 * h]), s_thr, s_qsq, qbase,
+                                             nbase, wm * PM + 64 * h, wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------

@@ -435,7 +435,10 @@ struct Shard {
   u32x4 *d_split = nullptr;
   int64_t split_cap = 0;    // rows allocated
   int64_t split_valid = 0;  // rows [0, split_valid) are converted
-  int batch_kernel = 1;     // TSH_OPT_BATCH_KERNEL: 0 f32 MFMA, 1 bf16x3
+  int batch_kernel = 3;     // TSH_OPT_BATCH_KERNEL: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (cosine: f16, else bf16x3)
+  int split_mode = 0;       // which kernel the planes were built for (1 / 2); 0 = none
+  int64_t split_bytes = 0;
+  int split_exp = 0;        // f16 planes: rows were scaled by 2^split_exp
 
   bool safe_mode() const {
     if (nonfinite_rows) return true;
@@ -1110,6 +1113,16 @@ template <int METRIC>
 void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
   int grid = a.q_tiles * a.n_tiles;
   if (grid <= 0) return;
+  if (a.dot_scale != 0.f) {  // f16 variant
+    if (a.tile_m == 256) {
+      if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
+      else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
+    } else {
+      if (dense) batch_score_bf16x3_kernel<METRIC, true, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
+      else batch_score_bf16x3_kernel<METRIC, false, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
+    }
+    return;
+  }
   if (a.tile_m == 256) {  // 256 x 256 tiles, 8 waves (batches of more than 128 queries)
     if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128><<<grid, 512, 0, st>>>(a);
     else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128><<<grid, 512, 0, st>>>(a);
@@ -1139,25 +1152,36 @@ int64_t batch_sample_rows(int64_t rows, int32_t k) {
 }
 
 // 2 * (error bound of the f32 MFMA key), absolute, per query
-bool batch_delta2(const Shard *s, const float *q, bool bf16x3, float *out_delta2, float *out_qsq) {
+bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2, float *out_qsq, float *out_qmax) {
   double qn2 = 0;
+  float qmax = 0.f;
   for (int i = 0; i < s->dim; ++i) {
     float a = std::fabs(q[i]);
     if (!(a <= BIG_ABS)) return false;
+    qmax = a > qmax ? a : qmax;
     qn2 += (double)q[i] * (double)q[i];
   }
+  if (out_qmax) *out_qmax = qmax;
   const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
   const double u2 = 1.1920928955078125e-07;        // 2^-23
   double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
-  if (bf16x3) {
+  if (kernel == 1) {
     // three partial products per k accumulate in f32 (chain of 3 ld terms, each product exact),
     // and hi + lo drops 3.1 * 2^-18 |q_i||v_i| per element (tsh_batch.hip.h, bf16x3 variant)
     const double hld = (double)round_up(s->dim, 32);
     gam = (3.0 * hld + 8.0) * u2 * (1.0 + 0.00391) + 3.1 * 3.814697265625e-06;
+  } else if (kernel == 2) {
+    // both operands rounded to fp16 (2^-11 each, + their product), exact products accumulated in f32;
+    // 2^-21: the f32 scaling / normalisation before the rounding; 2^-30: fp16 subnormal steps, which
+    // sit >= 27 binades under the largest operand value after the power-of-two scaling
+    const double hld = (double)round_up(s->dim, 64);
+    // (a query is only batched when its largest element is within 2^8 of the batch's, see top_q)
+    gam = (hld + 8.0) * u2 * (1.0 + 0.001) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
+          std::sqrt(hld) * 9.3e-10;
   }
   double delta;
   if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
-  else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07);
+  else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07) * (kernel == 2 ? 1.0 + 1e-6 : 1.0);
   else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
   delta += (double)s->dim * 7.5e-37;
   double d2 = 2.0 * delta * 1.0001;
@@ -1187,7 +1211,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int64_t rows = s->rows, ld = s->ld;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   // bf16x3 kernel: 256 x 256 tiles for batches of more than 128 queries, 128 x 128 otherwise
-  const int32_t tile = (s->batch_kernel == 1 && nq > 128) ? 256 : 128;
+  const int32_t tile = (s->batch_kernel != 0 && nq > 128) ? 256 : 128;  // (every kernel but the f32 one has both tiles)
   const int32_t nq_pad = (int32_t)round_up(nq, tile);
   // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
@@ -1214,32 +1238,52 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
   if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
 
-  // ---- bf16x3 kernel: keep the (hi, lo) planes of the rows current -----------------------
-  const bool use_bf16 = s->batch_kernel == 1;
-  const int32_t hchunks = (int32_t)((s->dim + 31) / 32);
-  if (use_bf16) {
-    if (s->split_cap < s->cap) {  // first use, or the row store grew: (re)allocate, convert everything
+  // ---- bf16x3 / f16 kernels: keep the converted planes of the rows current ----------------------
+  // auto: cosine keys are scale-free (unit rows, unit query), so fp16's fixed relative precision gives a
+  // band that is narrow against ANY data; IP / L2 bands scale with the largest row norm, where bf16x3's
+  // 25x tighter error keeps the candidate lists short when norms vary widely
+  int kern = s->batch_kernel == 3 ? (s->metric == TSH_METRIC_COSINE ? 2 : 1) : s->batch_kernel;
+  int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
+  if (kern == 2) {
+    const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
+    int e = 0;
+    if (top > 0.f) std::frexp(top, &e);  // top = m * 2^e, m in [0.5, 1)
+    v_exp = 14 - e;
+    if (v_exp > 55 || v_exp < -55) kern = 1;  // scales near the edge of f32's exponent range: bf16x3 instead
+  }
+  const bool use_bf16 = kern == 1, use_f16 = kern == 2, use_planes = use_bf16 || use_f16;
+  const int32_t hchunks = use_f16 ? (int32_t)((s->dim + 63) / 64) : (int32_t)((s->dim + 31) / 32);
+  if (use_planes) {
+    const int64_t row_bytes = (int64_t)hchunks * 128;
+    if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
+    if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
       if (s->d_split) hipFree(s->d_split);
       s->d_split = nullptr;
-      s->bytes -= s->split_cap * hchunks * 128;
+      s->bytes -= s->split_bytes;
+      s->split_bytes = 0;
       s->split_cap = 0;
       s->split_valid = 0;
-      HIPCHK(hipMalloc(&s->d_split, (size_t)s->cap * hchunks * 128));
+      HIPCHK(hipMalloc(&s->d_split, (size_t)s->cap * (size_t)row_bytes));
       s->split_cap = s->cap;
-      s->bytes += s->split_cap * hchunks * 128;
+      s->split_bytes = s->cap * row_bytes;
+      s->bytes += s->split_bytes;
     }
+    s->split_mode = kern;
+    s->split_exp = v_exp;
     if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, (int64_t)nq_pad * hchunks * 8, &b->bytes))) return rc;
   }
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
   std::vector<char> bad((size_t)nq, 0);
+  std::vector<float> qmax((size_t)nq_pad, 0.f);
   parallel_for(nq_pad, [&](int32_t q) {
     float *dst = b->h_Q + (size_t)q * ld;
     if (q < nq) {
       memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
       for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
-      if (!batch_delta2(s, dst, use_bf16, &h_d2[q], &h_qsq[q])) {
+      if (!batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q])) {
+        qmax[(size_t)q] = 0.f;
         bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
         memset(dst, 0, (size_t)ld * sizeof(float));
         h_d2[q] = 0.f;
@@ -1251,6 +1295,35 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       h_qsq[q] = 0.f;
     }
   });
+  // f16: one power-of-two scale for the whole batch; queries much smaller than the largest one would sit
+  // in fp16's subnormal range, so they are answered alone
+  float top_q = 0.f;
+  int q_exp = 0;
+  if (use_f16) {
+    for (int32_t q = 0; q < nq; ++q) top_q = std::max(top_q, qmax[(size_t)q]);
+    for (int32_t q = 0; q < nq; ++q)
+      if (!bad[(size_t)q] && !(qmax[(size_t)q] >= top_q * 0.00390625f)) {
+        bad[(size_t)q] = 1;
+        memset(b->h_Q + (size_t)q * ld, 0, (size_t)ld * sizeof(float));
+        h_d2[q] = 0.f;
+        h_qsq[q] = 0.f;
+      }
+    if (top_q > 0.f) {
+      int eq = 0;
+      std::frexp(top_q, &eq);
+      q_exp = 14 - eq;
+    }
+    if (q_exp > 55 || q_exp < -55) {  // same guard on the query side: answer them one by one
+      q_exp = 0;
+      for (int32_t q = 0; q < nq; ++q)
+        if (!bad[(size_t)q]) {
+          bad[(size_t)q] = 1;
+          memset(b->h_Q + (size_t)q * ld, 0, (size_t)ld * sizeof(float));
+          h_d2[q] = 0.f;
+          h_qsq[q] = 0.f;
+        }
+    }
+  }
   if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
 
   const double t_prep = now_us();
@@ -1283,10 +1356,35 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.Qs = b->d_Qs;
       a.Vs = s->d_split;
       a.hchunks = hchunks;
+    } else if (use_f16) {
+      auto half = [&](const float *src, const float *inv, int64_t first, int64_t n, u32x4 *dst, int e) {
+        HalfArgs ha{};
+        ha.rows = src;
+        ha.inv_norm = inv;
+        ha.out = dst;
+        ha.ld = ld;
+        ha.first = first;
+        ha.n = n;
+        ha.dim = s->dim;
+        ha.hchunks = hchunks;
+        ha.scale = std::ldexp(1.0f, e);
+        const int64_t total = n * hchunks * 8;
+        half_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
+      };
+      if (s->split_valid < rows) {
+        half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, s->split_valid,
+             rows - s->split_valid, s->d_split, v_exp);
+        s->split_valid = rows;
+      }
+      half(b->d_Q, nullptr, 0, nq_pad, b->d_Qs, q_exp);
+      a.Qs = b->d_Qs;
+      a.Vs = s->d_split;
+      a.hchunks = hchunks;
+      a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
     }
     a.Q = b->d_Q;
     a.V = s->d_rows;
-    a.inv_norm = s->d_inv_norm;
+    a.inv_norm = use_f16 ? nullptr : s->d_inv_norm;  // f16 planes of a cosine corpus hold unit rows
     a.sqnorm = s->d_sqnorm;
     a.qsq = d_qsq;
     a.thr = d_thr;
@@ -2001,7 +2099,7 @@ int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
     return TSH_OK;
   }
   if (option == TSH_OPT_BATCH_KERNEL) {
-    if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "batch kernel must be 0 (f32 MFMA) or 1 (bf16x3)");
+    if (value < 0 || value > 3) return set_err(TSH_E_BAD_ARG, "batch kernel must be 0 (f32 MFMA), 1 (bf16x3), 2 (f16) or 3 (auto)");
     for (auto &sh : idx->shards) {
       std::unique_lock<RwLock> xl(sh->mu);
       sh->batch_kernel = (int)value;
