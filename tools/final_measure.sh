@@ -10,8 +10,9 @@ timeout 900 python bench.py 2>$O/bench_default.err > $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_default -o d -- python bench.py --steps 1500 --warmup 200 --no-cpu-baseline --recall-queries 0 > $O/prof_default.log 2>&1
 python tools/rocpd_summary.py $O/prof_default/d_results.db > $O/bench_default_kernel_stats.txt 2>&1
 rm -rf $O/prof_default
-# 3. config C3, both batch kernels
-timeout 600 python bench.py --batch 1024 --metric cosine --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_bf16x3.json
+# 3. config C3: library default (auto = fp16 keys for cosine), then each kernel forced
+timeout 600 python bench.py --batch 1024 --metric cosine --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_f16.json
+timeout 600 python bench.py --batch 1024 --metric cosine --steps 10 --warmup 2 --batch-kernel 1 2>>$O/c3.err > $O/bench_c3_bf16x3.json
 timeout 600 python bench.py --batch 1024 --metric cosine --steps 10 --warmup 2 --batch-kernel 0 2>>$O/c3.err > $O/bench_c3_f32mfma.json
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o c -- python bench.py --batch 1024 --metric cosine --steps 6 --warmup 2 --no-cpu-baseline > $O/prof_c3.log 2>&1
 python tools/rocpd_summary.py $O/prof_c3/c_results.db > $O/bench_c3_kernel_stats.txt 2>&1
@@ -35,4 +36,4 @@ rm -rf $O/prof_c3
 } > $O/side_configs.txt 2>&1
 cat $O/side_configs.txt
 python -c "import json; j=json.load(open('$O/bench_default.json')); print({k: j[k] for k in ('value','ms_per_step','recall_at_k','ids_and_distances_bit_exact','cpu_baseline') if k in j}); print(j['roofline'])"
-python -c "import json; [print(f, round(json.load(open('$O/'+f))['value'])) for f in ('bench_c3_bf16x3.json','bench_c3_f32mfma.json')]"
+python -c "import json; [print(f, round(json.load(open('$O/'+f))['value'])) for f in ('bench_c3_f16.json','bench_c3_bf16x3.json','bench_c3_f32mfma.json')]"
