@@ -106,8 +106,6 @@ def bench_batch(a, idx, host_rows, metric, world, rank):
     steps, warm = max(1, min(a.steps, 20)), max(1, min(a.warmup, 3))
     qs = make_queries(nq * 2, d, metric)
     idx.set_batch_kernel(a.batch_kernel)
-    if a.batch_kernel == 3:
-        a.batch_kernel = 2 if metric == 2 else 1  # what auto resolves to, for the report below
     for i in range(warm):
         idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)
     torch.cuda.synchronize()
@@ -117,6 +115,7 @@ def bench_batch(a, idx, host_rows, metric, world, rank):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gemm_us, flops = idx.bench_batch(qs[:nq], k, iters=3)
+    a.batch_kernel = idx.counters()["batch_kernel_last"]  # what auto resolved to, for the report below
     tf = flops / (gemm_us * 1e-6) / 1e12
     out = {"metric": "kNN queries/sec, %dx%d f32 %s k=%d, %d-query batch (matrix-core path)" % (n, d, a.metric, k, nq),
            "value": nq * steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm,

@@ -72,6 +72,8 @@ typedef struct tsh_counters {
    * on, inside real searches (every 4th query): sum of microseconds / samples */
   double scan_us_sum;
   int64_t scan_us_samples;
+  int32_t batch_kernel_last; /* TSH_OPT_BATCH_KERNEL variant the last batched search ran (0/1/2; -1 none yet) */
+  int32_t reserved;
 } tsh_counters;
 
 int32_t tsh_abi_version(void);
@@ -299,8 +301,10 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
  *   2  f16: operands rounded to fp16 after an exact power-of-two scaling (cosine
  *      rows normalised first), one f16 MFMA per product (error 2^-10 |q||v|);
  *      costs a copy of 2 B per element;
- *   3  (default) auto: f16 for cosine indexes, whose keys are scale-free, bf16x3
- *      for inner-product and L2 indexes, whose bands scale with the largest row.
+ *   3  (default) auto: f16 for cosine indexes, whose keys are scale-free, and for
+ *      inner-product / L2 indexes whose row norms lie within a factor of 8 of each
+ *      other (normalised embeddings); bf16x3 otherwise, because those bands scale
+ *      with the largest row.
  * The copy is built by the first batched search and kept current across appends. */
 #define TSH_OPT_BATCH_KERNEL 2
 int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value);

@@ -186,3 +186,27 @@ def test_bf16x3_wide_dynamic_range(hip_lib, oracle_mod):
                 idx.set_batch_kernel(kernel)
                 idx.append(0, rows)
                 _check_batch(oracle_mod, idx, rows, qm, metric, 25, tag=f"range m{metric} kernel{kernel}")
+
+
+def test_auto_kernel_choice(hip_lib, oracle_mod):
+    """TSH_OPT_BATCH_KERNEL auto: fp16 keys for cosine and for IP / L2 corpora of nearly equal row norms,
+    bf16x3 when the norms spread widely (bands scale with the largest row) -- results exact either way."""
+    from tostore_amd import HipVectorIndex
+
+    n, d, nq, k = 12_000, 64, 40, 20
+    unit = _mk(n, d, 71)
+    spread = unit * np.exp2(np.random.default_rng(72).integers(-6, 7, (n, 1))).astype(np.float32)
+    for metric, rows, want in ((COS, spread, 2), (IP, unit, 2), (L2, unit * np.float32(3.0), 2), (IP, spread, 1),
+                               (L2, spread, 1)):
+        qs = _queries(oracle_mod, nq, d, 73, metric)
+        with HipVectorIndex(d, metric) as idx:
+            assert idx.counters()["batch_kernel_last"] == -1
+            idx.append(0, rows)
+            _check_batch(oracle_mod, idx, rows, qs, metric, k, tag=f"auto m{metric}")
+            assert idx.counters()["batch_kernel_last"] == want
+    with HipVectorIndex(d, IP) as idx:  # a zero row: the smallest norm is 0, so the spread is unbounded
+        rows = unit.copy()
+        rows[17] = 0.0
+        idx.append(0, rows)
+        _check_batch(oracle_mod, idx, rows, _queries(oracle_mod, nq, d, 74, IP), IP, k, tag="zero row")
+        assert idx.counters()["batch_kernel_last"] == 1

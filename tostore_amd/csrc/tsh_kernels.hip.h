@@ -843,6 +843,7 @@ struct IngestStats {
   uint32_t max_abs_bits;   // max finite |element|
   uint32_t nonfinite_rows; // rows holding an inf / nan element
   uint32_t tiny_rows;      // rows whose norm is nonzero but < 2^-50 (cosine error model breaks)
+  uint32_t inv_min_norm_bits;  // ~(f32 bits of the smallest |row|, rounded down); 0 = no row yet
 };
 
 __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t ld, int dim,
@@ -853,7 +854,7 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
   int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   // per-wave running statistics, published once at the end (one atomic per
   // wave, not per row)
-  uint32_t w_norm = 0, w_abs = 0, w_bad = 0, w_tiny = 0;
+  uint32_t w_norm = 0, w_abs = 0, w_bad = 0, w_tiny = 0, w_inv_min = 0;
   for (int64_t r = w; r < n; r += nw) {
     const float *rp = rows + (first + r) * ld;
     double s = 0.0;
@@ -891,6 +892,10 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
       float nf = (float)nrm;
       if ((double)nf < nrm) nf = __uint_as_float(__float_as_uint(nf) + 1u);
       if (!bad && __float_as_uint(nf) > w_norm) w_norm = __float_as_uint(nf);
+      if (!bad) {
+        const uint32_t lo = ~__float_as_uint((float)nrm > nrm ? __uint_as_float(__float_as_uint((float)nrm) - 1u) : (float)nrm);
+        if (lo > w_inv_min) w_inv_min = lo;
+      }
       if (__float_as_uint(mx) > w_abs) w_abs = __float_as_uint(mx);
       w_bad += bad ? 1u : 0u;
       w_tiny += tiny ? 1u : 0u;
@@ -901,6 +906,7 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
     if (w_abs) atomicMax(&st->max_abs_bits, w_abs);
     if (w_bad) atomicAdd(&st->nonfinite_rows, w_bad);
     if (w_tiny) atomicAdd(&st->tiny_rows, w_tiny);
+    if (w_inv_min) atomicMax(&st->inv_min_norm_bits, w_inv_min);
   }
 }
 

@@ -398,6 +398,7 @@ struct Shard {
   int64_t deleted = 0;
   bool all_live = true;  // every row in [0,rows) is present and not deleted
   float max_norm = 0.f, max_abs = 0.f;
+  float min_norm = 0.f;  // smallest |row| seen (0 until rows exist, or when a zero row exists)
   uint32_t nonfinite_rows = 0, tiny_rows = 0;
   hipStream_t ingest_stream = nullptr;
   // every query's scan -> select -> rerank runs on this one in-order stream,
@@ -436,6 +437,7 @@ struct Shard {
   int64_t split_cap = 0;    // rows allocated
   int64_t split_valid = 0;  // rows [0, split_valid) are converted
   int batch_kernel = 3;     // TSH_OPT_BATCH_KERNEL: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (cosine: f16, else bf16x3)
+  int batch_kernel_last = -1;  // variant the last batched search ran
   int split_mode = 0;       // which kernel the planes were built for (1 / 2); 0 = none
   int64_t split_bytes = 0;
   int split_exp = 0;        // f16 planes: rows were scaled by 2^split_exp
@@ -557,6 +559,10 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
   memcpy(&s->max_abs, &ab, 4);
   s->nonfinite_rows = hs.nonfinite_rows;
   s->tiny_rows = hs.tiny_rows;
+  {
+    uint32_t nb = hs.inv_min_norm_bits ? ~hs.inv_min_norm_bits : 0u;
+    memcpy(&s->min_norm, &nb, 4);
+  }
   if (first > s->rows) s->all_live = false;  // gap of absent rows
   if (first + n > s->rows) s->rows = first + n;
   s->split_valid = std::min(s->split_valid, first);  // overwritten / new rows need re-splitting
@@ -1242,7 +1248,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // auto: cosine keys are scale-free (unit rows, unit query), so fp16's fixed relative precision gives a
   // band that is narrow against ANY data; IP / L2 bands scale with the largest row norm, where bf16x3's
   // 25x tighter error keeps the candidate lists short when norms vary widely
-  int kern = s->batch_kernel == 3 ? (s->metric == TSH_METRIC_COSINE ? 2 : 1) : s->batch_kernel;
+  // -- unless the rows are nearly equal in norm (the usual normalised embeddings), when f16 serves them too
+  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm;
+  int kern = s->batch_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : s->batch_kernel;
   int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
   if (kern == 2) {
     const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
@@ -1251,6 +1259,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     v_exp = 14 - e;
     if (v_exp > 55 || v_exp < -55) kern = 1;  // scales near the edge of f32's exponent range: bf16x3 instead
   }
+  s->batch_kernel_last = kern;
   const bool use_bf16 = kern == 1, use_f16 = kern == 2, use_planes = use_bf16 || use_f16;
   const int32_t hchunks = use_f16 ? (int32_t)((s->dim + 63) / 64) : (int32_t)((s->dim + 31) / 32);
   if (use_planes) {
@@ -2043,6 +2052,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
       for (auto &c : s->ctx_all) b += c->bytes;
       out->scan_us_sum += s->scan_us_sum;
       out->scan_us_samples += s->scan_us_samples;
+      out->batch_kernel_last = s->batch_kernel_last;
     }
     out->bytes_resident += b;
     if (s->safe_mode()) out->safe_mode = 1;
