@@ -45,7 +45,7 @@ extern "C" {
 #define TSH_E_OVERFLOW (-6) /* a candidate block was too small; retry with more entries */
 #define TSH_E_IO (-7)
 #define TSH_E_FORMAT (-8)
-#define TSH_E_BUSY (-9) /* too many un-waited asynchronous searches on the handle */
+#define TSH_E_BUSY (-9) /* tsh_max_inflight() asynchronous searches are already un-waited on the handle: wait for one */
 
 /* metric = enum order of VectorDistanceMetric, lib/src/model/table_schema.dart:2511-2531 */
 #define TSH_METRIC_L2 0

@@ -350,6 +350,54 @@ def test_concurrent_threads_share_one_handle(hip_lib, oracle_mod):
     assert not errs, errs
 
 
+def test_concurrent_multi_query_callers(hip_lib, oracle_mod):
+    """Several threads, each handing over MANY queries per call (every call wants several of the shard's
+    eight contexts; callers that each held some and waited for more used to deadlock), mixing the
+    pipelined single-query path, the batched path and async tickets on one handle."""
+    import threading
+
+    from tostore_amd import HipVectorIndex
+
+    d, n, k = 96, 30000, 15
+    rows = _mk(n, d, 191)
+    qs = _mk(240, d, 192)
+    want = [oracle_mod.search_heap(rows, q, L2, k) for q in qs]
+    errs = []
+    with HipVectorIndex(d, L2) as idx:
+        idx.append(0, rows)
+
+        def check(lo, ids, dist, cnt):
+            for j in range(len(cnt)):
+                assert cnt[j] == k and np.array_equal(ids[j], want[lo + j][0]) and np.array_equal(dist[j], want[lo + j][1])
+
+        def pipelined(lo, hi):  # 80 queries per call, batching off for this thread's handle-wide setting
+            try:
+                for _ in range(3):
+                    check(lo, *idx.search(qs[lo:hi], k))
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        def tickets(lo, hi):
+            try:
+                for i in range(lo, hi):
+                    t = idx.submit(qs[i], k)
+                    ids, dist = idx.wait(t)
+                    assert np.array_equal(ids, want[i][0]) and np.array_equal(dist, want[i][1])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        for min_nq in (0, 8):  # 0: every call runs pipelined single scans; 8: the 80-query calls go batched
+            idx.set_batch_min_nq(min_nq)
+            th = [threading.Thread(target=pipelined, args=(0, 80)), threading.Thread(target=pipelined, args=(80, 160)),
+                  threading.Thread(target=pipelined, args=(160, 240)), threading.Thread(target=tickets, args=(0, 40))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(timeout=120)
+            assert not any(t.is_alive() for t in th), "deadlock"
+            assert not errs, errs
+
+
 @pytest.mark.parametrize("metric", METRICS)
 def test_more_than_16384_tiles(hip_lib, oracle_mod, metric):
     """> 1,048,576 rows: the select kernel walks gmin[] in memory instead of registers."""

@@ -1557,6 +1557,7 @@ struct tsh_index {
   std::mutex mu;  // serialises append routing
   std::mutex tk_mu;
   std::vector<std::unique_ptr<Ticket>> tickets;
+  std::atomic<int> tickets_open{0};  // submitted, not yet waited for: each holds one context per shard
   std::atomic<int32_t> batch_min_nq{8};  // nq at which tsh_search switches to the matrix-core path
 };
 
@@ -1880,9 +1881,12 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
     Shard *s = idx->shards[g].get();
     t->locks[g] = std::shared_lock<RwLock>(s->mu);
     if (s->rows == 0) continue;
-    Ctx *c = ctx_acquire(s, false);
+    // Contexts held by synchronous callers come back on their own, so wait for one -- unless the
+    // un-waited tickets alone could hold them all: waiting would then never end for a caller that
+    // submits before it waits
+    Ctx *c = ctx_acquire(s, idx->tickets_open.load() < MAX_CTX);
     if (!c) {
-      rc = set_err(TSH_E_BUSY, "more than %d searches in flight on this handle", MAX_CTX);
+      rc = set_err(TSH_E_BUSY, "%d asynchronous searches are already in flight on this handle", MAX_CTX);
       break;
     }
     t->jobs[g].c = c;
@@ -1919,6 +1923,7 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
     slot = (int)idx->tickets.size() - 1;
   }
   idx->tickets[(size_t)slot] = std::move(t);
+  idx->tickets_open.fetch_add(1);
   *out_ticket = slot;
   return TSH_OK;
 }
@@ -1932,6 +1937,7 @@ int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double thr, int64_t *out
     if (ticket < 0 || (size_t)ticket >= idx->tickets.size() || !idx->tickets[(size_t)ticket])
       return set_err(TSH_E_BAD_ARG, "unknown ticket %d", ticket);
     t = std::move(idx->tickets[(size_t)ticket]);
+    idx->tickets_open.fetch_sub(1);
   }
   *out_count = 0;
   int rc = TSH_OK;
