@@ -1,0 +1,490 @@
+// tsh_host_batch.inl.h -- host side of the batched (matrix-core) path: scratch, band computation, launch sequence
+// Part of the single translation unit tsh_lib.hip (textually included there; not compiled alone).
+
+// ---- batched (matrix-core) path ---------------------------------------------------
+struct BatchCtx {
+  std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
+  float *d_Q = nullptr, *h_Q = nullptr;
+  u32x4 *d_Qs = nullptr;  // bf16 planes of the padded queries
+  int64_t qs_cap = 0;     // in u32x4 units
+  float *d_qaux = nullptr, *h_qaux = nullptr;  // [qsq | delta2 | thr] x nq_pad
+  int64_t q_cap = 0, aux_cap = 0, cc_cap = 0;  // element capacities
+  float *d_dense = nullptr;
+  int64_t dense_cap = 0;  // floats
+  uint32_t *d_ck = nullptr, *d_cr = nullptr, *d_cc = nullptr;
+  int64_t cand_total = 0;  // nq * cand_cap capacity
+  uint8_t *d_blocks = nullptr, *h_blocks = nullptr;
+  uint32_t *d_final = nullptr;
+  int64_t blocks_cap = 0, final_cap = 0;
+  uint64_t *d_mask = nullptr, *h_mask = nullptr;
+  int64_t mask_words = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
+  int64_t bytes = 0;
+  double last_gemm_us = 0, last_flops = 0;
+};
+
+void batch_free(BatchCtx *b) {
+  hipFree(b->d_Q);
+  hipFree(b->d_Qs);
+  hipHostFree(b->h_Q);
+  hipFree(b->d_qaux);
+  hipHostFree(b->h_qaux);
+  hipFree(b->d_dense);
+  hipFree(b->d_ck);
+  hipFree(b->d_cr);
+  hipFree(b->d_cc);
+  hipFree(b->d_blocks);
+  hipHostFree(b->h_blocks);
+  hipFree(b->d_final);
+  hipFree(b->d_mask);
+  hipHostFree(b->h_mask);
+  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done})
+    if (e) hipEventDestroy(e);
+}
+
+template <typename T>
+int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
+  if (want <= *cap) return TSH_OK;
+  hipFree(*dev);
+  *dev = nullptr;
+  if (host) {
+    hipHostFree(*host);
+    *host = nullptr;
+  }
+  HIPCHK(hipMalloc(dev, (size_t)want * sizeof(T)));
+  if (host) HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
+  *bytes += (want - *cap) * (int64_t)sizeof(T);
+  *cap = want;
+  return TSH_OK;
+}
+
+template <int METRIC>
+void launch_batch_score(const BatchArgs &a, bool dense, hipStream_t st) {
+  int grid = a.q_tiles * a.n_tiles;
+  if (grid <= 0) return;
+  if (dense) batch_score_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
+  else batch_score_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
+}
+template <int METRIC>
+void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
+  int grid = a.q_tiles * a.n_tiles;
+  if (grid <= 0) return;
+  if (a.dot_scale != 0.f) {  // f16 variant
+    if (a.tile_m == 256) {
+      if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
+      else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
+    } else {
+      if (dense) batch_score_bf16x3_kernel<METRIC, true, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
+      else batch_score_bf16x3_kernel<METRIC, false, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
+    }
+    return;
+  }
+  if (a.tile_m == 256) {  // 256 x 256 tiles, 8 waves (batches of more than 128 queries)
+    if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128><<<grid, 512, 0, st>>>(a);
+    else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128><<<grid, 512, 0, st>>>(a);
+    return;
+  }
+  if (dense) batch_score_bf16x3_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
+  else batch_score_bf16x3_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
+}
+void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st) {
+  if (a.Vs) {
+    if (metric == TSH_METRIC_L2) launch_batch_score_bf16<METRIC_L2>(a, dense, st);
+    else if (metric == TSH_METRIC_IP) launch_batch_score_bf16<METRIC_IP>(a, dense, st);
+    else launch_batch_score_bf16<METRIC_COS>(a, dense, st);
+    return;
+  }
+  if (metric == TSH_METRIC_L2) launch_batch_score<METRIC_L2>(a, dense, st);
+  else if (metric == TSH_METRIC_IP) launch_batch_score<METRIC_IP>(a, dense, st);
+  else launch_batch_score<METRIC_COS>(a, dense, st);
+}
+
+int64_t batch_sample_rows(int64_t rows, int32_t k) {
+  if (rows <= 16384) return rows;
+  int64_t n = std::max<int64_t>(rows / 32, (int64_t)k * rows / 3000);
+  n = std::max<int64_t>(round_up(n, 256), 8192);  // whole row tiles of either tile shape
+  n = std::max<int64_t>(n, round_up((int64_t)k * 4, 256));
+  return std::min(n, rows);
+}
+
+// 2 * (error bound of the f32 MFMA key), absolute, per query
+bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2, float *out_qsq, float *out_qmax) {
+  double qn2 = 0;
+  float qmax = 0.f;
+  for (int i = 0; i < s->dim; ++i) {
+    float a = std::fabs(q[i]);
+    if (!(a <= BIG_ABS)) return false;
+    qmax = a > qmax ? a : qmax;
+    qn2 += (double)q[i] * (double)q[i];
+  }
+  if (out_qmax) *out_qmax = qmax;
+  const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
+  const double u2 = 1.1920928955078125e-07;        // 2^-23
+  double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
+  if (kernel == 1) {
+    // three partial products per k accumulate in f32 (chain of 3 ld terms, each product exact),
+    // and hi + lo drops 3.1 * 2^-18 |q_i||v_i| per element (tsh_batch.hip.h, bf16x3 variant)
+    const double hld = (double)round_up(s->dim, 32);
+    gam = (3.0 * hld + 8.0) * u2 * (1.0 + 0.00391) + 3.1 * 3.814697265625e-06;
+  } else if (kernel == 2) {
+    // both operands rounded to fp16 (2^-11 each, + their product), exact products accumulated in f32;
+    // 2^-21: the f32 scaling / normalisation before the rounding; 2^-30: fp16 subnormal steps, which
+    // sit >= 27 binades under the largest operand value after the power-of-two scaling
+    const double hld = (double)round_up(s->dim, 64);
+    // (a query is only batched when its largest element is within 2^8 of the batch's, see top_q)
+    gam = (hld + 8.0) * u2 * (1.0 + 0.001) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
+          std::sqrt(hld) * 9.3e-10;
+  }
+  double delta;
+  if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
+  else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07) * (kernel == 2 ? 1.0 + 1e-6 : 1.0);
+  else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
+  delta += (double)s->dim * 7.5e-37;
+  double d2 = 2.0 * delta * 1.0001;
+  if (!(d2 < 1e30)) return false;
+  *out_delta2 = (float)d2;
+  if ((double)*out_delta2 < d2) *out_delta2 = std::nextafter(*out_delta2, INFINITY);
+  *out_qsq = (float)qn2;
+  return true;
+}
+
+inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool trace_batch() {
+  static const bool on = getenv("TSH_TRACE_BATCH") != nullptr;
+  return on;
+}
+
+// All nq queries in one pass over the rows on the matrix cores.  Queries the
+// error model cannot cover, or whose lists overflow (ties), are reported in
+// *redo and answered by the single-query path.  Caller holds s->mu shared.
+int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
+                       const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo) {
+  std::lock_guard<std::mutex> lk(b->mu);
+  const double t_in = now_us();
+  HIPCHK(hipSetDevice(s->device));
+  const int64_t rows = s->rows, ld = s->ld;
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  // bf16x3 kernel: 256 x 256 tiles for batches of more than 128 queries, 128 x 128 otherwise
+  const int32_t tile = (s->batch_kernel != 0 && nq > 128) ? 256 : 128;  // (every kernel but the f32 one has both tiles)
+  const int32_t nq_pad = (int32_t)round_up(nq, tile);
+  // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
+  // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
+  const int64_t n_sample = batch_sample_rows(rows, k);
+  const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
+  const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
+  if (!b->e0) {
+    for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
+    HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming));
+  }
+  int rc;
+  if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 3, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
+  {
+    int64_t want = (int64_t)nq * cand_cap, c1 = b->cand_total, c2 = b->cand_total;
+    if ((rc = regrow(&b->d_ck, (uint32_t **)nullptr, &c1, want, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_cr, (uint32_t **)nullptr, &c2, want, &b->bytes))) return rc;
+    b->cand_total = std::max(b->cand_total, want);
+    if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad, &b->bytes))) return rc;
+  }
+  if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
+  const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
+  if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
+
+  // ---- bf16x3 / f16 kernels: keep the converted planes of the rows current ----------------------
+  // auto: cosine keys are scale-free (unit rows, unit query), so fp16's fixed relative precision gives a
+  // band that is narrow against ANY data; IP / L2 bands scale with the largest row norm, where bf16x3's
+  // 25x tighter error keeps the candidate lists short when norms vary widely
+  // -- unless the rows are nearly equal in norm (the usual normalised embeddings), when f16 serves them too
+  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm;
+  int kern = s->batch_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : s->batch_kernel;
+  int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
+  if (kern == 2) {
+    const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
+    int e = 0;
+    if (top > 0.f) std::frexp(top, &e);  // top = m * 2^e, m in [0.5, 1)
+    v_exp = 14 - e;
+    if (v_exp > 55 || v_exp < -55) kern = 1;  // scales near the edge of f32's exponent range: bf16x3 instead
+  }
+  s->batch_kernel_last = kern;
+  const bool use_bf16 = kern == 1, use_f16 = kern == 2, use_planes = use_bf16 || use_f16;
+  const int32_t hchunks = use_f16 ? (int32_t)((s->dim + 63) / 64) : (int32_t)((s->dim + 31) / 32);
+  if (use_planes) {
+    const int64_t row_bytes = (int64_t)hchunks * 128;
+    if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
+    if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
+      if (s->d_split) hipFree(s->d_split);
+      s->d_split = nullptr;
+      s->bytes -= s->split_bytes;
+      s->split_bytes = 0;
+      s->split_cap = 0;
+      s->split_valid = 0;
+      HIPCHK(hipMalloc(&s->d_split, (size_t)s->cap * (size_t)row_bytes));
+      s->split_cap = s->cap;
+      s->split_bytes = s->cap * row_bytes;
+      s->bytes += s->split_bytes;
+    }
+    s->split_mode = kern;
+    s->split_exp = v_exp;
+    if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, (int64_t)nq_pad * hchunks * 8, &b->bytes))) return rc;
+  }
+
+  // ---- host prep: padded queries, per-query bands ------------------------------------
+  float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
+  std::vector<char> bad((size_t)nq, 0);
+  std::vector<float> qmax((size_t)nq_pad, 0.f);
+  parallel_for(nq_pad, [&](int32_t q) {
+    float *dst = b->h_Q + (size_t)q * ld;
+    if (q < nq) {
+      memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
+      for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
+      if (!batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q])) {
+        qmax[(size_t)q] = 0.f;
+        bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
+        memset(dst, 0, (size_t)ld * sizeof(float));
+        h_d2[q] = 0.f;
+        h_qsq[q] = 0.f;
+      }
+    } else {
+      memset(dst, 0, (size_t)ld * sizeof(float));
+      h_d2[q] = 0.f;
+      h_qsq[q] = 0.f;
+    }
+  });
+  // f16: one power-of-two scale for the whole batch; queries much smaller than the largest one would sit
+  // in fp16's subnormal range, so they are answered alone
+  float top_q = 0.f;
+  int q_exp = 0;
+  if (use_f16) {
+    for (int32_t q = 0; q < nq; ++q) top_q = std::max(top_q, qmax[(size_t)q]);
+    for (int32_t q = 0; q < nq; ++q)
+      if (!bad[(size_t)q] && !(qmax[(size_t)q] >= top_q * 0.00390625f)) {
+        bad[(size_t)q] = 1;
+        memset(b->h_Q + (size_t)q * ld, 0, (size_t)ld * sizeof(float));
+        h_d2[q] = 0.f;
+        h_qsq[q] = 0.f;
+      }
+    if (top_q > 0.f) {
+      int eq = 0;
+      std::frexp(top_q, &eq);
+      q_exp = 14 - eq;
+    }
+    if (q_exp > 55 || q_exp < -55) {  // same guard on the query side: answer them one by one
+      q_exp = 0;
+      for (int32_t q = 0; q < nq; ++q)
+        if (!bad[(size_t)q]) {
+          bad[(size_t)q] = 1;
+          memset(b->h_Q + (size_t)q * ld, 0, (size_t)ld * sizeof(float));
+          h_d2[q] = 0.f;
+          h_qsq[q] = 0.f;
+        }
+    }
+  }
+  if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
+
+  const double t_prep = now_us();
+  // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
+  {
+    hipStream_t st = s->batch_stream;
+    HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
+    float *d_qsq = b->d_qaux, *d_d2 = b->d_qaux + nq_pad, *d_thr = b->d_qaux + 2 * (size_t)nq_pad;
+    BatchArgs a{};
+    if (use_bf16) {
+      auto split = [&](const float *src, int64_t first, int64_t n, u32x4 *dst) {
+        SplitArgs sa{};
+        sa.rows = src;
+        sa.out = dst;
+        sa.ld = ld;
+        sa.first = first;
+        sa.n = n;
+        sa.dim = s->dim;
+        sa.hchunks = hchunks;
+        const int64_t total = n * hchunks * 4;
+        split_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(sa);
+      };
+      if (s->split_valid < rows) {
+        split(s->d_rows, s->split_valid, rows - s->split_valid, s->d_split);
+        s->split_valid = rows;
+      }
+      split(b->d_Q, 0, nq_pad, b->d_Qs);
+      a.Qs = b->d_Qs;
+      a.Vs = s->d_split;
+      a.hchunks = hchunks;
+    } else if (use_f16) {
+      auto half = [&](const float *src, const float *inv, int64_t first, int64_t n, u32x4 *dst, int e) {
+        HalfArgs ha{};
+        ha.rows = src;
+        ha.inv_norm = inv;
+        ha.out = dst;
+        ha.ld = ld;
+        ha.first = first;
+        ha.n = n;
+        ha.dim = s->dim;
+        ha.hchunks = hchunks;
+        ha.scale = std::ldexp(1.0f, e);
+        const int64_t total = n * hchunks * 8;
+        half_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
+      };
+      if (s->split_valid < rows) {
+        half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, s->split_valid,
+             rows - s->split_valid, s->d_split, v_exp);
+        s->split_valid = rows;
+      }
+      half(b->d_Q, nullptr, 0, nq_pad, b->d_Qs, q_exp);
+      a.Qs = b->d_Qs;
+      a.Vs = s->d_split;
+      a.hchunks = hchunks;
+      a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
+    }
+    a.Q = b->d_Q;
+    a.V = s->d_rows;
+    a.inv_norm = use_f16 ? nullptr : s->d_inv_norm;  // f16 planes of a cosine corpus hold unit rows
+    a.sqnorm = s->d_sqnorm;
+    a.qsq = d_qsq;
+    a.thr = d_thr;
+    a.live = s->all_live ? nullptr : s->d_live;
+    a.mask = mask ? b->d_mask : nullptr;
+    a.dense = b->d_dense;
+    a.cand_key = b->d_ck;
+    a.cand_row = b->d_cr;
+    a.cand_cnt = b->d_cc;
+    a.ld = ld;
+    a.dense_ld = n_sample;
+    a.nq = nq;
+    a.nq_pad = nq_pad;
+    a.kchunks = (int32_t)((ld + BT_K - 1) / BT_K);
+    a.cand_cap = cand_cap;
+    a.tile_m = tile;
+    a.q_tiles = nq_pad / tile;
+    // B0: dense keys of the sample rows
+    a.row0 = 0;
+    a.row1 = (int32_t)n_sample;
+    a.n_tiles = (int32_t)((n_sample + tile - 1) / tile);
+    HIPCHK(hipEventRecord(b->e0, st));
+    launch_batch_score_m(s->metric, a, true, st);
+    HIPCHK(hipEventRecord(b->e1, st));
+    // B0s: per-query threshold + the sample's own candidates
+    SampleSelArgs ss{};
+    ss.dense = b->d_dense;
+    ss.delta2 = d_d2;
+    ss.thr = d_thr;
+    ss.cand_key = b->d_ck;
+    ss.cand_row = b->d_cr;
+    ss.cand_cnt = b->d_cc;
+    ss.dense_ld = n_sample;
+    ss.n_sample = (int32_t)n_sample;
+    ss.k = k;
+    ss.cand_cap = cand_cap;
+    ss.row0 = 0;
+    batch_sample_select_kernel<<<nq, BS_THREADS, 0, st>>>(ss);
+    // B1: everything else, filtered
+    HIPCHK(hipEventRecord(b->e2, st));
+    if (rows > n_sample) {
+      a.row0 = (int32_t)n_sample;
+      a.row1 = (int32_t)rows;
+      a.n_tiles = (int32_t)((rows - n_sample + tile - 1) / tile);
+      launch_batch_score_m(s->metric, a, false, st);
+    }
+    HIPCHK(hipEventRecord(b->e3, st));
+    // B2 + rerank
+    FinalSelArgs fs{};
+    fs.cand_key = b->d_ck;
+    fs.cand_row = b->d_cr;
+    fs.cand_cnt = b->d_cc;
+    fs.delta2 = d_d2;
+    fs.blocks = b->d_blocks;
+    fs.final_rows = b->d_final;
+    fs.block_bytes = (int64_t)bb;
+    fs.row_base = s->row_base;
+    fs.shard_rows = rows;
+    fs.k = k;
+    fs.cand_cap = cand_cap;
+    fs.entries = entries;
+    fs.metric = s->metric;
+    batch_final_select_kernel<<<nq, BS_THREADS, 0, st>>>(fs);
+    RerankBatchArgs rb{};
+    rb.rows = s->d_rows;
+    rb.Q = b->d_Q;
+    rb.final_rows = b->d_final;
+    rb.blocks = b->d_blocks;
+    rb.block_bytes = (int64_t)bb;
+    rb.ld = ld;
+    rb.row_base = s->row_base;
+    rb.dim = s->dim;
+    rb.entries = entries;
+    rb.metric = s->metric;
+    rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)nq), 64, 0, st>>>(rb);
+    HIPCHK(hipMemcpyAsync(b->h_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(b->e_done, st));
+  }
+  const double t_enq = now_us();
+  HIPCHK(hipEventSynchronize(b->e_done));
+  HIPCHK(hipGetLastError());
+  const double t_gpu = now_us();
+  float ms0 = 0.f, ms1 = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
+  HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
+  b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
+  b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  s->c_batches++;
+  for (int32_t q = 0; q < nq; ++q) {
+    const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
+    if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) redo->push_back(q);
+    else s->c_cands += h->count;
+  }
+  s->c_searches += nq - (int64_t)redo->size();
+  if (out->h_blocks) memcpy(out->h_blocks, b->h_blocks, (size_t)nq * bb);
+  if (out->d_blocks) {
+    hipStream_t us = out->user_stream ? out->user_stream : s->batch_stream;
+    HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
+    HIPCHK(hipStreamSynchronize(us));
+  }
+  if (trace_batch())
+    fprintf(stderr, "[tsh batch] nq=%d prep %.0f us, enqueue %.0f us, gpu wait %.0f us, post %.0f us (gemm %.0f us)\n", nq,
+            t_prep - t_in, t_enq - t_prep, t_gpu - t_enq, now_us() - t_gpu, b->last_gemm_us);
+  return TSH_OK;
+}
+
+// nq queries on one shard: matrix-core batch when it pays, single-query pipeline
+// otherwise and for whatever the batch hands back.
+int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
+                     const uint8_t *mask, int32_t entries, SearchOut *out) {
+  const bool use_batch = batch_min_nq > 0 && nq >= batch_min_nq && !s->safe_mode() && s->rows >= 4096 &&
+                         k <= 1024 && s->rows < 0x7FFFFF00ll;
+  if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
+  std::vector<int32_t> redo;
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  // the dense sample matrix (nq_pad x n_sample floats) is kept under 8 GB per call
+  const int64_t per_q = batch_sample_rows(s->rows, k) * 4;
+  const int32_t chunk = (int32_t)std::max<int64_t>(256, (int64_t)(8e9 / (double)per_q) / 256 * 256);
+  for (int32_t q0 = 0; q0 < nq; q0 += chunk) {
+    const int32_t nc = std::min(chunk, nq - q0);
+    SearchOut part;
+    part.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q0 * bb : nullptr;
+    part.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q0 * bb : nullptr;
+    part.user_stream = out->user_stream;
+    std::vector<int32_t> r;
+    int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);
+    if (rc) return rc;
+    for (int32_t q : r) redo.push_back(q0 + q);
+  }
+  int rc = TSH_OK;
+  for (int32_t q : redo) {
+    SearchOut one;
+    std::vector<std::vector<BlockEntry>> sp(1);
+    one.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q * bb : nullptr;
+    one.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr;
+    one.user_stream = out->user_stream;
+    one.spill = out->spill ? &sp : nullptr;
+    rc = shard_search_blocks(s, queries + (size_t)q * s->dim, 1, k, mask, entries, &one, 1);
+    if (rc) return rc;
+    if (out->spill) (*out->spill)[(size_t)q] = std::move(sp[0]);
+  }
+  return TSH_OK;
+}
+

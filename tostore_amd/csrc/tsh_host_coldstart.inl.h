@@ -1,0 +1,446 @@
+// tsh_host_coldstart.inl.h -- cold start from ToStore's files: raw-vector partition loader, meta.json, graph tombstones
+// Part of the single translation unit tsh_lib.hip (textually included there; not compiled alone).
+
+// ---- rawvec partition file loader -------------
+namespace {
+
+// IEEE CRC-32 (core/btree_page.dart:61-89: the reference's byte-at-a-time table loop), computed
+// eight bytes per step (slicing-by-8) -- same polynomial, same result
+uint32_t crc32_ieee(const uint8_t *p, size_t n) {
+  static uint32_t table[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+  });
+  uint32_t c = 0xFFFFFFFFu;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+        table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  for (size_t i = 0; i < n; ++i) c = table[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+inline uint32_t rd16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t rd32(const uint8_t *p) { return rd16(p) | (rd16(p + 2) << 16); }
+
+enum PageKind { PAGE_ERROR = -1, PAGE_EMPTY = 0, PAGE_OK = 1 };
+
+// Decodes one page into out (vpp x dim floats, pre-zeroed); *vcount = vectors present.
+PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int dim, int vpp, float *out,
+                            int *vcount) {
+  *vcount = vpp;  // an "empty" page is NghRawVectorPage.empty(capacity: vectorsPerRawPage)
+  if (avail == 0) return PAGE_EMPTY;              // ngh_partition_manager.dart:276-281
+  if (avail < 20) return PAGE_ERROR;              // btree_page.dart:162-163 -> StateError
+  if (rd32(pg) != 0x32475054u) return PAGE_ERROR; // 'TPG2'
+  if (rd16(pg + 4) != 20) return PAGE_ERROR;
+  if (pg[6] >= 10) return PAGE_ERROR;
+  uint32_t plen = rd32(pg + 8), crc = rd32(pg + 12);
+  if ((uint64_t)20 + plen > avail) return PAGE_ERROR;  // :221-224
+  const uint8_t *pl = pg + 20;
+  if (crc32_ieee(pl, plen) != crc) return PAGE_ERROR;  // :226-230
+  // NghRawVectorPage.tryDecodePayload, ngh_page.dart:431-450 (null -> empty page)
+  if (plen < 8) return PAGE_EMPTY;
+  uint32_t vc = rd16(pl), dims = rd16(pl + 2);
+  int prec = pl[4];
+  if (dims == 0) return PAGE_EMPTY;
+  int bpe = prec == 0 ? 8 : (prec == 2 ? 1 : 4);
+  if ((uint64_t)plen < 8 + (uint64_t)vc * dims * bpe) return PAGE_EMPTY;
+  if ((int)dims != dim) return PAGE_ERROR;  // not this index's column
+  int take = (int)std::min<uint32_t>(vc, (uint32_t)vpp);
+  const uint8_t *d = pl + 8;
+  if (prec == 1) {  // little-endian f32 on a little-endian host: the per-element getFloat32 loop is a copy
+    memcpy(out, d, (size_t)take * dim * sizeof(float));
+    *vcount = take;
+    return PAGE_OK;
+  }
+  for (int v = 0; v < take; ++v)
+    for (int i = 0; i < dim; ++i) {  // getVectorAsFloat32, ngh_page.dart:364-391
+      const uint8_t *e = d + ((size_t)v * dim + i) * bpe;
+      float f;
+      if (prec == 1) {
+        uint32_t u = rd32(e);
+        memcpy(&f, &u, 4);
+      } else if (prec == 0) {
+        uint64_t u = (uint64_t)rd32(e) | ((uint64_t)rd32(e + 4) << 32);
+        double dv;
+        memcpy(&dv, &u, 8);
+        f = (float)dv;
+      } else {
+        f = (float)((double)(int8_t)*e / 127.0);
+      }
+      out[(size_t)v * dim + i] = f;
+    }
+  *vcount = take;
+  (void)page_size;
+  return PAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size,
+                                              int32_t precision, int64_t first_row_id, int64_t max_rows,
+                                              int64_t *out_rows) {
+  if (out_rows) *out_rows = 0;
+  if (!idx || !path) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  if (page_size < 64 || precision < 0 || precision > 2 || first_row_id < 0 || max_rows < 0)
+    return set_err(TSH_E_BAD_ARG, "bad page_size / precision / row range");
+  int dim = idx->dim;
+  int bpe = precision == 0 ? 8 : (precision == 2 ? 1 : 4);
+  int usable = page_size - 20 - 8 - 64;  // ngh_page.dart:575-579
+  int vpp = usable > 0 ? usable / (dim * bpe) : 0;
+  if (vpp <= 0) return set_err(TSH_E_BAD_ARG, "page_size %d holds no %d-dim vector", page_size, dim);
+  FILE *f = fopen(path, "rb");
+  if (!f) return set_err(TSH_E_IO, "cannot open %s", path);
+  int64_t n_pages = (max_rows + vpp - 1) / vpp;  // data pages needed to cover the ids
+  const int BATCH = std::max(1, (int)((32 << 20) / ((int64_t)vpp * dim * 4)));
+  // one read per block of BATCH pages, pages decoded (CRC + copy / widen) in parallel on the host pool
+  std::vector<uint8_t> raw((size_t)BATCH * (size_t)page_size);
+  std::vector<float> rows((size_t)BATCH * vpp * dim);
+  std::vector<int> kinds((size_t)BATCH), counts((size_t)BATCH);
+  int64_t loaded = 0;
+  int rc = TSH_OK;
+  for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
+    int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
+    size_t got_total = 0;
+    if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // pageNo 0 is the partition meta page
+      got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
+    parallel_for((int32_t)nb, [&](int32_t b) {
+      const size_t off = (size_t)b * (size_t)page_size;
+      const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
+      float *dst = rows.data() + (size_t)b * vpp * dim;
+      int vc = 0;
+      PageKind k = decode_rawvec_page(raw.data() + off, got, page_size, dim, vpp, dst, &vc);
+      if (k != PAGE_OK) vc = k == PAGE_EMPTY ? vpp : 0;
+      if (k != PAGE_OK || vc < vpp)  // empty pages and slots past vectorCount read as zero vectors
+        std::fill(dst + (k == PAGE_OK ? (size_t)vc * dim : 0), dst + (size_t)vpp * dim, 0.f);
+      kinds[(size_t)b] = (int)k;
+      counts[(size_t)b] = vc;
+    });
+    // runs of consecutive present rows inside the batch are appended together
+    int64_t run_start = -1, run_len = 0;
+    auto flush = [&]() {
+      if (run_len > 0 && rc == TSH_OK) {
+        rc = tsh_index_append(idx, first_row_id + p0 * vpp + run_start, run_len,
+                              rows.data() + (size_t)run_start * dim);
+        if (rc == TSH_OK) loaded += run_len;
+      }
+      run_start = -1;
+      run_len = 0;
+    };
+    for (int64_t b = 0; b < nb && rc == TSH_OK; ++b) {
+      if (kinds[(size_t)b] == (int)PAGE_ERROR) {
+        flush();
+        if (rc == TSH_OK)
+          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path, (long long)(1 + p0 + b));
+        break;
+      }
+      int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
+      int64_t lim = std::min<int64_t>(counts[(size_t)b], max_rows - base);
+      if (lim <= 0) continue;
+      if (run_len > 0 && run_start + run_len == b * vpp) {
+        run_len += lim;
+      } else {
+        flush();
+        run_start = b * vpp;
+        run_len = lim;
+      }
+      if (lim < vpp) flush();  // slots past vectorCount are absent rows
+    }
+    flush();
+  }
+  fclose(f);
+  if (out_rows) *out_rows = loaded;
+  return rc;
+}
+
+// ---- open an on-disk NGH index directory (N1: meta.json + rawvec + graph tombstones) ----
+namespace {
+
+// Top-level scalar members of a JSON object (what NghIndexMeta.fromJson reads for the
+// fields used here, model/ngh_index_meta.dart:359-408); nested values are skipped.
+struct JsonScan {
+  const char *p, *end;
+  bool ok = true;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
+  bool lit(const char *w) {
+    size_t n = strlen(w);
+    if ((size_t)(end - p) >= n && memcmp(p, w, n) == 0) { p += n; return true; }
+    return false;
+  }
+  std::string str() {
+    std::string o;
+    if (p >= end || *p != '"') { ok = false; return o; }
+    for (++p; p < end && *p != '"'; ++p) {
+      if (*p == '\\' && p + 1 < end) {
+        ++p;
+        switch (*p) {
+          case 'n': o += '\n'; break;
+          case 't': o += '\t'; break;
+          case 'r': o += '\r'; break;
+          case 'b': o += '\b'; break;
+          case 'f': o += '\f'; break;
+          case 'u': o += '?'; p += (end - p > 4) ? 4 : 0; break;  // names only; not needed verbatim
+          default: o += *p;
+        }
+      } else {
+        o += *p;
+      }
+    }
+    if (p >= end) { ok = false; return o; }
+    ++p;
+    return o;
+  }
+  void skip() {  // any value
+    ws();
+    if (p >= end) { ok = false; return; }
+    if (*p == '"') { str(); return; }
+    if (*p == '{' || *p == '[') {
+      const char close = *p == '{' ? '}' : ']';
+      const bool obj = *p == '{';
+      ++p; ws();
+      if (p < end && *p == close) { ++p; return; }
+      while (ok) {
+        if (obj) { ws(); str(); ws(); if (p >= end || *p != ':') { ok = false; return; } ++p; }
+        skip(); ws();
+        if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == close) { ++p; return; }
+        ok = false;
+      }
+      return;
+    }
+    if (lit("true") || lit("false") || lit("null")) return;
+    const char *q = p;
+    while (p < end && (isdigit((unsigned char)*p) || *p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E')) ++p;
+    if (p == q) ok = false;
+  }
+};
+
+bool json_top_level(const std::string &text, std::map<std::string, std::string> &out) {
+  JsonScan j{text.data(), text.data() + text.size()};
+  j.ws();
+  if (j.p >= j.end || *j.p != '{') return false;
+  ++j.p; j.ws();
+  if (j.p < j.end && *j.p == '}') return true;
+  while (j.ok) {
+    j.ws();
+    std::string key = j.str();
+    j.ws();
+    if (!j.ok || j.p >= j.end || *j.p != ':') return false;
+    ++j.p; j.ws();
+    if (j.p < j.end && *j.p == '"') {
+      out[key] = j.str();
+    } else {
+      const char *q = j.p;
+      j.skip();
+      if (j.ok && *q != '{' && *q != '[') out[key] = std::string(q, j.p);
+    }
+    j.ws();
+    if (j.p < j.end && *j.p == ',') { ++j.p; continue; }
+    if (j.p < j.end && *j.p == '}') return j.ok;
+    return false;
+  }
+  return false;
+}
+
+// (json[k] as num?)?.toInt() ?? dflt -- Dart's toInt truncates a fractional number
+int64_t json_int(const std::map<std::string, std::string> &m, const char *k, int64_t dflt, bool *present = nullptr) {
+  auto it = m.find(k);
+  if (present) *present = false;
+  if (it == m.end() || it->second == "null" || it->second.empty()) return dflt;
+  char *e = nullptr;
+  double v = strtod(it->second.c_str(), &e);
+  if (e == it->second.c_str()) return dflt;
+  if (present) *present = true;
+  if (it->second.find_first_of(".eE") == std::string::npos) return strtoll(it->second.c_str(), nullptr, 10);
+  return (int64_t)v;
+}
+
+std::string ngh_partition_path(const std::string &dir, const char *category, int64_t partition, int64_t per_dir) {
+  // core/path_manager.dart:293-324: <ngh>/<category>/dir_{partition ~/ maxEntriesPerDir}/p{partition}.ngh
+  char buf[96];
+  snprintf(buf, sizeof buf, "/%s/dir_%lld/p%lld.ngh", category, (long long)(partition / per_dir), (long long)partition);
+  return dir + buf;
+}
+
+// Validates a page frame (BTreePageIO.parsePageBytes, core/btree_page.dart:215-233).
+// Returns payload pointer/len, nullptr + *err=false for "nothing there" and *err=true for a corrupt page.
+const uint8_t *page_payload(const uint8_t *pg, size_t avail, uint32_t *plen, int *type, bool *err) {
+  *err = false;
+  if (avail == 0) return nullptr;
+  *err = true;
+  if (avail < 20 || rd32(pg) != 0x32475054u || rd16(pg + 4) != 20 || pg[6] >= 10) return nullptr;
+  *plen = rd32(pg + 8);
+  if ((uint64_t)20 + *plen > avail) return nullptr;
+  if (crc32_ieee(pg + 20, *plen) != rd32(pg + 12)) return nullptr;
+  *type = pg[6];
+  *err = false;
+  return pg + 20;
+}
+
+}  // namespace
+
+extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices,
+                                      tsh_index **out, tsh_ngh_info *info) {
+  if (out) *out = nullptr;
+  if (info) memset(info, 0, sizeof *info);
+  if (!ngh_dir || !out) return set_err(TSH_E_BAD_ARG, "NULL pointer");
+  if (max_entries_per_dir <= 0) max_entries_per_dir = 500;  // handler/common.dart:43
+  const std::string dir(ngh_dir);
+  std::string text;
+  {
+    FILE *f = fopen((dir + "/meta.json").c_str(), "rb");
+    if (!f) return set_err(TSH_E_IO, "cannot open %s/meta.json", ngh_dir);
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+  }
+  std::map<std::string, std::string> m;
+  if (!json_top_level(text, m)) return set_err(TSH_E_FORMAT, "%s/meta.json is not a JSON object", ngh_dir);
+  bool has_dim = false;
+  const int64_t dim = json_int(m, "dimensions", 0, &has_dim);
+  if (!has_dim || dim < 1 || dim > 65535) return set_err(TSH_E_FORMAT, "meta.json: dimensions missing or out of range");
+  const std::string ms = m.count("distanceMetric") ? m["distanceMetric"] : "";
+  const int metric = ms == "l2" ? 0 : (ms == "innerProduct" ? 1 : 2);  // ngh_index_meta.dart:494-503
+  const std::string ps = m.count("precision") ? m["precision"] : "";
+  const int precision = ps == "float64" ? 0 : (ps == "int8" ? 2 : 1);  // :505-514
+  const int64_t next_id = json_int(m, "nextNodeId", 0);
+  const int64_t page_size = json_int(m, "nghPageSize", 16384);
+  const int64_t max_file = json_int(m, "maxPartitionFileSize", 16 * 1024 * 1024);
+  const int64_t max_degree = json_int(m, "maxDegree", 64);
+  if (page_size < 64 || page_size > (1 << 26) || next_id < 0 || max_degree < 1 || max_degree > 65535)
+    return set_err(TSH_E_FORMAT, "meta.json: nghPageSize / nextNodeId / maxDegree out of range");
+  const int bpe = precision == 0 ? 8 : (precision == 2 ? 1 : 4);
+  const int64_t usable_raw = page_size - 20 - 8 - 64;  // ngh_page.dart:575-579
+  const int64_t vpp = usable_raw > 0 ? usable_raw / (dim * bpe) : 0;
+  const int64_t usable_graph = page_size - 20 - 4 - 64;  // ngh_page.dart:556-565
+  const int64_t slot_size = 2 + max_degree * 4;
+  const int64_t npg = usable_graph > 0 ? usable_graph / slot_size : 0;
+  const int64_t ppp = max_file / page_size;  // ngh_index_meta.dart:178
+  if (vpp <= 0 || ppp <= 0) return set_err(TSH_E_FORMAT, "meta.json: a %lld-byte page holds no %lld-dim vector", (long long)page_size, (long long)dim);
+  if (info) {
+    info->dimensions = (int32_t)dim;
+    info->metric = metric;
+    info->precision = precision;
+    info->page_size = (int32_t)page_size;
+    info->max_degree = (int32_t)max_degree;
+    info->next_node_id = next_id;
+    info->total_vectors = json_int(m, "totalVectors", 0);
+    info->deleted_count = json_int(m, "deletedCount", 0);
+    info->max_partition_file_size = max_file;
+  }
+  tsh_index *idx = nullptr;
+  int32_t rc = tsh_index_create((int32_t)dim, metric, next_id, n_devices, &idx);
+  if (rc != TSH_OK) return rc;
+  // raw vectors: node id -> (partition, page, slot), ngh_index_meta.dart:480-490
+  int64_t rows_loaded = 0, files = 0;
+  const int64_t rows_per_part = ppp * vpp;
+  for (int64_t part = 0; rc == TSH_OK && part * rows_per_part < next_id; ++part) {
+    const int64_t first = part * rows_per_part, want = std::min(rows_per_part, next_id - first);
+    const std::string path = ngh_partition_path(dir, "rawvec", part, max_entries_per_dir);
+    if (access(path.c_str(), R_OK) == 0) {
+      int64_t got = 0;
+      rc = tsh_index_load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got);
+      rows_loaded += got;
+      ++files;
+    } else {
+      // a missing file reads as empty bytes -> NghRawVectorPage.empty(...): zero vectors
+      // (core/file_storage_impl.dart:387-415, ngh_partition_manager.dart:270-281)
+      const int64_t chunk = std::max<int64_t>(1, (8 << 20) / (dim * 4));
+      std::vector<float> zeros((size_t)std::min(chunk, want) * dim, 0.f);
+      for (int64_t o = 0; rc == TSH_OK && o < want; o += chunk) {
+        const int64_t nrow = std::min(chunk, want - o);
+        rc = tsh_index_append(idx, first + o, nrow, zeros.data());
+        if (rc == TSH_OK) rows_loaded += nrow;
+      }
+    }
+  }
+  // tombstones: flags byte of each graph slot (ngh_page.dart:105-108,198-213)
+  int64_t tombstones = 0;
+  if (rc == TSH_OK && npg > 0) {
+    const int64_t ids_per_part = ppp * npg;
+    const int64_t BLOCK = std::max<int64_t>(64, (32 << 20) / page_size);  // pages per read
+    std::vector<uint8_t> raw((size_t)BLOCK * (size_t)page_size);
+    std::vector<std::vector<int64_t>> found((size_t)BLOCK);  // per page, filled in parallel
+    std::vector<char> bad_page((size_t)BLOCK);
+    std::vector<int64_t> dead;
+    for (int64_t part = 0; rc == TSH_OK && part * ids_per_part < next_id; ++part) {
+      const std::string path = ngh_partition_path(dir, "graph", part, max_entries_per_dir);
+      FILE *f = fopen(path.c_str(), "rb");
+      if (!f) continue;  // no file: every page reads as NghGraphPage.empty -> flags 0
+      ++files;
+      const int64_t first = part * ids_per_part;
+      const int64_t n_pages = (std::min(ids_per_part, next_id - first) + npg - 1) / npg;
+      for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BLOCK) {
+        const int64_t nb = std::min(BLOCK, n_pages - p0);
+        size_t got_total = 0;
+        if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // page 0 is the partition meta page
+          got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
+        if (got_total == 0) break;  // past the end of the file: empty pages from here on
+        parallel_for((int32_t)nb, [&](int32_t b) {
+          found[(size_t)b].clear();
+          bad_page[(size_t)b] = 0;
+          const size_t off = (size_t)b * (size_t)page_size;
+          const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
+          uint32_t plen = 0;
+          int type = 0;
+          bool bad = false;
+          const uint8_t *pl = page_payload(raw.data() + off, got, &plen, &type, &bad);
+          if (bad) {
+            bad_page[(size_t)b] = 1;
+            return;
+          }
+          // NghGraphPage.tryDecodePayload, ngh_page.dart:193-222 (null -> empty page)
+          if (!pl || plen < 4) return;
+          const uint32_t slot_count = rd16(pl), deg = rd16(pl + 2);
+          if (deg == 0) return;
+          const uint64_t ss = 2 + (uint64_t)deg * 4;
+          if ((uint64_t)plen < 4 + slot_count * ss) return;
+          const int64_t base = first + (p0 + b) * npg;
+          for (uint32_t sl = 0; sl < slot_count && (int64_t)sl < npg; ++sl) {
+            const int64_t id = base + sl;
+            if (id >= next_id) break;
+            if (pl[4 + sl * ss] & 0x01) found[(size_t)b].push_back(id);
+          }
+        });
+        for (int64_t b = 0; b < nb; ++b) {
+          if (bad_page[(size_t)b]) {
+            rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path.c_str(), (long long)(1 + p0 + b));
+            break;
+          }
+          dead.insert(dead.end(), found[(size_t)b].begin(), found[(size_t)b].end());
+        }
+      }
+      fclose(f);
+    }
+    if (rc == TSH_OK && !dead.empty()) {
+      rc = tsh_index_set_deleted(idx, dead.data(), (int64_t)dead.size());
+      tombstones = (int64_t)dead.size();
+    }
+  }
+  if (rc != TSH_OK) {
+    const std::string keep = g_err;
+    tsh_index_destroy(idx);
+    return set_err(rc, "%s", keep.c_str());
+  }
+  if (info) {
+    info->rows_loaded = rows_loaded;
+    info->tombstones = tombstones;
+    info->files_read = files;
+  }
+  *out = idx;
+  return TSH_OK;
+}
+

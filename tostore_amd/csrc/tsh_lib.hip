@@ -1051,492 +1051,7 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   return TSH_OK;
 }
 
-// ---- batched (matrix-core) path ---------------------------------------------------
-struct BatchCtx {
-  std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
-  float *d_Q = nullptr, *h_Q = nullptr;
-  u32x4 *d_Qs = nullptr;  // bf16 planes of the padded queries
-  int64_t qs_cap = 0;     // in u32x4 units
-  float *d_qaux = nullptr, *h_qaux = nullptr;  // [qsq | delta2 | thr] x nq_pad
-  int64_t q_cap = 0, aux_cap = 0, cc_cap = 0;  // element capacities
-  float *d_dense = nullptr;
-  int64_t dense_cap = 0;  // floats
-  uint32_t *d_ck = nullptr, *d_cr = nullptr, *d_cc = nullptr;
-  int64_t cand_total = 0;  // nq * cand_cap capacity
-  uint8_t *d_blocks = nullptr, *h_blocks = nullptr;
-  uint32_t *d_final = nullptr;
-  int64_t blocks_cap = 0, final_cap = 0;
-  uint64_t *d_mask = nullptr, *h_mask = nullptr;
-  int64_t mask_words = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
-  int64_t bytes = 0;
-  double last_gemm_us = 0, last_flops = 0;
-};
-
-void batch_free(BatchCtx *b) {
-  hipFree(b->d_Q);
-  hipFree(b->d_Qs);
-  hipHostFree(b->h_Q);
-  hipFree(b->d_qaux);
-  hipHostFree(b->h_qaux);
-  hipFree(b->d_dense);
-  hipFree(b->d_ck);
-  hipFree(b->d_cr);
-  hipFree(b->d_cc);
-  hipFree(b->d_blocks);
-  hipHostFree(b->h_blocks);
-  hipFree(b->d_final);
-  hipFree(b->d_mask);
-  hipHostFree(b->h_mask);
-  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done})
-    if (e) hipEventDestroy(e);
-}
-
-template <typename T>
-int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
-  if (want <= *cap) return TSH_OK;
-  hipFree(*dev);
-  *dev = nullptr;
-  if (host) {
-    hipHostFree(*host);
-    *host = nullptr;
-  }
-  HIPCHK(hipMalloc(dev, (size_t)want * sizeof(T)));
-  if (host) HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
-  *bytes += (want - *cap) * (int64_t)sizeof(T);
-  *cap = want;
-  return TSH_OK;
-}
-
-template <int METRIC>
-void launch_batch_score(const BatchArgs &a, bool dense, hipStream_t st) {
-  int grid = a.q_tiles * a.n_tiles;
-  if (grid <= 0) return;
-  if (dense) batch_score_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
-  else batch_score_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
-}
-template <int METRIC>
-void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
-  int grid = a.q_tiles * a.n_tiles;
-  if (grid <= 0) return;
-  if (a.dot_scale != 0.f) {  // f16 variant
-    if (a.tile_m == 256) {
-      if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
-      else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
-    } else {
-      if (dense) batch_score_bf16x3_kernel<METRIC, true, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
-      else batch_score_bf16x3_kernel<METRIC, false, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
-    }
-    return;
-  }
-  if (a.tile_m == 256) {  // 256 x 256 tiles, 8 waves (batches of more than 128 queries)
-    if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128><<<grid, 512, 0, st>>>(a);
-    else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128><<<grid, 512, 0, st>>>(a);
-    return;
-  }
-  if (dense) batch_score_bf16x3_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
-  else batch_score_bf16x3_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
-}
-void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st) {
-  if (a.Vs) {
-    if (metric == TSH_METRIC_L2) launch_batch_score_bf16<METRIC_L2>(a, dense, st);
-    else if (metric == TSH_METRIC_IP) launch_batch_score_bf16<METRIC_IP>(a, dense, st);
-    else launch_batch_score_bf16<METRIC_COS>(a, dense, st);
-    return;
-  }
-  if (metric == TSH_METRIC_L2) launch_batch_score<METRIC_L2>(a, dense, st);
-  else if (metric == TSH_METRIC_IP) launch_batch_score<METRIC_IP>(a, dense, st);
-  else launch_batch_score<METRIC_COS>(a, dense, st);
-}
-
-int64_t batch_sample_rows(int64_t rows, int32_t k) {
-  if (rows <= 16384) return rows;
-  int64_t n = std::max<int64_t>(rows / 32, (int64_t)k * rows / 3000);
-  n = std::max<int64_t>(round_up(n, 256), 8192);  // whole row tiles of either tile shape
-  n = std::max<int64_t>(n, round_up((int64_t)k * 4, 256));
-  return std::min(n, rows);
-}
-
-// 2 * (error bound of the f32 MFMA key), absolute, per query
-bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2, float *out_qsq, float *out_qmax) {
-  double qn2 = 0;
-  float qmax = 0.f;
-  for (int i = 0; i < s->dim; ++i) {
-    float a = std::fabs(q[i]);
-    if (!(a <= BIG_ABS)) return false;
-    qmax = a > qmax ? a : qmax;
-    qn2 += (double)q[i] * (double)q[i];
-  }
-  if (out_qmax) *out_qmax = qmax;
-  const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
-  const double u2 = 1.1920928955078125e-07;        // 2^-23
-  double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
-  if (kernel == 1) {
-    // three partial products per k accumulate in f32 (chain of 3 ld terms, each product exact),
-    // and hi + lo drops 3.1 * 2^-18 |q_i||v_i| per element (tsh_batch.hip.h, bf16x3 variant)
-    const double hld = (double)round_up(s->dim, 32);
-    gam = (3.0 * hld + 8.0) * u2 * (1.0 + 0.00391) + 3.1 * 3.814697265625e-06;
-  } else if (kernel == 2) {
-    // both operands rounded to fp16 (2^-11 each, + their product), exact products accumulated in f32;
-    // 2^-21: the f32 scaling / normalisation before the rounding; 2^-30: fp16 subnormal steps, which
-    // sit >= 27 binades under the largest operand value after the power-of-two scaling
-    const double hld = (double)round_up(s->dim, 64);
-    // (a query is only batched when its largest element is within 2^8 of the batch's, see top_q)
-    gam = (hld + 8.0) * u2 * (1.0 + 0.001) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
-          std::sqrt(hld) * 9.3e-10;
-  }
-  double delta;
-  if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
-  else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07) * (kernel == 2 ? 1.0 + 1e-6 : 1.0);
-  else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
-  delta += (double)s->dim * 7.5e-37;
-  double d2 = 2.0 * delta * 1.0001;
-  if (!(d2 < 1e30)) return false;
-  *out_delta2 = (float)d2;
-  if ((double)*out_delta2 < d2) *out_delta2 = std::nextafter(*out_delta2, INFINITY);
-  *out_qsq = (float)qn2;
-  return true;
-}
-
-inline double now_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-inline bool trace_batch() {
-  static const bool on = getenv("TSH_TRACE_BATCH") != nullptr;
-  return on;
-}
-
-// All nq queries in one pass over the rows on the matrix cores.  Queries the
-// error model cannot cover, or whose lists overflow (ties), are reported in
-// *redo and answered by the single-query path.  Caller holds s->mu shared.
-int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
-                       const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo) {
-  std::lock_guard<std::mutex> lk(b->mu);
-  const double t_in = now_us();
-  HIPCHK(hipSetDevice(s->device));
-  const int64_t rows = s->rows, ld = s->ld;
-  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  // bf16x3 kernel: 256 x 256 tiles for batches of more than 128 queries, 128 x 128 otherwise
-  const int32_t tile = (s->batch_kernel != 0 && nq > 128) ? 256 : 128;  // (every kernel but the f32 one has both tiles)
-  const int32_t nq_pad = (int32_t)round_up(nq, tile);
-  // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
-  // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
-  const int64_t n_sample = batch_sample_rows(rows, k);
-  const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
-  const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
-  if (!b->e0) {
-    for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
-    HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming));
-  }
-  int rc;
-  if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
-  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 3, &b->bytes))) return rc;
-  if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
-  {
-    int64_t want = (int64_t)nq * cand_cap, c1 = b->cand_total, c2 = b->cand_total;
-    if ((rc = regrow(&b->d_ck, (uint32_t **)nullptr, &c1, want, &b->bytes))) return rc;
-    if ((rc = regrow(&b->d_cr, (uint32_t **)nullptr, &c2, want, &b->bytes))) return rc;
-    b->cand_total = std::max(b->cand_total, want);
-    if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad, &b->bytes))) return rc;
-  }
-  if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
-  if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
-  const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
-  if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
-
-  // ---- bf16x3 / f16 kernels: keep the converted planes of the rows current ----------------------
-  // auto: cosine keys are scale-free (unit rows, unit query), so fp16's fixed relative precision gives a
-  // band that is narrow against ANY data; IP / L2 bands scale with the largest row norm, where bf16x3's
-  // 25x tighter error keeps the candidate lists short when norms vary widely
-  // -- unless the rows are nearly equal in norm (the usual normalised embeddings), when f16 serves them too
-  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm;
-  int kern = s->batch_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : s->batch_kernel;
-  int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
-  if (kern == 2) {
-    const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
-    int e = 0;
-    if (top > 0.f) std::frexp(top, &e);  // top = m * 2^e, m in [0.5, 1)
-    v_exp = 14 - e;
-    if (v_exp > 55 || v_exp < -55) kern = 1;  // scales near the edge of f32's exponent range: bf16x3 instead
-  }
-  s->batch_kernel_last = kern;
-  const bool use_bf16 = kern == 1, use_f16 = kern == 2, use_planes = use_bf16 || use_f16;
-  const int32_t hchunks = use_f16 ? (int32_t)((s->dim + 63) / 64) : (int32_t)((s->dim + 31) / 32);
-  if (use_planes) {
-    const int64_t row_bytes = (int64_t)hchunks * 128;
-    if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
-    if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
-      if (s->d_split) hipFree(s->d_split);
-      s->d_split = nullptr;
-      s->bytes -= s->split_bytes;
-      s->split_bytes = 0;
-      s->split_cap = 0;
-      s->split_valid = 0;
-      HIPCHK(hipMalloc(&s->d_split, (size_t)s->cap * (size_t)row_bytes));
-      s->split_cap = s->cap;
-      s->split_bytes = s->cap * row_bytes;
-      s->bytes += s->split_bytes;
-    }
-    s->split_mode = kern;
-    s->split_exp = v_exp;
-    if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, (int64_t)nq_pad * hchunks * 8, &b->bytes))) return rc;
-  }
-
-  // ---- host prep: padded queries, per-query bands ------------------------------------
-  float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
-  std::vector<char> bad((size_t)nq, 0);
-  std::vector<float> qmax((size_t)nq_pad, 0.f);
-  parallel_for(nq_pad, [&](int32_t q) {
-    float *dst = b->h_Q + (size_t)q * ld;
-    if (q < nq) {
-      memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
-      for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
-      if (!batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q])) {
-        qmax[(size_t)q] = 0.f;
-        bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
-        memset(dst, 0, (size_t)ld * sizeof(float));
-        h_d2[q] = 0.f;
-        h_qsq[q] = 0.f;
-      }
-    } else {
-      memset(dst, 0, (size_t)ld * sizeof(float));
-      h_d2[q] = 0.f;
-      h_qsq[q] = 0.f;
-    }
-  });
-  // f16: one power-of-two scale for the whole batch; queries much smaller than the largest one would sit
-  // in fp16's subnormal range, so they are answered alone
-  float top_q = 0.f;
-  int q_exp = 0;
-  if (use_f16) {
-    for (int32_t q = 0; q < nq; ++q) top_q = std::max(top_q, qmax[(size_t)q]);
-    for (int32_t q = 0; q < nq; ++q)
-      if (!bad[(size_t)q] && !(qmax[(size_t)q] >= top_q * 0.00390625f)) {
-        bad[(size_t)q] = 1;
-        memset(b->h_Q + (size_t)q * ld, 0, (size_t)ld * sizeof(float));
-        h_d2[q] = 0.f;
-        h_qsq[q] = 0.f;
-      }
-    if (top_q > 0.f) {
-      int eq = 0;
-      std::frexp(top_q, &eq);
-      q_exp = 14 - eq;
-    }
-    if (q_exp > 55 || q_exp < -55) {  // same guard on the query side: answer them one by one
-      q_exp = 0;
-      for (int32_t q = 0; q < nq; ++q)
-        if (!bad[(size_t)q]) {
-          bad[(size_t)q] = 1;
-          memset(b->h_Q + (size_t)q * ld, 0, (size_t)ld * sizeof(float));
-          h_d2[q] = 0.f;
-          h_qsq[q] = 0.f;
-        }
-    }
-  }
-  if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
-
-  const double t_prep = now_us();
-  // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
-  {
-    hipStream_t st = s->batch_stream;
-    HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-    if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
-    float *d_qsq = b->d_qaux, *d_d2 = b->d_qaux + nq_pad, *d_thr = b->d_qaux + 2 * (size_t)nq_pad;
-    BatchArgs a{};
-    if (use_bf16) {
-      auto split = [&](const float *src, int64_t first, int64_t n, u32x4 *dst) {
-        SplitArgs sa{};
-        sa.rows = src;
-        sa.out = dst;
-        sa.ld = ld;
-        sa.first = first;
-        sa.n = n;
-        sa.dim = s->dim;
-        sa.hchunks = hchunks;
-        const int64_t total = n * hchunks * 4;
-        split_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(sa);
-      };
-      if (s->split_valid < rows) {
-        split(s->d_rows, s->split_valid, rows - s->split_valid, s->d_split);
-        s->split_valid = rows;
-      }
-      split(b->d_Q, 0, nq_pad, b->d_Qs);
-      a.Qs = b->d_Qs;
-      a.Vs = s->d_split;
-      a.hchunks = hchunks;
-    } else if (use_f16) {
-      auto half = [&](const float *src, const float *inv, int64_t first, int64_t n, u32x4 *dst, int e) {
-        HalfArgs ha{};
-        ha.rows = src;
-        ha.inv_norm = inv;
-        ha.out = dst;
-        ha.ld = ld;
-        ha.first = first;
-        ha.n = n;
-        ha.dim = s->dim;
-        ha.hchunks = hchunks;
-        ha.scale = std::ldexp(1.0f, e);
-        const int64_t total = n * hchunks * 8;
-        half_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
-      };
-      if (s->split_valid < rows) {
-        half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, s->split_valid,
-             rows - s->split_valid, s->d_split, v_exp);
-        s->split_valid = rows;
-      }
-      half(b->d_Q, nullptr, 0, nq_pad, b->d_Qs, q_exp);
-      a.Qs = b->d_Qs;
-      a.Vs = s->d_split;
-      a.hchunks = hchunks;
-      a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
-    }
-    a.Q = b->d_Q;
-    a.V = s->d_rows;
-    a.inv_norm = use_f16 ? nullptr : s->d_inv_norm;  // f16 planes of a cosine corpus hold unit rows
-    a.sqnorm = s->d_sqnorm;
-    a.qsq = d_qsq;
-    a.thr = d_thr;
-    a.live = s->all_live ? nullptr : s->d_live;
-    a.mask = mask ? b->d_mask : nullptr;
-    a.dense = b->d_dense;
-    a.cand_key = b->d_ck;
-    a.cand_row = b->d_cr;
-    a.cand_cnt = b->d_cc;
-    a.ld = ld;
-    a.dense_ld = n_sample;
-    a.nq = nq;
-    a.nq_pad = nq_pad;
-    a.kchunks = (int32_t)((ld + BT_K - 1) / BT_K);
-    a.cand_cap = cand_cap;
-    a.tile_m = tile;
-    a.q_tiles = nq_pad / tile;
-    // B0: dense keys of the sample rows
-    a.row0 = 0;
-    a.row1 = (int32_t)n_sample;
-    a.n_tiles = (int32_t)((n_sample + tile - 1) / tile);
-    HIPCHK(hipEventRecord(b->e0, st));
-    launch_batch_score_m(s->metric, a, true, st);
-    HIPCHK(hipEventRecord(b->e1, st));
-    // B0s: per-query threshold + the sample's own candidates
-    SampleSelArgs ss{};
-    ss.dense = b->d_dense;
-    ss.delta2 = d_d2;
-    ss.thr = d_thr;
-    ss.cand_key = b->d_ck;
-    ss.cand_row = b->d_cr;
-    ss.cand_cnt = b->d_cc;
-    ss.dense_ld = n_sample;
-    ss.n_sample = (int32_t)n_sample;
-    ss.k = k;
-    ss.cand_cap = cand_cap;
-    ss.row0 = 0;
-    batch_sample_select_kernel<<<nq, BS_THREADS, 0, st>>>(ss);
-    // B1: everything else, filtered
-    HIPCHK(hipEventRecord(b->e2, st));
-    if (rows > n_sample) {
-      a.row0 = (int32_t)n_sample;
-      a.row1 = (int32_t)rows;
-      a.n_tiles = (int32_t)((rows - n_sample + tile - 1) / tile);
-      launch_batch_score_m(s->metric, a, false, st);
-    }
-    HIPCHK(hipEventRecord(b->e3, st));
-    // B2 + rerank
-    FinalSelArgs fs{};
-    fs.cand_key = b->d_ck;
-    fs.cand_row = b->d_cr;
-    fs.cand_cnt = b->d_cc;
-    fs.delta2 = d_d2;
-    fs.blocks = b->d_blocks;
-    fs.final_rows = b->d_final;
-    fs.block_bytes = (int64_t)bb;
-    fs.row_base = s->row_base;
-    fs.shard_rows = rows;
-    fs.k = k;
-    fs.cand_cap = cand_cap;
-    fs.entries = entries;
-    fs.metric = s->metric;
-    batch_final_select_kernel<<<nq, BS_THREADS, 0, st>>>(fs);
-    RerankBatchArgs rb{};
-    rb.rows = s->d_rows;
-    rb.Q = b->d_Q;
-    rb.final_rows = b->d_final;
-    rb.blocks = b->d_blocks;
-    rb.block_bytes = (int64_t)bb;
-    rb.ld = ld;
-    rb.row_base = s->row_base;
-    rb.dim = s->dim;
-    rb.entries = entries;
-    rb.metric = s->metric;
-    rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)nq), 64, 0, st>>>(rb);
-    HIPCHK(hipMemcpyAsync(b->h_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(b->e_done, st));
-  }
-  const double t_enq = now_us();
-  HIPCHK(hipEventSynchronize(b->e_done));
-  HIPCHK(hipGetLastError());
-  const double t_gpu = now_us();
-  float ms0 = 0.f, ms1 = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
-  HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
-  b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
-  b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
-  s->c_batches++;
-  for (int32_t q = 0; q < nq; ++q) {
-    const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
-    if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) redo->push_back(q);
-    else s->c_cands += h->count;
-  }
-  s->c_searches += nq - (int64_t)redo->size();
-  if (out->h_blocks) memcpy(out->h_blocks, b->h_blocks, (size_t)nq * bb);
-  if (out->d_blocks) {
-    hipStream_t us = out->user_stream ? out->user_stream : s->batch_stream;
-    HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
-    HIPCHK(hipStreamSynchronize(us));
-  }
-  if (trace_batch())
-    fprintf(stderr, "[tsh batch] nq=%d prep %.0f us, enqueue %.0f us, gpu wait %.0f us, post %.0f us (gemm %.0f us)\n", nq,
-            t_prep - t_in, t_enq - t_prep, t_gpu - t_enq, now_us() - t_gpu, b->last_gemm_us);
-  return TSH_OK;
-}
-
-// nq queries on one shard: matrix-core batch when it pays, single-query pipeline
-// otherwise and for whatever the batch hands back.
-int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
-                     const uint8_t *mask, int32_t entries, SearchOut *out) {
-  const bool use_batch = batch_min_nq > 0 && nq >= batch_min_nq && !s->safe_mode() && s->rows >= 4096 &&
-                         k <= 1024 && s->rows < 0x7FFFFF00ll;
-  if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
-  std::vector<int32_t> redo;
-  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  // the dense sample matrix (nq_pad x n_sample floats) is kept under 8 GB per call
-  const int64_t per_q = batch_sample_rows(s->rows, k) * 4;
-  const int32_t chunk = (int32_t)std::max<int64_t>(256, (int64_t)(8e9 / (double)per_q) / 256 * 256);
-  for (int32_t q0 = 0; q0 < nq; q0 += chunk) {
-    const int32_t nc = std::min(chunk, nq - q0);
-    SearchOut part;
-    part.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q0 * bb : nullptr;
-    part.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q0 * bb : nullptr;
-    part.user_stream = out->user_stream;
-    std::vector<int32_t> r;
-    int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);
-    if (rc) return rc;
-    for (int32_t q : r) redo.push_back(q0 + q);
-  }
-  int rc = TSH_OK;
-  for (int32_t q : redo) {
-    SearchOut one;
-    std::vector<std::vector<BlockEntry>> sp(1);
-    one.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q * bb : nullptr;
-    one.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr;
-    one.user_stream = out->user_stream;
-    one.spill = out->spill ? &sp : nullptr;
-    rc = shard_search_blocks(s, queries + (size_t)q * s->dim, 1, k, mask, entries, &one, 1);
-    if (rc) return rc;
-    if (out->spill) (*out->spill)[(size_t)q] = std::move(sp[0]);
-  }
-  return TSH_OK;
-}
+#include "tsh_host_batch.inl.h"  // batched (matrix-core) path, host side
 
 }  // namespace
 
@@ -2151,573 +1666,5 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
 
 }  // extern "C"
 
-// ---- rawvec partition file loader -------------
-namespace {
-
-// IEEE CRC-32 (core/btree_page.dart:61-89: the reference's byte-at-a-time table loop), computed
-// eight bytes per step (slicing-by-8) -- same polynomial, same result
-uint32_t crc32_ieee(const uint8_t *p, size_t n) {
-  static uint32_t table[8][256];
-  static std::once_flag once;
-  std::call_once(once, [] {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-      table[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i)
-      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
-  });
-  uint32_t c = 0xFFFFFFFFu;
-  while (n >= 8) {
-    uint32_t lo, hi;
-    memcpy(&lo, p, 4);
-    memcpy(&hi, p + 4, 4);
-    lo ^= c;
-    c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
-        table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
-    p += 8;
-    n -= 8;
-  }
-  for (size_t i = 0; i < n; ++i) c = table[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
-  return c ^ 0xFFFFFFFFu;
-}
-inline uint32_t rd16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
-inline uint32_t rd32(const uint8_t *p) { return rd16(p) | (rd16(p + 2) << 16); }
-
-enum PageKind { PAGE_ERROR = -1, PAGE_EMPTY = 0, PAGE_OK = 1 };
-
-// Decodes one page into out (vpp x dim floats, pre-zeroed); *vcount = vectors present.
-PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int dim, int vpp, float *out,
-                            int *vcount) {
-  *vcount = vpp;  // an "empty" page is NghRawVectorPage.empty(capacity: vectorsPerRawPage)
-  if (avail == 0) return PAGE_EMPTY;              // ngh_partition_manager.dart:276-281
-  if (avail < 20) return PAGE_ERROR;              // btree_page.dart:162-163 -> StateError
-  if (rd32(pg) != 0x32475054u) return PAGE_ERROR; // 'TPG2'
-  if (rd16(pg + 4) != 20) return PAGE_ERROR;
-  if (pg[6] >= 10) return PAGE_ERROR;
-  uint32_t plen = rd32(pg + 8), crc = rd32(pg + 12);
-  if ((uint64_t)20 + plen > avail) return PAGE_ERROR;  // :221-224
-  const uint8_t *pl = pg + 20;
-  if (crc32_ieee(pl, plen) != crc) return PAGE_ERROR;  // :226-230
-  // NghRawVectorPage.tryDecodePayload, ngh_page.dart:431-450 (null -> empty page)
-  if (plen < 8) return PAGE_EMPTY;
-  uint32_t vc = rd16(pl), dims = rd16(pl + 2);
-  int prec = pl[4];
-  if (dims == 0) return PAGE_EMPTY;
-  int bpe = prec == 0 ? 8 : (prec == 2 ? 1 : 4);
-  if ((uint64_t)plen < 8 + (uint64_t)vc * dims * bpe) return PAGE_EMPTY;
-  if ((int)dims != dim) return PAGE_ERROR;  // not this index's column
-  int take = (int)std::min<uint32_t>(vc, (uint32_t)vpp);
-  const uint8_t *d = pl + 8;
-  if (prec == 1) {  // little-endian f32 on a little-endian host: the per-element getFloat32 loop is a copy
-    memcpy(out, d, (size_t)take * dim * sizeof(float));
-    *vcount = take;
-    return PAGE_OK;
-  }
-  for (int v = 0; v < take; ++v)
-    for (int i = 0; i < dim; ++i) {  // getVectorAsFloat32, ngh_page.dart:364-391
-      const uint8_t *e = d + ((size_t)v * dim + i) * bpe;
-      float f;
-      if (prec == 1) {
-        uint32_t u = rd32(e);
-        memcpy(&f, &u, 4);
-      } else if (prec == 0) {
-        uint64_t u = (uint64_t)rd32(e) | ((uint64_t)rd32(e + 4) << 32);
-        double dv;
-        memcpy(&dv, &u, 8);
-        f = (float)dv;
-      } else {
-        f = (float)((double)(int8_t)*e / 127.0);
-      }
-      out[(size_t)v * dim + i] = f;
-    }
-  *vcount = take;
-  (void)page_size;
-  return PAGE_OK;
-}
-
-}  // namespace
-
-extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size,
-                                              int32_t precision, int64_t first_row_id, int64_t max_rows,
-                                              int64_t *out_rows) {
-  if (out_rows) *out_rows = 0;
-  if (!idx || !path) return set_err(TSH_E_BAD_ARG, "NULL pointer");
-  if (page_size < 64 || precision < 0 || precision > 2 || first_row_id < 0 || max_rows < 0)
-    return set_err(TSH_E_BAD_ARG, "bad page_size / precision / row range");
-  int dim = idx->dim;
-  int bpe = precision == 0 ? 8 : (precision == 2 ? 1 : 4);
-  int usable = page_size - 20 - 8 - 64;  // ngh_page.dart:575-579
-  int vpp = usable > 0 ? usable / (dim * bpe) : 0;
-  if (vpp <= 0) return set_err(TSH_E_BAD_ARG, "page_size %d holds no %d-dim vector", page_size, dim);
-  FILE *f = fopen(path, "rb");
-  if (!f) return set_err(TSH_E_IO, "cannot open %s", path);
-  int64_t n_pages = (max_rows + vpp - 1) / vpp;  // data pages needed to cover the ids
-  const int BATCH = std::max(1, (int)((32 << 20) / ((int64_t)vpp * dim * 4)));
-  // one read per block of BATCH pages, pages decoded (CRC + copy / widen) in parallel on the host pool
-  std::vector<uint8_t> raw((size_t)BATCH * (size_t)page_size);
-  std::vector<float> rows((size_t)BATCH * vpp * dim);
-  std::vector<int> kinds((size_t)BATCH), counts((size_t)BATCH);
-  int64_t loaded = 0;
-  int rc = TSH_OK;
-  for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
-    int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
-    size_t got_total = 0;
-    if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // pageNo 0 is the partition meta page
-      got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
-    parallel_for((int32_t)nb, [&](int32_t b) {
-      const size_t off = (size_t)b * (size_t)page_size;
-      const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
-      float *dst = rows.data() + (size_t)b * vpp * dim;
-      int vc = 0;
-      PageKind k = decode_rawvec_page(raw.data() + off, got, page_size, dim, vpp, dst, &vc);
-      if (k != PAGE_OK) vc = k == PAGE_EMPTY ? vpp : 0;
-      if (k != PAGE_OK || vc < vpp)  // empty pages and slots past vectorCount read as zero vectors
-        std::fill(dst + (k == PAGE_OK ? (size_t)vc * dim : 0), dst + (size_t)vpp * dim, 0.f);
-      kinds[(size_t)b] = (int)k;
-      counts[(size_t)b] = vc;
-    });
-    // runs of consecutive present rows inside the batch are appended together
-    int64_t run_start = -1, run_len = 0;
-    auto flush = [&]() {
-      if (run_len > 0 && rc == TSH_OK) {
-        rc = tsh_index_append(idx, first_row_id + p0 * vpp + run_start, run_len,
-                              rows.data() + (size_t)run_start * dim);
-        if (rc == TSH_OK) loaded += run_len;
-      }
-      run_start = -1;
-      run_len = 0;
-    };
-    for (int64_t b = 0; b < nb && rc == TSH_OK; ++b) {
-      if (kinds[(size_t)b] == (int)PAGE_ERROR) {
-        flush();
-        if (rc == TSH_OK)
-          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path, (long long)(1 + p0 + b));
-        break;
-      }
-      int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
-      int64_t lim = std::min<int64_t>(counts[(size_t)b], max_rows - base);
-      if (lim <= 0) continue;
-      if (run_len > 0 && run_start + run_len == b * vpp) {
-        run_len += lim;
-      } else {
-        flush();
-        run_start = b * vpp;
-        run_len = lim;
-      }
-      if (lim < vpp) flush();  // slots past vectorCount are absent rows
-    }
-    flush();
-  }
-  fclose(f);
-  if (out_rows) *out_rows = loaded;
-  return rc;
-}
-
-// ---- open an on-disk NGH index directory (N1: meta.json + rawvec + graph tombstones) ----
-namespace {
-
-// Top-level scalar members of a JSON object (what NghIndexMeta.fromJson reads for the
-// fields used here, model/ngh_index_meta.dart:359-408); nested values are skipped.
-struct JsonScan {
-  const char *p, *end;
-  bool ok = true;
-  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
-  bool lit(const char *w) {
-    size_t n = strlen(w);
-    if ((size_t)(end - p) >= n && memcmp(p, w, n) == 0) { p += n; return true; }
-    return false;
-  }
-  std::string str() {
-    std::string o;
-    if (p >= end || *p != '"') { ok = false; return o; }
-    for (++p; p < end && *p != '"'; ++p) {
-      if (*p == '\\' && p + 1 < end) {
-        ++p;
-        switch (*p) {
-          case 'n': o += '\n'; break;
-          case 't': o += '\t'; break;
-          case 'r': o += '\r'; break;
-          case 'b': o += '\b'; break;
-          case 'f': o += '\f'; break;
-          case 'u': o += '?'; p += (end - p > 4) ? 4 : 0; break;  // names only; not needed verbatim
-          default: o += *p;
-        }
-      } else {
-        o += *p;
-      }
-    }
-    if (p >= end) { ok = false; return o; }
-    ++p;
-    return o;
-  }
-  void skip() {  // any value
-    ws();
-    if (p >= end) { ok = false; return; }
-    if (*p == '"') { str(); return; }
-    if (*p == '{' || *p == '[') {
-      const char close = *p == '{' ? '}' : ']';
-      const bool obj = *p == '{';
-      ++p; ws();
-      if (p < end && *p == close) { ++p; return; }
-      while (ok) {
-        if (obj) { ws(); str(); ws(); if (p >= end || *p != ':') { ok = false; return; } ++p; }
-        skip(); ws();
-        if (p < end && *p == ',') { ++p; continue; }
-        if (p < end && *p == close) { ++p; return; }
-        ok = false;
-      }
-      return;
-    }
-    if (lit("true") || lit("false") || lit("null")) return;
-    const char *q = p;
-    while (p < end && (isdigit((unsigned char)*p) || *p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E')) ++p;
-    if (p == q) ok = false;
-  }
-};
-
-bool json_top_level(const std::string &text, std::map<std::string, std::string> &out) {
-  JsonScan j{text.data(), text.data() + text.size()};
-  j.ws();
-  if (j.p >= j.end || *j.p != '{') return false;
-  ++j.p; j.ws();
-  if (j.p < j.end && *j.p == '}') return true;
-  while (j.ok) {
-    j.ws();
-    std::string key = j.str();
-    j.ws();
-    if (!j.ok || j.p >= j.end || *j.p != ':') return false;
-    ++j.p; j.ws();
-    if (j.p < j.end && *j.p == '"') {
-      out[key] = j.str();
-    } else {
-      const char *q = j.p;
-      j.skip();
-      if (j.ok && *q != '{' && *q != '[') out[key] = std::string(q, j.p);
-    }
-    j.ws();
-    if (j.p < j.end && *j.p == ',') { ++j.p; continue; }
-    if (j.p < j.end && *j.p == '}') return j.ok;
-    return false;
-  }
-  return false;
-}
-
-// (json[k] as num?)?.toInt() ?? dflt -- Dart's toInt truncates a fractional number
-int64_t json_int(const std::map<std::string, std::string> &m, const char *k, int64_t dflt, bool *present = nullptr) {
-  auto it = m.find(k);
-  if (present) *present = false;
-  if (it == m.end() || it->second == "null" || it->second.empty()) return dflt;
-  char *e = nullptr;
-  double v = strtod(it->second.c_str(), &e);
-  if (e == it->second.c_str()) return dflt;
-  if (present) *present = true;
-  if (it->second.find_first_of(".eE") == std::string::npos) return strtoll(it->second.c_str(), nullptr, 10);
-  return (int64_t)v;
-}
-
-std::string ngh_partition_path(const std::string &dir, const char *category, int64_t partition, int64_t per_dir) {
-  // core/path_manager.dart:293-324: <ngh>/<category>/dir_{partition ~/ maxEntriesPerDir}/p{partition}.ngh
-  char buf[96];
-  snprintf(buf, sizeof buf, "/%s/dir_%lld/p%lld.ngh", category, (long long)(partition / per_dir), (long long)partition);
-  return dir + buf;
-}
-
-// Validates a page frame (BTreePageIO.parsePageBytes, core/btree_page.dart:215-233).
-// Returns payload pointer/len, nullptr + *err=false for "nothing there" and *err=true for a corrupt page.
-const uint8_t *page_payload(const uint8_t *pg, size_t avail, uint32_t *plen, int *type, bool *err) {
-  *err = false;
-  if (avail == 0) return nullptr;
-  *err = true;
-  if (avail < 20 || rd32(pg) != 0x32475054u || rd16(pg + 4) != 20 || pg[6] >= 10) return nullptr;
-  *plen = rd32(pg + 8);
-  if ((uint64_t)20 + *plen > avail) return nullptr;
-  if (crc32_ieee(pg + 20, *plen) != rd32(pg + 12)) return nullptr;
-  *type = pg[6];
-  *err = false;
-  return pg + 20;
-}
-
-}  // namespace
-
-extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices,
-                                      tsh_index **out, tsh_ngh_info *info) {
-  if (out) *out = nullptr;
-  if (info) memset(info, 0, sizeof *info);
-  if (!ngh_dir || !out) return set_err(TSH_E_BAD_ARG, "NULL pointer");
-  if (max_entries_per_dir <= 0) max_entries_per_dir = 500;  // handler/common.dart:43
-  const std::string dir(ngh_dir);
-  std::string text;
-  {
-    FILE *f = fopen((dir + "/meta.json").c_str(), "rb");
-    if (!f) return set_err(TSH_E_IO, "cannot open %s/meta.json", ngh_dir);
-    char buf[4096];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
-    fclose(f);
-  }
-  std::map<std::string, std::string> m;
-  if (!json_top_level(text, m)) return set_err(TSH_E_FORMAT, "%s/meta.json is not a JSON object", ngh_dir);
-  bool has_dim = false;
-  const int64_t dim = json_int(m, "dimensions", 0, &has_dim);
-  if (!has_dim || dim < 1 || dim > 65535) return set_err(TSH_E_FORMAT, "meta.json: dimensions missing or out of range");
-  const std::string ms = m.count("distanceMetric") ? m["distanceMetric"] : "";
-  const int metric = ms == "l2" ? 0 : (ms == "innerProduct" ? 1 : 2);  // ngh_index_meta.dart:494-503
-  const std::string ps = m.count("precision") ? m["precision"] : "";
-  const int precision = ps == "float64" ? 0 : (ps == "int8" ? 2 : 1);  // :505-514
-  const int64_t next_id = json_int(m, "nextNodeId", 0);
-  const int64_t page_size = json_int(m, "nghPageSize", 16384);
-  const int64_t max_file = json_int(m, "maxPartitionFileSize", 16 * 1024 * 1024);
-  const int64_t max_degree = json_int(m, "maxDegree", 64);
-  if (page_size < 64 || page_size > (1 << 26) || next_id < 0 || max_degree < 1 || max_degree > 65535)
-    return set_err(TSH_E_FORMAT, "meta.json: nghPageSize / nextNodeId / maxDegree out of range");
-  const int bpe = precision == 0 ? 8 : (precision == 2 ? 1 : 4);
-  const int64_t usable_raw = page_size - 20 - 8 - 64;  // ngh_page.dart:575-579
-  const int64_t vpp = usable_raw > 0 ? usable_raw / (dim * bpe) : 0;
-  const int64_t usable_graph = page_size - 20 - 4 - 64;  // ngh_page.dart:556-565
-  const int64_t slot_size = 2 + max_degree * 4;
-  const int64_t npg = usable_graph > 0 ? usable_graph / slot_size : 0;
-  const int64_t ppp = max_file / page_size;  // ngh_index_meta.dart:178
-  if (vpp <= 0 || ppp <= 0) return set_err(TSH_E_FORMAT, "meta.json: a %lld-byte page holds no %lld-dim vector", (long long)page_size, (long long)dim);
-  if (info) {
-    info->dimensions = (int32_t)dim;
-    info->metric = metric;
-    info->precision = precision;
-    info->page_size = (int32_t)page_size;
-    info->max_degree = (int32_t)max_degree;
-    info->next_node_id = next_id;
-    info->total_vectors = json_int(m, "totalVectors", 0);
-    info->deleted_count = json_int(m, "deletedCount", 0);
-    info->max_partition_file_size = max_file;
-  }
-  tsh_index *idx = nullptr;
-  int32_t rc = tsh_index_create((int32_t)dim, metric, next_id, n_devices, &idx);
-  if (rc != TSH_OK) return rc;
-  // raw vectors: node id -> (partition, page, slot), ngh_index_meta.dart:480-490
-  int64_t rows_loaded = 0, files = 0;
-  const int64_t rows_per_part = ppp * vpp;
-  for (int64_t part = 0; rc == TSH_OK && part * rows_per_part < next_id; ++part) {
-    const int64_t first = part * rows_per_part, want = std::min(rows_per_part, next_id - first);
-    const std::string path = ngh_partition_path(dir, "rawvec", part, max_entries_per_dir);
-    if (access(path.c_str(), R_OK) == 0) {
-      int64_t got = 0;
-      rc = tsh_index_load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got);
-      rows_loaded += got;
-      ++files;
-    } else {
-      // a missing file reads as empty bytes -> NghRawVectorPage.empty(...): zero vectors
-      // (core/file_storage_impl.dart:387-415, ngh_partition_manager.dart:270-281)
-      const int64_t chunk = std::max<int64_t>(1, (8 << 20) / (dim * 4));
-      std::vector<float> zeros((size_t)std::min(chunk, want) * dim, 0.f);
-      for (int64_t o = 0; rc == TSH_OK && o < want; o += chunk) {
-        const int64_t nrow = std::min(chunk, want - o);
-        rc = tsh_index_append(idx, first + o, nrow, zeros.data());
-        if (rc == TSH_OK) rows_loaded += nrow;
-      }
-    }
-  }
-  // tombstones: flags byte of each graph slot (ngh_page.dart:105-108,198-213)
-  int64_t tombstones = 0;
-  if (rc == TSH_OK && npg > 0) {
-    const int64_t ids_per_part = ppp * npg;
-    const int64_t BLOCK = std::max<int64_t>(64, (32 << 20) / page_size);  // pages per read
-    std::vector<uint8_t> raw((size_t)BLOCK * (size_t)page_size);
-    std::vector<std::vector<int64_t>> found((size_t)BLOCK);  // per page, filled in parallel
-    std::vector<char> bad_page((size_t)BLOCK);
-    std::vector<int64_t> dead;
-    for (int64_t part = 0; rc == TSH_OK && part * ids_per_part < next_id; ++part) {
-      const std::string path = ngh_partition_path(dir, "graph", part, max_entries_per_dir);
-      FILE *f = fopen(path.c_str(), "rb");
-      if (!f) continue;  // no file: every page reads as NghGraphPage.empty -> flags 0
-      ++files;
-      const int64_t first = part * ids_per_part;
-      const int64_t n_pages = (std::min(ids_per_part, next_id - first) + npg - 1) / npg;
-      for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BLOCK) {
-        const int64_t nb = std::min(BLOCK, n_pages - p0);
-        size_t got_total = 0;
-        if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // page 0 is the partition meta page
-          got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
-        if (got_total == 0) break;  // past the end of the file: empty pages from here on
-        parallel_for((int32_t)nb, [&](int32_t b) {
-          found[(size_t)b].clear();
-          bad_page[(size_t)b] = 0;
-          const size_t off = (size_t)b * (size_t)page_size;
-          const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
-          uint32_t plen = 0;
-          int type = 0;
-          bool bad = false;
-          const uint8_t *pl = page_payload(raw.data() + off, got, &plen, &type, &bad);
-          if (bad) {
-            bad_page[(size_t)b] = 1;
-            return;
-          }
-          // NghGraphPage.tryDecodePayload, ngh_page.dart:193-222 (null -> empty page)
-          if (!pl || plen < 4) return;
-          const uint32_t slot_count = rd16(pl), deg = rd16(pl + 2);
-          if (deg == 0) return;
-          const uint64_t ss = 2 + (uint64_t)deg * 4;
-          if ((uint64_t)plen < 4 + slot_count * ss) return;
-          const int64_t base = first + (p0 + b) * npg;
-          for (uint32_t sl = 0; sl < slot_count && (int64_t)sl < npg; ++sl) {
-            const int64_t id = base + sl;
-            if (id >= next_id) break;
-            if (pl[4 + sl * ss] & 0x01) found[(size_t)b].push_back(id);
-          }
-        });
-        for (int64_t b = 0; b < nb; ++b) {
-          if (bad_page[(size_t)b]) {
-            rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path.c_str(), (long long)(1 + p0 + b));
-            break;
-          }
-          dead.insert(dead.end(), found[(size_t)b].begin(), found[(size_t)b].end());
-        }
-      }
-      fclose(f);
-    }
-    if (rc == TSH_OK && !dead.empty()) {
-      rc = tsh_index_set_deleted(idx, dead.data(), (int64_t)dead.size());
-      tombstones = (int64_t)dead.size();
-    }
-  }
-  if (rc != TSH_OK) {
-    const std::string keep = g_err;
-    tsh_index_destroy(idx);
-    return set_err(rc, "%s", keep.c_str());
-  }
-  if (info) {
-    info->rows_loaded = rows_loaded;
-    info->tombstones = tombstones;
-    info->files_read = files;
-  }
-  *out = idx;
-  return TSH_OK;
-}
-
-// ---- N4: batch PQ encode of resident rows -------------------------------------------
-extern "C" int32_t tsh_pq_train(int32_t device, const float *samples, int64_t n, int32_t dim, int32_t subspaces,
-                                int32_t centroids, int32_t iterations, const int32_t *init_index,
-                                float *out_codebook) {
-  if (!samples || !init_index || !out_codebook) return set_err(TSH_E_BAD_ARG, "NULL pointer");
-  if (n < 1 || n > (1 << 24) || dim < 1) return set_err(TSH_E_BAD_ARG, "samples %lld x %d out of range", (long long)n, dim);
-  if (subspaces < 1 || subspaces > dim || centroids < 1 || centroids > 256 || iterations < 0)
-    return set_err(TSH_E_BAD_ARG, "subspaces %d / centroids %d / iterations %d out of range", subspaces, centroids,
-                   iterations);
-  const int32_t sd = dim / subspaces;
-  if (sd < 1 || sd > 64) return set_err(TSH_E_BAD_ARG, "sub-space width %d outside [1,64]", sd);
-  for (int64_t i = 0; i < (int64_t)subspaces * centroids; ++i)
-    if (init_index[i] < 0 || init_index[i] >= n) return set_err(TSH_E_BAD_ARG, "init_index[%lld] outside the samples", (long long)i);
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return set_err(TSH_E_NO_DEVICE, "no HIP device");
-  if (device < 0 || device >= ndev) return set_err(TSH_E_BAD_ARG, "device %d of %d", device, ndev);
-  HIPCHK(hipSetDevice(device));
-  const size_t cb_elems = (size_t)subspaces * centroids * sd;
-  float *d_samples = nullptr, *d_cent = nullptr, *d_norms = nullptr;
-  int32_t *d_ints = nullptr;  // assign | init | active | changed
-  const size_t n_ints = (size_t)subspaces * n + (size_t)subspaces * centroids + 2 * (size_t)subspaces;
-  hipStream_t st = nullptr;
-  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc(&d_samples, (size_t)n * dim * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&d_cent, cb_elems * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&d_norms, (size_t)subspaces * centroids * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&d_ints, n_ints * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_samples, samples, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) {
-    PqTrainArgs a{};
-    a.samples = d_samples;
-    a.centroids = d_cent;
-    a.norms = d_norms;
-    a.assign = d_ints;
-    int32_t *d_init = d_ints + (size_t)subspaces * n;
-    a.init_idx = d_init;
-    a.active = d_init + (size_t)subspaces * centroids;
-    a.changed = a.active + subspaces;
-    a.n = (int32_t)n;
-    a.dim = dim;
-    a.subspaces = subspaces;
-    a.k = centroids;
-    a.sub_dim = sd;
-    e = hipMemcpyAsync(d_init, init_index, (size_t)subspaces * centroids * sizeof(int32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-      pq_train_init_kernel<<<dim3(centroids, subspaces), 64, 0, st>>>(a);
-      const dim3 ga((unsigned)((n + 255) / 256), subspaces);
-      for (int it = 0; it < iterations; ++it) {
-        pq_train_norms_kernel<<<subspaces, 256, 0, st>>>(a);
-        if (sd == 8) pq_train_assign_kernel<8, true><<<ga, 256, 0, st>>>(a);
-        else if (sd == 4) pq_train_assign_kernel<4, true><<<ga, 256, 0, st>>>(a);
-        else if (sd == 16) pq_train_assign_kernel<16, true><<<ga, 256, 0, st>>>(a);
-        else if (sd % 4 == 0) pq_train_assign_kernel<0, true><<<ga, 256, 0, st>>>(a);
-        else pq_train_assign_kernel<0, false><<<ga, 256, 0, st>>>(a);
-        pq_train_update_kernel<<<dim3(centroids, subspaces), 64, 0, st>>>(a);
-        pq_train_flag_kernel<<<(subspaces + 255) / 256, 256, 0, st>>>(a);
-      }
-      e = hipMemcpyAsync(out_codebook, d_cent, cb_elems * sizeof(float), hipMemcpyDeviceToHost, st);
-    }
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e == hipSuccess) e = hipGetLastError();
-  if (d_samples) hipFree(d_samples);
-  if (d_cent) hipFree(d_cent);
-  if (d_norms) hipFree(d_norms);
-  if (d_ints) hipFree(d_ints);
-  if (st) hipStreamDestroy(st);
-  if (e != hipSuccess) return set_err(TSH_E_HIP, "pq_train: %s", hipGetErrorString(e));
-  return TSH_OK;
-}
-
-extern "C" int32_t tsh_index_pq_encode(tsh_index *idx, int64_t first_row_id, int64_t n_rows, const float *codebook,
-                                       int32_t subspaces, int32_t centroids, uint8_t *out_codes) {
-  if (!idx || !codebook || !out_codes) return set_err(TSH_E_BAD_ARG, "NULL pointer");
-  if (n_rows < 0 || first_row_id < 0) return set_err(TSH_E_BAD_ARG, "negative row range");
-  if (subspaces < 1 || subspaces > idx->dim || centroids < 1 || centroids > 256)
-    return set_err(TSH_E_BAD_ARG, "subspaces %d / centroids %d out of range", subspaces, centroids);
-  const int32_t sub_dim = idx->dim / subspaces;  // PqCodebook: dimensions = subspaces * subDimensions
-  if (sub_dim < 1 || sub_dim > 64) return set_err(TSH_E_BAD_ARG, "sub-space width %d outside [1,64]", sub_dim);
-  if (n_rows == 0) return TSH_OK;
-  const size_t cb_elems = (size_t)subspaces * centroids * sub_dim;
-  std::vector<double> cb64(cb_elems);
-  for (size_t i = 0; i < cb_elems; ++i) cb64[i] = (double)codebook[i];  // exact widening
-  int64_t done = 0;
-  while (done < n_rows) {
-    const int64_t gid = first_row_id + done;
-    Shard *s = shard_for_row(idx, gid);
-    std::shared_lock<RwLock> sl(s->mu);
-    const int64_t local = gid - s->row_base;
-    if (local < 0 || local >= s->rows)
-      return set_err(TSH_E_BAD_ARG, "row %lld is not resident", (long long)gid);
-    const int64_t take = std::min(n_rows - done, s->rows - local);
-    HIPCHK(hipSetDevice(s->device));
-    double *d_cb = nullptr;
-    uint8_t *d_codes = nullptr;
-    HIPCHK(hipMalloc(&d_cb, cb_elems * sizeof(double)));
-    hipError_t e = hipMalloc(&d_codes, (size_t)take * subspaces);
-    hipStream_t st = s->ingest_stream;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cb, cb64.data(), cb_elems * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-      PqEncodeArgs a{};
-      a.rows = s->d_rows;
-      a.codebook = d_cb;
-      a.codes = d_codes;
-      a.ld = s->ld;
-      a.first = local;
-      a.n = take;
-      a.subspaces = subspaces;
-      a.centroids = centroids;
-      a.sub_dim = sub_dim;
-      const unsigned grid = (unsigned)((take + 255) / 256);
-      if (sub_dim == 8) pq_encode_kernel<8><<<grid, 256, 0, st>>>(a);
-      else if (sub_dim == 4) pq_encode_kernel<4><<<grid, 256, 0, st>>>(a);
-      else if (sub_dim == 16) pq_encode_kernel<16><<<grid, 256, 0, st>>>(a);
-      else pq_encode_kernel<0><<<grid, 256, 0, st>>>(a);
-      e = hipMemcpyAsync(out_codes + (size_t)done * subspaces, d_codes, (size_t)take * subspaces,
-                         hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipGetLastError();
-    hipFree(d_cb);
-    if (d_codes) hipFree(d_codes);
-    if (e != hipSuccess) return set_err(TSH_E_HIP, "pq_encode: %s", hipGetErrorString(e));
-    done += take;
-  }
-  return TSH_OK;
-}
+#include "tsh_host_coldstart.inl.h"  // raw-vector file loader, tsh_index_open_ngh
+#include "tsh_host_pq.inl.h"         // tsh_pq_train, tsh_index_pq_encode
