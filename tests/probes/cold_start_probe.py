@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """Cold-start rate of tsh_index_open_ngh: writes an index directory with the writer restatement
 (oracle/ngh_dir.py), then times opening it (meta.json + raw-vector pages + graph flags -> HBM).
-  python tools/cold_start_probe.py [rows=200000] [dim=768]"""
+  python tests/probes/cold_start_probe.py [rows=200000] [dim=768]"""
 import os, sys, time, tempfile, shutil
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from oracle import ngh_dir
 from tostore_amd import HipVectorIndex
 import torch

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
 """Extended run of the seeded fuzz cases of tests/test_gpu_fuzz.py (many more seeds than the test suite).
-  python tools/long_fuzz.py [minutes=8]"""
+  python tests/probes/long_fuzz.py [minutes=8]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import torch
 torch.cuda.init()
 import oracle
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_fuzz as f
 budget = float(sys.argv[1]) * 60 if len(sys.argv) > 1 else 480
 t0 = time.time()

@@ -7,7 +7,7 @@ bench.py, and reports its recall@k against the exhaustive-exact oracle and its C
 GPU present, the exhaustive HIP path's latency on the same rows and queries is printed beside it.
 Statistical, not bit-level: Dart's PRNG seeds the reference's PQ training (see ngh_ann.c header).
 
-  python tools/reference_ann_probe.py [--rows 10000 --dim 128 --metric l2 --k 10 --queries 500]
+  python tests/probes/reference_ann_probe.py [--rows 10000 --dim 128 --metric l2 --k 10 --queries 500]
 """
 import argparse
 import os
@@ -16,7 +16,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 
 
