@@ -354,12 +354,13 @@ __global__ void __launch_bounds__(256) half_rows_kernel(HalfArgs a) {
 // bytes (all 32 banks once), and the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table) hit
 // 16 distinct 16-B bank quads.  A lane's fragment for the k16 slab s is piece 2s + (lane >> 5) of the hi
 // or lo half.  Global loads run NSETS - 1 ... NSETS chunks ahead of the multiply in NSETS register sets.
-template <int TM, int TN, int PM>
+template <int TM, int TN, int PM, int MODE = 0>
 struct HbTile {
   static constexpr int WM = TM / PM, WN = TN / 64, WAVES = WM * WN, THREADS = 64 * WAVES;
   static constexpr int NA = TM * 8 / THREADS, NB = TN * 8 / THREADS;  // 16-B pieces a thread stages per chunk
   static constexpr int MI = PM / 32;                                  // MFMA block rows per wave
-  static constexpr int NSETS = PM == 64 ? 2 : 1;
+  // the f16 kernel keeps fewer fragments, so the big tile affords a second register set as well
+  static constexpr int NSETS = (PM == 64 || MODE == 1) ? 2 : 1;
   static constexpr int MIN_WG = PM == 64 ? 2 : 1;
 };
 
@@ -368,7 +369,7 @@ struct HbTile {
 template <int METRIC, bool DENSE, int TM = 128, int TN = 128, int PM = 64, int DBG = 0, int MODE = 0>
 __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN, PM>::MIN_WG))
     batch_score_bf16x3_kernel(BatchArgs a) {
-  using T = HbTile<TM, TN, PM>;
+  using T = HbTile<TM, TN, PM, MODE>;
   constexpr int THREADS = T::THREADS, NA = T::NA, NB = T::NB, MI = T::MI, NSETS = T::NSETS;
   __shared__ u32x4 As[2][TM][8];
   __shared__ u32x4 Bs[2][TN][8];
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
 #pragma unroll
     for (int j = 0; j < NA; ++j) ra[S][j] = qg[j][kc * 8];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[S][j] = __builtin_nontemporal_load(vg[j] + kc * 8);
+    for (int j = 0; j < NB; ++j) rb[S][j] = vg[j][kc * 8];  // through L2: the other q-tiles of this row tile re-read it
   };
   auto lstore = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;

@@ -167,7 +167,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int64_t rows = s->rows, ld = s->ld;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   // bf16x3 kernel: 256 x 256 tiles for batches of more than 128 queries, 128 x 128 otherwise
-  const int32_t tile = (s->batch_kernel != 0 && nq > 128) ? 256 : 128;  // (every kernel but the f32 one has both tiles)
+  static const int forced_tile = getenv("TSH_BATCH_TILE") ? atoi(getenv("TSH_BATCH_TILE")) : 0;  // experiments
+  const int32_t tile = (forced_tile == 128 || forced_tile == 256) && s->batch_kernel != 0
+                           ? forced_tile
+                           : ((s->batch_kernel != 0 && nq > 128) ? 256 : 128);  // (the f32 kernel has the 128 tile only)
   const int32_t nq_pad = (int32_t)round_up(nq, tile);
   // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
