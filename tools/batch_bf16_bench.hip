@@ -37,7 +37,7 @@ static void split(const float *src, int64_t ld, int64_t n, int dim, int hch, u32
   split_rows_kernel<<<(int)std::min<int64_t>((total + 255) / 256, 65536), 256>>>(sa);
 }
 
-template <int METRIC, int TM = 128, int TN = 128, int PM = 64>
+template <int METRIC, int TM = 128, int TN = 128, int PM = 64, int KIND = 0>
 int check(int n, int d, int nq, float scale) {
   int ld = (d + 3) / 4 * 4, nq_pad = (nq + TM - 1) / TM * TM, hch = (d + 31) / 32;
   constexpr int THREADS = HbTile<TM, TN, PM>::THREADS;
@@ -60,7 +60,7 @@ int check(int n, int d, int nq, float scale) {
   CK(hipMalloc(&dV, V.size() * 4)); CK(hipMalloc(&dQ, Q.size() * 4)); CK(hipMalloc(&dinv, n * 4));
   CK(hipMalloc(&dsq, n * 4)); CK(hipMalloc(&dqsq, nq_pad * 4)); CK(hipMalloc(&dthr, nq_pad * 4));
   CK(hipMalloc(&dd, (size_t)nq_pad * n * 4));
-  CK(hipMalloc(&dVs, (size_t)n * hch * 128)); CK(hipMalloc(&dQs, (size_t)nq_pad * hch * 128));
+  CK(hipMalloc(&dVs, (size_t)((n + 255) / 256 * 256) * hch * 128)); CK(hipMalloc(&dQs, (size_t)((nq_pad + 255) / 256 * 256) * hch * 128));
   CK(hipMalloc(&ck, (size_t)nq * cap * 4)); CK(hipMalloc(&cr, (size_t)nq * cap * 4)); CK(hipMalloc(&cc, nq * 4));
   CK(hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
@@ -123,7 +123,7 @@ int check(int n, int d, int nq, float scale) {
   // bound: 3.1 * 2^-18 (representation) + (3 ld + 8) 2^-23 (accumulation, worst case)
   double bound = 3.1 / 262144.0 + (3.0 * ld + 8) / 8388608.0;
   bool ok = maxerr < bound && bad == 0;
-  printf("tile %dx%d metric %d  n=%d d=%d nq=%d scale=%g: dot err / |q||v| max %.3g (bound %.3g)  filter mismatches %d  %s\n", TM, TN, METRIC, n,
+  printf("kind %d tile %dx%d metric %d  n=%d d=%d nq=%d scale=%g: dot err / |q||v| max %.3g (bound %.3g)  filter mismatches %d  %s\n", KIND, TM, TN, METRIC, n,
          d, nq, scale, maxerr, bound, bad, ok ? "OK" : "FAIL");
   hipFree(dV); hipFree(dQ); hipFree(dinv); hipFree(dsq); hipFree(dqsq); hipFree(dthr); hipFree(dd);
   hipFree(dVs); hipFree(dQs); hipFree(ck); hipFree(cr); hipFree(cc);
@@ -160,7 +160,7 @@ int main(int argc, char **argv) {
   u32x4 *dVs, *dQs;
   uint32_t *ck, *cr, *cc;
   CK(hipMalloc(&dV, (size_t)n * ld * 4)); CK(hipMalloc(&dQ, (size_t)nq_pad * ld * 4));
-  CK(hipMalloc(&dVs, (size_t)n * hch * 128)); CK(hipMalloc(&dQs, (size_t)nq_pad * hch * 128));
+  CK(hipMalloc(&dVs, (size_t)((n + 255) / 256 * 256) * hch * 128)); CK(hipMalloc(&dQs, (size_t)((nq_pad + 255) / 256 * 256) * hch * 128));
   CK(hipMalloc(&dinv, (size_t)n * 4)); CK(hipMalloc(&dthr, nq_pad * 4));
   CK(hipMalloc(&ck, (size_t)nq * 1024 * 4)); CK(hipMalloc(&cr, (size_t)nq * 1024 * 4)); CK(hipMalloc(&cc, nq * 4));
   fill_normal_kernel<<<4096, 256>>>(dV, (size_t)n * ld, 11u, 1.0f / sqrtf((float)d));
@@ -214,6 +214,7 @@ int main(int argc, char **argv) {
   using I256 = std::integral_constant<int, 256>;
   time_tile(I128{}, I128{}, I64{});
   if (nq_pad % 256 == 0) time_tile(I256{}, I256{}, I128{});
+
   {  // bottleneck probes: 1 = no MFMA (loads + LDS stores + barriers), 2 = no global loads / LDS stores
     std::vector<float> th(nq_pad, -1e30f);
     CK(hipMemcpy(dthr, th.data(), nq_pad * 4, hipMemcpyHostToDevice));
@@ -223,16 +224,23 @@ int main(int argc, char **argv) {
     auto run = [&](int dbg) {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, 0));
-        if (dbg == 1) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 1><<<(nq_pad / 256) * ((n + 255) / 256), 512>>>(bb);
-        else batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 2><<<(nq_pad / 256) * ((n + 255) / 256), 512>>>(bb);
+        const int g = (nq_pad / 256) * ((n + 255) / 256);
+        if (dbg == 1) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 1><<<g, 512>>>(bb);
+        else if (dbg == 2) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 2><<<g, 512>>>(bb);
+        else if (dbg == 3) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 3><<<g, 512>>>(bb);
+        else batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 4><<<g, 512>>>(bb);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
-      printf("probe %d on the 256x256 tile (%s): %.3f ms\n", dbg, dbg == 1 ? "no MFMA" : "no global loads / LDS stores", ms);
+      const char *what[] = {"", "no MFMA", "no global loads / LDS stores", "no loads / stores / barriers",
+                            "no loads / stores / barriers, one LDS stage only"};
+      printf("probe %d on the 256x256 tile (%s): %.3f ms\n", dbg, what[dbg], ms);
     };
     run(1);
     run(2);
+    run(3);
+    run(4);
   }
   return fails;
 }

@@ -56,8 +56,8 @@ struct BatchArgs {
   int32_t q_tiles;        // nq_pad / BT_M
   int32_t n_tiles;        // ceil((row1-row0) / BT_N)
   // bf16x3 variant: operands pre-split into bf16 (hi, lo) planes, see split_rows_kernel
-  const u32x4 *Qs;        // nq_pad x hchunks x 128 B
-  const u32x4 *Vs;        // n x hchunks x 128 B
+  const u32x4 *Qs;        // nq_pad x hchunks x 128 B, see plane_piece()
+  const u32x4 *Vs;        // round_up(n, 256) x hchunks x 128 B
   int32_t hchunks;        // ceil(dim / 32)
   int32_t tile_m;         // workgroup tile (queries = rows): 128 or 256 (host-side dispatch only)
   float dot_scale;        // f16 variant: 2^-(eq + ev), undoes the power-of-two operand scales (0 = unused)
@@ -265,6 +265,15 @@ __global__ void __launch_bounds__(BT_THREADS, BK == 32 ? 2 : 3) batch_score_kern
 // i.e. 4 B per element like the f32 rows, one full cache line per (row, chunk).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Plane layout, in 16-byte pieces: rows are grouped by 256 and a group's chunk is contiguous,
+//   piece(row, chunk, p) = (((row / 256) * hchunks + chunk) * 256 + row % 256) * 8 + p,
+// so the 128 / 256 rows a workgroup stages for one chunk are one 16 / 32 KB run.  (With the rows of a
+// tile 1.5-3 KB apart -- row-major planes -- every line of a chunk fell on 2-4 of the 16 L2 channels.)
+constexpr int PLANE_GROUP = 256;
+__host__ __device__ __forceinline__ int64_t plane_piece(int64_t row, int chunk, int hchunks) {
+  return (((row / PLANE_GROUP) * hchunks + chunk) * PLANE_GROUP + row % PLANE_GROUP) * 8;
+}
+
 __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {  // finite inputs (|x| <= 1e15 outside safe mode)
   uint32_t u = __float_as_uint(f);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(SplitArgs a) {
       hi[e] = h2[0] | (h2[1] << 16);
       lo[e] = l2[0] | (l2[1] << 16);
     }
-    u32x4 *dst = a.out + (row * a.hchunks + kc) * 8;
+    u32x4 *dst = a.out + plane_piece(row, kc, a.hchunks);
     dst[c] = u32x4{hi[0], hi[1], hi[2], hi[3]};
     dst[4 + c] = u32x4{lo[0], lo[1], lo[2], lo[3]};
   }
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(256) half_rows_kernel(HalfArgs a) {
     f16x8 h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = (_Float16)(k0 + e < a.dim ? src[e] * mul : 0.f);  // round to nearest even
-    a.out[row * per_row + p] = __builtin_bit_cast(u32x4, h);
+    a.out[plane_piece(row, p >> 3, a.hchunks) + (p & 7)] = __builtin_bit_cast(u32x4, h);
   }
 }
 
@@ -397,7 +406,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
     const int p = tid + THREADS * j, r = p >> 3, c8 = p & 7;
     sa_row[j] = r;
     sa_col[j] = c8 ^ ((r >> 1) & 7);
-    qg[j] = a.Qs + (int64_t)(qbase + r) * a.hchunks * 8 + c8;
+    qg[j] = a.Qs + plane_piece(qbase + r, 0, a.hchunks) + c8;
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -406,7 +415,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
     sb_col[j] = c8 ^ ((r >> 1) & 7);
     int vr = nbase + r;
     if (vr >= a.row1) vr = a.row1 - 1;  // clamp: tail columns are discarded in the epilogue
-    vg[j] = a.Vs + (int64_t)vr * a.hchunks * 8 + c8;
+    vg[j] = a.Vs + plane_piece(vr, 0, a.hchunks) + c8;
   }
 
   f32x16 acc[MI][2];
@@ -421,9 +430,9 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
   auto gload = [&](auto SET, int kc) {
     constexpr int S = decltype(SET)::value;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) ra[S][j] = qg[j][kc * 8];
+    for (int j = 0; j < NA; ++j) ra[S][j] = qg[j][kc * (PLANE_GROUP * 8)];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[S][j] = vg[j][kc * 8];  // through L2: the other q-tiles of this row tile re-read it
+    for (int j = 0; j < NB; ++j) rb[S][j] = vg[j][kc * (PLANE_GROUP * 8)];  // through L2: other q-tiles re-read it
   };
   auto lstore = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;
@@ -509,11 +518,11 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
     lstore(S0{}, 0);
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-      if (DBG != 2 && kc + 1 < nk) gload(S0{}, kc + 1);  // in flight while this chunk is multiplied
-      if (DBG != 1) multiply(kc & 1);
+      if (DBG < 2 && kc + 1 < nk) gload(S0{}, kc + 1);  // in flight while this chunk is multiplied
+      if (DBG != 1) multiply(DBG == 4 ? 0 : (kc & 1));
       if (kc + 1 < nk) {
-        if (DBG != 2) lstore(S0{}, (kc + 1) & 1);
-        __syncthreads();
+        if (DBG < 2) lstore(S0{}, (kc + 1) & 1);
+        if (DBG < 3) __syncthreads();
       }
     }
   }

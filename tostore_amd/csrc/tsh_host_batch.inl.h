@@ -225,14 +225,16 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       s->split_bytes = 0;
       s->split_cap = 0;
       s->split_valid = 0;
-      HIPCHK(hipMalloc(&s->d_split, (size_t)s->cap * (size_t)row_bytes));
+      const int64_t prow = round_up(s->cap, PLANE_GROUP);  // whole 256-row groups (plane_piece)
+      HIPCHK(hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes));
       s->split_cap = s->cap;
-      s->split_bytes = s->cap * row_bytes;
+      s->split_bytes = prow * row_bytes;
       s->bytes += s->split_bytes;
     }
     s->split_mode = kern;
     s->split_exp = v_exp;
-    if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, (int64_t)nq_pad * hchunks * 8, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, round_up(nq_pad, PLANE_GROUP) * hchunks * 8, &b->bytes)))
+      return rc;
   }
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
