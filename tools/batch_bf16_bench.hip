@@ -228,19 +228,21 @@ int main(int argc, char **argv) {
         if (dbg == 1) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 1><<<g, 512>>>(bb);
         else if (dbg == 2) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 2><<<g, 512>>>(bb);
         else if (dbg == 3) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 3><<<g, 512>>>(bb);
-        else batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 4><<<g, 512>>>(bb);
+        else if (dbg == 4) batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 4><<<g, 512>>>(bb);
+        else batch_score_bf16x3_kernel<METRIC_COS, false, 256, 256, 128, 5><<<g, 512>>>(bb);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
       }
       const char *what[] = {"", "no MFMA", "no global loads / LDS stores", "no loads / stores / barriers",
-                            "no loads / stores / barriers, one LDS stage only"};
+                            "no loads / stores / barriers, one LDS stage only", "MFMAs only (operands from registers)"};
       printf("probe %d on the 256x256 tile (%s): %.3f ms\n", dbg, what[dbg], ms);
     };
     run(1);
     run(2);
     run(3);
     run(4);
+    run(5);
   }
   return fails;
 }

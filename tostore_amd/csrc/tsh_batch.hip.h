@@ -469,6 +469,18 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
     for (int s2 = 0; s2 < 2; ++s2) {
       const int pc = 2 * s2 + half;
       bf16x8 ah[MI], al[MI], bh[2], bl[2];
+      if (DBG == 5) {  // probe: no LDS reads in the loop, operands = whatever the accumulators hold
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[i] = __builtin_bit_cast(bf16x8, f32x4{acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3]});
+          al[i] = __builtin_bit_cast(bf16x8, f32x4{acc[i][1][0], acc[i][1][1], acc[i][1][2], acc[i][1][3]});
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[j] = __builtin_bit_cast(bf16x8, f32x4{acc[0][j][4], acc[0][j][5], acc[0][j][6], acc[0][j][7]});
+          bl[j] = __builtin_bit_cast(bf16x8, f32x4{acc[1][j][4], acc[1][j][5], acc[1][j][6], acc[1][j][7]});
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         ah[i] = __builtin_bit_cast(bf16x8, As[buf][arow + 32 * i][pc ^ asw]);
@@ -478,6 +490,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
       for (int j = 0; j < 2; ++j) {
         bh[j] = __builtin_bit_cast(bf16x8, Bs[buf][brow + 32 * j][pc ^ bsw]);
         bl[j] = __builtin_bit_cast(bf16x8, Bs[buf][brow + 32 * j][(4 + pc) ^ bsw]);
+      }
       }
       // product type outermost: MFMAs into the same accumulator are 2 MI issues apart
 #pragma unroll
