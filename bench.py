@@ -374,6 +374,11 @@ def run_bench(a):
                          "kernel_us_back_to_back_alone": scan_alone_us,
                          "algorithmic_bytes_per_launch": shard_bytes},
         }
+        if (hi - lo + 63) // 64 < 6144 and a.inflight > 1 and os.environ.get("TSH_SCAN_STREAMS") != "1":
+            # shards below 6144 tiles alternate their scans between two streams: two scans
+            # run side by side, so one launch's own duration is about twice its share of the HBM time
+            out["roofline"]["scans_side_by_side"] = 2
+            out["roofline"]["achieved_alone"] = shard_bytes / (scan_alone_us * 1e-6) / 1e9
         if ref is not None:
             hits, tot, exact = 0, 0, True
             for i in range(n_cpu):
