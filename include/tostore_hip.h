@@ -287,9 +287,11 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters,
 int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_t k, int32_t iters,
                         double *out_avg_gemm_us, double *out_flops);
 
-/* Tuning knobs (no reference counterpart).  TSH_OPT_BATCH_MIN_NQ: smallest nq
- * for which tsh_search / tsh_search_shard use the batched matrix-core path
- * (default 8; 0 = never).  Results are identical either way. */
+/* Tuning knobs (no reference counterpart).  TSH_OPT_BATCH_MIN_NQ: when tsh_search /
+ * tsh_search_shard answer a multi-query call on the batched matrix-core path:
+ * 0 = never; 1 (default) = whenever its estimated cost is below that of nq pipelined
+ * single-query scans (on 1 M x 768 rows from two queries on, on 100 k rows from about
+ * six); n >= 2 = from n queries per call on.  Results are identical either way. */
 #define TSH_OPT_BATCH_MIN_NQ 1
 /* TSH_OPT_BATCH_KERNEL: how the batched path forms its pre-filter keys (the f64
  * rerank decides, and each variant's band covers its own error, so results are

@@ -8,6 +8,21 @@ L2, IP, COS = 0, 1, 2
 METRICS = [L2, IP, COS]
 
 
+@pytest.fixture(autouse=True)
+def _batch_from_two_queries(monkeypatch):
+    """These tests are about the batched path: take it from two queries per call on, whatever the cost
+    estimate of the default setting would choose for these small indexes."""
+    from tostore_amd import HipVectorIndex
+
+    orig = HipVectorIndex.__init__
+
+    def init(self, *a, **kw):
+        orig(self, *a, **kw)
+        self.set_batch_min_nq(2)
+
+    monkeypatch.setattr(HipVectorIndex, "__init__", init)
+
+
 def _mk(n, d, seed, normalize=True, scale=None):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((n, d)).astype(np.float32)
@@ -210,3 +225,26 @@ def test_auto_kernel_choice(hip_lib, oracle_mod):
         idx.append(0, rows)
         _check_batch(oracle_mod, idx, rows, _queries(oracle_mod, nq, d, 74, IP), IP, k, tag="zero row")
         assert idx.counters()["batch_kernel_last"] == 1
+
+
+def test_default_switches_to_batched_by_estimated_cost(hip_lib, oracle_mod):
+    """TSH_OPT_BATCH_MIN_NQ = 1 (default): 300 k x 768 rows -- two queries are cheaper as two pipelined scans,
+    three are cheaper as one batched pass; the answers are the same bytes either way."""
+    from tostore_amd import HipVectorIndex
+
+    n, d, k = 300_000, 768, 10
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((3, d)).astype(np.float32)
+    with HipVectorIndex(d, L2, capacity_rows=n) as idx:
+        idx.set_batch_min_nq(1)
+        idx.append(0, rows)
+        a = idx.search(qs[:2], k)
+        c = idx.counters()
+        assert c["batch_launches"] == 0 and c["scan_launches"] == 2
+        b = idx.search(qs, k)
+        c = idx.counters()
+        assert c["batch_launches"] == 1 and c["scan_launches"] == 2
+        assert np.array_equal(a[0], b[0][:2]) and np.array_equal(a[1], b[1][:2])
+        eids, edist = oracle_mod.search_heap_mt(rows, qs[2], L2, k)
+        assert np.array_equal(b[0][2], eids) and np.array_equal(b[1][2], edist)

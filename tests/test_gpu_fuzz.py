@@ -97,6 +97,7 @@ def _batch_case(oracle, rng, case):
     alive = np.ones(n, bool)
     with HipVectorIndex(d, metric) as idx:
         idx.set_batch_kernel(kernel)
+        idx.set_batch_min_nq(2)  # this case is about the batched path, whatever the cost estimate says
         half = int(rng.integers(1, n))
         idx.append(0, rows[:half])
         if rng.random() < 0.5:

@@ -189,7 +189,8 @@ class HipVectorIndex:
         return ids[:cnt.value], dist[:cnt.value]
 
     def set_batch_min_nq(self, nq: int) -> None:
-        """nq at which search() switches to the matrix-core path (0 = never); results are identical."""
+        """When search() uses the batched matrix-core path: 0 never, 1 by estimated cost (default), n >= 2 from n
+        queries per call on.  Results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 1, int(nq)))
 
     def set_batch_kernel(self, kind: int) -> None:

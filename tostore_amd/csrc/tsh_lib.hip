@@ -1073,7 +1073,7 @@ struct tsh_index {
   std::mutex tk_mu;
   std::vector<std::unique_ptr<Ticket>> tickets;
   std::atomic<int> tickets_open{0};  // submitted, not yet waited for: each holds one context per shard
-  std::atomic<int32_t> batch_min_nq{8};  // nq at which tsh_search switches to the matrix-core path
+  std::atomic<int32_t> batch_min_nq{1};  // 0 never, 1 by estimated cost, n >= 2: from n queries per call on
 };
 
 namespace {
