@@ -350,6 +350,46 @@ def test_concurrent_threads_share_one_handle(hip_lib, oracle_mod):
     assert not errs, errs
 
 
+def test_many_open_indexes_share_the_device_streams(hip_lib, oracle_mod):
+    """A database holds many vector indexes.  Streams (CU-masked ones above all) are finite -- about 85 open
+    handles with streams of their own crashed the runtime -- so every handle on a device uses one shared
+    set; two threads searching two different indexes still get exact answers."""
+    import threading
+
+    from tostore_amd import HipVectorIndex
+
+    d, n, k = 48, 6000, 8
+    rows = [_mk(n, d, 300 + i) for i in range(3)]
+    qs = _mk(24, d, 310)
+    handles = [HipVectorIndex(d, L2) for _ in range(150)]
+    try:
+        for i, h in enumerate(handles):
+            h.append(0, rows[i % 3][: 200 if i >= 3 else n])
+        errs = []
+
+        def work(i):
+            try:
+                for _ in range(3):
+                    ids, dist, cnt = handles[i].search(qs, k)
+                    for j in range(len(qs)):
+                        eids, edist = oracle_mod.search_heap(rows[i], qs[j], L2, k)
+                        assert np.array_equal(ids[j], eids) and np.array_equal(dist[j], edist)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        ids, dist, cnt = handles[149].search(rows[149 % 3][5], 1)
+        assert ids[0, 0] == 5
+    finally:
+        for h in handles:
+            h.close()
+
+
 def test_concurrent_multi_query_callers(hip_lib, oracle_mod):
     """Several threads, each handing over MANY queries per call (every call wants several of the shard's
     eight contexts; callers that each held some and waited for more used to deadlock), mixing the

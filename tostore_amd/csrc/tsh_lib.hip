@@ -356,7 +356,6 @@ class RwLock {
 
 // ---- per-search scratch: one context = one query in flight ---------------------
 struct Ctx {
-  hipStream_t stream = nullptr;  // input upload, result copy, fallback path
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_done = nullptr;  // recorded after a job's last kernel
   hipEvent_t ev_scanned = nullptr;  // scan stream -> tail stream hand-off
@@ -382,6 +381,22 @@ struct Ctx {
   int64_t bytes = 0;
 };
 
+// Streams are a finite resource (CU-masked ones especially: about 85 open indexes with their own
+// five streams plus context streams crashed the runtime), and everything on one GPU shares its HBM and
+// CUs anyway -- so all shards of a device share ONE set, created on first use and never destroyed.
+struct DeviceStreams {
+  hipStream_t ingest = nullptr;
+  hipStream_t scan = nullptr, scan2 = nullptr;  // pipeline streams (240-CU mask when cu_split)
+  hipStream_t tail = nullptr;                   // the other 16 CUs
+  hipStream_t batch = nullptr;                  // unmasked: matrix-core batches
+  hipStream_t aux = nullptr;                    // rare synchronous work (fallback filter, bench hooks)
+  bool cu_split = false;
+  std::mutex scan_mu;                           // one enqueue sequence (scan + hand-off + tail) at a time
+  int rc = TSH_OK;
+  std::string err;
+};
+DeviceStreams *device_streams(int device);  // defined after set_err / HIPCHK users below
+
 struct Shard {
   int device = 0;
   int dim = 0, metric = 0, nch = 0;
@@ -400,7 +415,8 @@ struct Shard {
   float max_norm = 0.f, max_abs = 0.f;
   float min_norm = 0.f;  // smallest |row| seen (0 until rows exist, or when a zero row exists)
   uint32_t nonfinite_rows = 0, tiny_rows = 0;
-  hipStream_t ingest_stream = nullptr;
+  hipStream_t ingest_stream = nullptr;  // all streams below belong to the device's DeviceStreams
+  hipStream_t aux_stream = nullptr;
   // every query's scan -> select -> rerank runs on this one in-order stream,
   // back to back; only the small input / result copies use the context streams.
   // (Running a query's tail beside the next query's scan was measured 10-25x
@@ -415,7 +431,7 @@ struct Shard {
   hipStream_t tail_stream = nullptr;
   bool cu_split = false;
   hipStream_t batch_stream = nullptr;  // matrix-core batches: compute-bound, so all CUs (no mask)
-  std::mutex scan_mu;
+  std::mutex *scan_mu = nullptr;  // the device's (DeviceStreams): streams are shared by its shards
   std::atomic<int> inflight{0};
 
   RwLock mu;  // search: shared; append/delete: exclusive
@@ -450,35 +466,63 @@ struct Shard {
   }
 };
 
+DeviceStreams *device_streams(int device) {
+  static std::mutex mu;
+  static std::map<int, DeviceStreams *> sets;  // leaked on purpose: live as long as the process
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = sets.find(device);
+  if (it != sets.end()) return it->second;
+  DeviceStreams *ds = new DeviceStreams();
+  sets[device] = ds;
+  auto fail = [&](hipError_t e, const char *what) {
+    ds->rc = e == hipErrorOutOfMemory ? TSH_E_OOM : TSH_E_HIP;
+    ds->err = std::string(what) + " failed: " + hipGetErrorString(e);
+    return ds;
+  };
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&ds->ingest, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  // CU mask bit i = CU slot i/8 of XCD i%8 on MI355X (measured, tools/cumask_probe.hip):
+  // bits 0..15 = two CUs of every XCD, reserved for the tails.
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
+  const char *env = getenv("TSH_NO_CU_SPLIT");
+  const int cus = prop.multiProcessorCount;
+  if (!(env && env[0] == '1') && cus >= 64 && cus % 32 == 0) {
+    std::vector<uint32_t> scan_mask((size_t)cus / 32, 0xFFFFFFFFu), tail_mask((size_t)cus / 32, 0u);
+    scan_mask[0] = 0xFFFF0000u;
+    tail_mask[0] = 0x0000FFFFu;
+    if (hipExtStreamCreateWithCUMask(&ds->scan, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
+        hipExtStreamCreateWithCUMask(&ds->scan2, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
+        hipExtStreamCreateWithCUMask(&ds->tail, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
+      ds->cu_split = true;
+    } else {
+      if (ds->scan) (void)hipStreamDestroy(ds->scan);
+      if (ds->scan2) (void)hipStreamDestroy(ds->scan2);
+      if (ds->tail) (void)hipStreamDestroy(ds->tail);
+      ds->scan = ds->scan2 = ds->tail = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  if (!ds->cu_split && (e = hipStreamCreateWithFlags(&ds->scan, hipStreamNonBlocking)) != hipSuccess)
+    return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreateWithFlags(&ds->batch, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreateWithFlags(&ds->aux, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  return ds;
+}
+
 int shard_init(Shard *s) {
   HIPCHK(hipSetDevice(s->device));
-  HIPCHK(hipStreamCreateWithFlags(&s->ingest_stream, hipStreamNonBlocking));
-  {
-    // CU mask bit i = CU slot i/8 of XCD i%8 on MI355X (measured, tools/cumask_probe.hip):
-    // bits 0..15 = two CUs of every XCD, reserved for the tails.
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, s->device));
-    const char *env = getenv("TSH_NO_CU_SPLIT");
-    int cus = prop.multiProcessorCount;
-    if (!(env && env[0] == '1') && cus >= 64 && cus % 32 == 0) {
-      std::vector<uint32_t> scan_mask((size_t)cus / 32, 0xFFFFFFFFu), tail_mask((size_t)cus / 32, 0u);
-      scan_mask[0] = 0xFFFF0000u;
-      tail_mask[0] = 0x0000FFFFu;
-      if (hipExtStreamCreateWithCUMask(&s->scan_stream, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&s->scan_stream2, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&s->tail_stream, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
-        s->cu_split = true;
-      } else {
-        if (s->scan_stream) hipStreamDestroy(s->scan_stream);
-        if (s->scan_stream2) hipStreamDestroy(s->scan_stream2);
-        if (s->tail_stream) hipStreamDestroy(s->tail_stream);
-        s->scan_stream = s->scan_stream2 = s->tail_stream = nullptr;
-        (void)hipGetLastError();
-      }
-    }
-    if (!s->cu_split) HIPCHK(hipStreamCreateWithFlags(&s->scan_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&s->batch_stream, hipStreamNonBlocking));
-  }
+  DeviceStreams *ds = device_streams(s->device);
+  if (ds->rc != TSH_OK) return set_err(ds->rc, "%s", ds->err.c_str());
+  s->ingest_stream = ds->ingest;
+  s->scan_stream = ds->scan;
+  s->scan_stream2 = ds->scan2;
+  s->tail_stream = ds->tail;
+  s->batch_stream = ds->batch;
+  s->aux_stream = ds->aux;
+  s->cu_split = ds->cu_split;
+  s->scan_mu = &ds->scan_mu;
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
   HIPCHK(hipMalloc(&s->d_tmp_u32, 64));
@@ -570,7 +614,6 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
 }
 
 void ctx_free_all(Ctx *c) {
-  if (c->stream) hipStreamDestroy(c->stream);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->ev_done) hipEventDestroy(c->ev_done);
@@ -591,10 +634,7 @@ void ctx_free_all(Ctx *c) {
 
 int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
   HIPCHK(hipSetDevice(s->device));
-  if (!c->stream) {
-    int least = 0, greatest = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+  if (!c->ev0) {
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
@@ -823,7 +863,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   const bool overlap = s->inflight.fetch_add(1) > 0 && s->cu_split;
   j->counted = true;
   {
-    std::lock_guard<std::mutex> lk(s->scan_mu);
+    std::lock_guard<std::mutex> lk(*s->scan_mu);
     hipStream_t ps = s->scan_stream;
     {
       // Between two scans on one in-order stream the GPU idles for about 13 us (drain, write-back,
@@ -866,7 +906,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
 // whole-grid filter of this context's keys[] + f64 rerank of everything in the band.
 int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *spill) {
   Ctx *c = j->c;
-  hipStream_t st = c->stream;
+  hipStream_t st = s->aux_stream;
   int64_t n_keys = ((s->rows + 63) / 64) * 64;
   if (s->cap > c->big_cap) {
     hipFree(c->d_big_rows);
@@ -1106,11 +1146,7 @@ void shard_destroy(Shard *s) {
     delete s->batch;
     s->batch = nullptr;
   }
-  if (s->ingest_stream) hipStreamDestroy(s->ingest_stream);
-  if (s->scan_stream) hipStreamDestroy(s->scan_stream);
-  if (s->scan_stream2) hipStreamDestroy(s->scan_stream2);
-  if (s->tail_stream) hipStreamDestroy(s->tail_stream);
-  if (s->batch_stream) hipStreamDestroy(s->batch_stream);
+  // (streams are the device's, not the shard's: nothing to destroy)
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
   hipFree(s->d_sqnorm);
@@ -1597,7 +1633,7 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   } rel{s, c};
   int rc = ctx_prepare(s, c, tsh_default_block_entries(100), row_mask != nullptr);
   if (rc) return rc;
-  hipStream_t st = c->stream;
+  hipStream_t st = s->aux_stream;
   bool masked = row_mask != nullptr || !s->all_live;
   int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
   if (row_mask) {
