@@ -88,7 +88,9 @@ int32_t tsh_last_error(char *buf, int32_t len);
  * Created lazily by the Dart side on the first vectorSearch / writeChanges of
  * an index (the reference loads nothing vector-related at open:
  * lib/src/core/data_store_impl.dart:822-846, vector_index_manager.dart:39-43).
- * dim/metric come from NghIndexMeta (lib/src/model/ngh_index_meta.dart:82-100). */
+ * dim/metric come from NghIndexMeta (lib/src/model/ngh_index_meta.dart:82-100).
+ * 1 <= dim <= 4096 (a 16 KiB raw-vector page holds float32 vectors up to
+ * dim 4073, lib/src/core/ngh_page.dart:575-579). */
 int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows,
                          int32_t n_devices, tsh_index **out);
 

@@ -350,6 +350,34 @@ def test_concurrent_threads_share_one_handle(hip_lib, oracle_mod):
     assert not errs, errs
 
 
+@pytest.mark.parametrize("d", [260, 1028, 1100, 1284, 1540, 1700, 2052, 2500, 3072, 3500, 4073, 4096])
+def test_row_widths_between_kernel_variants(hip_lib, oracle_mod, d):
+    """The scan kernel is compiled for a short list of chunk counts (1 KiB per lane-chunk); a row of any other
+    width ends inside one chunk and leaves later ones empty -- every such chunk must contribute zeros, not the
+    next row's bytes (L2 once summed (0 - next_row)^2 for d in (1024, 1280) and (1536, 1792)).  Widths up to
+    4096: the reference's 16 KiB pages hold f32 vectors up to d = 4073."""
+    from tostore_amd import HipVectorIndex
+
+    n, k = 4500, 12  # >= 4096 rows: the batched path takes part too
+    rows = _mk(n, d, 700 + d, normalize=False)
+    qs = _mk(3, d, 701 + d, normalize=False)
+    for metric in METRICS:
+        with HipVectorIndex(d, metric) as idx:
+            idx.set_batch_min_nq(0)
+            idx.append(0, rows)
+            keep = np.packbits(np.random.default_rng(d).random(n) < 0.5, bitorder="little")
+            for q0 in qs:
+                q = _prep_query(oracle_mod, q0, metric)
+                _check(oracle_mod, idx, rows, q, metric, k, tag=f"d{d}")
+                _check(oracle_mod, idx, rows, q, metric, k, keep=keep, tag=f"d{d} masked")
+            idx.set_batch_min_nq(2)
+            ids, dist, cnt = idx.search(np.stack([_prep_query(oracle_mod, q0, metric) for q0 in qs]), k)
+            assert idx.counters()["batch_launches"] == 1
+            for i, q0 in enumerate(qs):
+                eids, edist = oracle_mod.search_heap(rows, _prep_query(oracle_mod, q0, metric), metric, k)
+                assert np.array_equal(ids[i], eids) and np.array_equal(dist[i], edist)
+
+
 def test_many_open_indexes_share_the_device_streams(hip_lib, oracle_mod):
     """A database holds many vector indexes.  Streams (CU-masked ones above all) are finite -- about 85 open
     handles with streams of their own crashed the runtime -- so every handle on a device uses one shared

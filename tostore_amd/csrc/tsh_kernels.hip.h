@@ -164,19 +164,25 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   // per workgroup so the dispatcher can balance tiles across CUs
   const int wpb = __builtin_amdgcn_readfirstlane((int)blockDim.x >> 6);
   const int stride = gridDim.x * wpb;
-  const bool tail_ok = FULL || (NCH - 1) * 64 + lane < a.d4;
-  const int tail_off = tail_ok ? (NCH - 1) * 256 : 0;
+  // !FULL: the row ends inside chunk d4/64 and every later chunk is empty (NCH comes from a short list of
+  // widths, so more than the last chunk can lie beyond the row).  vmask bit c = this lane's 16 bytes of chunk
+  // c exist; lanes without them reload chunk 0 (valid memory) and contribute zeros.
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) vmask |= (FULL || c * 64 + lane < a.d4) ? (1u << c) : 0u;
+  auto has = [&](int c) { return FULL || ((vmask >> c) & 1u) != 0u; };
+  auto off = [&](int c) { return has(c) ? c * 256 : 0; };
 
   f32x4 q[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    q[c] = *reinterpret_cast<const f32x4 *>(qsrc + 4 * lane + (c < NCH - 1 ? c * 256 : tail_off));
-    if (!FULL && c == NCH - 1 && !tail_ok) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    q[c] = *reinterpret_cast<const f32x4 *>(qsrc + 4 * lane + off(c));
+    if (!has(c)) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   if (a.query_out && blockIdx.x == 0 && wave == 0) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
-      if (c < NCH - 1 || tail_ok)
+      if (has(c))
         *reinterpret_cast<f32x4 *>(a.query_out + 4 * lane + c * 256) = q[c];
   }
 
@@ -220,7 +226,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
         const float *rp = tbase + (int64_t)r * a.ld;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
-          v[buf][j][c] = ld16<NT>(rp + (c < NCH - 1 ? c * 256 : tail_off));
+          v[buf][j][c] = ld16<NT>(rp + off(c));
       }
     };
 
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             f32x4 x = v[k & 1][j][c];
-            if (!FULL && c == NCH - 1 && !tail_ok) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!has(c)) x = f32x4{0.f, 0.f, 0.f, 0.f};
             s = accum4<METRIC>(s, q[c], x);
           }
           // tie the finished sum to the fence: pure math would otherwise be

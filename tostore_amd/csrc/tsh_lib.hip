@@ -71,7 +71,7 @@ constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
 constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
 constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgroups, two scan streams
 constexpr int SUBMIT_THREADS = 1;     // host threads that submit a multi-query call (more did not help: the pipeline is GPU-bound)
-constexpr int MAX_DIM_SCAN = 2048;    // register-resident query (NCH <= 8)
+constexpr int MAX_DIM_SCAN = 4096;    // register-resident query (NCH <= 16; the reference's f32 pages hold d <= 4073)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -232,7 +232,7 @@ void parallel_for(int32_t n, F fn) {
 // ---- kernel dispatch ---------------------------------------------------------
 inline int pick_nch(int d4) {
   int need = (d4 + 63) / 64;
-  static const int opts[] = {1, 2, 3, 4, 6, 8};
+  static const int opts[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
   for (int o : opts)
     if (o >= need) return o;
   return -1;
@@ -242,7 +242,8 @@ inline int pick_nch(int d4) {
 // R*NCH*4 VGPRs plus NCH*4 for the query must fit 512/MINW registers.
 template <int NCH, bool MASKED> struct ScanTune {
   static constexpr int R = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 2 : 4) : 2);
-  static constexpr int MINW = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH == 6 ? 3 : 2)));
+  static constexpr int MINW =
+      (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH <= 6 ? 3 : (NCH <= 8 ? 2 : 1))));
 };
 // Events that ride on the scan's own dispatch packet (hipExtLaunchKernel): a separate
 // hipEventRecord is a barrier packet of its own, and two or three of those between
@@ -316,8 +317,14 @@ void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream
     case 2: launch_scan_n<2>(a, metric, masked, grid, s, ev); break;
     case 3: launch_scan_n<3>(a, metric, masked, grid, s, ev); break;
     case 4: launch_scan_n<4>(a, metric, masked, grid, s, ev); break;
+    case 5: launch_scan_n<5>(a, metric, masked, grid, s, ev); break;
     case 6: launch_scan_n<6>(a, metric, masked, grid, s, ev); break;
-    default: launch_scan_n<8>(a, metric, masked, grid, s, ev); break;
+    case 7: launch_scan_n<7>(a, metric, masked, grid, s, ev); break;
+    case 8: launch_scan_n<8>(a, metric, masked, grid, s, ev); break;
+    case 10: launch_scan_n<10>(a, metric, masked, grid, s, ev); break;
+    case 12: launch_scan_n<12>(a, metric, masked, grid, s, ev); break;
+    case 14: launch_scan_n<14>(a, metric, masked, grid, s, ev); break;
+    default: launch_scan_n<16>(a, metric, masked, grid, s, ev); break;
   }
 }
 
