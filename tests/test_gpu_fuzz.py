@@ -2,6 +2,8 @@
 of 64), dimensions 1..300 (every scan-kernel variant incl. tails and the packed narrow-row
 kernels), k, metrics, masks, tombstones, thresholds, duplicate rows, chunked appends, both the
 single-query and the batched path.  Every answer must equal the oracle bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,8 +14,10 @@ def _one_case(oracle, rng, case):
     from tostore_amd import HipVectorIndex
 
     d = int(rng.choice([1, 2, 3, 4, 5, 8, 13, 16, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256,
-                        257, 300]))
+                        257, 300, 513, 700, 1030, 1300, 1600, 2100, 2700, 3300, 4096]))
     n = int(rng.integers(1, 9000)) if rng.random() < 0.8 else int(rng.integers(9000, 40000))
+    if d > 400:
+        n = min(n, 6000)  # keeps the CPU oracle quick
     metric = int(rng.integers(0, 3))
     k = int(rng.choice([1, 2, 7, 10, 33, 100, 257, n, n + 3]))
     rows = rng.standard_normal((n, d)).astype(np.float32)
@@ -35,6 +39,8 @@ def _one_case(oracle, rng, case):
     if rng.random() < 0.4:
         keep = np.packbits(rng.random(n) < rng.choice([0.02, 0.5, 0.95]), bitorder="little")
     alive = np.ones(n, bool)
+    if os.environ.get("TSH_FUZZ_VERBOSE"):
+        print(f"case {case}: n={n} d={d} metric={metric} k={k} nq={nq} mask={keep is not None}", flush=True)
     with HipVectorIndex(d, metric) as idx:
         cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 3)))]))
         for lo, hi in zip(cuts[:-1], cuts[1:]):

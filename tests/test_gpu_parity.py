@@ -378,6 +378,27 @@ def test_row_widths_between_kernel_variants(hip_lib, oracle_mod, d):
                 assert np.array_equal(ids[i], eids) and np.array_equal(dist[i], edist)
 
 
+@pytest.mark.parametrize("d,n", [(16, 12224), (4, 1024), (8, 65536), (100, 20480)])
+def test_narrow_rows_filling_the_allocation_exactly(hip_lib, oracle_mod, d, n):
+    """Lanes beyond a narrow row's end must not read `4 * lane` floats past the row start: in the last rows of an
+    allocation that ends on a page boundary that address is unmapped (memory access fault, found by the
+    extended fuzz run)."""
+    from tostore_amd import HipVectorIndex
+
+    rows = _mk(n, d, 900 + d, normalize=False)
+    with HipVectorIndex(d, L2, capacity_rows=n) as idx:
+        idx.set_batch_min_nq(0)
+        idx.append(0, rows)
+        idx.set_deleted([n - 1, n - 64])  # the masked variant walks the same addresses
+        alive = np.ones(n, bool)
+        alive[[n - 1, n - 64]] = False
+        for i in (0, n - 2, n // 2):
+            q = rows[i]
+            ids, dist, cnt = idx.search(q, 5)
+            eids, edist = oracle_mod.search_exhaustive(rows, q, L2, 5, None, np.packbits(alive, bitorder="little"))
+            assert np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
+
+
 def test_many_open_indexes_share_the_device_streams(hip_lib, oracle_mod):
     """A database holds many vector indexes.  Streams (CU-masked ones above all) are finite -- about 85 open
     handles with streams of their own crashed the runtime -- so every handle on a device uses one shared

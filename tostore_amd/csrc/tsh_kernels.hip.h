@@ -166,12 +166,14 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   const int stride = gridDim.x * wpb;
   // !FULL: the row ends inside chunk d4/64 and every later chunk is empty (NCH comes from a short list of
   // widths, so more than the last chunk can lie beyond the row).  vmask bit c = this lane's 16 bytes of chunk
-  // c exist; lanes without them reload chunk 0 (valid memory) and contribute zeros.
+  // c exist; lanes without them reload the row's first 16 bytes (valid memory) and contribute zeros.
   uint32_t vmask = 0;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) vmask |= (FULL || c * 64 + lane < a.d4) ? (1u << c) : 0u;
   auto has = [&](int c) { return FULL || ((vmask >> c) & 1u) != 0u; };
-  auto off = [&](int c) { return has(c) ? c * 256 : 0; };
+  // (row and query pointers already include + 4 * lane: lanes without data fall back to element 0 of the row --
+  // 4 * lane floats further on may be past the end of the last row's allocation when rows are narrow)
+  auto off = [&](int c) { return has(c) ? c * 256 : -4 * lane; };
 
   f32x4 q[NCH];
 #pragma unroll
