@@ -120,3 +120,34 @@ def test_merge_reports_truncated_blocks(oracle_mod):
     ids, dist, cnt = merge_candidate_blocks(IP, 4, np.zeros(4, np.float32), 2, None,
                                             np.frombuffer(_block(8, c3, 2, IP), np.uint8), 1, 8)
     assert ids[0].tolist() == [5, 6]
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/tostore_hip.h compiles as strict C99 and a C program links against the library: the boundary
+    really is a C ABI (what dart:ffi binds).  Without a GPU every compute entry fails loudly."""
+    import shutil
+    import subprocess
+
+    from tostore_amd import _ffi, build
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    so = build.build_library()
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "tostore_hip.h"\n#include <stdio.h>\n'
+        "int main(void) {\n  tsh_index *idx = 0; char buf[256];\n"
+        "  int n = tsh_device_count();\n  int rc = tsh_index_create(8, 0, 0, 1, &idx);\n"
+        "  tsh_last_error(buf, (int32_t)sizeof buf);\n"
+        '  printf("%d %d %d %s\\n", tsh_abi_version(), n, rc, buf);\n'
+        "  if (rc == 0) tsh_index_destroy(idx);\n  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(so)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", libdir, "-ltostore_hip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
+    assert out[0] == "1"
+    if int(out[1]) == 0:
+        assert int(out[2]) == _ffi.TSH_E_NO_DEVICE
+    else:
+        assert int(out[2]) == 0
