@@ -151,3 +151,38 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
         assert int(out[2]) == _ffi.TSH_E_NO_DEVICE
     else:
         assert int(out[2]) == 0
+
+
+def test_open_ngh_reads_meta_before_it_needs_a_device(tmp_path):
+    """Host logic of the cold start that needs no GPU: meta.json is found, parsed and validated first
+    (TSH_E_IO / TSH_E_FORMAT); only a well-formed one gets as far as creating the device index."""
+    import json
+
+    from tostore_amd import _ffi
+
+    L = _ffi.lib()
+    out = ctypes.c_void_p()
+
+    def rc_of(text):
+        d = tmp_path / "ngh"
+        d.mkdir(exist_ok=True)
+        if text is None:
+            if (d / "meta.json").exists():
+                (d / "meta.json").unlink()
+        else:
+            (d / "meta.json").write_text(text)
+        return L.tsh_index_open_ngh(str(d).encode(), 0, 1, ctypes.byref(out), None)
+
+    assert rc_of(None) == _ffi.TSH_E_IO
+    assert rc_of("[1, 2]") == _ffi.TSH_E_FORMAT
+    assert rc_of('{"name": "x"') == _ffi.TSH_E_FORMAT                       # truncated
+    assert rc_of('{"name": "x", "tableName": "t"}') == _ffi.TSH_E_FORMAT    # no dimensions
+    assert rc_of(json.dumps({"dimensions": 70000})) == _ffi.TSH_E_FORMAT
+    assert rc_of(json.dumps({"dimensions": 8, "nghPageSize": 16})) == _ffi.TSH_E_FORMAT
+    good = {"name": "i", "dimensions": 8, "nested": {"a": [1, {"b": '}\\"]'}]}, "nextNodeId": 0, "precision": "float32"}
+    rc = rc_of(json.dumps(good))
+    if L.tsh_device_count() == 0:
+        assert rc == _ffi.TSH_E_NO_DEVICE
+    else:
+        assert rc == 0
+        L.tsh_index_destroy(out)
