@@ -131,3 +131,82 @@ def test_fuzz_batched(hip_lib, oracle_mod, seed):
     rng = np.random.default_rng(7000 + seed)
     for case in range(12):
         _batch_case(oracle_mod, rng, f"{seed}/{case}")
+
+
+def _sequence_case(oracle, rng, case, steps=25):
+    """A random SEQUENCE of calls on one handle against a NumPy model of the rows: appends (new ids, gaps,
+    overwrites, growth past the capacity), tombstones, option changes, single / multi-query / masked /
+    thresholded / asynchronous searches -- state kept across calls (live bitmap, norms statistics, converted
+    planes, contexts) must stay consistent."""
+    from tostore_amd import HipVectorIndex
+
+    d = int(rng.choice([8, 33, 64, 100, 256, 300]))
+    metric = int(rng.integers(0, 3))
+    cap = int(rng.integers(64, 9000))
+    model = np.zeros((0, d), np.float32)
+    present = np.zeros(0, bool)
+    alive = np.zeros(0, bool)
+
+    def grow(n):
+        nonlocal model, present, alive
+        if n > len(model):
+            model = np.concatenate([model, np.zeros((n - len(model), d), np.float32)])
+            present = np.concatenate([present, np.zeros(n - len(present), bool)])
+            alive = np.concatenate([alive, np.zeros(n - len(alive), bool)])
+
+    with HipVectorIndex(d, metric, capacity_rows=cap) as idx:
+        for step in range(steps):
+            op = rng.choice(["append", "append", "delete", "search", "search", "multi", "option", "async"])
+            tag = f"sequence {case} step {step} {op} d={d} metric={metric}"
+            if op == "append":
+                first = int(rng.integers(0, len(model) + 1 + (20 if rng.random() < 0.2 else 0)))
+                n = int(rng.integers(1, 3000))
+                block = rng.standard_normal((n, d)).astype(np.float32)
+                if rng.random() < 0.3:
+                    block *= rng.uniform(0.1, 30.0, (n, 1)).astype(np.float32)
+                idx.append(first, block)
+                grow(first + n)
+                model[first:first + n] = block
+                present[first:first + n] = True
+                alive[first:first + n] = True  # a (re)written row is live again, as _writeGraphNode clears the slot flags
+                continue
+            if len(model) == 0:
+                continue
+            if op == "delete":
+                ids = rng.integers(0, len(model), size=int(rng.integers(1, 50)))
+                idx.set_deleted(ids)
+                alive[ids] = False
+                continue
+            if op == "option":
+                idx.set_batch_kernel(int(rng.integers(0, 4)))
+                idx.set_batch_min_nq(int(rng.choice([0, 1, 2, 8])))
+                continue
+            eff = present & alive
+            keep = None
+            if rng.random() < 0.3:
+                kb = rng.random(len(model)) < 0.5
+                keep = np.packbits(kb, bitorder="little")
+                eff = eff & kb
+            eff_mask = np.packbits(eff, bitorder="little")
+            k = int(rng.choice([1, 5, 40, 300]))
+            nq = 1 if op in ("search", "async") else int(rng.choice([2, 9, 140]))
+            qs = rng.standard_normal((nq, d)).astype(np.float32)
+            if metric == 2:
+                qs = np.stack([oracle.normalize_f32(q) for q in qs])
+            if op == "async":
+                ids, dist = idx.wait(idx.submit(qs[0], k, keep))
+                eids, edist = oracle.search_exhaustive(model, qs[0], metric, k, None, eff_mask)
+                assert np.array_equal(ids, eids) and np.array_equal(dist, edist), tag
+                continue
+            ids, dist, cnt = idx.search(qs, k, None, keep)
+            for i in range(nq):
+                eids, edist = oracle.search_exhaustive(model, qs[i], metric, k, None, eff_mask)
+                assert cnt[i] == len(eids), tag
+                assert np.array_equal(ids[i, :cnt[i]], eids) and np.array_equal(dist[i, :cnt[i]], edist), tag
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_call_sequences(hip_lib, oracle_mod, seed):
+    rng = np.random.default_rng(4000 + seed)
+    for case in range(6):
+        _sequence_case(oracle_mod, rng, f"{seed}/{case}")
