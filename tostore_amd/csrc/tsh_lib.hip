@@ -805,7 +805,10 @@ struct Job {
 };
 
 void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
-  if (n_tiles <= SEL_VPT * SEL_THREADS) select_kernel<SEL_THREADS, true><<<1, SEL_THREADS, 0, st>>>(se);
+  // a few hundred tiles (an index of some ten thousand rows): four waves instead of sixteen synchronise
+  // faster (10 k x 128: p50 42.8 -> 39.8 us); from a few thousand tiles on the wide workgroup wins
+  if (n_tiles <= 512 && se.k <= 256) select_kernel<256, true><<<1, 256, 0, st>>>(se);
+  else if (n_tiles <= SEL_VPT * SEL_THREADS) select_kernel<SEL_THREADS, true><<<1, SEL_THREADS, 0, st>>>(se);
   else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
 }
 
