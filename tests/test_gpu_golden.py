@@ -124,3 +124,25 @@ def test_rawvec_partition_file_loader(hip_lib, oracle_mod, tmp_path, precision):
             idx.load_rawvec_file(str(bad), page_size, precision, 0, n)
         assert e.value.code == _ffi.TSH_E_FORMAT
         assert idx.size == vpp  # page 1 was loaded before the bad page 2
+
+
+def test_plain_c_driver_without_python_or_torch(hip_lib, tmp_path):
+    """tools/cabi_driver.c: a host program with nothing but the C ABI -- the Dart process's situation.  The
+    library must bring up HIP on its own, and every stored row must find itself first at distance 0."""
+    import os
+    import shutil
+    import subprocess
+
+    from tostore_amd import build
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = build.build_library()
+    exe = tmp_path / "cabi_driver"
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tools", "cabi_driver.c"), "-o", str(exe), "-L", os.path.dirname(so),
+                    "-ltostore_hip", "-Wl,-rpath," + os.path.dirname(so), "-lm"], check=True)
+    p = subprocess.run([str(exe), "30000", "200", "64", "10"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout + p.stderr
+    assert "self-hits wrong: 0" in p.stdout and "batches 2" in p.stdout
