@@ -733,6 +733,7 @@ struct RerankBatchArgs {
   int64_t block_bytes;
   int64_t ld, row_base;
   int32_t dim, entries, metric;
+  int32_t q0;  // first query of this launch (the tail of a batch runs in chunks of queries)
 };
 
 // One wave = up to 64 candidates of ONE query, one candidate per lane.  The exact sums must
@@ -744,7 +745,7 @@ constexpr int RB_CH = 32;  // dimensions per step
 
 __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
 #pragma clang fp contract(off)
-  const int lane = threadIdx.x, q = blockIdx.y;
+  const int lane = threadIdx.x, q = a.q0 + (int)blockIdx.y;
   uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
   uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
   if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;

@@ -19,6 +19,7 @@ struct BatchCtx {
   uint64_t *d_mask = nullptr, *h_mask = nullptr;
   int64_t mask_words = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
+  hipEvent_t e_chunk[3] = {nullptr, nullptr, nullptr};  // tail chunks but the last
   int64_t bytes = 0;
   double last_gemm_us = 0, last_flops = 0;
 };
@@ -38,7 +39,7 @@ void batch_free(BatchCtx *b) {
   hipFree(b->d_final);
   hipFree(b->d_mask);
   hipHostFree(b->h_mask);
-  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done})
+  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done, b->e_chunk[0], b->e_chunk[1], b->e_chunk[2]})
     if (e) hipEventDestroy(e);
 }
 
@@ -180,6 +181,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if (!b->e0) {
     for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
     HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming));
+    for (hipEvent_t &e : b->e_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
@@ -291,6 +293,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
 
   const double t_prep = now_us();
+  int n_chunks = 1;
   // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
   {
     hipStream_t st = s->batch_stream;
@@ -423,27 +426,47 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     rb.dim = s->dim;
     rb.entries = entries;
     rb.metric = s->metric;
-    rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)nq), 64, 0, st>>>(rb);
-    HIPCHK(hipMemcpyAsync(b->h_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(b->e_done, st));
+    // the tail runs in chunks of queries: while the GPU re-ranks chunk c + 1 and copies it out, the host already
+    // finalises chunk c (out->on_chunk)
+    n_chunks = (out->on_chunk && nq >= 512) ? 4 : 1;
+    for (int c = 0; c < n_chunks; ++c) {
+      const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
+      rb.q0 = q0;
+      rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)(q1 - q0)), 64, 0, st>>>(rb);
+      HIPCHK(hipMemcpyAsync(b->h_blocks + (size_t)q0 * bb, b->d_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb,
+                            hipMemcpyDeviceToHost, st));
+      HIPCHK(hipEventRecord(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done, st));
+    }
   }
   const double t_enq = now_us();
-  HIPCHK(hipEventSynchronize(b->e_done));
-  HIPCHK(hipGetLastError());
-  const double t_gpu = now_us();
+  std::vector<char> skip((size_t)nq, 0);
+  double t_gpu = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
+    HIPCHK(hipEventSynchronize(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done));
+    if (c + 1 == n_chunks) {
+      HIPCHK(hipGetLastError());
+      t_gpu = now_us();
+    }
+    for (int32_t q = q0; q < q1; ++q) {
+      const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
+      if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) {
+        redo->push_back(q);
+        skip[(size_t)q] = 1;
+      } else {
+        s->c_cands += h->count;
+      }
+    }
+    if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
+    if (out->on_chunk) out->on_chunk(q0, q1, skip.data());
+  }
   float ms0 = 0.f, ms1 = 0.f;
   HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
   HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
   b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
   b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
   s->c_batches++;
-  for (int32_t q = 0; q < nq; ++q) {
-    const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
-    if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) redo->push_back(q);
-    else s->c_cands += h->count;
-  }
   s->c_searches += nq - (int64_t)redo->size();
-  if (out->h_blocks) memcpy(out->h_blocks, b->h_blocks, (size_t)nq * bb);
   if (out->d_blocks) {
     hipStream_t us = out->user_stream ? out->user_stream : s->batch_stream;
     HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
@@ -484,6 +507,8 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
     part.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q0 * bb : nullptr;
     part.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q0 * bb : nullptr;
     part.user_stream = out->user_stream;
+    if (out->on_chunk)  // indices of the callback are the caller's: shift this part's
+      part.on_chunk = [out, q0](int32_t a, int32_t b2, const char *skip) { out->on_chunk(q0 + a, q0 + b2, skip - q0); };
     std::vector<int32_t> r;
     int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);
     if (rc) return rc;

@@ -221,6 +221,13 @@ class HostPool {
 };
 
 template <typename F>
+void parallel_for(int32_t n, F fn);
+template <typename F>
+void parallel_for_range(int32_t q0, int32_t q1, F fn) {
+  parallel_for(q1 - q0, [&](int32_t i) { fn(q0 + i); });
+}
+
+template <typename F>
 void parallel_for(int32_t n, F fn) {
   if (n >= 64) {
     std::function<void(int32_t)> f = fn;
@@ -1011,6 +1018,9 @@ struct SearchOut {
   std::vector<std::vector<BlockEntry>> *spill = nullptr;
   uint8_t *d_blocks = nullptr;  // device mode
   hipStream_t user_stream = nullptr;
+  // batched path, host mode: called as soon as the blocks of queries [q0, q1) are in h_blocks, while the GPU
+  // still re-ranks the next chunk; skip[q] != 0 marks queries the single-query path will redo
+  std::function<void(int32_t q0, int32_t q1, const char *skip)> on_chunk;
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1124,6 +1134,26 @@ struct tsh_index {
   std::vector<std::unique_ptr<Ticket>> tickets;
   std::atomic<int> tickets_open{0};  // submitted, not yet waited for: each holds one context per shard
   std::atomic<int32_t> batch_min_nq{1};  // 0 never, 1 by estimated cost, n >= 2: from n queries per call on
+  // result-block buffers of multi-query calls, kept between calls: a fresh 6 MB allocation per call spends
+  // ~0.3 ms in page faults when it is first written
+  std::mutex pool_mu;
+  std::vector<std::pair<size_t, std::unique_ptr<uint8_t[]>>> block_pool;
+  std::unique_ptr<uint8_t[]> take_blocks(size_t bytes, size_t *cap) {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    for (size_t i = 0; i < block_pool.size(); ++i)
+      if (block_pool[i].first >= bytes) {
+        *cap = block_pool[i].first;
+        std::unique_ptr<uint8_t[]> p = std::move(block_pool[i].second);
+        block_pool.erase(block_pool.begin() + (long)i);
+        return p;
+      }
+    *cap = bytes;
+    return std::unique_ptr<uint8_t[]>(new uint8_t[bytes]);
+  }
+  void give_blocks(std::unique_ptr<uint8_t[]> p, size_t cap) {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    if (block_pool.size() < 4 && cap <= ((size_t)64 << 20)) block_pool.emplace_back(cap, std::move(p));
+  }
 };
 
 namespace {
@@ -1371,21 +1401,45 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
   int32_t entries = tsh_default_block_entries(k);
   size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   std::vector<std::unique_ptr<uint8_t[]>> blocks(ns);  // uninitialised: every block is written whole
+  std::vector<size_t> block_caps(ns, 0);
+  struct GiveBack {
+    tsh_index *idx;
+    std::vector<std::unique_ptr<uint8_t[]>> *b;
+    std::vector<size_t> *c;
+    ~GiveBack() {
+      for (size_t g = 0; g < b->size(); ++g)
+        if ((*b)[g]) idx->give_blocks(std::move((*b)[g]), (*c)[g]);
+    }
+  } give_back{idx, &blocks, &block_caps};
   std::vector<std::vector<std::vector<BlockEntry>>> spills(ns);
   std::vector<int> rcs(ns, TSH_OK);
   std::vector<std::string> errs(ns);
   std::vector<char> active(ns, 0);
+  std::vector<char> finalized((size_t)nq, 0);  // done early by the batched path's chunk callback
 
   auto run = [&](size_t g) {
     Shard *s = idx->shards[g].get();
     std::shared_lock<RwLock> sl(s->mu);
     if (s->rows == 0) return;
     active[g] = 1;
-    blocks[g].reset(new uint8_t[bb * (size_t)nq]);
+    blocks[g] = idx->take_blocks(bb * (size_t)nq, &block_caps[g]);
     spills[g].resize((size_t)nq);
     SearchOut so;
     so.h_blocks = blocks[g].get();
     so.spill = &spills[g];
+    if (ns == 1)  // batched path: finalise a chunk of queries while the GPU still works on the next one
+      so.on_chunk = [&](int32_t q0, int32_t q1, const char *skip) {
+        parallel_for_range(q0, q1, [&](int32_t q) {
+          if (skip[q]) return;
+          const uint8_t *b = blocks[0].get() + (size_t)q * bb;
+          const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b);
+          std::vector<std::pair<const BlockEntry *, uint32_t>> one{
+              {reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)), std::min(h->count, h->entries)}};
+          out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, one,
+                                        out_ids + (size_t)q * k, out_dist + (size_t)q * k);
+          finalized[(size_t)q] = 1;
+        });
+      };
     rcs[g] = shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
     if (rcs[g]) errs[g] = g_err;
   };
@@ -1403,6 +1457,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     }
   const double t_shards = now_us();
   parallel_for(nq, [&](int32_t q) {
+    if (finalized[(size_t)q]) return;
     std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
     for (size_t g = 0; g < ns; ++g) {
       if (!active[g]) continue;
