@@ -513,10 +513,11 @@ def test_more_than_16384_tiles(hip_lib, oracle_mod, metric):
             assert np.array_equal(ids[i], eids) and np.array_equal(dist[i], edist)
 
 
-@pytest.mark.parametrize("k", [513, 1000, 1024, 1500])
+@pytest.mark.parametrize("k", [513, 1000, 1024, 1025, 1500, 7000])
 def test_large_k_single_query(hip_lib, oracle_mod, k):
-    """k above 512 uses 2048 tile-minimum groups in the select kernel; above 1024 every live row
-    is a candidate (wide path) -- always exact."""
+    """k above 512 uses 2048 tile-minimum groups in the select kernel; above 1024 the fallback finds the exact
+    k-th key with a radix select over all keys and re-ranks only what lies inside its band -- always exact,
+    masks and tombstones included."""
     from tostore_amd import HipVectorIndex
 
     d, n = 16, 300_000  # 4688 tiles: more than the select kernel's short list holds
@@ -526,10 +527,20 @@ def test_large_k_single_query(hip_lib, oracle_mod, k):
         idx.append(0, rows)
         idx.set_batch_min_nq(0)
         ids, dist, cnt = idx.search(q, k)
-        eids, edist = oracle_mod.search_heap_mt(rows, q, L2, k)
+        eids, edist = oracle_mod.search_exhaustive(rows, q, L2, k)
         assert cnt[0] == k and np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
         if k <= 1024:
             assert idx.counters()["fallback_searches"] == 0
+        else:
+            c = idx.counters()
+            assert c["fallback_searches"] == 1 and c["candidates_total"] < k + 300  # not "every row"
+            keep = np.packbits(np.random.default_rng(k).random(n) < 0.4, bitorder="little")
+            idx.set_deleted(np.arange(0, n, 97))
+            alive = np.unpackbits(keep, bitorder="little")[:n].astype(bool)
+            alive[np.arange(0, n, 97)] = False
+            ids, dist, cnt = idx.search(q, k, None, keep)
+            eids, edist = oracle_mod.search_exhaustive(rows, q, L2, k, None, np.packbits(alive, bitorder="little"))
+            assert cnt[0] == len(eids) and np.array_equal(ids[0, :cnt[0]], eids) and np.array_equal(dist[0, :cnt[0]], edist)
 
 
 def test_appends_and_deletes_while_searching(hip_lib, oracle_mod):

@@ -753,6 +753,26 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
   }
 }
 
+// K3a: one pass of a radix select over the WHOLE key array (fallback path, k beyond what the tile-minimum
+// bound of K2 can serve): histogram of bits [shift, shift + 8) of the keys that share `prefix` above them.
+// Dead tiles are skipped through gmin (their keys are stale); dead rows inside live tiles carry KEY_DEAD.
+__global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
+                                                         uint32_t prefix, int shift, uint32_t *hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) {
+    if (gmin[i >> 6] == KEY_DEAD) continue;  // a wave covers one tile: uniform
+    const uint32_t key = keys[i];
+    if (key == KEY_DEAD) continue;
+    if (shift < 24 && (key >> (shift + 8)) != (prefix >> (shift + 8))) continue;
+    atomicAdd(&h[(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
 // K3: whole-grid filter (fallback).  count accumulates in *out_count.
 __global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
                                                      uint32_t band, uint32_t *out_rows,
