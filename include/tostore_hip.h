@@ -65,15 +65,17 @@ typedef struct tsh_counters {
   int64_t fallback_searches; /* queries that took the wide-band fallback */
   int64_t candidates_total;  /* rows re-ranked in f64 */
   int64_t bytes_resident;    /* device bytes held by this handle */
-  int32_t safe_mode;         /* !=0: corpus values outside the f32 error model; every
-                                search re-ranks all rows in f64 (exact, slow) */
+  int32_t safe_mode;         /* !=0: corpus values outside the f32 error model (more than 1024 such rows in a shard,
+                                or a handle searched through tsh_search_shard); every search re-ranks all rows
+                                in f64 (exact, slow) */
   int32_t device_id;
   /* scan-kernel device time sampled with HIP events on the stream the kernel runs
    * on, inside real searches (every 4th query): sum of microseconds / samples */
   double scan_us_sum;
   int64_t scan_us_samples;
   int32_t batch_kernel_last; /* TSH_OPT_BATCH_KERNEL variant the last batched search ran (0/1/2; -1 none yet) */
-  int32_t reserved;
+  int32_t quarantined_rows;  /* live rows outside the f32 error model (non-finite or > 1e15 elements; cosine: norm
+                                below 2^-50) that are kept out of the scan and re-ranked exactly on every search */
 } tsh_counters;
 
 int32_t tsh_abi_version(void);

@@ -20,6 +20,8 @@ struct BatchCtx {
   int64_t mask_words = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
   hipEvent_t e_chunk[3] = {nullptr, nullptr, nullptr};  // tail chunks but the last
+  BlockEntry *d_quar_out = nullptr, *h_quar_out = nullptr;  // [query][quarantined row] exact sums
+  int64_t quar_cap = 0;
   int64_t bytes = 0;
   double last_gemm_us = 0, last_flops = 0;
 };
@@ -39,6 +41,8 @@ void batch_free(BatchCtx *b) {
   hipFree(b->d_final);
   hipFree(b->d_mask);
   hipHostFree(b->h_mask);
+  hipFree(b->d_quar_out);
+  hipHostFree(b->h_quar_out);
   for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done, b->e_chunk[0], b->e_chunk[1], b->e_chunk[2]})
     if (e) hipEventDestroy(e);
 }
@@ -291,6 +295,16 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     }
   }
   if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
+  // quarantined rows (not live on the device): their exact sums for every query, added to the blocks below
+  std::vector<uint32_t> quar_sel;
+  const int32_t n_quar = (int32_t)s->quar_ids.size();
+  if (n_quar) {
+    quarantine_select(s, mask ? b->h_mask : nullptr, &quar_sel);
+    if (!quar_sel.empty()) {
+      if (!out->extra) return set_err(TSH_E_BAD_ARG, "quarantined rows on a device-block search");
+      if ((rc = regrow(&b->d_quar_out, &b->h_quar_out, &b->quar_cap, (int64_t)nq * n_quar, &b->bytes))) return rc;
+    }
+  }
 
   const double t_prep = now_us();
   int n_chunks = 1;
@@ -300,6 +314,22 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
+    if (!quar_sel.empty()) {
+      QuarArgs qa{};
+      qa.rows = s->d_rows;
+      qa.Q = b->d_Q;
+      qa.list = s->d_quar;
+      qa.out = b->d_quar_out;
+      qa.ld = ld;
+      qa.ldq = ld;
+      qa.row_base = s->row_base;
+      qa.dim = s->dim;
+      qa.cap = n_quar;
+      qa.metric = s->metric;
+      quarantine_kernel<<<dim3((unsigned)((n_quar + 63) / 64), (unsigned)nq), 64, 0, st>>>(qa);
+      HIPCHK(hipMemcpyAsync(b->h_quar_out, b->d_quar_out, (size_t)nq * n_quar * sizeof(BlockEntry),
+                            hipMemcpyDeviceToHost, st));
+    }
     float *d_qsq = b->d_qaux, *d_d2 = b->d_qaux + nq_pad, *d_thr = b->d_qaux + 2 * (size_t)nq_pad;
     BatchArgs a{};
     if (use_bf16) {
@@ -455,6 +485,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         skip[(size_t)q] = 1;
       } else {
         s->c_cands += h->count;
+        if (!quar_sel.empty()) {  // the quarantined rows join this query's candidates
+          std::vector<BlockEntry> &ex = (*out->extra)[(size_t)(out->q_base + q)];
+          ex.clear();
+          for (uint32_t i : quar_sel) ex.push_back(b->h_quar_out[(size_t)q * n_quar + i]);
+        }
       }
     }
     if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
@@ -507,6 +542,8 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
     part.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q0 * bb : nullptr;
     part.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q0 * bb : nullptr;
     part.user_stream = out->user_stream;
+    part.extra = out->extra;
+    part.q_base = out->q_base + q0;
     if (out->on_chunk)  // indices of the callback are the caller's: shift this part's
       part.on_chunk = [out, q0](int32_t a, int32_t b2, const char *skip) { out->on_chunk(q0 + a, q0 + b2, skip - q0); };
     std::vector<int32_t> r;
@@ -517,14 +554,16 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
   int rc = TSH_OK;
   for (int32_t q : redo) {
     SearchOut one;
-    std::vector<std::vector<BlockEntry>> sp(1);
+    std::vector<std::vector<BlockEntry>> sp(1), ex(1);
     one.h_blocks = out->h_blocks ? out->h_blocks + (size_t)q * bb : nullptr;
     one.d_blocks = out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr;
     one.user_stream = out->user_stream;
     one.spill = out->spill ? &sp : nullptr;
+    one.extra = out->extra ? &ex : nullptr;
     rc = shard_search_blocks(s, queries + (size_t)q * s->dim, 1, k, mask, entries, &one, 1);
     if (rc) return rc;
     if (out->spill) (*out->spill)[(size_t)q] = std::move(sp[0]);
+    if (out->extra) (*out->extra)[(size_t)(out->q_base + q)] = std::move(ex[0]);
   }
   return TSH_OK;
 }

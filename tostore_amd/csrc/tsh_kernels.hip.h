@@ -863,6 +863,54 @@ __global__ void __launch_bounds__(64) rerank_kernel(RerankArgs a) {
   }
 }
 
+// Exact sums (rerank_kernel's arithmetic: strictly sequential f64, element order) of a shard's QUARANTINED rows
+// -- rows outside the f32 error model, kept out of the scan (see ingest_kernel) -- for nq queries: one lane
+// per (row, query).  A handful of rows, so no tiling: each lane walks its own row.
+struct QuarArgs {
+  const float *rows;
+  const float *Q;        // nq queries, ldq floats apart
+  const uint32_t *list;  // [0] = count, [1 ..] = local row ids
+  BlockEntry *out;       // [query][cap]
+  int64_t ld, ldq, row_base;
+  int32_t dim, cap, metric;
+};
+
+__global__ void __launch_bounds__(64) quarantine_kernel(QuarArgs a) {
+#pragma clang fp contract(off)
+  uint32_t count = a.list[0];
+  if (count > (uint32_t)a.cap) count = (uint32_t)a.cap;
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= count) return;
+  const uint32_t row = a.list[1 + c];
+  const float *__restrict__ rp = a.rows + (int64_t)row * a.ld;
+  const float *__restrict__ qp = a.Q + (int64_t)blockIdx.y * a.ldq;
+  const bool cosine = a.metric == METRIC_COS, l2 = a.metric == METRIC_L2;
+  double s0 = 0.0, s1 = 0.0;
+  auto step = [&](float qf, float bf) {
+    const double qd = (double)qf, bd = (double)bf;
+    if (l2) {
+      const double diff = qd - bd;
+      s0 = s0 + diff * diff;
+    } else {
+      s0 = s0 + qd * bd;
+      if (cosine) s1 = s1 + bd * bd;
+    }
+  };
+  int i = 0;
+  for (; i + 4 <= a.dim; i += 4) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(rp + i), q4 = *reinterpret_cast<const f32x4 *>(qp + i);
+    step(q4.x, b4.x);
+    step(q4.y, b4.y);
+    step(q4.z, b4.z);
+    step(q4.w, b4.w);
+  }
+  for (; i < a.dim; ++i) step(qp[i], rp[i]);  // pad elements stay out: s + 0.0 would turn a -0.0 sum into +0.0
+  BlockEntry &o = a.out[(int64_t)blockIdx.y * a.cap + c];
+  o.id = a.row_base + (int64_t)row;
+  o.s0 = s0;
+  o.s1 = cosine ? s1 : 0.0;
+}
+
 // ---------------------------------------------------------------------------
 // ingest helpers
 // per-row f64 norm -> inv_norm (f32), and chunk statistics for the error model
@@ -874,9 +922,14 @@ struct IngestStats {
   uint32_t inv_min_norm_bits;  // ~(f32 bits of the smallest |row|, rounded down); 0 = no row yet
 };
 
+// irr: nullable; irr[0] = count, irr[1 ..] = local ids of IRREGULAR rows of this call -- rows the f32 error model
+// cannot cover (a non-finite or > 1e15 element; for cosine a norm below 2^-50).  Up to irr_cap of them are
+// listed (the host quarantines them: not live on the device, exact sums by quarantine_kernel) and stay out of the
+// statistics; the rest count as before and put the shard into safe mode.
 __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t ld, int dim,
                                                      int64_t first, int64_t n, float *inv_norm,
-                                                     float *sqnorm, IngestStats *st) {
+                                                     float *sqnorm, IngestStats *st, uint32_t *irr,
+                                                     uint32_t irr_cap, int cosine) {
   const int lane = threadIdx.x & 63;
   int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -914,6 +967,19 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
       if (!bad && nrm > 0.0) {
         if (nrm < 8.9e-16 /*2^-50*/) tiny = true;
         else inv = (float)(1.0 / nrm);
+      }
+      bool listed = false;
+      if (irr && (bad || mx > 1.0e15f || (cosine && tiny))) {
+        const uint32_t p = atomicAdd(&irr[0], 1u);
+        if (p < irr_cap) {
+          irr[1 + p] = (uint32_t)(first + r);
+          listed = true;
+        }
+      }
+      if (listed) {  // quarantined: contributes nothing on the device
+        if (inv_norm) inv_norm[first + r] = 0.f;
+        if (sqnorm) sqnorm[first + r] = 0.f;
+        continue;
       }
       if (inv_norm) inv_norm[first + r] = inv;
       if (sqnorm) sqnorm[first + r] = (float)s;  // batched L2 key: |q|^2 + |v|^2 - 2 q.v
@@ -953,6 +1019,16 @@ __global__ void live_range_kernel(uint64_t *live, int64_t first, int64_t n, int 
       live[w] = set ? ~0ull : 0ull;
     }
   }
+}
+
+__global__ void live_clear_u32_kernel(uint64_t *live, const uint32_t *ids, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    atomicAnd((unsigned long long *)&live[ids[i] >> 6], ~(1ull << (ids[i] & 63)));
+}
+
+__global__ void live_set_u32_kernel(uint64_t *live, const uint32_t *ids, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    atomicOr((unsigned long long *)&live[ids[i] >> 6], 1ull << (ids[i] & 63));
 }
 
 __global__ void live_clear_ids_kernel(uint64_t *live, const int64_t *ids, int64_t n, int64_t row_base,

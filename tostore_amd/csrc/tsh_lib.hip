@@ -69,6 +69,7 @@ int device_count_cached() {
 
 constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
 constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
+constexpr uint32_t QUARANTINE_MAX = 1024;  // quarantined rows per shard; beyond that the shard goes to safe mode
 constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgroups, two scan streams
 constexpr int SUBMIT_THREADS = 1;     // host threads that submit a multi-query call (more did not help: the pipeline is GPU-bound)
 constexpr int MAX_DIM_SCAN = 4096;    // register-resident query (NCH <= 16; the reference's f32 pages hold d <= 4073)
@@ -393,6 +394,7 @@ struct Ctx {
   BlockEntry *d_big_entries = nullptr;
   uint32_t *d_big_count = nullptr;
   int64_t big_cap = 0;
+  BlockEntry *h_quar = nullptr, *h_quar_dev = nullptr;  // pinned + mapped: sums of the quarantined rows
   int64_t bytes = 0;
 };
 
@@ -430,6 +432,16 @@ struct Shard {
   float max_norm = 0.f, max_abs = 0.f;
   float min_norm = 0.f;  // smallest |row| seen (0 until rows exist, or when a zero row exists)
   uint32_t nonfinite_rows = 0, tiny_rows = 0;
+  // Rows the f32 error model cannot cover (non-finite / > 1e15 elements, tiny cosine norms) are QUARANTINED: their
+  // live bit stays clear, so no scan / batch kernel ever offers them, and every search adds their exact sums
+  // (quarantine_kernel) to its candidates instead -- a few broken embeddings then do not push every search of
+  // the shard onto the rerank-everything path.  Sorted local ids + device copy ([0] = count); changed under the
+  // exclusive lock only.  More than QUARANTINE_MAX of them, or a shard searched through tsh_search_shard (its
+  // device blocks have no room for extra entries), fall back to safe mode.
+  std::vector<uint32_t> quar_ids;
+  uint32_t *d_quar = nullptr;
+  uint32_t *d_irr = nullptr;  // 1 + QUARANTINE_MAX: count and ids of the irregular rows of one append
+  bool can_quarantine = true;
   hipStream_t ingest_stream = nullptr;  // all streams below belong to the device's DeviceStreams
   hipStream_t aux_stream = nullptr;
   // every query's scan -> select -> rerank runs on this one in-order stream,
@@ -541,6 +553,9 @@ int shard_init(Shard *s) {
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
   HIPCHK(hipMalloc(&s->d_tmp_u32, 64));
+  HIPCHK(hipMalloc(&s->d_quar, (1 + QUARANTINE_MAX) * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&s->d_irr, (1 + QUARANTINE_MAX) * sizeof(uint32_t)));
+  HIPCHK(hipMemset(s->d_quar, 0, 4));
   return TSH_OK;
 }
 
@@ -591,6 +606,40 @@ int shard_reserve(Shard *s, int64_t want_rows) {
 }
 
 // rows [first, first+n) local ids; src host or device
+// device copy of the quarantine list; caller holds s->mu exclusively
+int quarantine_upload(Shard *s) {
+  std::vector<uint32_t> h(1 + s->quar_ids.size());
+  h[0] = (uint32_t)s->quar_ids.size();
+  std::copy(s->quar_ids.begin(), s->quar_ids.end(), h.begin() + 1);
+  HIPCHK(hipMemcpyAsync(s->d_quar, h.data(), h.size() * 4, hipMemcpyHostToDevice, s->ingest_stream));
+  HIPCHK(hipStreamSynchronize(s->ingest_stream));
+  return TSH_OK;
+}
+
+// A shard about to hand out device blocks (tsh_search_shard) cannot add entries on the host: its quarantined
+// rows go back to being live rows that count as non-finite ones (safe mode).  Caller holds s->mu exclusively.
+int quarantine_disable(Shard *s) {
+  s->can_quarantine = false;
+  if (s->quar_ids.empty()) return TSH_OK;
+  HIPCHK(hipSetDevice(s->device));
+  const uint32_t n = (uint32_t)s->quar_ids.size();
+  live_set_u32_kernel<<<(n + 255) / 256, 256, 0, s->ingest_stream>>>(s->d_live, s->d_quar + 1, n);
+  HIPCHK(hipStreamSynchronize(s->ingest_stream));
+  s->nonfinite_rows += n;
+  s->quar_ids.clear();
+  return quarantine_upload(s);
+}
+
+// indices into quar_ids of the quarantined rows a caller's mask lets through (mask_words: the shard's slice,
+// bit r = local row r; NULL = all)
+void quarantine_select(const Shard *s, const uint64_t *mask_words, std::vector<uint32_t> *sel) {
+  sel->clear();
+  for (uint32_t i = 0; i < (uint32_t)s->quar_ids.size(); ++i) {
+    const uint32_t r = s->quar_ids[i];
+    if (!mask_words || ((mask_words[r >> 6] >> (r & 63)) & 1ull)) sel->push_back(i);
+  }
+}
+
 int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_is_device) {
   if (n <= 0) return TSH_OK;
   int rc = shard_reserve(s, first + n);
@@ -605,14 +654,46 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
     HIPCHK(hipMemcpy2DAsync(dst, (size_t)s->ld * sizeof(float), src, (size_t)s->dim * sizeof(float),
                             (size_t)s->dim * sizeof(float), (size_t)n, kind, st));
   }
+  // quarantine: rows of [first, first + n) are replaced, so their old entries go; the kernel lists the new ones
+  uint32_t irr_cap = 0;
+  bool quar_dirty = false;
+  if (s->can_quarantine) {
+    auto lo = std::lower_bound(s->quar_ids.begin(), s->quar_ids.end(), (uint32_t)first);
+    auto hi = std::lower_bound(lo, s->quar_ids.end(), (uint32_t)std::min<int64_t>(first + n, 0xFFFFFFFFll));
+    if (lo != hi) {
+      s->quar_ids.erase(lo, hi);
+      quar_dirty = true;
+    }
+    irr_cap = QUARANTINE_MAX - (uint32_t)s->quar_ids.size();
+    HIPCHK(hipMemsetAsync(s->d_irr, 0, 4, st));
+  }
   int blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);
-  ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_sqnorm, s->d_stats);
+  ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_sqnorm, s->d_stats,
+                                        s->can_quarantine ? s->d_irr : nullptr, irr_cap,
+                                        s->metric == TSH_METRIC_COSINE ? 1 : 0);
   int lb = (int)std::min<int64_t>(((first + n - 1) / 64 - first / 64 + 1 + 255) / 256, 1024);
   live_range_kernel<<<lb, 256, 0, st>>>(s->d_live, first, n, 1);
   IngestStats hs;
+  uint32_t n_irr = 0;
   HIPCHK(hipMemcpyAsync(&hs, s->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
+  if (s->can_quarantine) HIPCHK(hipMemcpyAsync(&n_irr, s->d_irr, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
+  n_irr = std::min(n_irr, irr_cap);
+  if (n_irr) {
+    std::vector<uint32_t> ids(n_irr);
+    live_clear_u32_kernel<<<(n_irr + 255) / 256, 256, 0, st>>>(s->d_live, s->d_irr + 1, n_irr);
+    HIPCHK(hipMemcpyAsync(ids.data(), s->d_irr + 1, (size_t)n_irr * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    s->quar_ids.insert(s->quar_ids.end(), ids.begin(), ids.end());
+    std::sort(s->quar_ids.begin(), s->quar_ids.end());
+    s->all_live = false;
+    quar_dirty = true;
+  }
+  if (quar_dirty) {
+    rc = quarantine_upload(s);
+    if (rc) return rc;
+  }
   uint32_t mb = hs.max_norm_bits, ab = hs.max_abs_bits;
   memcpy(&s->max_norm, &mb, 4);
   memcpy(&s->max_abs, &ab, 4);
@@ -642,6 +723,7 @@ void ctx_free_all(Ctx *c) {
   hipFree(c->d_hist);
   hipFree(c->d_block);
   hipHostFree(c->h_block);
+  hipHostFree(c->h_quar);
   hipFree(c->d_cand);
   hipFree(c->d_big_rows);
   hipFree(c->d_big_entries);
@@ -813,6 +895,7 @@ struct Job {
   bool counted = false;           // contributes to Shard::inflight
   float eps_rel = 0.f, delta_abs = 0.f;  // this query's error band (for the fallback's own threshold)
   bool force_all = false;
+  std::vector<uint32_t> quar_sel;  // entries of c->h_quar that belong to this query's candidates
 };
 
 void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
@@ -836,6 +919,14 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   j->user_mask = mask_words != nullptr;
   j->masked = j->user_mask || !s->all_live;
   j->dev_target = dev_target;
+  j->quar_sel.clear();
+  if (!s->quar_ids.empty()) {
+    quarantine_select(s, mask_words, &j->quar_sel);
+    if (!j->quar_sel.empty() && !c->h_quar) {
+      HIPCHK(hipHostMalloc(&c->h_quar, QUARANTINE_MAX * sizeof(BlockEntry), hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_quar_dev), c->h_quar, 0));
+    }
+  }
   uint8_t *dev_block = dev_target ? dev_target : c->d_block;  // where the device header lives
   const bool upload_mask = mask_words && c->mask_epoch != epoch;
   if (upload_mask) {
@@ -920,6 +1011,20 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     }
     launch_select(se, n_tiles, ts);
     rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
+    if (!j->quar_sel.empty()) {
+      QuarArgs qa{};
+      qa.rows = s->d_rows;
+      qa.Q = c->d_query;
+      qa.list = s->d_quar;
+      qa.out = c->h_quar_dev;
+      qa.ld = s->ld;
+      qa.ldq = s->ld;
+      qa.row_base = s->row_base;
+      qa.dim = s->dim;
+      qa.cap = (int32_t)QUARANTINE_MAX;
+      qa.metric = s->metric;
+      quarantine_kernel<<<dim3((unsigned)((s->quar_ids.size() + 63) / 64), 1), 64, 0, ts>>>(qa);
+    }
     HIPCHK(hipEventRecord(c->ev_done, ts));
   }
   s->c_scans++;
@@ -1042,8 +1147,8 @@ int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *s
 }
 
 // Waits for a job; afterwards c->h_block / c->d_block hold the final block
-// (and *spill every candidate when they did not fit).
-int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill) {
+// (and *spill every candidate when they did not fit); *extra gets the quarantined rows' entries.
+int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill, std::vector<BlockEntry> *extra) {
   Ctx *c = j->c;
   if (j->counted) {
     s->inflight.fetch_sub(1);
@@ -1068,6 +1173,11 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill) {
   } else {
     s->c_cands += h->count;
   }
+  if (!j->quar_sel.empty()) {  // the quarantined rows join the candidates
+    if (!extra) return set_err(TSH_E_BAD_ARG, "quarantined rows on a device-block search");
+    extra->clear();
+    for (uint32_t i : j->quar_sel) extra->push_back(c->h_quar[i]);
+  }
   s->c_searches++;
   return TSH_OK;
 }
@@ -1075,6 +1185,8 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill) {
 struct SearchOut {
   uint8_t *h_blocks = nullptr;  // host mode: nq blocks (caller memory)
   std::vector<std::vector<BlockEntry>> *spill = nullptr;
+  std::vector<std::vector<BlockEntry>> *extra = nullptr;  // per query: entries of the quarantined rows
+  int32_t q_base = 0;  // batched path: this part's query 0 is (*extra)[q_base]
   uint8_t *d_blocks = nullptr;  // device mode
   hipStream_t user_stream = nullptr;
   // batched path, host mode: called as soon as the blocks of queries [q0, q1) are in h_blocks, while the GPU
@@ -1120,7 +1232,8 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
     }
     Job &j = jobs[(size_t)((finished - q0) % depth)];
     std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[(size_t)finished] : nullptr;
-    rc = job_finish(s, &j, sp);
+    std::vector<BlockEntry> *ex = out->extra ? &(*out->extra)[(size_t)finished] : nullptr;
+    rc = job_finish(s, &j, sp, ex);
     if (rc) {
       release_all();
       return rc;
@@ -1253,6 +1366,8 @@ void shard_destroy(Shard *s) {
   hipFree(s->d_split);
   hipFree(s->d_stats);
   hipFree(s->d_tmp_u32);
+  hipFree(s->d_quar);
+  hipFree(s->d_irr);
 }
 
 int check_create_args(int32_t dim, int32_t metric, int64_t cap, tsh_index **out) {
@@ -1371,6 +1486,7 @@ int32_t tsh_index_create_shard(int32_t dim, int32_t metric, int64_t capacity_row
   std::unique_ptr<Shard> s;
   rc = make_shard(dim, metric, dev, row_base, capacity_rows, &s);
   if (rc) return rc;
+  s->can_quarantine = false;  // searched through device blocks (tsh_search_shard)
   idx->shards.push_back(std::move(s));
   *out = idx.release();
   return TSH_OK;
@@ -1420,6 +1536,20 @@ int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n) {
     if (e != hipSuccess) return set_err(TSH_E_HIP, "set_deleted: %s", hipGetErrorString(e));
     s->deleted += cleared;
     if (cleared) s->all_live = false;
+    if (!s->quar_ids.empty()) {  // a quarantined row's live bit is clear already: take it off the list
+      size_t before = s->quar_ids.size();
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = ids[i] - s->row_base;
+        if (r < 0 || r >= s->rows) continue;
+        auto it = std::lower_bound(s->quar_ids.begin(), s->quar_ids.end(), (uint32_t)r);
+        if (it != s->quar_ids.end() && *it == (uint32_t)r) s->quar_ids.erase(it);
+      }
+      if (s->quar_ids.size() != before) {
+        s->deleted += (int64_t)(before - s->quar_ids.size());
+        int rc = quarantine_upload(s);
+        if (rc) return rc;
+      }
+    }
   }
   return TSH_OK;
 }
@@ -1470,7 +1600,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
         if ((*b)[g]) idx->give_blocks(std::move((*b)[g]), (*c)[g]);
     }
   } give_back{idx, &blocks, &block_caps};
-  std::vector<std::vector<std::vector<BlockEntry>>> spills(ns);
+  std::vector<std::vector<std::vector<BlockEntry>>> spills(ns), extras(ns);
   std::vector<int> rcs(ns, TSH_OK);
   std::vector<std::string> errs(ns);
   std::vector<char> active(ns, 0);
@@ -1483,9 +1613,11 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     active[g] = 1;
     blocks[g] = idx->take_blocks(bb * (size_t)nq, &block_caps[g]);
     spills[g].resize((size_t)nq);
+    extras[g].resize((size_t)nq);
     SearchOut so;
     so.h_blocks = blocks[g].get();
     so.spill = &spills[g];
+    so.extra = &extras[g];
     if (ns == 1)  // batched path: finalise a chunk of queries while the GPU still works on the next one
       so.on_chunk = [&](int32_t q0, int32_t q1, const char *skip) {
         parallel_for_range(q0, q1, [&](int32_t q) {
@@ -1494,6 +1626,8 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
           const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b);
           std::vector<std::pair<const BlockEntry *, uint32_t>> one{
               {reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)), std::min(h->count, h->entries)}};
+          const std::vector<BlockEntry> &ex = extras[0][(size_t)q];
+          if (!ex.empty()) one.push_back({ex.data(), (uint32_t)ex.size()});
           out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, one,
                                         out_ids + (size_t)q * k, out_dist + (size_t)q * k);
           finalized[(size_t)q] = 1;
@@ -1528,6 +1662,8 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
         lists.push_back({reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)),
                          std::min(h->count, h->entries)});
       }
+      const std::vector<BlockEntry> &ex = extras[g][(size_t)q];
+      if (!ex.empty()) lists.push_back({ex.data(), (uint32_t)ex.size()});
     }
     out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, lists,
                                   out_ids + (size_t)q * k, out_dist + (size_t)q * k);
@@ -1616,14 +1752,14 @@ int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double thr, int64_t *out
   }
   *out_count = 0;
   int rc = TSH_OK;
-  std::vector<std::vector<BlockEntry>> spills(idx->shards.size());
+  std::vector<std::vector<BlockEntry>> spills(idx->shards.size()), extras(idx->shards.size());
   std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
   for (size_t g = 0; g < idx->shards.size(); ++g) {
     Job &j = t->jobs[g];
     if (!j.c) continue;
     Shard *s = idx->shards[g].get();
     if (rc == TSH_OK) {
-      rc = job_finish(s, &j, &spills[g]);
+      rc = job_finish(s, &j, &spills[g], &extras[g]);
     } else {
       if (j.counted) hipEventSynchronize(j.c->ev_done);
       if (j.counted) s->inflight.fetch_sub(1);
@@ -1637,6 +1773,7 @@ int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double thr, int64_t *out
         lists.push_back({reinterpret_cast<const BlockEntry *>(j.c->h_block + sizeof(BlockHeader)),
                          std::min(h->count, h->entries)});
       }
+      if (!extras[g].empty()) lists.push_back({extras[g].data(), (uint32_t)extras[g].size()});
     }
   }
   if (rc == TSH_OK)
@@ -1654,6 +1791,18 @@ int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32
   if (nq <= 0 || !queries || !d_out_blocks || k <= 0 || entries < 1)
     return set_err(TSH_E_BAD_ARG, "bad nq / k / entries / pointers");
   Shard *s = idx->shards[0].get();
+  {
+    bool convert;
+    {
+      std::shared_lock<RwLock> peek(s->mu);
+      convert = s->can_quarantine;
+    }
+    if (convert) {  // a tsh_index_create handle used in shard mode: from now on it behaves like a shard handle
+      std::unique_lock<RwLock> xl(s->mu);
+      int rc = quarantine_disable(s);
+      if (rc) return rc;
+    }
+  }
   std::shared_lock<RwLock> sl(s->mu);
   size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   if (s->rows == 0) {  // an empty shard contributes empty blocks
@@ -1737,6 +1886,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     }
     out->bytes_resident += b;
     if (s->safe_mode()) out->safe_mode = 1;
+    out->quarantined_rows += (int32_t)s->quar_ids.size();
     out->device_id = s->device;
   }
   return TSH_OK;
