@@ -65,9 +65,8 @@ typedef struct tsh_counters {
   int64_t fallback_searches; /* queries that took the wide-band fallback */
   int64_t candidates_total;  /* rows re-ranked in f64 */
   int64_t bytes_resident;    /* device bytes held by this handle */
-  int32_t safe_mode;         /* !=0: corpus values outside the f32 error model (more than 1024 such rows in a shard,
-                                or a handle searched through tsh_search_shard); every search re-ranks all rows
-                                in f64 (exact, slow) */
+  int32_t safe_mode;         /* !=0: more than 1024 rows of one shard hold values outside the f32 error model
+                                (see quarantined_rows); every search re-ranks all rows in f64 (exact, slow) */
   int32_t device_id;
   /* scan-kernel device time sampled with HIP events on the stream the kernel runs
    * on, inside real searches (every 4th query): sum of microseconds / samples */

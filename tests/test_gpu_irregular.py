@@ -189,48 +189,89 @@ def test_more_irregular_rows_than_the_quarantine_holds(hip_lib, oracle_mod):
             _same(ids[i], dist[i], cnt[i], eids, edist, f"overflow batch {i}")
 
 
-@pytest.mark.parametrize("converted", [False, True])
-def test_shard_handles_keep_safe_mode(hip_lib, oracle_mod, converted):
-    """device candidate blocks (tsh_search_shard) have no room for extra entries: such handles do not
-    quarantine, and a tsh_index_create handle searched that way stops doing so"""
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("n_bad", [3, 400])
+def test_shard_mode_appends_quarantined_rows_to_the_device_blocks(hip_lib, oracle_mod, metric, n_bad):
+    """tsh_search_shard: the quarantined rows' entries are appended to the device candidate blocks; when they do
+    not fit, count > entries makes the merge ask for a retry with more entries (the blocks' overflow protocol)"""
     import torch
 
     from tostore_amd import HipVectorIndex, _ffi
     from tostore_amd.sharded import merge_candidate_blocks
 
-    n, d, k = 5000, 32, 10
+    n, d, k, base = 6000, 32, 10, 1003
+    rng = np.random.default_rng(11)
     rows = _rows(n, d, 11)
-    rows[17, 0] = np.nan
-    rows[4000, 5] = np.inf
-    qs = _rows(3, d, 12)
-    idx = HipVectorIndex(d, IP) if converted else HipVectorIndex(d, IP, shard_device=0, row_base=0)
+    bad = rng.choice(n, size=n_bad, replace=False)
+    for i, r in enumerate(bad):
+        rows[r, int(rng.integers(0, d))] = [np.nan, np.inf, -np.inf, 1e20][i % 4]
+    keep_bits = rng.random(n) < 0.5
+    keep_bits[bad[::2]] = True
+    keep_bits[bad[1::2]] = False
+    L = _ffi.lib()
+    idx = HipVectorIndex(d, metric, shard_device=0, row_base=base)
+    try:
+        idx.set_batch_min_nq(2)
+        idx.append(base, rows)  # shard handles take GLOBAL ids
+        c = idx.counters()
+        assert (c["quarantined_rows"], c["safe_mode"]) == (n_bad, 0)
+        for nq in (3, 24):  # 24: the batched path
+            qs = np.stack([_q(oracle_mod, d, 60 + i, metric) for i in range(nq)])
+            for bits in (None, keep_bits):
+                mask = None if bits is None else np.packbits(np.concatenate([np.zeros(base, bool), bits]), bitorder="little")
+                entries, retries = L.tsh_default_block_entries(k), 0
+                while True:
+                    buf = torch.empty(nq * L.tsh_candidate_block_bytes(entries), dtype=torch.uint8, device="cuda")
+                    _ffi.check(L.tsh_search_shard(idx._h, qs.ctypes.data_as(_ffi.p_f32), nq, k,
+                                                  None if mask is None else mask.ctypes.data_as(_ffi.p_u8), entries,
+                                                  ctypes.c_void_p(buf.data_ptr()), None))
+                    try:
+                        ids, dist, cnt = merge_candidate_blocks(metric, d, qs, k, None, buf.cpu().numpy(), 1, entries)
+                        break
+                    except _ffi.TshError as e:
+                        assert e.code == _ffi.TSH_E_OVERFLOW and retries == 0
+                        entries, retries = int(e.needed_entries), retries + 1
+                assert retries == (1 if n_bad > 200 else 0)
+                omask = None if bits is None else np.packbits(bits, bitorder="little")
+                for i in range(nq):
+                    eids, edist = oracle_mod.search_exhaustive(rows, qs[i], metric, k, None, omask)
+                    _same(ids[i] - base, dist[i], cnt[i], eids, edist, f"shard m{metric} nq{nq} q{i} mask{bits is not None}")
+        assert idx.counters()["fallback_searches"] == 0
+    finally:
+        idx.close()
+
+
+def test_shard_mode_fallback_rewrites_the_block_and_appends_again(hip_lib, oracle_mod):
+    """k > 1024 on more tiles than the select kernel can refine over (4096) takes the wide-band fallback, which
+    rewrites the device block"""
+    import torch
+
+    from tostore_amd import HipVectorIndex, _ffi
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    n, d, k = 300000, 8, 1100
+    rows = _rows(n, d, 13)
+    rows[7, 0] = np.nan
+    rows[70000, 3] = np.inf
+    rows[299999, 7] = 1e20
+    qs = _rows(2, d, 14)
+    L = _ffi.lib()
+    idx = HipVectorIndex(d, L2, shard_device=0, row_base=0)
     try:
         idx.append(0, rows)
+        entries = L.tsh_default_block_entries(k)
+        buf = torch.empty(2 * L.tsh_candidate_block_bytes(entries), dtype=torch.uint8, device="cuda")
+        _ffi.check(L.tsh_search_shard(idx._h, qs.ctypes.data_as(_ffi.p_f32), 2, k, None, entries,
+                                      ctypes.c_void_p(buf.data_ptr()), None))
+        blocks = buf.cpu().numpy()
+        ids, dist, cnt = merge_candidate_blocks(L2, d, qs, k, None, blocks, 1, entries)
         c = idx.counters()
-        assert (c["quarantined_rows"], c["safe_mode"]) == ((2, 0) if converted else (0, 1))
-        L = _ffi.lib()
-        entries = 512
-        buf = torch.empty(len(qs) * L.tsh_candidate_block_bytes(entries), dtype=torch.uint8, device="cuda")
-        for _ in range(2):
-            while True:
-                rc = L.tsh_search_shard(idx._h, qs.ctypes.data_as(_ffi.p_f32), len(qs), k, None, entries,
-                                        ctypes.c_void_p(buf.data_ptr()), None)
-                _ffi.check(rc)
-                try:
-                    ids, dist, cnt = merge_candidate_blocks(IP, d, qs, k, None, buf.cpu().numpy(), 1, entries)
-                    break
-                except _ffi.TshError as e:  # safe mode offers every row: retry with the size it asks for
-                    assert e.code == _ffi.TSH_E_OVERFLOW
-                    entries = int(e.needed_entries)
-                    buf = torch.empty(len(qs) * L.tsh_candidate_block_bytes(entries), dtype=torch.uint8, device="cuda")
-            for i in range(len(qs)):
-                eids, edist = oracle_mod.search_exhaustive(rows, qs[i], IP, k)
-                _same(ids[i], dist[i], cnt[i], eids, edist, f"shard q{i}")
-            c = idx.counters()
-            assert (c["quarantined_rows"], c["safe_mode"]) == (0, 1)
-        # the converted handle still answers tsh_search, through safe mode now
-        ids, dist, cnt = idx.search(qs[0], k)
-        eids, edist = oracle_mod.search_exhaustive(rows, qs[0], IP, k)
-        _same(ids[0], dist[0], cnt[0], eids, edist, "after conversion")
+        assert (c["fallback_searches"], c["quarantined_rows"], c["safe_mode"]) == (2, 3, 0)
+        bb = L.tsh_candidate_block_bytes(entries)
+        for i in range(2):
+            blk_ids = blocks[i * bb + 64:(i + 1) * bb].view(np.int64)[::3][:int(blocks[i * bb:i * bb + 4].view(np.uint32)[0])]
+            assert {7, 70000, 299999} <= set(blk_ids.tolist())  # offered by the block (they sort last for L2)
+            eids, edist = oracle_mod.search_exhaustive(rows, qs[i], L2, k)
+            _same(ids[i], dist[i], cnt[i], eids, edist, f"shard fallback q{i}")
     finally:
         idx.close()

@@ -300,8 +300,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t n_quar = (int32_t)s->quar_ids.size();
   if (n_quar) {
     quarantine_select(s, mask ? b->h_mask : nullptr, &quar_sel);
-    if (!quar_sel.empty()) {
-      if (!out->extra) return set_err(TSH_E_BAD_ARG, "quarantined rows on a device-block search");
+    if (!quar_sel.empty() && !out->d_blocks) {
+      if (!out->extra) return set_err(TSH_E_BAD_ARG, "no room for the quarantined rows' entries");
       if ((rc = regrow(&b->d_quar_out, &b->h_quar_out, &b->quar_cap, (int64_t)nq * n_quar, &b->bytes))) return rc;
     }
   }
@@ -314,7 +314,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
-    if (!quar_sel.empty()) {
+    if (!quar_sel.empty() && !out->d_blocks) {
       QuarArgs qa{};
       qa.rows = s->d_rows;
       qa.Q = b->d_Q;
@@ -463,6 +463,22 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
       rb.q0 = q0;
       rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)(q1 - q0)), 64, 0, st>>>(rb);
+      if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
+        QuarAppendArgs qa{};
+        qa.rows = s->d_rows;
+        qa.Q = b->d_Q + (size_t)q0 * ld;
+        qa.list = s->d_quar;
+        qa.mask = mask ? b->d_mask : nullptr;
+        qa.blocks = b->d_blocks + (size_t)q0 * bb;
+        qa.ld = ld;
+        qa.ldq = ld;
+        qa.row_base = s->row_base;
+        qa.block_bytes = (int64_t)bb;
+        qa.dim = s->dim;
+        qa.entries = entries;
+        qa.metric = s->metric;
+        quarantine_append_kernel<<<dim3((unsigned)((n_quar + 63) / 64), (unsigned)(q1 - q0)), 64, 0, st>>>(qa);
+      }
       HIPCHK(hipMemcpyAsync(b->h_blocks + (size_t)q0 * bb, b->d_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb,
                             hipMemcpyDeviceToHost, st));
       HIPCHK(hipEventRecord(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done, st));
@@ -485,7 +501,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         skip[(size_t)q] = 1;
       } else {
         s->c_cands += h->count;
-        if (!quar_sel.empty()) {  // the quarantined rows join this query's candidates
+        if (!quar_sel.empty() && !out->d_blocks) {  // the quarantined rows join this query's candidates
           std::vector<BlockEntry> &ex = (*out->extra)[(size_t)(out->q_base + q)];
           ex.clear();
           for (uint32_t i : quar_sel) ex.push_back(b->h_quar_out[(size_t)q * n_quar + i]);

@@ -875,16 +875,11 @@ struct QuarArgs {
   int32_t dim, cap, metric;
 };
 
-__global__ void __launch_bounds__(64) quarantine_kernel(QuarArgs a) {
+// one lane's row against one query
+__device__ __forceinline__ void quarantine_sums(const float *__restrict__ rp, const float *__restrict__ qp, int dim,
+                                                int metric, double *o0, double *o1) {
 #pragma clang fp contract(off)
-  uint32_t count = a.list[0];
-  if (count > (uint32_t)a.cap) count = (uint32_t)a.cap;
-  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
-  if (c >= count) return;
-  const uint32_t row = a.list[1 + c];
-  const float *__restrict__ rp = a.rows + (int64_t)row * a.ld;
-  const float *__restrict__ qp = a.Q + (int64_t)blockIdx.y * a.ldq;
-  const bool cosine = a.metric == METRIC_COS, l2 = a.metric == METRIC_L2;
+  const bool cosine = metric == METRIC_COS, l2 = metric == METRIC_L2;
   double s0 = 0.0, s1 = 0.0;
   auto step = [&](float qf, float bf) {
     const double qd = (double)qf, bd = (double)bf;
@@ -897,18 +892,54 @@ __global__ void __launch_bounds__(64) quarantine_kernel(QuarArgs a) {
     }
   };
   int i = 0;
-  for (; i + 4 <= a.dim; i += 4) {
+  for (; i + 4 <= dim; i += 4) {
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(rp + i), q4 = *reinterpret_cast<const f32x4 *>(qp + i);
     step(q4.x, b4.x);
     step(q4.y, b4.y);
     step(q4.z, b4.z);
     step(q4.w, b4.w);
   }
-  for (; i < a.dim; ++i) step(qp[i], rp[i]);  // pad elements stay out: s + 0.0 would turn a -0.0 sum into +0.0
+  for (; i < dim; ++i) step(qp[i], rp[i]);  // pad elements stay out: s + 0.0 would turn a -0.0 sum into +0.0
+  *o0 = s0;
+  *o1 = cosine ? s1 : 0.0;
+}
+
+__global__ void __launch_bounds__(64) quarantine_kernel(QuarArgs a) {
+  uint32_t count = a.list[0];
+  if (count > (uint32_t)a.cap) count = (uint32_t)a.cap;
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= count) return;
+  const uint32_t row = a.list[1 + c];
   BlockEntry &o = a.out[(int64_t)blockIdx.y * a.cap + c];
   o.id = a.row_base + (int64_t)row;
-  o.s0 = s0;
-  o.s1 = cosine ? s1 : 0.0;
+  quarantine_sums(a.rows + (int64_t)row * a.ld, a.Q + (int64_t)blockIdx.y * a.ldq, a.dim, a.metric, &o.s0, &o.s1);
+}
+
+// Shard mode (device candidate blocks, tsh_search_shard): the quarantined rows the caller's mask lets through
+// are APPENDED to each query's block.  count keeps growing past `entries` (nothing is written there), which is
+// the blocks' own overflow protocol: the merge then asks for a retry with that many entries.
+struct QuarAppendArgs {
+  const float *rows;
+  const float *Q;
+  const uint32_t *list;
+  const uint64_t *mask;  // nullable: bit r = local row r may be returned
+  uint8_t *blocks;       // query q's block at blocks + q * block_bytes
+  int64_t ld, ldq, row_base, block_bytes;
+  int32_t dim, entries, metric;
+};
+
+__global__ void __launch_bounds__(64) quarantine_append_kernel(QuarAppendArgs a) {
+  const uint32_t count = a.list[0];
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  if (c >= count) return;
+  const uint32_t row = a.list[1 + c];
+  if (a.mask && !((a.mask[row >> 6] >> (row & 63)) & 1ull)) return;
+  uint8_t *blk = a.blocks + (int64_t)blockIdx.y * a.block_bytes;
+  const uint32_t pos = atomicAdd(&reinterpret_cast<BlockHeader *>(blk)->count, 1u);
+  if (pos >= (uint32_t)a.entries) return;
+  BlockEntry &o = reinterpret_cast<BlockEntry *>(blk + sizeof(BlockHeader))[pos];
+  o.id = a.row_base + (int64_t)row;
+  quarantine_sums(a.rows + (int64_t)row * a.ld, a.Q + (int64_t)blockIdx.y * a.ldq, a.dim, a.metric, &o.s0, &o.s1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1024,11 +1055,6 @@ __global__ void live_range_kernel(uint64_t *live, int64_t first, int64_t n, int 
 __global__ void live_clear_u32_kernel(uint64_t *live, const uint32_t *ids, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     atomicAnd((unsigned long long *)&live[ids[i] >> 6], ~(1ull << (ids[i] & 63)));
-}
-
-__global__ void live_set_u32_kernel(uint64_t *live, const uint32_t *ids, uint32_t n) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    atomicOr((unsigned long long *)&live[ids[i] >> 6], 1ull << (ids[i] & 63));
 }
 
 __global__ void live_clear_ids_kernel(uint64_t *live, const int64_t *ids, int64_t n, int64_t row_base,

@@ -436,12 +436,12 @@ struct Shard {
   // live bit stays clear, so no scan / batch kernel ever offers them, and every search adds their exact sums
   // (quarantine_kernel) to its candidates instead -- a few broken embeddings then do not push every search of
   // the shard onto the rerank-everything path.  Sorted local ids + device copy ([0] = count); changed under the
-  // exclusive lock only.  More than QUARANTINE_MAX of them, or a shard searched through tsh_search_shard (its
-  // device blocks have no room for extra entries), fall back to safe mode.
+  // exclusive lock only.  Host-side searches hand the entries to the finaliser as an extra list; shard mode
+  // (tsh_search_shard) appends them to the device blocks (quarantine_append_kernel).  More than
+  // QUARANTINE_MAX of them fall back to safe mode.
   std::vector<uint32_t> quar_ids;
   uint32_t *d_quar = nullptr;
   uint32_t *d_irr = nullptr;  // 1 + QUARANTINE_MAX: count and ids of the irregular rows of one append
-  bool can_quarantine = true;
   hipStream_t ingest_stream = nullptr;  // all streams below belong to the device's DeviceStreams
   hipStream_t aux_stream = nullptr;
   // every query's scan -> select -> rerank runs on this one in-order stream,
@@ -616,20 +616,6 @@ int quarantine_upload(Shard *s) {
   return TSH_OK;
 }
 
-// A shard about to hand out device blocks (tsh_search_shard) cannot add entries on the host: its quarantined
-// rows go back to being live rows that count as non-finite ones (safe mode).  Caller holds s->mu exclusively.
-int quarantine_disable(Shard *s) {
-  s->can_quarantine = false;
-  if (s->quar_ids.empty()) return TSH_OK;
-  HIPCHK(hipSetDevice(s->device));
-  const uint32_t n = (uint32_t)s->quar_ids.size();
-  live_set_u32_kernel<<<(n + 255) / 256, 256, 0, s->ingest_stream>>>(s->d_live, s->d_quar + 1, n);
-  HIPCHK(hipStreamSynchronize(s->ingest_stream));
-  s->nonfinite_rows += n;
-  s->quar_ids.clear();
-  return quarantine_upload(s);
-}
-
 // indices into quar_ids of the quarantined rows a caller's mask lets through (mask_words: the shard's slice,
 // bit r = local row r; NULL = all)
 void quarantine_select(const Shard *s, const uint64_t *mask_words, std::vector<uint32_t> *sel) {
@@ -657,7 +643,7 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
   // quarantine: rows of [first, first + n) are replaced, so their old entries go; the kernel lists the new ones
   uint32_t irr_cap = 0;
   bool quar_dirty = false;
-  if (s->can_quarantine) {
+  {
     auto lo = std::lower_bound(s->quar_ids.begin(), s->quar_ids.end(), (uint32_t)first);
     auto hi = std::lower_bound(lo, s->quar_ids.end(), (uint32_t)std::min<int64_t>(first + n, 0xFFFFFFFFll));
     if (lo != hi) {
@@ -669,14 +655,14 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
   }
   int blocks = (int)std::min<int64_t>((n + 3) / 4, 2048);
   ingest_kernel<<<blocks, 256, 0, st>>>(s->d_rows, s->ld, s->dim, first, n, s->d_inv_norm, s->d_sqnorm, s->d_stats,
-                                        s->can_quarantine ? s->d_irr : nullptr, irr_cap,
+                                        s->d_irr, irr_cap,
                                         s->metric == TSH_METRIC_COSINE ? 1 : 0);
   int lb = (int)std::min<int64_t>(((first + n - 1) / 64 - first / 64 + 1 + 255) / 256, 1024);
   live_range_kernel<<<lb, 256, 0, st>>>(s->d_live, first, n, 1);
   IngestStats hs;
   uint32_t n_irr = 0;
   HIPCHK(hipMemcpyAsync(&hs, s->d_stats, sizeof hs, hipMemcpyDeviceToHost, st));
-  if (s->can_quarantine) HIPCHK(hipMemcpyAsync(&n_irr, s->d_irr, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&n_irr, s->d_irr, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   n_irr = std::min(n_irr, irr_cap);
@@ -906,6 +892,24 @@ void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
   else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
 }
 
+// shard mode: the quarantined rows go into the job's device block
+void launch_quarantine_append(Shard *s, Ctx *c, Job *j, hipStream_t st) {
+  QuarAppendArgs qa{};
+  qa.rows = s->d_rows;
+  qa.Q = c->d_query;
+  qa.list = s->d_quar;
+  qa.mask = j->user_mask ? c->d_mask : nullptr;
+  qa.blocks = j->dev_target;
+  qa.ld = s->ld;
+  qa.ldq = s->ld;
+  qa.row_base = s->row_base;
+  qa.block_bytes = 0;
+  qa.dim = s->dim;
+  qa.entries = j->entries;
+  qa.metric = s->metric;
+  quarantine_append_kernel<<<dim3((unsigned)((s->quar_ids.size() + 63) / 64), 1), 64, 0, st>>>(qa);
+}
+
 // mask_words: this shard's slice of the caller mask (host), or NULL; epoch
 // identifies it so a context uploads it once per call
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
@@ -922,7 +926,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   j->quar_sel.clear();
   if (!s->quar_ids.empty()) {
     quarantine_select(s, mask_words, &j->quar_sel);
-    if (!j->quar_sel.empty() && !c->h_quar) {
+    if (!j->quar_sel.empty() && !dev_target && !c->h_quar) {
       HIPCHK(hipHostMalloc(&c->h_quar, QUARANTINE_MAX * sizeof(BlockEntry), hipHostMallocMapped));
       HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_quar_dev), c->h_quar, 0));
     }
@@ -1011,7 +1015,9 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     }
     launch_select(se, n_tiles, ts);
     rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
-    if (!j->quar_sel.empty()) {
+    if (!j->quar_sel.empty() && dev_target) {
+      launch_quarantine_append(s, c, j, ts);
+    } else if (!j->quar_sel.empty()) {
       QuarArgs qa{};
       qa.rows = s->d_rows;
       qa.Q = c->d_query;
@@ -1170,11 +1176,15 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill, std::vector<Blo
   if (h->flags & FLAG_LIST_OVERFLOW) {
     int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
     if (rc) return rc;
+    if (!j->quar_sel.empty() && j->dev_target) {  // the fallback rewrote the device block: append again
+      launch_quarantine_append(s, c, j, s->aux_stream);
+      HIPCHK(hipStreamSynchronize(s->aux_stream));
+    }
   } else {
     s->c_cands += h->count;
   }
-  if (!j->quar_sel.empty()) {  // the quarantined rows join the candidates
-    if (!extra) return set_err(TSH_E_BAD_ARG, "quarantined rows on a device-block search");
+  if (!j->quar_sel.empty() && !j->dev_target) {  // the quarantined rows join the candidates
+    if (!extra) return set_err(TSH_E_BAD_ARG, "no room for the quarantined rows' entries");
     extra->clear();
     for (uint32_t i : j->quar_sel) extra->push_back(c->h_quar[i]);
   }
@@ -1486,7 +1496,6 @@ int32_t tsh_index_create_shard(int32_t dim, int32_t metric, int64_t capacity_row
   std::unique_ptr<Shard> s;
   rc = make_shard(dim, metric, dev, row_base, capacity_rows, &s);
   if (rc) return rc;
-  s->can_quarantine = false;  // searched through device blocks (tsh_search_shard)
   idx->shards.push_back(std::move(s));
   *out = idx.release();
   return TSH_OK;
@@ -1791,18 +1800,6 @@ int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32
   if (nq <= 0 || !queries || !d_out_blocks || k <= 0 || entries < 1)
     return set_err(TSH_E_BAD_ARG, "bad nq / k / entries / pointers");
   Shard *s = idx->shards[0].get();
-  {
-    bool convert;
-    {
-      std::shared_lock<RwLock> peek(s->mu);
-      convert = s->can_quarantine;
-    }
-    if (convert) {  // a tsh_index_create handle used in shard mode: from now on it behaves like a shard handle
-      std::unique_lock<RwLock> xl(s->mu);
-      int rc = quarantine_disable(s);
-      if (rc) return rc;
-    }
-  }
   std::shared_lock<RwLock> sl(s->mu);
   size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   if (s->rows == 0) {  // an empty shard contributes empty blocks
