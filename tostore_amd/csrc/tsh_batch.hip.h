@@ -441,6 +441,16 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
 #pragma unroll
     for (int j = 0; j < NB; ++j) Bs[buf][sb_row[j]][sb_col[j]] = rb[S][j];
   };
+  // quarter `part` of a set's LDS stores (the f16 kernel spreads them over the four k16 slabs of the multiply)
+  auto lstore_part = [&](auto SET, int buf, int part) {
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if ((j & 3) == part) As[buf][sa_row[j]][sa_col[j]] = ra[S][j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if ((j & 3) == part) Bs[buf][sb_row[j]][sb_col[j]] = rb[S][j];
+  };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, NSETS - 1>;
 
@@ -448,7 +458,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
   const int half = lane >> 5;
   // (row >> 1) & 7 is the same for row and row + 32
   const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf, auto &&mid) {
     if (MODE == 1) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -462,6 +472,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        mid(s4);
       }
       return;
     }
@@ -512,17 +523,41 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
     // one step: chunk kc is in LDS stage kc & 1, chunk kc + 1 in flight in the OTHER register set
     auto step = [&](auto CUR, auto NXT, int kc) {
       if (DBG != 2 && kc + 2 < nk) gload(CUR, kc + 2);  // set CUR held chunk kc, already stored to LDS
-      if (DBG != 1) multiply(kc & 1);
+      if (DBG != 1) multiply(kc & 1, [](int) {});
       if (kc + 1 < nk) {
         if (DBG != 2) lstore(NXT, (kc + 1) & 1);
         __syncthreads();
       }
     };
+    // steady state without branches: the compiler's s_waitcnt insertion can then COUNT the loads in flight
+    // (vmcnt(8 ...) before the LDS stores of the older set); behind an `if` it assumes the worst at the join
+    // and drains everything, which cuts the run-ahead from two chunks to one and parks the waves
+    auto fstep = [&](auto CUR, auto NXT, int kc) {
+      if (DBG != 2) gload(CUR, kc + 2);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads AHEAD of the multiply (the scheduler sinks them behind it)
+      if (MODE == 1 && DBG == 0) {
+        // the other set's LDS stores ride between the slabs: the store path (13 cycles per ds_write_b128) works
+        // while the matrix pipe still has the slab's MFMAs queued, instead of all waves storing at once
+        multiply(kc & 1, [&](int s4) {
+          lstore_part(NXT, (kc + 1) & 1, s4);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+        if (DBG != 1) multiply(kc & 1, [](int) {});
+        if (DBG != 2) lstore(NXT, (kc + 1) & 1);
+      }
+      __syncthreads();
+    };
     gload(S0{}, 0);
     lstore(S0{}, 0);
-    if (nk > 1) gload(S1{}, 1);
+    gload(S1{}, nk > 1 ? 1 : 0);  // (a one-chunk row re-reads chunk 0: never stored)
     __syncthreads();
-    for (int kc = 0; kc < nk; kc += 2) {
+    int kc = 0;
+    for (; kc + 3 < nk; kc += 2) {
+      fstep(S0{}, S1{}, kc);
+      fstep(S1{}, S0{}, kc + 1);
+    }
+    for (; kc < nk; kc += 2) {
       step(S0{}, S1{}, kc);
       if (kc + 1 < nk) step(S1{}, S0{}, kc + 1);
     }
@@ -532,7 +567,7 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
       if (DBG < 2 && kc + 1 < nk) gload(S0{}, kc + 1);  // in flight while this chunk is multiplied
-      if (DBG != 1) multiply(DBG == 4 ? 0 : (kc & 1));
+      if (DBG != 1) multiply(DBG == 4 ? 0 : (kc & 1), [](int) {});
       if (kc + 1 < nk) {
         if (DBG < 2) lstore(S0{}, (kc + 1) & 1);
         if (DBG < 3) __syncthreads();
