@@ -493,10 +493,34 @@ struct Shard {
   }
 };
 
+// The stream sets live as long as the process -- except the CU-masked streams, which are destroyed by an
+// atexit handler: left to the runtime's own teardown they crash a python host at exit under rocprofv3
+// (tools/exitcheck.sh: SIGSEGV in __cxa_finalize after the tool wrote its output; plain streams are fine).  The
+// handler is registered after the first HIP call, so it runs before the runtime's exit handlers.
+static std::mutex g_streams_mu;
+static std::map<int, DeviceStreams *> *g_stream_sets = nullptr;  // never freed
+static void destroy_masked_streams_at_exit() {
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  if (!g_stream_sets) return;
+  for (auto &kv : *g_stream_sets) {
+    DeviceStreams *ds = kv.second;
+    if (!ds->cu_split || hipSetDevice(kv.first) != hipSuccess) continue;
+    for (hipStream_t *st : {&ds->scan, &ds->scan2, &ds->tail})
+      if (*st) {
+        (void)hipStreamSynchronize(*st);
+        (void)hipStreamDestroy(*st);
+        *st = nullptr;
+      }
+  }
+}
+
 DeviceStreams *device_streams(int device) {
-  static std::mutex mu;
-  static std::map<int, DeviceStreams *> sets;  // leaked on purpose: live as long as the process
-  std::lock_guard<std::mutex> lk(mu);
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  if (!g_stream_sets) {
+    g_stream_sets = new std::map<int, DeviceStreams *>();
+    atexit(destroy_masked_streams_at_exit);
+  }
+  std::map<int, DeviceStreams *> &sets = *g_stream_sets;
   auto it = sets.find(device);
   if (it != sets.end()) return it->second;
   DeviceStreams *ds = new DeviceStreams();
