@@ -233,13 +233,18 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
     };
 
     float val = 0.f;
+    // The previous tile's key / gmin stores share vmcnt with the loads, and stores may retire out of order with
+    // loads: while one MIGHT be pending the compiler must wait for vmcnt(0) instead of counting.  Retire them here.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     load_group(0);
-#pragma nounroll
-    for (int b = 0; b < nb; ++b) {
+    // One 8-row batch.  The LAST batch is a separate instance without the trailing load instead of an `if` inside
+    // the loop: behind a branch the compiler's s_waitcnt insertion no longer knows which loads are in flight
+    // and waits for vmcnt(0) -- the group just issued included -- before every group's arithmetic.
+    auto batch = [&](int b, auto LAST) {
       float acc[8];
 #pragma unroll
       for (int k = 0; k < G; ++k) {
-        if (!(k == G - 1 && b == nb - 1)) load_group((k + 1) & 1);
+        if (!(decltype(LAST)::value && k == G - 1)) load_group((k + 1) & 1);
         TSH_FENCE();
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -263,7 +268,10 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
       o += __shfl_xor(o, 16);
       o += __shfl_xor(o, 32);
       if ((lane >> 3) == b) val = o;  // slot b*8 + (lane&7) == lane
-    }
+    };
+#pragma nounroll
+    for (int b = 0; b < nb - 1; ++b) batch(b, std::false_type{});
+    batch(nb - 1, std::true_type{});
     // dense: val = key sum of row t*64+lane; masked: of the lane-th live row
 
     bool alive;
