@@ -776,7 +776,7 @@ struct RerankBatchArgs {
 // run side by side and nothing crosses lanes: each lane streams its own row (16 B at a time,
 // 8 loads in flight, the next 32 dimensions prefetched while the current ones are added) and
 // the query values are wave-uniform (scalar loads).
-constexpr int RB_CH = 32;  // dimensions per step
+constexpr int RB_CH = 64;  // dimensions per step (two register buffers of RB_CH floats per lane)
 
 __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
 #pragma clang fp contract(off)
@@ -795,35 +795,52 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
   const int ld = (int)a.ld;  // multiple of 4; rows and queries are zero beyond dim
   double s0 = 0.0, s1 = 0.0;
   f32x4 cur[RB_CH / 4], nxt[RB_CH / 4];
+  // No branch around any load (offsets past the row are clamped to its last 16 bytes and never used) and none in
+  // the loop body: the compiler then counts the loads in flight (vmcnt(8) before a step's arithmetic) instead of
+  // draining the step just prefetched as well.
   auto fetch = [&](f32x4 (&dst)[RB_CH / 4], int base) {
 #pragma unroll
-    for (int j = 0; j < RB_CH / 4; ++j)
-      dst[j] = base + 4 * j < ld ? *reinterpret_cast<const f32x4 *>(rp + base + 4 * j)  // through L1: a lane's 8
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};                          // loads share one 128-B line
+    for (int j = 0; j < RB_CH / 4; ++j) {
+      const int o = base + 4 * j < ld - 4 ? base + 4 * j : ld - 4;  // through L1: a lane's 8 loads share one 128-B line
+      dst[j] = *reinterpret_cast<const f32x4 *>(rp + o);
+    }
   };
-  fetch(cur, 0);
-  for (int base = 0; base < a.dim; base += RB_CH) {
-    if (base + RB_CH < a.dim) fetch(nxt, base + RB_CH);
-    const int m = a.dim - base < RB_CH ? a.dim - base : RB_CH;  // wave-uniform
+  const int nfull = a.dim / RB_CH;  // whole steps; the remaining dim % RB_CH elements follow
+  auto run = [&](auto METRIC) {  // the metric is a compile-time constant inside: no per-element branches
+    constexpr int M = decltype(METRIC)::value;
+    auto term = [&](float qf, float bf) {
+      const double qd = (double)qf, bd = (double)bf;
+      if (M == METRIC_L2) {
+        const double diff = qd - bd;
+        s0 = s0 + diff * diff;
+      } else {
+        s0 = s0 + qd * bd;
+        if (M == METRIC_COS) s1 = s1 + bd * bd;
+      }
+    };
+    fetch(cur, 0);
+    for (int it = 0; it < nfull; ++it) {
+      const int base = it * RB_CH;
+      fetch(nxt, base + RB_CH);
+      __builtin_amdgcn_sched_barrier(0);  // the prefetch stays AHEAD of the arithmetic (the scheduler sinks it)
+#pragma unroll
+      for (int j = 0; j < RB_CH / 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) term(qp[base + 4 * j + e], cur[j][e]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < RB_CH / 4; ++j) cur[j] = nxt[j];
+    }
+    const int base = nfull * RB_CH, m = a.dim - base;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < RB_CH / 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * j + e;
-        if (i < m) {
-          const double qd = (double)qp[base + i], bd = (double)cur[j][e];
-          if (l2) {
-            const double diff = qd - bd;
-            s0 = s0 + diff * diff;
-          } else {
-            s0 = s0 + qd * bd;
-            if (cosine) s1 = s1 + bd * bd;
-          }
-        }
-      }
-#pragma unroll
-    for (int j = 0; j < RB_CH / 4; ++j) cur[j] = nxt[j];
-  }
+      for (int e = 0; e < 4; ++e)
+        if (4 * j + e < m) term(qp[base + 4 * j + e], cur[j][e]);
+  };
+  if (l2) run(std::integral_constant<int, METRIC_L2>{});
+  else if (cosine) run(std::integral_constant<int, METRIC_COS>{});
+  else run(std::integral_constant<int, METRIC_IP>{});
   if (mine) {
     out[c0 + lane].id = a.row_base + (int64_t)row;
     out[c0 + lane].s0 = s0;
