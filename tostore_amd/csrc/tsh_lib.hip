@@ -936,8 +936,9 @@ void launch_quarantine_append(Shard *s, Ctx *c, Job *j, hipStream_t st) {
 
 // mask_words: this shard's slice of the caller mask (host), or NULL; epoch
 // identifies it so a context uploads it once per call
+// rows_est: rows the scan will actually read (popcount of the caller's mask; <= 0: all of them)
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
-                const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target) {
+                const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target, int64_t rows_est = 0) {
   Ctx *c = j->c;
   int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
   if (rc) return rc;
@@ -1016,7 +1017,10 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       // then run side by side, so each one's own duration roughly doubles; large shards keep one
       // stream, where a scan's duration is its HBM time.  TSH_SCAN_STREAMS=1 / 2 forces either.
       static const int forced = getenv("TSH_SCAN_STREAMS") ? atoi(getenv("TSH_SCAN_STREAMS")) : 0;
-      const bool two = forced == 2 || (forced != 1 && n_tiles < SMALL_SHARD_TILES);
+      // (a selective row mask makes a big shard's scan just as short: count the rows it keeps)
+      const int64_t tiles_read = rows_est > 0 ? std::min<int64_t>(n_tiles, (rows_est + 63) / 64) : n_tiles;
+      static const int min_tiles = getenv("TSH_TWO_STREAM_MIN_TILES") ? atoi(getenv("TSH_TWO_STREAM_MIN_TILES")) : 0;
+      const bool two = forced == 2 || (forced != 1 && tiles_read < SMALL_SHARD_TILES && tiles_read >= min_tiles);
       if (overlap && two && s->scan_stream2 && (s->scan_seq++ & 1)) ps = s->scan_stream2;
     }
     if (upload_mask)
@@ -1232,7 +1236,7 @@ struct SearchOut {
 // `depth` of them in flight on separate contexts so one query's select / rerank / copies hide
 // behind the next query's scan.
 int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, int32_t k, const uint64_t *mask_words,
-                       uint64_t epoch, int32_t entries, SearchOut *out, int depth) {
+                       uint64_t epoch, int32_t entries, SearchOut *out, int depth, int64_t rows_est) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   depth = std::max(1, std::min(depth, std::min(q1 - q0, MAX_CTX)));
   std::vector<Job> jobs((size_t)depth);
@@ -1257,7 +1261,7 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
       Job &j = jobs[(size_t)((submitted - q0) % depth)];
       j.c = c;
       rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries, mask_words, epoch,
-                       out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr);
+                       out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr, rows_est);
       if (rc) {
         release_all();
         return rc;
@@ -1289,20 +1293,23 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
   std::vector<uint64_t> mask_words;
   uint64_t epoch = 0;
+  int64_t rows_est = 0;
   if (mask) {
     mask_words.resize((size_t)n_tiles);
     slice_mask(s, mask, mask_words.data(), n_tiles);
     epoch = s->mask_epoch_src.fetch_add(1);
+    if (nq > 1)  // one pass over the mask per call: how long will each scan be?
+      for (uint64_t w : mask_words) rows_est += __builtin_popcountll(w);
   }
   const uint64_t *mw = mask ? mask_words.data() : nullptr;
   const int T = std::min(SUBMIT_THREADS, nq / 8);
-  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth);
+  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est);
   std::vector<int> rcs((size_t)T, TSH_OK);
   std::vector<std::string> errs((size_t)T);
   const int per_depth = std::max(2, depth / T);
   auto run = [&](int t) {
     const int32_t q0 = (int32_t)((int64_t)nq * t / T), q1 = (int32_t)((int64_t)nq * (t + 1) / T);
-    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth);
+    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth, rows_est);
     if (rcs[(size_t)t]) errs[(size_t)t] = g_err;
   };
   std::vector<std::thread> th;
