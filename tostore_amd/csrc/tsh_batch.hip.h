@@ -370,7 +370,7 @@ struct HbTile {
   static constexpr int MI = PM / 32;                                  // MFMA block rows per wave
   // the f16 kernel keeps fewer fragments, so the big tile affords a second register set as well
   static constexpr int NSETS = (PM == 64 || MODE == 1) ? 2 : 1;
-  static constexpr int MIN_WG = PM == 64 ? 2 : 1;
+  static constexpr int MIN_WG = (PM == 64 && THREADS <= 256) ? 2 : 1;
 };
 
 // MODE 0: bf16x3 (chunk = 32 k: 4 hi + 4 lo pieces, three MFMAs per block and slab of 16 k);

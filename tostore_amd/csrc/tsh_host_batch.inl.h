@@ -75,7 +75,14 @@ void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
   int grid = a.q_tiles * a.n_tiles;
   if (grid <= 0) return;
   if (a.dot_scale != 0.f) {  // f16 variant
-    if (a.tile_m == 256) {
+    // 256 x 256 tile: sixteen waves of 64 x 64 (four per SIMD) hide the LDS / barrier waits better than eight of
+    // 128 x 64: f16 pass 2.09-2.13 -> 1.95-2.00 ms.  (bf16x3 with its three MFMAs per fragment pair is LDS-read
+    // bound that way: 6.3 vs 4.85 ms, so it keeps eight waves.)  TSH_BATCH_F16_WAVES8=1 selects the old shape.
+    static const bool many_waves = getenv("TSH_BATCH_F16_WAVES8") == nullptr;
+    if (a.tile_m == 256 && many_waves) {
+      if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 64, 0, 1><<<grid, 1024, 0, st>>>(a);
+      else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 64, 0, 1><<<grid, 1024, 0, st>>>(a);
+    } else if (a.tile_m == 256) {
       if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
       else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
     } else {
