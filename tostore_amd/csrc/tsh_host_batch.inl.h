@@ -515,8 +515,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         }
       }
     }
-    if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
-    if (out->on_chunk) out->on_chunk(q0, q1, skip.data());
+    if (out->on_chunk) out->on_chunk(q0, q1, skip.data(), b->h_blocks);  // finalised straight from the pinned buffer
+    else if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
   }
   float ms0 = 0.f, ms1 = 0.f;
   HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
@@ -568,7 +568,9 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
     part.extra = out->extra;
     part.q_base = out->q_base + q0;
     if (out->on_chunk)  // indices of the callback are the caller's: shift this part's
-      part.on_chunk = [out, q0](int32_t a, int32_t b2, const char *skip) { out->on_chunk(q0 + a, q0 + b2, skip - q0); };
+      part.on_chunk = [out, q0, bb](int32_t a, int32_t b2, const char *skip, const uint8_t *base) {
+        out->on_chunk(q0 + a, q0 + b2, skip - q0, base - (size_t)q0 * bb);
+      };
     std::vector<int32_t> r;
     int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);
     if (rc) return rc;

@@ -1227,9 +1227,11 @@ struct SearchOut {
   int32_t q_base = 0;  // batched path: this part's query 0 is (*extra)[q_base]
   uint8_t *d_blocks = nullptr;  // device mode
   hipStream_t user_stream = nullptr;
-  // batched path, host mode: called as soon as the blocks of queries [q0, q1) are in h_blocks, while the GPU
-  // still re-ranks the next chunk; skip[q] != 0 marks queries the single-query path will redo
-  std::function<void(int32_t q0, int32_t q1, const char *skip)> on_chunk;
+  // batched path, host mode: called as soon as the blocks of queries [q0, q1) have arrived from the GPU, while it
+  // still re-ranks the next chunk; query q's block is at base + q * block bytes (the batch's own pinned buffer:
+  // valid during the call only -- with a callback the blocks are NOT copied to h_blocks); skip[q] != 0 marks
+  // queries the single-query path will redo (those do land in h_blocks)
+  std::function<void(int32_t q0, int32_t q1, const char *skip, const uint8_t *base)> on_chunk;
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1659,10 +1661,10 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     so.spill = &spills[g];
     so.extra = &extras[g];
     if (ns == 1)  // batched path: finalise a chunk of queries while the GPU still works on the next one
-      so.on_chunk = [&](int32_t q0, int32_t q1, const char *skip) {
+      so.on_chunk = [&](int32_t q0, int32_t q1, const char *skip, const uint8_t *base) {
         parallel_for_range(q0, q1, [&](int32_t q) {
           if (skip[q]) return;
-          const uint8_t *b = blocks[0].get() + (size_t)q * bb;
+          const uint8_t *b = base + (size_t)q * bb;
           const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b);
           std::vector<std::pair<const BlockEntry *, uint32_t>> one{
               {reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)), std::min(h->count, h->entries)}};
