@@ -712,6 +712,7 @@ struct FinalSelArgs {
   const uint32_t *cand_key, *cand_row, *cand_cnt;
   const float *delta2;
   uint8_t *blocks;       // nq blocks (BlockHeader + entries), device
+  uint8_t *blocks_host;  // nullable: the same blocks in pinned host memory (headers are stored to both)
   uint32_t *final_rows;  // nq x entries
   int64_t block_bytes;
   int64_t row_base, shard_rows;
@@ -755,6 +756,7 @@ __global__ void __launch_bounds__(BS_THREADS) batch_final_select_kernel(FinalSel
     hv.shard_rows = a.shard_rows;
     hv.pad[0] = hv.pad[1] = hv.pad[2] = hv.pad[3] = 0u;
     *reinterpret_cast<BlockHeader *>(a.blocks + (int64_t)q * a.block_bytes) = hv;
+    if (a.blocks_host) *reinterpret_cast<BlockHeader *>(a.blocks_host + (int64_t)q * a.block_bytes) = hv;
   }
 }
 
@@ -764,7 +766,8 @@ struct RerankBatchArgs {
   const float *rows;
   const float *Q;  // nq_pad x ld
   const uint32_t *final_rows;  // nq x entries
-  uint8_t *blocks;
+  uint8_t *blocks;      // headers (device)
+  uint8_t *out_blocks;  // where the entries go: the device blocks, or their pinned host twin (zero-copy results)
   int64_t block_bytes;
   int64_t ld, row_base;
   int32_t dim, entries, metric;
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
   const uint32_t c0 = blockIdx.x * 64u;
   if (c0 >= count) return;
   const bool mine = c0 + lane < count;
-  BlockEntry *out = reinterpret_cast<BlockEntry *>(blk + sizeof(BlockHeader));
+  BlockEntry *out = reinterpret_cast<BlockEntry *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader));
   const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;
   const uint32_t row = mine ? a.final_rows[(int64_t)q * a.entries + c0 + lane] : 0u;
   const float *__restrict__ rp = a.rows + (int64_t)row * a.ld;

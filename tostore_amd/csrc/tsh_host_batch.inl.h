@@ -14,6 +14,7 @@ struct BatchCtx {
   uint32_t *d_ck = nullptr, *d_cr = nullptr, *d_cc = nullptr;
   int64_t cand_total = 0;  // nq * cand_cap capacity
   uint8_t *d_blocks = nullptr, *h_blocks = nullptr;
+  uint8_t *h_blocks_dev = nullptr;  // h_blocks as the device sees it (results are stored straight into it)
   uint32_t *d_final = nullptr;
   int64_t blocks_cap = 0, final_cap = 0;
   uint64_t *d_mask = nullptr, *h_mask = nullptr;
@@ -160,9 +161,6 @@ bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2,
   return true;
 }
 
-inline double now_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 inline bool trace_batch() {
   static const bool on = getenv("TSH_TRACE_BATCH") != nullptr;
   return on;
@@ -206,6 +204,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad, &b->bytes))) return rc;
   }
   if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
+  HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_blocks_dev), b->h_blocks, 0));
   if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
   const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
   if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
@@ -442,7 +441,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     fs.cand_row = b->d_cr;
     fs.cand_cnt = b->d_cc;
     fs.delta2 = d_d2;
+    // host mode: headers and re-ranked entries are stored straight into pinned host memory (only the `count`
+    // valid entries cross PCIe, and no copy sits between the last kernel and the host)
+    const bool zero_copy = out->d_blocks == nullptr;
     fs.blocks = b->d_blocks;
+    fs.blocks_host = zero_copy ? b->h_blocks_dev : nullptr;
     fs.final_rows = b->d_final;
     fs.block_bytes = (int64_t)bb;
     fs.row_base = s->row_base;
@@ -457,6 +460,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     rb.Q = b->d_Q;
     rb.final_rows = b->d_final;
     rb.blocks = b->d_blocks;
+    rb.out_blocks = zero_copy ? b->h_blocks_dev : b->d_blocks;
     rb.block_bytes = (int64_t)bb;
     rb.ld = ld;
     rb.row_base = s->row_base;
@@ -486,8 +490,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         qa.metric = s->metric;
         quarantine_append_kernel<<<dim3((unsigned)((n_quar + 63) / 64), (unsigned)(q1 - q0)), 64, 0, st>>>(qa);
       }
-      HIPCHK(hipMemcpyAsync(b->h_blocks + (size_t)q0 * bb, b->d_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb,
-                            hipMemcpyDeviceToHost, st));
+      if (!zero_copy)
+        HIPCHK(hipMemcpyAsync(b->h_blocks + (size_t)q0 * bb, b->d_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb,
+                              hipMemcpyDeviceToHost, st));
       HIPCHK(hipEventRecord(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done, st));
     }
   }
@@ -515,7 +520,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         }
       }
     }
+    const double t_c0 = now_us();
     if (out->on_chunk) out->on_chunk(q0, q1, skip.data(), b->h_blocks);  // finalised straight from the pinned buffer
+    if (trace_batch()) fprintf(stderr, "[tsh batch]   chunk %d: event at %.0f us, finalised in %.0f us\n", c, t_c0 - t_enq, now_us() - t_c0);
     else if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
   }
   float ms0 = 0.f, ms1 = 0.f;

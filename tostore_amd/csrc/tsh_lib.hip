@@ -155,28 +155,37 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
 // run fn(q) for q in [0,n) on a few host threads (per-query preparation / finalisation of a
 // batch).  The workers are created once and parked on a condition variable: spawning threads
 // per call costs more than the work itself (about 30 us per thread on a 128-core host).
+inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 class HostPool {
  public:
   static HostPool &get() {
     static HostPool *p = new HostPool();  // never destroyed: workers may outlive static teardown
     return *p;
   }
-  // false when the pool is busy with another caller's job (the caller then runs inline)
+  // false when the pool is busy with another caller's job (the caller then runs inline).
+  // A job is complete when all its ITEMS are done, not when every worker has reported: a worker that wakes up
+  // late (a parked thread needs 30-50 us, a descheduled one milliseconds) finds the job closed and goes back to
+  // waiting -- the caller and the workers that are awake have done its share.
   bool run(int32_t n, const std::function<void(int32_t)> &fn) {
     std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
     if (!own.owns_lock()) return false;
+    fn_ = &fn;
+    n_ = n;
+    done_items_.store(0, std::memory_order_relaxed);
+    next_.store(0, std::memory_order_relaxed);
+    open_.store(true, std::memory_order_release);
     {
-      std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn;
-      n_ = n;
-      next_.store(0);
-      pending_ = (int)workers_.size();
-      ++gen_;
+      std::lock_guard<std::mutex> lk(m_);  // a worker between its last look at gen_ and cv_.wait must not miss this
+      gen_.fetch_add(1, std::memory_order_release);
     }
-    cv_.notify_all();
+    if (parked_.load(std::memory_order_acquire) > 0) cv_.notify_all();
     chunks();
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&] { return pending_ == 0; });
+    spin_until([&] { return done_items_.load(std::memory_order_acquire) >= n; });
+    open_.store(false, std::memory_order_release);
+    spin_until([&] { return active_.load(std::memory_order_acquire) == 0; });  // nobody still looks at fn_ / n_
     fn_ = nullptr;
     return true;
   }
@@ -185,40 +194,66 @@ class HostPool {
  private:
   HostPool() {
     unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, 15);
+    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 64 ? 31 : 15);
     for (int i = 0; i < nt; ++i) {
       workers_.emplace_back([this] { loop(); });
       workers_.back().detach();
     }
   }
-  void chunks() {
-    for (;;) {
-      int32_t q0 = next_.fetch_add(8);
-      if (q0 >= n_) return;
-      for (int32_t q = q0; q < std::min(n_, q0 + 8); ++q) (*fn_)(q);
+  template <typename F>
+  static void spin_until(F &&cond) {
+    for (int spins = 0; !cond(); ++spins) {
+      if (spins < 20000) __builtin_ia32_pause();
+      else std::this_thread::yield();
     }
   }
+  void chunks() {
+    for (;;) {
+      int32_t q0 = next_.fetch_add(8, std::memory_order_acq_rel);
+      if (q0 >= n_) return;
+      const int32_t q1 = std::min(n_, q0 + 8);
+      for (int32_t q = q0; q < q1; ++q) (*fn_)(q);
+      done_items_.fetch_add(q1 - q0, std::memory_order_acq_rel);
+    }
+  }
+  // A batch hands the pool several jobs a few hundred microseconds apart (one per chunk of its tail); waking a
+  // parked thread costs more than such a job itself, so a worker keeps polling for SPIN_US after a job before
+  // it parks on the condition variable again.
+  static constexpr double SPIN_US = 400.0;
   void loop() {
     uint64_t seen = 0;
     for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return gen_ != seen; });
-        seen = gen_;
+      const double t0 = now_us();
+      bool got = false;
+      for (int i = 0;; ++i) {
+        if (gen_.load(std::memory_order_acquire) != seen) {
+          got = true;
+          break;
+        }
+        __builtin_ia32_pause();
+        if ((i & 255) == 255 && now_us() - t0 > SPIN_US) break;
       }
-      chunks();
-      std::lock_guard<std::mutex> lk(m_);
-      if (--pending_ == 0) done_.notify_all();
+      if (!got) {
+        std::unique_lock<std::mutex> lk(m_);
+        parked_.fetch_add(1, std::memory_order_acq_rel);
+        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        parked_.fetch_sub(1, std::memory_order_acq_rel);
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      active_.fetch_add(1, std::memory_order_acq_rel);
+      if (open_.load(std::memory_order_acquire)) chunks();  // closed: the job finished without this worker
+      active_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
   std::vector<std::thread> workers_;
   std::mutex owner_, m_;
-  std::condition_variable cv_, done_;
+  std::condition_variable cv_;
   const std::function<void(int32_t)> *fn_ = nullptr;
   int32_t n_ = 0;
-  std::atomic<int32_t> next_{0};
-  int pending_ = 0;
-  uint64_t gen_ = 0;
+  std::atomic<int32_t> next_{0}, done_items_{0};
+  std::atomic<int> active_{0}, parked_{0};
+  std::atomic<bool> open_{false};
+  std::atomic<uint64_t> gen_{0};
 };
 
 template <typename F>
