@@ -613,7 +613,26 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   uint32_t lmin[BS_GPT];
 #pragma unroll
   for (int u = 0; u < BS_GPT; ++u) lmin[u] = KEY_DEAD;
-  for (int base = 0; base < n; base += BS_GROUPS) {
+  // 16-byte loads when the list is 16-byte aligned (the dense sample rows and the candidate lists are): four
+  // consecutive entries then share a group, which is as good a partition as any
+  const bool vec = (reinterpret_cast<uintptr_t>(keys) & 15) == 0;
+  const int n4 = vec ? n >> 2 : 0;
+  const f32x4 *keys4 = reinterpret_cast<const f32x4 *>(keys);
+  for (int base = 0; base < n4; base += BS_GROUPS) {
+#pragma unroll
+    for (int u = 0; u < BS_GPT; ++u) {
+      int i = base + u * BS_THREADS + tid;
+      if (i < n4) {
+        const f32x4 f = keys4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t x = fkey_or_dead(f[e]);
+          lmin[u] = x < lmin[u] ? x : lmin[u];
+        }
+      }
+    }
+  }
+  for (int base = 4 * n4; base < n; base += BS_GROUPS) {
 #pragma unroll
     for (int u = 0; u < BS_GPT; ++u) {
       int i = base + u * BS_THREADS + tid;
@@ -636,13 +655,19 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   }
   __syncthreads();
   const uint32_t U = sc->U;
-  for (int i = tid; i < n; i += BS_THREADS) {
-    uint32_t x = fkey_or_dead(keys[i]);
+  auto offer = [&](float f) {
+    uint32_t x = fkey_or_dead(f);
     if (x <= U && x != KEY_DEAD) {
       uint32_t p = atomicAdd(&sc->n_list, 1u);
       if (p < BS_LIST) sc->list[p] = x;
     }
+  };
+  for (int i = tid; i < n4; i += BS_THREADS) {
+    const f32x4 f = keys4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) offer(f[e]);
   }
+  for (int i = 4 * n4 + tid; i < n; i += BS_THREADS) offer(keys[i]);
   __syncthreads();
   if (wave == 0) {
     const uint32_t m = sc->n_list;
@@ -694,8 +719,7 @@ __global__ void __launch_bounds__(BS_THREADS) batch_sample_select_kernel(SampleS
     s_cnt = 0;
   }
   __syncthreads();
-  for (int i = tid; i < a.n_sample; i += BS_THREADS) {
-    float f = keys[i];
+  auto offer = [&](float f, int i) {
     if (f <= thr) {  // NaN (dead) never passes
       uint32_t p = atomicAdd(&s_cnt, 1u);
       if (p < (uint32_t)a.cand_cap) {
@@ -703,7 +727,14 @@ __global__ void __launch_bounds__(BS_THREADS) batch_sample_select_kernel(SampleS
         a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)(a.row0 + i);
       }
     }
+  };
+  const int n4 = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? a.n_sample >> 2 : 0;
+  for (int i = tid; i < n4; i += BS_THREADS) {
+    const f32x4 f = reinterpret_cast<const f32x4 *>(keys)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) offer(f[e], 4 * i + e);
   }
+  for (int i = 4 * n4 + tid; i < a.n_sample; i += BS_THREADS) offer(keys[i], i);
   __syncthreads();
   if (tid == 0) a.cand_cnt[q] = s_cnt;
 }
