@@ -261,7 +261,9 @@ int32_t tsh_default_block_entries(int32_t k);
  * handle's device; the kernels store the blocks into it directly and the call
  * returns after they completed (host-synchronised), so any stream may read it
  * next.  stream: reserved (pass NULL or the consumer's hipStream_t).
- * row_mask is GLOBAL (bit = global row id). */
+ * row_mask is GLOBAL (bit = global row id).  Rows kept out of the scan (tsh_counters.quarantined_rows) are
+ * appended to every block the mask lets them into; a block they do not fit in reports count > entries like any
+ * other overflow, and tsh_merge_candidates answers TSH_E_OVERFLOW with the entry count to retry with. */
 int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                          const uint8_t *row_mask, int32_t entries, void *d_out_blocks,
                          void *stream);
