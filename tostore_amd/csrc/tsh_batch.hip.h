@@ -65,6 +65,11 @@ struct BatchArgs {
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
 // q_tiles consecutive workgroups that share one row tile (L2 reuse of V)
+// Per-query candidate counters sit one per 128-byte line: every survivor of the filtered pass is one returning
+// atomic on its query's counter, and packed counters (a small batch: all of them in a few lines, i.e. a few L2
+// channels) serialise there.
+constexpr int CC_STRIDE = 32;  // uint32 units (4 KiB apart measured the same)
+
 __device__ __forceinline__ void batch_tile_of(const BatchArgs &a, int b, int *q_tile, int *n_tile) {
   const int total = a.q_tiles * a.n_tiles;
   const int xcd = b & 7, i = b >> 3;
@@ -138,7 +143,7 @@ __device__ __forceinline__ void batch_epilogue(const BatchArgs &a, f32x16 (&acc)
             float kv = 0.f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) kv = u == r ? key[u] : kv;  // register select, no scratch
-            uint32_t p = atomicAdd(&a.cand_cnt[q], 1u);
+            uint32_t p = atomicAdd(&a.cand_cnt[(int64_t)q * CC_STRIDE], 1u);
             if (p < (uint32_t)a.cand_cap) {
               a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(kv);
               a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)col;
@@ -736,7 +741,7 @@ __global__ void __launch_bounds__(BS_THREADS) batch_sample_select_kernel(SampleS
   }
   for (int i = 4 * n4 + tid; i < a.n_sample; i += BS_THREADS) offer(keys[i], i);
   __syncthreads();
-  if (tid == 0) a.cand_cnt[q] = s_cnt;
+  if (tid == 0) a.cand_cnt[(int64_t)q * CC_STRIDE] = s_cnt;
 }
 
 struct FinalSelArgs {
@@ -756,7 +761,7 @@ __global__ void __launch_bounds__(BS_THREADS) batch_final_select_kernel(FinalSel
   __shared__ KthScratch sc;
   __shared__ uint32_t s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x;
-  const uint32_t total = a.cand_cnt[q];
+  const uint32_t total = a.cand_cnt[(int64_t)q * CC_STRIDE];
   const bool over_in = total > (uint32_t)a.cand_cap;
   const int n = (int)(over_in ? (uint32_t)a.cand_cap : total);
   const float *keys = reinterpret_cast<const float *>(a.cand_key + (int64_t)q * a.cand_cap);

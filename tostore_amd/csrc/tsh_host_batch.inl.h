@@ -201,7 +201,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if ((rc = regrow(&b->d_ck, (uint32_t **)nullptr, &c1, want, &b->bytes))) return rc;
     if ((rc = regrow(&b->d_cr, (uint32_t **)nullptr, &c2, want, &b->bytes))) return rc;
     b->cand_total = std::max(b->cand_total, want);
-    if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad * CC_STRIDE, &b->bytes))) return rc;
   }
   if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_blocks_dev), b->h_blocks, 0));
