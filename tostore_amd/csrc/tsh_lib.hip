@@ -193,8 +193,14 @@ class HostPool {
 
  private:
   HostPool() {
+    // workers poll between jobs, so they must not oversubscribe the host: one process per GPU shares the cores
+    // with its peers (torchrun exports LOCAL_WORLD_SIZE); TSH_HOST_THREADS overrides
     unsigned hw = std::thread::hardware_concurrency();
+    const char *peers_s = getenv("LOCAL_WORLD_SIZE");
+    const unsigned peers = peers_s && atoi(peers_s) > 0 ? (unsigned)atoi(peers_s) : 1u;
+    hw = std::max(1u, hw / peers);
     int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 64 ? 31 : 15);
+    if (const char *forced = getenv("TSH_HOST_THREADS")) nt = std::max(0, std::min(atoi(forced) - 1, 63));
     for (int i = 0; i < nt; ++i) {
       workers_.emplace_back([this] { loop(); });
       workers_.back().detach();
