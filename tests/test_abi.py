@@ -99,6 +99,33 @@ def test_merge_candidates_is_the_reference_ordering(oracle_mod, metric):
         assert np.array_equal(dist[0, :cnt[0]].view(np.uint64), edist.view(np.uint64))
 
 
+def test_merge_of_many_queries_runs_on_the_host_pool(oracle_mod):
+    """nq >= 64 goes through the library's pool of polling host threads (jobs complete on items, late workers find
+    the job closed): repeated calls, with pauses long enough for the workers to park in between, stay correct"""
+    import time
+
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    rng = np.random.default_rng(9)
+    n, d, k, entries, nq = 300, 8, 5, 64, 200
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    blocks = b""
+    expect = []
+    for q in qs:
+        ids, _ = oracle_mod.search_exhaustive(rows, q, L2, k + 3)
+        blocks += _block(entries, [(int(i),) + oracle_mod.exact_sums(q, rows[int(i)], L2) for i in ids], k, L2)
+        expect.append(oracle_mod.search_exhaustive(rows, q, L2, k))
+    buf = np.frombuffer(blocks, np.uint8)
+    for rep in range(30):
+        ids, dist, cnt = merge_candidate_blocks(L2, d, qs, k, None, buf, 1, entries)
+        for i in range(nq):
+            assert cnt[i] == k and np.array_equal(ids[i], expect[i][0])
+            assert np.array_equal(dist[i].view(np.uint64), expect[i][1].view(np.uint64))
+        if rep % 10 == 9:
+            time.sleep(0.01)  # > the workers' polling window: the next call has to wake them
+
+
 def test_merge_reports_truncated_blocks(oracle_mod):
     from tostore_amd import _ffi
     from tostore_amd.sharded import merge_candidate_blocks
