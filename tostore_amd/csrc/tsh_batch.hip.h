@@ -591,11 +591,11 @@ __global__ void __launch_bounds__((HbTile<TM, TN, PM>::THREADS), (HbTile<TM, TN,
 // Same idea as K2: thread minima -> one wave bisects them -> short list of
 // everything <= that bound -> exact k-th.  Returns KEY_NAN when fewer than k
 // entries are finite (caller then keeps everything).
-constexpr int BS_THREADS = 256;
+constexpr int BS_THREADS = 256;       // workgroup size for large batches
+constexpr int BS_THREADS_WIDE = 1024;  // ... and for small ones: few workgroups in flight, so each gets more waves
 constexpr int BS_LIST = 4096;
 
-constexpr int BS_GPT = 8;                    // group minima per thread
-constexpr int BS_GROUPS = BS_GPT * BS_THREADS;  // 2048 groups: the bound stays tight up to k = 1024
+constexpr int BS_GROUPS = 2048;  // strided groups (BS_GROUPS / THREADS per thread): the bound stays tight up to k = 1024
 
 struct KthScratch {
   uint32_t lm[BS_GROUPS];
@@ -605,7 +605,9 @@ struct KthScratch {
 
 __device__ __forceinline__ uint32_t fkey_or_dead(float f) { return f != f ? KEY_DEAD : f2key(f); }
 
+template <int THREADS>
 __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc) {
+  constexpr int BS_GPT = BS_GROUPS / THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
     sc->n_list = 0;
@@ -626,7 +628,7 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   for (int base = 0; base < n4; base += BS_GROUPS) {
 #pragma unroll
     for (int u = 0; u < BS_GPT; ++u) {
-      int i = base + u * BS_THREADS + tid;
+      int i = base + u * THREADS + tid;
       if (i < n4) {
         const f32x4 f = keys4[i];
 #pragma unroll
@@ -640,7 +642,7 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   for (int base = 4 * n4; base < n; base += BS_GROUPS) {
 #pragma unroll
     for (int u = 0; u < BS_GPT; ++u) {
-      int i = base + u * BS_THREADS + tid;
+      int i = base + u * THREADS + tid;
       if (i < n) {
         uint32_t x = fkey_or_dead(keys[i]);
         lmin[u] = x < lmin[u] ? x : lmin[u];
@@ -649,7 +651,7 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   }
   const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_GROUPS / 2 && n > BS_LIST;
 #pragma unroll
-  for (int u = 0; u < BS_GPT; ++u) sc->lm[u * BS_THREADS + tid] = lmin[u];
+  for (int u = 0; u < BS_GPT; ++u) sc->lm[u * THREADS + tid] = lmin[u];
   __syncthreads();
   if (narrow && wave == 0) {
     uint32_t v[BS_GROUPS / 64];
@@ -667,12 +669,12 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
       if (p < BS_LIST) sc->list[p] = x;
     }
   };
-  for (int i = tid; i < n4; i += BS_THREADS) {
+  for (int i = tid; i < n4; i += THREADS) {
     const f32x4 f = keys4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) offer(f[e]);
   }
-  for (int i = 4 * n4 + tid; i < n; i += BS_THREADS) offer(keys[i]);
+  for (int i = 4 * n4 + tid; i < n; i += THREADS) offer(keys[i]);
   __syncthreads();
   if (wave == 0) {
     const uint32_t m = sc->n_list;
@@ -712,12 +714,13 @@ struct SampleSelArgs {
 
 // B0s: one workgroup per query.  thr[q] = band(k-th smallest sample key); the
 // sample rows at or below it open the query's candidate list.
-__global__ void __launch_bounds__(BS_THREADS) batch_sample_select_kernel(SampleSelArgs a) {
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelArgs a) {
   __shared__ KthScratch sc;
   __shared__ uint32_t s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float *keys = a.dense + (int64_t)q * a.dense_ld;
-  uint32_t tau = block_kth_of_floats(keys, a.n_sample, (uint32_t)a.k, &sc);
+  uint32_t tau = block_kth_of_floats<THREADS>(keys, a.n_sample, (uint32_t)a.k, &sc);
   float thr = band_float(tau, a.delta2[q]);
   if (tid == 0) {
     a.thr[q] = thr;
@@ -734,12 +737,12 @@ __global__ void __launch_bounds__(BS_THREADS) batch_sample_select_kernel(SampleS
     }
   };
   const int n4 = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? a.n_sample >> 2 : 0;
-  for (int i = tid; i < n4; i += BS_THREADS) {
+  for (int i = tid; i < n4; i += THREADS) {
     const f32x4 f = reinterpret_cast<const f32x4 *>(keys)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) offer(f[e], 4 * i + e);
   }
-  for (int i = 4 * n4 + tid; i < a.n_sample; i += BS_THREADS) offer(keys[i], i);
+  for (int i = 4 * n4 + tid; i < a.n_sample; i += THREADS) offer(keys[i], i);
   __syncthreads();
   if (tid == 0) a.cand_cnt[(int64_t)q * CC_STRIDE] = s_cnt;
 }
@@ -757,7 +760,8 @@ struct FinalSelArgs {
 
 // B2: one workgroup per query: exact k-th smallest key of the candidate list,
 // widened by the band; survivors are the rows the f64 rerank will score.
-__global__ void __launch_bounds__(BS_THREADS) batch_final_select_kernel(FinalSelArgs a) {
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArgs a) {
   __shared__ KthScratch sc;
   __shared__ uint32_t s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x;
@@ -766,11 +770,11 @@ __global__ void __launch_bounds__(BS_THREADS) batch_final_select_kernel(FinalSel
   const int n = (int)(over_in ? (uint32_t)a.cand_cap : total);
   const float *keys = reinterpret_cast<const float *>(a.cand_key + (int64_t)q * a.cand_cap);
   const uint32_t *rows = a.cand_row + (int64_t)q * a.cand_cap;
-  uint32_t tau = block_kth_of_floats(keys, n, (uint32_t)a.k, &sc);
+  uint32_t tau = block_kth_of_floats<THREADS>(keys, n, (uint32_t)a.k, &sc);
   float band = band_float(tau, a.delta2[q]);
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += BS_THREADS) {
+  for (int i = tid; i < n; i += THREADS) {
     if (keys[i] <= band) {
       uint32_t p = atomicAdd(&s_cnt, 1u);
       if (p < (uint32_t)a.entries) a.final_rows[(int64_t)q * a.entries + p] = rows[i];

@@ -425,7 +425,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     ss.k = k;
     ss.cand_cap = cand_cap;
     ss.row0 = 0;
-    batch_sample_select_kernel<<<nq, BS_THREADS, 0, st>>>(ss);
+    // one workgroup per query: a small batch leaves most CUs empty, so its workgroups get sixteen waves instead of
+    // four (128 queries: 76 -> 54 and 58 -> 50 us); with a thousand workgroups the wide shape loses (the one-wave
+    // bisect phases idle fifteen waves: 103 -> 235 us)
+    const bool wide_select = nq <= 256;
+    if (wide_select) batch_sample_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(ss);
+    else batch_sample_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(ss);
     // B1: everything else, filtered
     HIPCHK(hipEventRecord(b->e2, st));
     if (rows > n_sample) {
@@ -454,7 +459,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     fs.cand_cap = cand_cap;
     fs.entries = entries;
     fs.metric = s->metric;
-    batch_final_select_kernel<<<nq, BS_THREADS, 0, st>>>(fs);
+    if (wide_select) batch_final_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(fs);
+    else batch_final_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(fs);
     RerankBatchArgs rb{};
     rb.rows = s->d_rows;
     rb.Q = b->d_Q;
