@@ -174,6 +174,7 @@ class HostPool {
     if (!own.owns_lock()) return false;
     fn_ = &fn;
     n_ = n;
+    grain_ = std::max(1, std::min(8, n / (4 * threads())));  // a 128-item job on 32 threads: items of one, not of eight
     done_items_.store(0, std::memory_order_relaxed);
     next_.store(0, std::memory_order_relaxed);
     open_.store(true, std::memory_order_release);
@@ -190,6 +191,13 @@ class HostPool {
     return true;
   }
   int threads() const { return (int)workers_.size() + 1; }
+  // A caller about to wait for the GPU and then hand the pool a job: keep the workers polling until `t_us`
+  // (now_us() clock) so the job does not start with waking them.  Bounded by the caller (a millisecond at most).
+  void stay_awake_until(double t_us) {
+    double cur = awake_until_.load(std::memory_order_relaxed);
+    while (t_us > cur && !awake_until_.compare_exchange_weak(cur, t_us, std::memory_order_relaxed)) {
+    }
+  }
 
  private:
   HostPool() {
@@ -215,9 +223,10 @@ class HostPool {
   }
   void chunks() {
     for (;;) {
-      int32_t q0 = next_.fetch_add(8, std::memory_order_acq_rel);
+      const int32_t g = grain_;
+      int32_t q0 = next_.fetch_add(g, std::memory_order_acq_rel);
       if (q0 >= n_) return;
-      const int32_t q1 = std::min(n_, q0 + 8);
+      const int32_t q1 = std::min(n_, q0 + g);
       for (int32_t q = q0; q < q1; ++q) (*fn_)(q);
       done_items_.fetch_add(q1 - q0, std::memory_order_acq_rel);
     }
@@ -237,7 +246,10 @@ class HostPool {
           break;
         }
         __builtin_ia32_pause();
-        if ((i & 255) == 255 && now_us() - t0 > SPIN_US) break;
+        if ((i & 255) == 255) {
+          const double t = now_us();
+          if (t - t0 > SPIN_US && t > awake_until_.load(std::memory_order_relaxed)) break;
+        }
       }
       if (!got) {
         std::unique_lock<std::mutex> lk(m_);
@@ -255,10 +267,11 @@ class HostPool {
   std::mutex owner_, m_;
   std::condition_variable cv_;
   const std::function<void(int32_t)> *fn_ = nullptr;
-  int32_t n_ = 0;
+  int32_t n_ = 0, grain_ = 8;
   std::atomic<int32_t> next_{0}, done_items_{0};
   std::atomic<int> active_{0}, parked_{0};
   std::atomic<bool> open_{false};
+  std::atomic<double> awake_until_{0.0};
   std::atomic<uint64_t> gen_{0};
 };
 
