@@ -476,7 +476,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     rb.metric = s->metric;
     // the tail runs in chunks of queries: while the GPU re-ranks chunk c + 1 and copies it out, the host already
     // finalises chunk c (out->on_chunk)
-    n_chunks = (out->on_chunk && nq >= 512) ? 4 : 1;
+    n_chunks = !out->on_chunk ? 1 : (nq >= 512 ? 4 : (nq >= 256 ? 2 : 1));  // (256 queries: 1.00 -> 0.94 ms; 128: no gain)
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
       rb.q0 = q0;
