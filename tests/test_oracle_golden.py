@@ -119,6 +119,56 @@ def test_two_restatements_agree(oracle_mod):
                 assert np.array_equal(_bits(dist[i, :cnt[i]]), _bits(e_dist))
 
 
+def test_two_restatements_agree_on_irregular_rows(oracle_mod):
+    """rows with NaN / inf / huge / tiny values: the reference's f64 arithmetic gives them inf / NaN / 0 distances and
+    `double.compareTo` orders those (NaN last, never `> threshold`) -- what the library's quarantined rows must
+    reproduce (tests/test_gpu_irregular.py); here the C and the NumPy restatement agree on it bit for bit"""
+    from oracle import np_oracle as npo
+
+    rng = np.random.default_rng(11)
+    d = 12
+    rows = rng.standard_normal((300, d)).astype(np.float32)
+    rows[3, 1] = np.nan
+    rows[10] = np.nan
+    rows[50, 0] = np.inf
+    rows[51, 5] = -np.inf
+    rows[52, 2] = np.inf
+    rows[52, 3] = -np.inf      # inf - inf
+    rows[100, 4] = 3e20        # finite; its square overflows f32, not f64
+    rows[101] = -2e16
+    rows[150] = 0.0
+    rows[150, 7] = 1e-30       # tiny norm
+    rows[151] = 0.0            # zero row: cosine similarity defined as 0
+    keep = np.packbits(rng.random(300) < 0.7, bitorder="little")
+    for qi in range(4):
+        q = rng.standard_normal(d).astype(np.float32)
+        for metric in (L2, IP, COS):
+            qq = oracle_mod.normalize_f32(q) if metric == COS else q
+            a = oracle_mod.all_distances(qq, rows, metric)
+            b = npo.all_distances(qq, rows, metric)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(_bits(a[~np.isnan(a)]), _bits(b[~np.isnan(b)]))
+            if metric == COS:  # `denom > 0 ? dot / denom : 0` (ngh_graph_engine.dart:945): a NaN denominator means similarity 0
+                assert a[3] == 1.0 and a[10] == 1.0
+            else:              # (row 52, inf and -inf: inf for L2, inf or NaN by the query's signs for IP)
+                assert np.isnan(a[3]) and np.isnan(a[10])
+            if metric == L2:
+                assert a[50] == np.inf and a[51] == np.inf and np.isfinite(a[100]) and a[100] > 1e20
+            if metric == COS:
+                assert a[151] == 1.0 and np.isfinite(a[150])
+            for k in (5, 300):
+                for thr in (None, float(np.nanmedian(a)), -1e300):
+                    for mask in (None, keep):
+                        x = oracle_mod.search_exhaustive(rows, qq, metric, k, thr, mask)
+                        y = npo.search_exhaustive(rows, qq, metric, k, thr, mask)
+                        assert np.array_equal(x[0], y[0]), (metric, k, thr)
+                        assert np.array_equal(np.isnan(x[1]), np.isnan(y[1]))
+                        assert np.array_equal(_bits(x[1][~np.isnan(x[1])]), _bits(y[1][~np.isnan(y[1])]))
+                        nan_at = np.flatnonzero(np.isnan(x[1]))
+                        assert len(nan_at) == 0 or nan_at[0] == len(x[1]) - len(nan_at)  # NaN sorts last ...
+                        if thr is not None and mask is None and k == 300 and metric != COS:
+                            assert {3, 10} <= set(x[0].tolist())                          # ... and passes any threshold
+
+
 def test_properties_on_all_distances(oracle_mod):
     """size-independent properties: symmetry of L2, IP linearity in sign, cosine in [0,2]."""
     rng = np.random.default_rng(9)
