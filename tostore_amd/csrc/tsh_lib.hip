@@ -77,31 +77,22 @@ constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-// ---- Dart double.compareTo ([external] Dart SDK): NaN greatest, -0 < +0 ------
-inline int dart_compare(double a, double b) {
-  if (a < b) return -1;
-  if (a > b) return 1;
-  if (a == b) {
-    if (a == 0.0) {
-      bool an = std::signbit(a), bn = std::signbit(b);
-      if (an == bn) return 0;
-      return an ? -1 : 1;
-    }
-    return 0;
-  }
-  if (std::isnan(a)) return std::isnan(b) ? 0 : 1;
-  return -1;
+// ---- Dart double.compareTo ([external] Dart SDK): NaN greatest (and equal to itself), -0 < +0 ------
+// double.compareTo as an integer order: key(a) < key(b)  <=>  dart_compare(a, b) < 0, equal keys <=> compareTo == 0
+// (every NaN maps to the one largest key; -0.0 sorts just below +0.0).  Sorting (key, id) pairs with integer
+// compares is what the finaliser does for every query.
+inline uint64_t dart_order_key(double d) {
+  if (d != d) return ~0ull;
+  uint64_t b;
+  memcpy(&b, &d, 8);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
-
 struct Hit {
-  double dist;
+  uint64_t key;  // dart_order_key(distance)
   int64_t id;
+  double dist;
 };
-inline bool hit_less(const Hit &a, const Hit &b) {
-  int c = dart_compare(a.dist, b.dist);
-  if (c) return c < 0;
-  return a.id < b.id;
-}
+inline bool hit_less(const Hit &a, const Hit &b) { return a.key != b.key ? a.key < b.key : a.id < b.id; }
 
 // Final per-candidate arithmetic of ngh_graph_engine.dart:908-946 given the
 // exact f64 sums; mag_a = sum q[i]*q[i] accumulated in element order.
@@ -132,7 +123,8 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
                        const std::vector<std::pair<const BlockEntry *, uint32_t>> &lists,
                        int64_t *out_ids, double *out_dist) {
   double mag_a = metric == TSH_METRIC_COSINE ? query_mag_a(query, dim) : 0.0;
-  std::vector<Hit> hits;
+  static thread_local std::vector<Hit> hits;  // (one allocation per thread, not per query)
+  hits.clear();
   size_t total = 0;
   for (auto &l : lists) total += l.second;
   hits.reserve(total);
@@ -141,10 +133,15 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
       const BlockEntry &e = l.first[i];
       double d = final_distance(metric, e.s0, e.s1, mag_a);
       if (!std::isnan(thr) && d > thr) continue;
-      hits.push_back({d, e.id});
+      hits.push_back({dart_order_key(d), e.id, d});
     }
   size_t r = std::min<size_t>(hits.size(), (size_t)std::max(k, 0));
-  std::partial_sort(hits.begin(), hits.begin() + r, hits.end(), hit_less);
+  if (hits.size() <= 4 * r) {  // the usual case (k + a band's worth of candidates): one plain sort is cheapest
+    std::sort(hits.begin(), hits.end(), hit_less);
+  } else {
+    std::nth_element(hits.begin(), hits.begin() + r, hits.end(), hit_less);
+    std::sort(hits.begin(), hits.begin() + r, hit_less);
+  }
   for (size_t i = 0; i < r; ++i) {
     out_ids[i] = hits[i].id;
     out_dist[i] = hits[i].dist;
