@@ -126,6 +126,33 @@ def test_merge_of_many_queries_runs_on_the_host_pool(oracle_mod):
             time.sleep(0.01)  # > the workers' polling window: the next call has to wake them
 
 
+def test_merge_orders_like_double_compare_to(oracle_mod):
+    """the finaliser's integer order keys against the restated double.compareTo on special values (IP: distance =
+    -sum0, so every double can be produced exactly): -inf < negatives < -0.0 < +0.0 < positives < +inf < NaN, NaNs
+    equal among themselves, ties by id"""
+    import functools
+
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    rng = np.random.default_rng(21)
+    specials = [0.0, -0.0, math.inf, -math.inf, math.nan, -math.nan, 5e-324, -5e-324, 1.0, -1.0, 1.7976931348623157e308,
+                -1.7976931348623157e308, 2.2250738585072014e-308]
+    for rep in range(20):
+        vals = [float(x) for x in rng.standard_normal(40)] + specials + [rng.choice(specials) for _ in range(20)]
+        vals += vals[:10]  # exact duplicates -> id order
+        rng.shuffle(vals)
+        cands = [(int(i), -v, 0.0) for i, v in enumerate(vals)]  # IP: dist = -s0 = v
+        blk = _block(128, cands, len(cands), IP)
+        ids, dist, cnt = merge_candidate_blocks(IP, 4, np.zeros(4, np.float32), len(cands), None,
+                                                np.frombuffer(blk, np.uint8), 1, 128)
+        order = sorted(range(len(vals)), key=functools.cmp_to_key(
+            lambda a, b: oracle_mod.compare_double(vals[a], vals[b]) or (a - b)))
+        assert cnt[0] == len(vals) and ids[0].tolist() == order
+        got = dist[0]
+        for g, i in zip(got, order):
+            assert (math.isnan(g) and math.isnan(vals[i])) or (g == vals[i] and math.copysign(1, g) == math.copysign(1, vals[i]))
+
+
 def test_merge_reports_truncated_blocks(oracle_mod):
     from tostore_amd import _ffi
     from tostore_amd.sharded import merge_candidate_blocks
