@@ -1,0 +1,243 @@
+"""bench.py without a GPU: the whole flow of run_bench() -- query pool, timed regions, group
+arithmetic, cpu_baseline / recall legs, side legs, JSON line -- driven through a CPU stand-in for
+the device side (the stand-in answers searches with the oracle; this file is test code, the
+product path never does that).  Round 1's bench died on `queries[25]` with the driver's own
+arguments (--steps 20 --warmup 5): every (steps, warmup) pair the driver or a profile run uses
+is exercised here, for N = 1 and for the N > 1 branch."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+class FakeIndex:
+    def __init__(self, oracle, d, metric, rows, lo):
+        self.o, self.dim, self.metric, self.rows, self.lo = oracle, d, metric, np.ascontiguousarray(rows), lo
+        self.c = {"searches": 0, "scan_launches": 0, "batch_launches": 0, "fallback_searches": 0,
+                  "candidates_total": 0, "scan_us_sum": 0.0, "scan_us_samples": 0, "batch_kernel_last": -1}
+        self.min_nq, self.kernel, self.closed = 1, 3, False
+        self.pending, self.next_ticket = {}, 0
+
+    @property
+    def size(self):
+        return self.lo + len(self.rows)
+
+    def _mask(self, row_mask):
+        if row_mask is None:
+            return None
+        assert len(row_mask) >= (self.size + 7) // 8
+        bits = np.unpackbits(np.asarray(row_mask, np.uint8), bitorder="little")[self.lo:self.lo + len(self.rows)]
+        return np.packbits(bits, bitorder="little")
+
+    def search(self, queries, k, thr=None, row_mask=None):
+        assert not self.closed
+        q = np.ascontiguousarray(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        assert q.shape[1] == self.dim and q.shape[0] >= 1
+        ids, dist, cnt = self.o.search_heap_many_mt(self.rows, q, self.metric, k, thr, self._mask(row_mask), threads=2)
+        ids = np.where(ids >= 0, ids + self.lo, ids)
+        self.c["searches"] += len(q)
+        self.c["candidates_total"] += int(cnt.sum())
+        if len(q) > 1 and self.min_nq >= 1:
+            self.c["batch_launches"] += 2
+            self.c["batch_kernel_last"] = 2 if self.kernel == 3 else self.kernel
+        else:
+            self.c["scan_launches"] += len(q)
+            self.c["scan_us_sum"] += 10.0 * ((len(q) + 3) // 4)
+            self.c["scan_us_samples"] += (len(q) + 3) // 4
+        return ids, dist, cnt
+
+    def submit(self, q, k, row_mask=None):
+        t, self.next_ticket = self.next_ticket, self.next_ticket + 1
+        self.pending[t] = self.search(q, k, None, row_mask)
+        return (t, k)
+
+    def wait(self, ticket, thr=None):
+        ids, dist, cnt = self.pending.pop(ticket[0])
+        return ids[0, :cnt[0]], dist[0, :cnt[0]]
+
+    def counters(self):
+        return dict(self.c)
+
+    def bench_scan(self, q, iters=20, row_mask=None):
+        return 10.0
+
+    def bench_batch(self, qs, k, iters=3):
+        return 100.0, 2.0 * len(qs) * len(self.rows) * self.dim
+
+    def set_batch_min_nq(self, v):
+        self.min_nq = v
+
+    def set_batch_kernel(self, v):
+        self.kernel = v
+
+    def close(self):
+        self.closed = True
+
+
+class FakeSearcher:
+    """Stands for ShardedSearcher: answers over the WHOLE corpus, as the merge of all ranks would."""
+
+    def __init__(self, whole):
+        self.whole = whole
+        self.groups = []
+
+    def search(self, q, k, thr=None, row_mask=None):
+        return self.whole.search(q, k, thr, row_mask)
+
+    def search_many(self, qs, k, thr=None, row_mask=None, group=8):
+        assert group >= 1 and len(qs) >= 1
+        self.groups.append((len(qs), group))
+        return self.whole.search(qs, k, thr, row_mask)
+
+
+class FakeEnv:
+    def __init__(self, oracle, world=1):
+        self.o, self.world, self.rank = oracle, world, 0
+        self.fences = 0
+        self.made = []
+        self.last_searcher = None
+
+    def corpus(self, n, d, metric):
+        rng = np.random.default_rng(7 + metric)
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+        if metric != 2:
+            x *= (rng.random((n, 1)) * 1.5 + 0.5).astype(np.float32)
+        return x
+
+    def corpus_host(self, c):
+        return c
+
+    def release(self, c):
+        pass
+
+    def make_index(self, d, metric, corpus, lo, hi):
+        idx = FakeIndex(self.o, d, metric, corpus[lo:hi], lo)
+        self.made.append(idx)
+        self._whole = FakeIndex(self.o, d, metric, corpus, 0)
+        return idx
+
+    def searcher(self, idx):
+        if self.world == 1:
+            return None
+        self.last_searcher = FakeSearcher(self._whole)
+        return self.last_searcher
+
+    def max_inflight(self):
+        return 8
+
+    def fence(self):
+        self.fences += 1
+
+    def reduce_max(self, x):
+        return float(x)
+
+    def bcast_int(self, x):
+        return int(x)
+
+    def finish(self):
+        pass
+
+
+def _args(*extra):
+    return bench.parse(["--rows", "3000", "--dim", "32", "--k", "10", "--cpu-seconds", "0.2",
+                        "--recall-queries", "150", "--recall-seconds", "5"] + list(extra))
+
+
+DRIVER_ARGS = [(1, 0), (5, 0), (20, 5), (1000, 50)]
+
+
+@pytest.mark.parametrize("steps,warmup", DRIVER_ARGS)
+def test_single_gpu_line(oracle_mod, steps, warmup):
+    a = _args("--steps", str(steps), "--warmup", str(warmup), "--side", "c5,c1" if steps != 20 else "c5,c1,c3")
+    env = FakeEnv(oracle_mod)
+    line = bench.run_bench(a, env)
+    out = json.loads(line)  # strict JSON: a bare NaN would fail here
+    assert "NaN" not in line and "Infinity" not in line
+    assert out["steps"] == steps and out["warmup"] == warmup and out["n_gpus"] == 1
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert out["timed_regions"]["count"] == len(out["timed_regions"]["seconds"]) == bench.auto_repeats(steps)
+    assert out["unit"] == "queries/s" and out["dtype"] == "f32" and out["vs_baseline"] is None
+    assert out["config"]["workload"].startswith("C2")
+    assert out["config"]["queries_in_flight"] == min(8, 64, steps)
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["algorithmic_bytes_per_launch"] == 3000 * 32 * 4
+    assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True
+    assert out["recall_queries"] == 150
+    side = out["side"]
+    for keep in ("keep_1%", "keep_10%", "keep_50%"):
+        assert side["C5"][keep]["ids_and_distances_bit_exact"] is True, side["C5"]
+    assert side["C1"]["ids_and_distances_bit_exact"] is True and side["C1"]["latency_us"]["p50"] > 0
+    if steps == 20:
+        c3 = side["C3"]
+        assert c3["ids_and_distances_bit_exact"] is True and c3["checked_queries"] == 128
+        assert c3["roofline"]["bound"] == "mfma" and c3["f32_mfma_variant"]["roofline"]["peak"] == 157.3
+        assert set(c3["smaller_calls"]) == {"16_queries", "128_queries"}
+    assert all(i.closed for i in env.made)
+
+
+@pytest.mark.parametrize("steps,warmup", DRIVER_ARGS)
+def test_sharded_branch_arithmetic(oracle_mod, steps, warmup):
+    """rank 0 of a two-rank job (collectives stubbed): group sizes, n_cpu clamp, JSON."""
+    a = _args("--steps", str(steps), "--warmup", str(warmup), "--gpus", "2")
+    env = FakeEnv(oracle_mod, world=2)
+    out = json.loads(bench.run_bench(a, env))
+    assert out["n_gpus"] == 2 and "side" not in out and out["value"] > 0
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == 1500 * 32 * 4
+    assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True
+    g = bench.sharded_group(64, steps)
+    assert out["config"]["queries_per_call"] == g >= 1
+    timed = [x for x in env.last_searcher.groups if x[0] == steps]
+    assert len(timed) == bench.auto_repeats(steps) and all(x[1] == g for x in timed)
+
+
+@pytest.mark.parametrize("extra", [["--inflight", "1"], ["--group", "0", "--inflight", "3"],
+                                   ["--mask-keep", "0.1"], ["--mask-keep", "0.5", "--mask-kind", "range"],
+                                   ["--no-cpu-baseline"], ["--metric", "cosine"], ["--metric", "ip"]])
+def test_option_paths(oracle_mod, extra):
+    a = _args("--steps", "7", "--warmup", "2", "--no-side", *extra)
+    out = json.loads(bench.run_bench(a, FakeEnv(oracle_mod)))
+    assert out["value"] > 0
+    if "--no-cpu-baseline" in extra:
+        assert "cpu_baseline" not in out
+    else:
+        assert out["ids_and_distances_bit_exact"] is True and out["recall_at_k"] == 1.0
+    if extra[:2] == ["--inflight", "1"]:
+        assert out["config"]["queries_in_flight"] == 1
+    if extra[:2] == ["--group", "0"]:
+        assert out["config"]["queries_in_flight"] == 3
+
+
+def test_batch_main_line(oracle_mod):
+    a = _args("--steps", "20", "--warmup", "5", "--batch", "64", "--metric", "cosine")
+    out = json.loads(bench.run_bench(a, FakeEnv(oracle_mod)))
+    assert out["config"]["workload"].startswith("C3") and out["ids_and_distances_bit_exact"] is True
+    assert out["roofline"]["bound"] == "mfma"
+
+
+def test_sizing_helpers():
+    for steps, warmup in DRIVER_ARGS:
+        pool = bench.query_pool_size(steps, warmup, 1000)
+        assert pool >= warmup + steps and pool >= 64 and pool >= 1000
+        assert 3 <= bench.auto_repeats(steps) <= 25
+        assert bench.sharded_group(64, steps) >= 1
+    assert bench.auto_repeats(20) == 25 and bench.auto_repeats(1000) == 3 and bench.auto_repeats(5, 4) == 4
+    # the round-1 crash: a fast host wants 32 baseline queries, the pool had 25
+    assert bench.cpu_sample_size(0.1, 15.0, 25) == 25
+    assert bench.cpu_sample_size(0.47, 15.0, 1000) == 31
+    assert bench.cpu_sample_size(100.0, 15.0, 1000) == 2
+    assert bench.cpu_sample_size(100.0, 15.0, 1) == 1
+    line = bench.dumps({"a": float("nan"), "b": [np.float32(1.5), float("inf")], "c": np.int64(3), "d": np.bool_(True)})
+    assert json.loads(line) == {"a": None, "b": [1.5, None], "c": 3, "d": True}
