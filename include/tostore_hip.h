@@ -139,10 +139,14 @@ int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n);
  * VectorPrecision index (0 f64, 1 f32, 2 i8) and fixes vectorsPerRawPage
  * (core/ngh_page.dart:575-579); data page p holds node ids
  * first_row_id + (p-1)*vectorsPerRawPage + slot (model/ngh_index_meta.dart:480-490).
- * Reader semantics follow readRawVectorPage (core/ngh_partition_manager.dart:239-295):
- * a page past the end of the file, or with an undecodable payload, reads as a
- * page of zero vectors; a bad magic / CRC is an error (the reference throws:
- * core/btree_page.dart:215-233) -> TSH_E_FORMAT, nothing appended from that page on.
+ * Reader semantics follow readRawVectorPage (core/ngh_partition_manager.dart:239-295)
+ * with ONE deliberate difference: where the reference makes up a page of zero
+ * vectors (a page past the end of the file, :270-281) the ids stay ABSENT rows here --
+ * the reference only meets such a slot if its graph walk reaches it, an exhaustive
+ * scan would return those zero rows to every query.  A bad magic / type / CRC is an
+ * error (the reference throws: core/btree_page.dart:215-233), and so is a page that
+ * passes its CRC but does not decode as a raw-vector payload (ciphertext of an index
+ * written with encryptVectorIndex): TSH_E_FORMAT, nothing appended from that page on.
  * Only ids < first_row_id + max_rows are loaded (meta.nextNodeId bounds them).
  * *out_rows = rows appended. */
 int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size,
@@ -162,9 +166,12 @@ typedef struct tsh_ngh_info {
   int64_t total_vectors; /* meta.json's own count of live vectors */
   int64_t deleted_count; /* meta.json's own count of tombstones */
   int64_t max_partition_file_size;
-  int64_t rows_loaded; /* node ids now resident (absent files/pages load as zero vectors) */
+  int64_t rows_loaded; /* node ids now resident */
   int64_t tombstones;  /* node ids whose graph slot carries NghNodeFlags.deleted */
   int64_t files_read;
+  int64_t pages_absent; /* raw-vector pages below nextNodeId that are not on disk (file missing or shorter): their
+                           node ids are ABSENT rows; a healthy index has 0 -- a caller may refuse the handle otherwise */
+  int64_t files_absent; /* raw-vector partition files below nextNodeId that are missing altogether */
 } tsh_ngh_info;
 
 /* Cold start from an index directory written by the reference, without Dart
@@ -175,13 +182,15 @@ typedef struct tsh_ngh_info {
  * handle; loads every raw-vector partition rawvec/dir_{p / max_entries_per_dir}/
  * p{p}.ngh with the addressing of ngh_index_meta.dart:480-490; then walks the
  * graph partitions and tombstones every node whose slot flags carry
- * NghNodeFlags.deleted (ngh_page.dart:105-108,198-213).  A missing file or a
- * page past the end of a file reads as an empty page exactly as in the
- * reference (zero vectors / no flags); a page with a bad frame or CRC is
- * TSH_E_FORMAT (the reference throws there, btree_page.dart:215-233).
- * max_entries_per_dir <= 0 selects the reference default of 500
- * (handler/common.dart:43).  Encrypted vector pages are not supported
- * (EncryptionConfig.encryptVectorIndex must be off).  info may be NULL. */
+ * NghNodeFlags.deleted (ngh_page.dart:105-108,198-213).  A missing graph file /
+ * page reads as "no flags" exactly as in the reference; a missing raw-vector
+ * file / page leaves its node ids ABSENT (never returned; counted in
+ * info->pages_absent / files_absent -- see tsh_index_load_rawvec_file); a page
+ * with a bad frame, type or CRC is TSH_E_FORMAT (the reference throws there,
+ * btree_page.dart:215-233).  max_entries_per_dir <= 0 selects the reference
+ * default of 500 (handler/common.dart:43).  Encrypted vector pages are not
+ * supported (EncryptionConfig.encryptVectorIndex must be off): their payloads
+ * pass the CRC but do not decode -> TSH_E_FORMAT.  info may be NULL. */
 int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices, tsh_index **out,
                            tsh_ngh_info *info);
 

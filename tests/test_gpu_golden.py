@@ -105,15 +105,42 @@ def test_rawvec_partition_file_loader(hip_lib, oracle_mod, tmp_path, precision):
         ids, dist, cnt = idx.search(q, 50)
         eids, edist = oracle_mod.search_exhaustive(expect, q, L2, 50)
         assert np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
-    # a page past the end of the file reads as zero vectors (ngh_partition_manager.dart:276-281)
+    # pages past the end of the file: the reference's reader makes up zero vectors there
+    # (ngh_partition_manager.dart:276-281); an exhaustive scan must not return those to every query, so
+    # their ids stay ABSENT rows (include/tostore_hip.h, tsh_index_load_rawvec_file)
     with HipVectorIndex(dims, L2) as idx:
         got = idx.load_rawvec_file(str(path), page_size, precision, 0, n + 2 * vpp)
-        assert got == n_pages * vpp + 2 * vpp - (n_pages * vpp - n) or got >= n
+        assert got == n_pages * vpp  # the last stored page is full-capacity; nothing beyond it
+        assert idx.size == n_pages * vpp
         full = np.zeros((idx.size, dims), np.float32)
         full[:n] = expect
-        ids, dist, cnt = idx.search(q, 20)
-        eids, edist = oracle_mod.search_exhaustive(full, q, L2, 20)
+        ids, dist, cnt = idx.search(np.zeros(dims, np.float32), 20)  # the zero query would rank zero rows first
+        eids, edist = oracle_mod.search_exhaustive(full, np.zeros(dims, np.float32), L2, 20)
         assert np.array_equal(ids[0], eids) and np.array_equal(dist[0], edist)
+        assert ids.max() < n_pages * vpp
+    # a page that passes its CRC but is no raw-vector payload (what ciphertext of an encryptVectorIndex
+    # database looks like): refused, not loaded as zero rows
+    raw = bytearray(open(path, "rb").read())
+    off = page_size * 2
+    plen = int.from_bytes(raw[off + 8:off + 12], "little")
+    raw[off + 20:off + 22] = (60000).to_bytes(2, "little")  # vectorCount the payload cannot hold
+    raw[off + 12:off + 16] = oracle_mod.crc32(bytes(raw[off + 20:off + 20 + plen])).to_bytes(4, "little")
+    enc = tmp_path / "enc.ngh"
+    enc.write_bytes(bytes(raw))
+    with HipVectorIndex(dims, L2) as idx:
+        with pytest.raises(_ffi.TshError) as e:
+            idx.load_rawvec_file(str(enc), page_size, precision, 0, n)
+        assert e.value.code == _ffi.TSH_E_FORMAT and "encryptVectorIndex" in e.value.message
+        assert idx.size == vpp
+    # a page of another type where a raw-vector page belongs
+    raw = bytearray(open(path, "rb").read())
+    raw[page_size * 2 + 6] = 6  # nghGraph
+    other = tmp_path / "other.ngh"
+    other.write_bytes(bytes(raw))
+    with HipVectorIndex(dims, L2) as idx:
+        with pytest.raises(_ffi.TshError) as e:
+            idx.load_rawvec_file(str(other), page_size, precision, 0, n)
+        assert e.value.code == _ffi.TSH_E_FORMAT
     # a flipped payload byte is a CRC error, as in the reference (btree_page.dart:226-230)
     raw = bytearray(open(path, "rb").read())
     raw[page_size * 2 + 100] ^= 0x40

@@ -51,8 +51,9 @@ def test_open_ngh_directory(hip_lib, oracle_mod, tmp_path, metric, precision, di
 
 
 def test_open_ngh_missing_and_short_files(hip_lib, oracle_mod, tmp_path):
-    """A missing partition file, and pages past the end of a file, read as empty pages
-    (zero vectors / no flags), as in the reference."""
+    """A missing graph file / page reads as "no flags", as in the reference.  A missing raw-vector file, and
+    raw-vector pages past the end of a file, are where the reference's reader makes up zero vectors
+    (ngh_partition_manager.dart:270-281): here those ids are ABSENT rows -- never returned -- and counted."""
     from oracle import ngh_dir
     from tostore_amd import HipVectorIndex
 
@@ -69,10 +70,16 @@ def test_open_ngh_missing_and_short_files(hip_lib, oracle_mod, tmp_path):
     # graph partition 0 = ids 0..503 (63 slots x 8 pages), rawvec partition 1 = ids 336..671 (42 x 8)
     assert not dead[3] and not dead[400] and dead[600] and dead[1999]
     assert not vec[336:672].any() and vec[335].any() and vec[672].any()
+    absent = ~vec.any(axis=1)  # the reader restatement yields zero vectors exactly for the ids not on disk
+    assert absent[336:672].all() and absent.sum() > 336
     idx, info = HipVectorIndex.open_ngh(str(root))
     with idx:
-        assert info["rows_loaded"] == n and info["tombstones"] == int(dead.sum())
-        _check_search(oracle_mod, idx, vec, dead, 0, k=60)
+        assert info["rows_loaded"] == n - int(absent.sum()) and info["tombstones"] == int(dead.sum())
+        assert info["files_absent"] == 1 and info["pages_absent"] == int(absent.sum()) // 42
+        _check_search(oracle_mod, idx, vec, dead | absent, 0, k=60)
+        # the zero query ranks zero vectors first: none of the made-up rows may come back
+        ids, dist, cnt = idx.search(np.zeros(dims, np.float32), 100)
+        assert not absent[ids[0][:cnt[0]]].any()
 
 
 def test_open_ngh_defaults_and_errors(hip_lib, oracle_mod, tmp_path):

@@ -52,7 +52,7 @@ class TshNghInfo(ctypes.Structure):
         ("dimensions", c_i32), ("metric", c_i32), ("precision", c_i32), ("page_size", c_i32),
         ("max_degree", c_i32), ("reserved", c_i32), ("next_node_id", c_i64), ("total_vectors", c_i64),
         ("deleted_count", c_i64), ("max_partition_file_size", c_i64), ("rows_loaded", c_i64),
-        ("tombstones", c_i64), ("files_read", c_i64),
+        ("tombstones", c_i64), ("files_read", c_i64), ("pages_absent", c_i64), ("files_absent", c_i64),
     ]
 
 

@@ -140,6 +140,18 @@ class HipVectorIndex:
         return {k: getattr(c, k) for k, _ in c._fields_}
 
     # -- search ---------------------------------------------------------------
+    def mask_arg(self, row_mask):
+        """(array kept alive by the caller, pointer) of a keep mask for the C ABI.  The ABI carries no mask
+        length: the library reads ceil(size / 8) bytes (bit i = GLOBAL row id i), so a short buffer is
+        rejected here, for every entry point that takes a mask."""
+        if row_mask is None:
+            return None, None
+        row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+        need = (self.size + 7) // 8
+        if row_mask.shape[0] < need:
+            raise ValueError(f"row_mask needs {need} bytes (one bit per row id below {self.size}), got {row_mask.shape[0]}")
+        return row_mask, row_mask.ctypes.data_as(_ffi.p_u8)
+
     def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
         """Raw C-ABI search: (ids[nq,k], dist[nq,k], count[nq])."""
         q = _f32c(queries)
@@ -152,13 +164,7 @@ class HipVectorIndex:
         dist = np.full((nq, max(kk, 1)), np.nan, dtype=np.float64)
         cnt = np.zeros(nq, dtype=np.int32)
         thr = math.nan if distance_threshold is None else float(distance_threshold)
-        mp = None
-        if row_mask is not None:
-            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
-            need = (self.size + 7) // 8
-            if row_mask.shape[0] < need:
-                raise ValueError(f"row_mask needs {need} bytes")
-            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        row_mask, mp = self.mask_arg(row_mask)
         _ffi.check(_ffi.lib().tsh_search(self._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, mp,
                                          ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
                                          cnt.ctypes.data_as(_ffi.p_i32)))
@@ -169,10 +175,7 @@ class HipVectorIndex:
         q = _f32c(query).reshape(-1)
         if q.shape[0] != self.dim:
             raise ValueError(f"query must have {self.dim} elements")
-        mp = None
-        if row_mask is not None:
-            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
-            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        row_mask, mp = self.mask_arg(row_mask)
         t = ctypes.c_int32(-1)
         _ffi.check(_ffi.lib().tsh_search_submit(self._h, q.ctypes.data_as(_ffi.p_f32), int(k), mp,
                                                 ctypes.byref(t)))
@@ -209,10 +212,7 @@ class HipVectorIndex:
     def bench_scan(self, query, iters: int = 20, row_mask=None) -> float:
         q = _f32c(query)
         out = ctypes.c_double(0)
-        mp = None
-        if row_mask is not None:
-            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
-            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        row_mask, mp = self.mask_arg(row_mask)
         _ffi.check(_ffi.lib().tsh_bench_scan(self._h, q.ctypes.data_as(_ffi.p_f32), iters, mp,
                                              ctypes.byref(out)))
         return out.value

@@ -511,10 +511,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HostPool::get().stay_awake_until(t_enq + b->last_wait_us * 1.1 + 50.0);
   std::vector<char> skip((size_t)nq, 0);
   double t_gpu = 0;
+  std::unique_ptr<HostPool::Hold> hold;  // from the first chunk on the pool gets a job every few hundred microseconds
   for (int c = 0; c < n_chunks; ++c) {
     const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
     HIPCHK(hipEventSynchronize(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done));
     if (c == 0) b->last_wait_us = now_us() - t_enq;
+    if (c == 0 && out->on_chunk && n_chunks > 1) hold.reset(new HostPool::Hold());
     if (c + 1 == n_chunks) {
       HIPCHK(hipGetLastError());
       t_gpu = now_us();

@@ -35,28 +35,40 @@ uint32_t crc32_ieee(const uint8_t *p, size_t n) {
 inline uint32_t rd16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
 inline uint32_t rd32(const uint8_t *p) { return rd16(p) | (rd16(p + 2) << 16); }
 
-enum PageKind { PAGE_ERROR = -1, PAGE_EMPTY = 0, PAGE_OK = 1 };
+enum PageKind { PAGE_ERROR = -1, PAGE_ABSENT = 0, PAGE_OK = 1, PAGE_UNDECODABLE = 2 };
+constexpr int PAGE_TYPE_NGH_RAW_VECTOR = 8;  // BTreePageType.nghRawVector.index, core/btree_page.dart:14-55
 
-// Decodes one page into out (vpp x dim floats, pre-zeroed); *vcount = vectors present.
+// Decodes one page into out (vpp x dim floats); *vcount = vectors present.
+//   PAGE_ABSENT       nothing stored at this offset (file ends before it).  The reference's reader hands out
+//                     NghRawVectorPage.empty there -- `capacity` all-zero vectors (ngh_partition_manager.dart:
+//                     270-281) -- which it only ever touches if its graph walk reaches such a node.  An
+//                     exhaustive scan would offer every one of those zero rows to every query, so here the ids
+//                     of an absent page are ABSENT rows (never returned), like ids skipped by an append gap.
+//   PAGE_UNDECODABLE  frame and CRC are fine, type is nghRawVector, but the payload is not an NghRawVectorPage
+//                     (tryDecodePayload -> null, ngh_page.dart:431-450): what ciphertext looks like when the
+//                     index was written with encryptVectorIndex (_decodePayload, ngh_partition_manager.dart:
+//                     1091-1102), which this loader cannot undo -> the caller refuses the index.
+//   PAGE_ERROR        bad magic / header size / type / CRC (the reference throws: btree_page.dart:215-233), or a
+//                     page of another type or another dimension where a raw-vector page of this index belongs.
 PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int dim, int vpp, float *out,
                             int *vcount) {
-  *vcount = vpp;  // an "empty" page is NghRawVectorPage.empty(capacity: vectorsPerRawPage)
-  if (avail == 0) return PAGE_EMPTY;              // ngh_partition_manager.dart:276-281
+  *vcount = 0;
+  if (avail == 0) return PAGE_ABSENT;
   if (avail < 20) return PAGE_ERROR;              // btree_page.dart:162-163 -> StateError
   if (rd32(pg) != 0x32475054u) return PAGE_ERROR; // 'TPG2'
   if (rd16(pg + 4) != 20) return PAGE_ERROR;
-  if (pg[6] >= 10) return PAGE_ERROR;
+  if (pg[6] != PAGE_TYPE_NGH_RAW_VECTOR) return PAGE_ERROR;
   uint32_t plen = rd32(pg + 8), crc = rd32(pg + 12);
   if ((uint64_t)20 + plen > avail) return PAGE_ERROR;  // :221-224
   const uint8_t *pl = pg + 20;
   if (crc32_ieee(pl, plen) != crc) return PAGE_ERROR;  // :226-230
-  // NghRawVectorPage.tryDecodePayload, ngh_page.dart:431-450 (null -> empty page)
-  if (plen < 8) return PAGE_EMPTY;
+  // NghRawVectorPage.tryDecodePayload, ngh_page.dart:431-450
+  if (plen < 8) return PAGE_UNDECODABLE;
   uint32_t vc = rd16(pl), dims = rd16(pl + 2);
   int prec = pl[4];
-  if (dims == 0) return PAGE_EMPTY;
+  if (dims == 0) return PAGE_UNDECODABLE;
   int bpe = prec == 0 ? 8 : (prec == 2 ? 1 : 4);
-  if ((uint64_t)plen < 8 + (uint64_t)vc * dims * bpe) return PAGE_EMPTY;
+  if ((uint64_t)plen < 8 + (uint64_t)vc * dims * bpe) return PAGE_UNDECODABLE;
   if ((int)dims != dim) return PAGE_ERROR;  // not this index's column
   int take = (int)std::min<uint32_t>(vc, (uint32_t)vpp);
   const uint8_t *d = pl + 8;
@@ -69,10 +81,7 @@ PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int 
     for (int i = 0; i < dim; ++i) {  // getVectorAsFloat32, ngh_page.dart:364-391
       const uint8_t *e = d + ((size_t)v * dim + i) * bpe;
       float f;
-      if (prec == 1) {
-        uint32_t u = rd32(e);
-        memcpy(&f, &u, 4);
-      } else if (prec == 0) {
+      if (prec == 0) {
         uint64_t u = (uint64_t)rd32(e) | ((uint64_t)rd32(e + 4) << 32);
         double dv;
         memcpy(&dv, &u, 8);
@@ -87,12 +96,23 @@ PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int 
   return PAGE_OK;
 }
 
+// tsh_index_load_rawvec_file with the page census tsh_index_open_ngh reports
+int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_t precision, int64_t first_row_id,
+                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages);
+
 }  // namespace
 
 extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size,
                                               int32_t precision, int64_t first_row_id, int64_t max_rows,
                                               int64_t *out_rows) {
+  return load_rawvec_file(idx, path, page_size, precision, first_row_id, max_rows, out_rows, nullptr);
+}
+
+namespace {
+int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_t precision, int64_t first_row_id,
+                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages) {
   if (out_rows) *out_rows = 0;
+  if (out_absent_pages) *out_absent_pages = 0;
   if (!idx || !path) return set_err(TSH_E_BAD_ARG, "NULL pointer");
   if (page_size < 64 || precision < 0 || precision > 2 || first_row_id < 0 || max_rows < 0)
     return set_err(TSH_E_BAD_ARG, "bad page_size / precision / row range");
@@ -109,7 +129,7 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
   std::vector<uint8_t> raw((size_t)BATCH * (size_t)page_size);
   std::vector<float> rows((size_t)BATCH * vpp * dim);
   std::vector<int> kinds((size_t)BATCH), counts((size_t)BATCH);
-  int64_t loaded = 0;
+  int64_t loaded = 0, absent = 0;
   int rc = TSH_OK;
   for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
     int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
@@ -119,16 +139,13 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
     parallel_for((int32_t)nb, [&](int32_t b) {
       const size_t off = (size_t)b * (size_t)page_size;
       const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
-      float *dst = rows.data() + (size_t)b * vpp * dim;
       int vc = 0;
-      PageKind k = decode_rawvec_page(raw.data() + off, got, page_size, dim, vpp, dst, &vc);
-      if (k != PAGE_OK) vc = k == PAGE_EMPTY ? vpp : 0;
-      if (k != PAGE_OK || vc < vpp)  // empty pages and slots past vectorCount read as zero vectors
-        std::fill(dst + (k == PAGE_OK ? (size_t)vc * dim : 0), dst + (size_t)vpp * dim, 0.f);
-      kinds[(size_t)b] = (int)k;
+      kinds[(size_t)b] = (int)decode_rawvec_page(raw.data() + off, got, page_size, dim, vpp,
+                                                 rows.data() + (size_t)b * vpp * dim, &vc);
       counts[(size_t)b] = vc;
     });
-    // runs of consecutive present rows inside the batch are appended together
+    // runs of consecutive present rows inside the batch are appended together; the ids of absent pages and of
+    // slots past a page's vectorCount stay absent rows
     int64_t run_start = -1, run_len = 0;
     auto flush = [&]() {
       if (run_len > 0 && rc == TSH_OK) {
@@ -140,11 +157,22 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
       run_len = 0;
     };
     for (int64_t b = 0; b < nb && rc == TSH_OK; ++b) {
-      if (kinds[(size_t)b] == (int)PAGE_ERROR) {
+      const int kind = kinds[(size_t)b];
+      if (kind == (int)PAGE_ERROR || kind == (int)PAGE_UNDECODABLE) {
         flush();
-        if (rc == TSH_OK)
-          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path, (long long)(1 + p0 + b));
+        if (rc != TSH_OK) break;
+        if (kind == (int)PAGE_ERROR)
+          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / type / CRC / dimension", path,
+                       (long long)(1 + p0 + b));
+        else
+          rc = set_err(TSH_E_FORMAT, "%s: page %lld passes its CRC but is no raw-vector payload -- an index written "
+                       "with encryptVectorIndex cannot be opened without Dart", path, (long long)(1 + p0 + b));
         break;
+      }
+      if (kind == (int)PAGE_ABSENT) {
+        ++absent;
+        flush();
+        continue;
       }
       int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
       int64_t lim = std::min<int64_t>(counts[(size_t)b], max_rows - base);
@@ -162,8 +190,10 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
   }
   fclose(f);
   if (out_rows) *out_rows = loaded;
+  if (out_absent_pages) *out_absent_pages = absent;
   return rc;
 }
+}  // namespace
 
 // ---- open an on-disk NGH index directory (N1: meta.json + rawvec + graph tombstones) ----
 namespace {
@@ -345,26 +375,22 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
   int32_t rc = tsh_index_create((int32_t)dim, metric, next_id, n_devices, &idx);
   if (rc != TSH_OK) return rc;
   // raw vectors: node id -> (partition, page, slot), ngh_index_meta.dart:480-490
-  int64_t rows_loaded = 0, files = 0;
+  int64_t rows_loaded = 0, files = 0, absent_pages = 0, absent_files = 0;
   const int64_t rows_per_part = ppp * vpp;
   for (int64_t part = 0; rc == TSH_OK && part * rows_per_part < next_id; ++part) {
     const int64_t first = part * rows_per_part, want = std::min(rows_per_part, next_id - first);
     const std::string path = ngh_partition_path(dir, "rawvec", part, max_entries_per_dir);
     if (access(path.c_str(), R_OK) == 0) {
-      int64_t got = 0;
-      rc = tsh_index_load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got);
+      int64_t got = 0, absent = 0;
+      rc = load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got, &absent);
       rows_loaded += got;
+      absent_pages += absent;
       ++files;
     } else {
-      // a missing file reads as empty bytes -> NghRawVectorPage.empty(...): zero vectors
-      // (core/file_storage_impl.dart:387-415, ngh_partition_manager.dart:270-281)
-      const int64_t chunk = std::max<int64_t>(1, (8 << 20) / (dim * 4));
-      std::vector<float> zeros((size_t)std::min(chunk, want) * dim, 0.f);
-      for (int64_t o = 0; rc == TSH_OK && o < want; o += chunk) {
-        const int64_t nrow = std::min(chunk, want - o);
-        rc = tsh_index_append(idx, first + o, nrow, zeros.data());
-        if (rc == TSH_OK) rows_loaded += nrow;
-      }
+      // A missing partition file: its ids are absent rows (see decode_rawvec_page: the reference's reader makes
+      // up zero vectors here, which an exhaustive scan must not offer to every query).
+      ++absent_files;
+      absent_pages += (want + vpp - 1) / vpp;
     }
   }
   // tombstones: flags byte of each graph slot (ngh_page.dart:105-108,198-213)
@@ -399,6 +425,10 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
           bool bad = false;
           const uint8_t *pl = page_payload(raw.data() + off, got, &plen, &type, &bad);
           if (bad) {
+            bad_page[(size_t)b] = 1;
+            return;
+          }
+          if (pl && type != 6 /* BTreePageType.nghGraph.index */) {
             bad_page[(size_t)b] = 1;
             return;
           }
@@ -439,6 +469,8 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
     info->rows_loaded = rows_loaded;
     info->tombstones = tombstones;
     info->files_read = files;
+    info->pages_absent = absent_pages;
+    info->files_absent = absent_files;
   }
   *out = idx;
   return TSH_OK;

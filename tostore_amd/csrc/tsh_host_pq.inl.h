@@ -88,7 +88,7 @@ extern "C" int32_t tsh_index_pq_encode(tsh_index *idx, int64_t first_row_id, int
   while (done < n_rows) {
     const int64_t gid = first_row_id + done;
     Shard *s = shard_for_row(idx, gid);
-    std::shared_lock<RwLock> sl(s->mu);
+    std::shared_lock<RwLock> sl = share(idx, s);
     const int64_t local = gid - s->row_base;
     if (local < 0 || local >= s->rows)
       return set_err(TSH_E_BAD_ARG, "row %lld is not resident", (long long)gid);

@@ -1,0 +1,289 @@
+// tsh_host_sync.h -- host-side synchronisation pieces of libtostore_hip.so: the handle lock, the pool that
+// finalises batches, the per-shard workers of an in-process multi-GPU handle.  Plain C++17 (no HIP) so that
+// tests/test_host_sync.py can compile and exercise it with g++ on a machine without a GPU.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace tsh {
+
+inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Reader/writer lock that may be released by a different thread than the one that took it (an asynchronous
+// search is submitted and waited independently).  Writers have preference: a reader that arrives while a writer
+// waits queues behind it -- EXCEPT a reader that says its handle already holds shared locks which it can only
+// give back after this call (open asynchronous tickets).  That reader would wait for the writer, the writer for
+// the ticket, and the ticket for the reader: it passes the gate instead (the writer cannot run before the ticket
+// is waited anyway).  So that a caller who always has a ticket open cannot starve the writer, tsh_search_submit
+// refuses new tickets (TSH_E_BUSY) while writer_pending() and tickets are open: the pipeline drains, the
+// writer runs.
+class RwLock {
+ public:
+  void lock_shared() { lock_shared_gate(false); }
+  void lock_shared_gate(bool bypass_gate) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !writer_ && (bypass_gate || writers_waiting_ == 0); });
+    ++readers_;
+  }
+  void unlock_shared() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (--readers_ == 0) cv_.notify_all();
+  }
+  void lock() {
+    std::unique_lock<std::mutex> lk(m_);
+    ++writers_waiting_;
+    cv_.wait(lk, [&] { return !writer_ && readers_ == 0; });
+    --writers_waiting_;
+    writer_ = true;
+  }
+  void unlock() {
+    std::lock_guard<std::mutex> lk(m_);
+    writer_ = false;
+    cv_.notify_all();
+  }
+  bool writer_pending() {
+    std::lock_guard<std::mutex> lk(m_);
+    return writer_ || writers_waiting_ > 0;
+  }
+  int readers() {
+    std::lock_guard<std::mutex> lk(m_);
+    return readers_;
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int readers_ = 0, writers_waiting_ = 0;
+  bool writer_ = false;
+};
+
+// run fn(q) for q in [0,n) on a few host threads (per-query preparation / finalisation of a batch).  The
+// workers are created once and parked on a condition variable: spawning threads per call costs more than the
+// work itself (about 30 us per thread on a 128-core host).
+//
+// Polling policy.  The library lives inside the database's own process, so an idle pool must cost nothing: a
+// worker parks the moment it finds no work -- unless a library call that is about to hand over more jobs has
+// said so: HostPool::Hold (the tail of a batched search: one job per chunk of queries, a few hundred
+// microseconds apart, and waking a parked thread costs more than such a job) or stay_awake_until (a GPU wait
+// the caller expects to be shorter than a millisecond).  Both end with the call.  TSH_HOST_SPIN_US=n adds n
+// microseconds of polling after every job (default 0; measurements only).
+class HostPool {
+ public:
+  static HostPool &get() {
+    static HostPool *p = new HostPool();  // never destroyed: workers may outlive static teardown
+    return *p;
+  }
+  // false when the pool is busy with another caller's job (the caller then runs inline).
+  // A job is complete when all its ITEMS are done, not when every worker has reported: a worker that wakes up
+  // late (a parked thread needs 30-50 us, a descheduled one milliseconds) finds the job closed and goes back to
+  // waiting -- the caller and the workers that are awake have done its share.
+  bool run(int32_t n, const std::function<void(int32_t)> &fn) {
+    std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
+    if (!own.owns_lock()) return false;
+    fn_ = &fn;
+    n_ = n;
+    grain_ = std::max(1, std::min(8, n / (4 * threads())));  // a 128-item job on 32 threads: items of one, not of eight
+    done_items_.store(0, std::memory_order_relaxed);
+    next_.store(0, std::memory_order_relaxed);
+    open_.store(true, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(m_);  // a worker between its last look at gen_ and cv_.wait must not miss this
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    if (parked_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+    chunks();
+    spin_until([&] { return done_items_.load(std::memory_order_acquire) >= n; });
+    open_.store(false, std::memory_order_release);
+    spin_until([&] { return active_.load(std::memory_order_acquire) == 0; });  // nobody still looks at fn_ / n_
+    fn_ = nullptr;
+    return true;
+  }
+  int threads() const { return (int)workers_.size() + 1; }
+  int parked() const { return parked_.load(std::memory_order_acquire); }
+  // A caller about to wait for the GPU and then hand the pool a job: keep the workers polling until `t_us`
+  // (now_us() clock) so the job does not start with waking them.  Bounded by the caller (a millisecond at most).
+  void stay_awake_until(double t_us) {
+    double cur = awake_until_.load(std::memory_order_relaxed);
+    while (t_us > cur && !awake_until_.compare_exchange_weak(cur, t_us, std::memory_order_relaxed)) {
+    }
+  }
+  // While a Hold exists the workers poll between jobs instead of parking.  Scope it to the stretch of ONE library
+  // call in which jobs follow each other closely.
+  class Hold {
+   public:
+    Hold() { get().holders_.fetch_add(1, std::memory_order_acq_rel); }
+    ~Hold() { get().holders_.fetch_sub(1, std::memory_order_acq_rel); }
+    Hold(const Hold &) = delete;
+    Hold &operator=(const Hold &) = delete;
+  };
+
+ private:
+  HostPool() {
+    // one process per GPU shares the cores with its peers (torchrun exports LOCAL_WORLD_SIZE); TSH_HOST_THREADS
+    // overrides
+    unsigned hw = std::thread::hardware_concurrency();
+    const char *peers_s = getenv("LOCAL_WORLD_SIZE");
+    const unsigned peers = peers_s && atoi(peers_s) > 0 ? (unsigned)atoi(peers_s) : 1u;
+    hw = std::max(1u, hw / peers);
+    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 64 ? 31 : 15);
+    if (const char *forced = getenv("TSH_HOST_THREADS")) nt = std::max(0, std::min(atoi(forced) - 1, 63));
+    if (const char *spin = getenv("TSH_HOST_SPIN_US")) spin_us_ = std::max(0.0, atof(spin));
+    for (int i = 0; i < nt; ++i) {
+      workers_.emplace_back([this] { loop(); });
+      workers_.back().detach();
+    }
+  }
+  template <typename F>
+  static void spin_until(F &&cond) {
+    for (int spins = 0; !cond(); ++spins) {
+      if (spins < 20000) __builtin_ia32_pause();
+      else std::this_thread::yield();
+    }
+  }
+  void chunks() {
+    for (;;) {
+      const int32_t g = grain_;
+      int32_t q0 = next_.fetch_add(g, std::memory_order_acq_rel);
+      if (q0 >= n_) return;
+      const int32_t q1 = std::min(n_, q0 + g);
+      for (int32_t q = q0; q < q1; ++q) (*fn_)(q);
+      done_items_.fetch_add(q1 - q0, std::memory_order_acq_rel);
+    }
+  }
+  bool keep_polling(double t0) const {
+    if (holders_.load(std::memory_order_acquire) > 0) return true;
+    const double t = now_us();
+    return t < awake_until_.load(std::memory_order_relaxed) || t - t0 < spin_us_;
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      const double t0 = now_us();
+      bool got = false;
+      for (int i = 0;; ++i) {
+        if (gen_.load(std::memory_order_acquire) != seen) {
+          got = true;
+          break;
+        }
+        if ((i & 63) == 0 && !keep_polling(t0)) break;
+        __builtin_ia32_pause();
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(m_);
+        parked_.fetch_add(1, std::memory_order_acq_rel);
+        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        parked_.fetch_sub(1, std::memory_order_acq_rel);
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      active_.fetch_add(1, std::memory_order_acq_rel);
+      if (open_.load(std::memory_order_acquire)) chunks();  // closed: the job finished without this worker
+      active_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex owner_, m_;
+  std::condition_variable cv_;
+  const std::function<void(int32_t)> *fn_ = nullptr;
+  int32_t n_ = 0, grain_ = 8;
+  double spin_us_ = 0.0;
+  std::atomic<int32_t> next_{0}, done_items_{0};
+  std::atomic<int> active_{0}, parked_{0}, holders_{0};
+  std::atomic<bool> open_{false};
+  std::atomic<double> awake_until_{0.0};
+  std::atomic<uint64_t> gen_{0};
+};
+
+template <typename F>
+void parallel_for(int32_t n, F fn) {
+  if (n >= 64) {
+    std::function<void(int32_t)> f = fn;
+    if (HostPool::get().run(n, f)) return;
+  }
+  for (int32_t q = 0; q < n; ++q) fn(q);
+}
+template <typename F>
+void parallel_for_range(int32_t q0, int32_t q1, F fn) {
+  parallel_for(q1 - q0, [&](int32_t i) { fn(q0 + i); });
+}
+
+// The shards of an in-process multi-GPU handle (tsh_index_create with n_devices > 1) are searched side by
+// side, one host thread per shard.  The threads live as long as the handle (starting one costs ~30 us, a
+// 125 k-row shard scan 70 us): run() hands shard g's share of a call to worker g and does shard 0 itself.
+class ShardWorkers {
+ public:
+  explicit ShardWorkers(int n_shards) {
+    for (int g = 1; g < n_shards; ++g) slots_.emplace_back(new Slot());
+    for (auto &s : slots_) s->th = std::thread([sp = s.get()] { sp->loop(); });
+  }
+  ~ShardWorkers() {
+    for (auto &s : slots_) {
+      {
+        std::lock_guard<std::mutex> lk(s->m);
+        s->stop = true;
+      }
+      s->cv.notify_all();
+      if (s->th.joinable()) s->th.join();
+    }
+  }
+  // fn(g) for g in [0, n_shards): g = 0 on the calling thread, the others on their workers.  One call at a time
+  // uses the workers; a concurrent caller (try_lock fails) gets false and starts threads of its own.
+  bool run(const std::function<void(size_t)> &fn) {
+    std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
+    if (!own.owns_lock()) return false;
+    for (size_t i = 0; i < slots_.size(); ++i) {
+      Slot &s = *slots_[i];
+      {
+        std::lock_guard<std::mutex> lk(s.m);
+        s.fn = &fn;
+        s.g = i + 1;
+        s.pending = true;
+      }
+      s.cv.notify_all();
+    }
+    fn(0);
+    for (auto &sp : slots_) {
+      std::unique_lock<std::mutex> lk(sp->m);
+      sp->cv.wait(lk, [&] { return !sp->pending; });
+    }
+    return true;
+  }
+
+ private:
+  struct Slot {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    const std::function<void(size_t)> *fn = nullptr;
+    size_t g = 0;
+    bool pending = false, stop = false;
+    void loop() {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [&] { return pending || stop; });
+        if (stop) return;
+        const std::function<void(size_t)> *f = fn;
+        const size_t gg = g;
+        lk.unlock();
+        (*f)(gg);
+        lk.lock();
+        pending = false;
+        cv.notify_all();
+      }
+    }
+  };
+  std::mutex owner_;
+  std::vector<std::unique_ptr<Slot>> slots_;
+};
+
+}  // namespace tsh

@@ -31,6 +31,7 @@
 
 #include "../../include/tostore_hip.h"
 #include "tsh_batch.hip.h"
+#include "tsh_host_sync.h"
 #include "tsh_kernels.hip.h"
 #include "tsh_pq.hip.h"
 
@@ -149,145 +150,6 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
   return (int32_t)r;
 }
 
-// run fn(q) for q in [0,n) on a few host threads (per-query preparation / finalisation of a
-// batch).  The workers are created once and parked on a condition variable: spawning threads
-// per call costs more than the work itself (about 30 us per thread on a 128-core host).
-inline double now_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-class HostPool {
- public:
-  static HostPool &get() {
-    static HostPool *p = new HostPool();  // never destroyed: workers may outlive static teardown
-    return *p;
-  }
-  // false when the pool is busy with another caller's job (the caller then runs inline).
-  // A job is complete when all its ITEMS are done, not when every worker has reported: a worker that wakes up
-  // late (a parked thread needs 30-50 us, a descheduled one milliseconds) finds the job closed and goes back to
-  // waiting -- the caller and the workers that are awake have done its share.
-  bool run(int32_t n, const std::function<void(int32_t)> &fn) {
-    std::unique_lock<std::mutex> own(owner_, std::try_to_lock);
-    if (!own.owns_lock()) return false;
-    fn_ = &fn;
-    n_ = n;
-    grain_ = std::max(1, std::min(8, n / (4 * threads())));  // a 128-item job on 32 threads: items of one, not of eight
-    done_items_.store(0, std::memory_order_relaxed);
-    next_.store(0, std::memory_order_relaxed);
-    open_.store(true, std::memory_order_release);
-    {
-      std::lock_guard<std::mutex> lk(m_);  // a worker between its last look at gen_ and cv_.wait must not miss this
-      gen_.fetch_add(1, std::memory_order_release);
-    }
-    if (parked_.load(std::memory_order_acquire) > 0) cv_.notify_all();
-    chunks();
-    spin_until([&] { return done_items_.load(std::memory_order_acquire) >= n; });
-    open_.store(false, std::memory_order_release);
-    spin_until([&] { return active_.load(std::memory_order_acquire) == 0; });  // nobody still looks at fn_ / n_
-    fn_ = nullptr;
-    return true;
-  }
-  int threads() const { return (int)workers_.size() + 1; }
-  // A caller about to wait for the GPU and then hand the pool a job: keep the workers polling until `t_us`
-  // (now_us() clock) so the job does not start with waking them.  Bounded by the caller (a millisecond at most).
-  void stay_awake_until(double t_us) {
-    double cur = awake_until_.load(std::memory_order_relaxed);
-    while (t_us > cur && !awake_until_.compare_exchange_weak(cur, t_us, std::memory_order_relaxed)) {
-    }
-  }
-
- private:
-  HostPool() {
-    // workers poll between jobs, so they must not oversubscribe the host: one process per GPU shares the cores
-    // with its peers (torchrun exports LOCAL_WORLD_SIZE); TSH_HOST_THREADS overrides
-    unsigned hw = std::thread::hardware_concurrency();
-    const char *peers_s = getenv("LOCAL_WORLD_SIZE");
-    const unsigned peers = peers_s && atoi(peers_s) > 0 ? (unsigned)atoi(peers_s) : 1u;
-    hw = std::max(1u, hw / peers);
-    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 64 ? 31 : 15);
-    if (const char *forced = getenv("TSH_HOST_THREADS")) nt = std::max(0, std::min(atoi(forced) - 1, 63));
-    for (int i = 0; i < nt; ++i) {
-      workers_.emplace_back([this] { loop(); });
-      workers_.back().detach();
-    }
-  }
-  template <typename F>
-  static void spin_until(F &&cond) {
-    for (int spins = 0; !cond(); ++spins) {
-      if (spins < 20000) __builtin_ia32_pause();
-      else std::this_thread::yield();
-    }
-  }
-  void chunks() {
-    for (;;) {
-      const int32_t g = grain_;
-      int32_t q0 = next_.fetch_add(g, std::memory_order_acq_rel);
-      if (q0 >= n_) return;
-      const int32_t q1 = std::min(n_, q0 + g);
-      for (int32_t q = q0; q < q1; ++q) (*fn_)(q);
-      done_items_.fetch_add(q1 - q0, std::memory_order_acq_rel);
-    }
-  }
-  // A batch hands the pool several jobs a few hundred microseconds apart (one per chunk of its tail); waking a
-  // parked thread costs more than such a job itself, so a worker keeps polling for SPIN_US after a job before
-  // it parks on the condition variable again.
-  static constexpr double SPIN_US = 400.0;
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      const double t0 = now_us();
-      bool got = false;
-      for (int i = 0;; ++i) {
-        if (gen_.load(std::memory_order_acquire) != seen) {
-          got = true;
-          break;
-        }
-        __builtin_ia32_pause();
-        if ((i & 255) == 255) {
-          const double t = now_us();
-          if (t - t0 > SPIN_US && t > awake_until_.load(std::memory_order_relaxed)) break;
-        }
-      }
-      if (!got) {
-        std::unique_lock<std::mutex> lk(m_);
-        parked_.fetch_add(1, std::memory_order_acq_rel);
-        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-        parked_.fetch_sub(1, std::memory_order_acq_rel);
-      }
-      seen = gen_.load(std::memory_order_acquire);
-      active_.fetch_add(1, std::memory_order_acq_rel);
-      if (open_.load(std::memory_order_acquire)) chunks();  // closed: the job finished without this worker
-      active_.fetch_sub(1, std::memory_order_acq_rel);
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex owner_, m_;
-  std::condition_variable cv_;
-  const std::function<void(int32_t)> *fn_ = nullptr;
-  int32_t n_ = 0, grain_ = 8;
-  std::atomic<int32_t> next_{0}, done_items_{0};
-  std::atomic<int> active_{0}, parked_{0};
-  std::atomic<bool> open_{false};
-  std::atomic<double> awake_until_{0.0};
-  std::atomic<uint64_t> gen_{0};
-};
-
-template <typename F>
-void parallel_for(int32_t n, F fn);
-template <typename F>
-void parallel_for_range(int32_t q0, int32_t q1, F fn) {
-  parallel_for(q1 - q0, [&](int32_t i) { fn(q0 + i); });
-}
-
-template <typename F>
-void parallel_for(int32_t n, F fn) {
-  if (n >= 64) {
-    std::function<void(int32_t)> f = fn;
-    if (HostPool::get().run(n, f)) return;
-  }
-  for (int32_t q = 0; q < n; ++q) fn(q);
-}
-
 // ---- kernel dispatch ---------------------------------------------------------
 inline int pick_nch(int d4) {
   int need = (d4 + 63) / 64;
@@ -387,39 +249,6 @@ void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream
   }
 }
 
-// Reader/writer lock that may be released by a different thread than the one
-// that took it (an asynchronous search is submitted and waited independently).
-class RwLock {
- public:
-  void lock_shared() {
-    std::unique_lock<std::mutex> lk(m_);
-    cv_.wait(lk, [&] { return !writer_ && writers_waiting_ == 0; });
-    ++readers_;
-  }
-  void unlock_shared() {
-    std::lock_guard<std::mutex> lk(m_);
-    if (--readers_ == 0) cv_.notify_all();
-  }
-  void lock() {
-    std::unique_lock<std::mutex> lk(m_);
-    ++writers_waiting_;
-    cv_.wait(lk, [&] { return !writer_ && readers_ == 0; });
-    --writers_waiting_;
-    writer_ = true;
-  }
-  void unlock() {
-    std::lock_guard<std::mutex> lk(m_);
-    writer_ = false;
-    cv_.notify_all();
-  }
-
- private:
-  std::mutex m_;
-  std::condition_variable cv_;
-  int readers_ = 0, writers_waiting_ = 0;
-  bool writer_ = false;
-};
-
 // ---- per-search scratch: one context = one query in flight ---------------------
 struct Ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -478,6 +307,8 @@ struct Shard {
   uint64_t *d_live = nullptr;
   IngestStats *d_stats = nullptr;
   uint32_t *d_tmp_u32 = nullptr;
+  int64_t *d_del_ids = nullptr;  // tsh_index_set_deleted's id buffer, kept between calls
+  int64_t del_ids_cap = 0;
   int64_t deleted = 0;
   bool all_live = true;  // every row in [0,rows) is present and not deleted
   float max_norm = 0.f, max_abs = 0.f;
@@ -1400,6 +1231,7 @@ struct tsh_index {
   std::vector<std::unique_ptr<Ticket>> tickets;
   std::atomic<int> tickets_open{0};  // submitted, not yet waited for: each holds one context per shard
   std::atomic<int32_t> batch_min_nq{1};  // 0 never, 1 by estimated cost, n >= 2: from n queries per call on
+  std::unique_ptr<ShardWorkers> workers;  // multi-device handles: one persistent host thread per further shard
   // result-block buffers of multi-query calls, kept between calls: a fresh 6 MB allocation per call spends
   // ~0.3 ms in page faults when it is first written
   std::mutex pool_mu;
@@ -1423,6 +1255,13 @@ struct tsh_index {
 };
 
 namespace {
+
+// Shared lock of a shard on behalf of a call on `idx`.  A handle with asynchronous tickets open passes a
+// waiting writer (RwLock: queueing behind it would deadlock ticket holder, writer and this call).
+inline std::shared_lock<RwLock> share(tsh_index *idx, Shard *s) {
+  s->mu.lock_shared_gate(idx->tickets_open.load() > 0);
+  return std::shared_lock<RwLock>(s->mu, std::adopt_lock);
+}
 
 int make_shard(int dim, int metric, int device, int64_t row_base, int64_t cap_rows,
                std::unique_ptr<Shard> *out) {
@@ -1460,6 +1299,7 @@ void shard_destroy(Shard *s) {
   hipFree(s->d_split);
   hipFree(s->d_stats);
   hipFree(s->d_tmp_u32);
+  hipFree(s->d_del_ids);
   hipFree(s->d_quar);
   hipFree(s->d_irr);
 }
@@ -1561,6 +1401,7 @@ int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows, int
       }
       idx->shards.push_back(std::move(s));
     }
+    idx->workers.reset(new ShardWorkers(n_devices));
   }
   *out = idx.release();
   return TSH_OK;
@@ -1587,6 +1428,7 @@ int32_t tsh_index_create_shard(int32_t dim, int32_t metric, int64_t capacity_row
 
 int32_t tsh_index_destroy(tsh_index *idx) {
   if (!idx) return TSH_OK;
+  idx->workers.reset();  // joins the shard threads
   for (auto &s : idx->shards) {
     std::unique_lock<RwLock> xl(s->mu);
     shard_destroy(s.get());
@@ -1613,8 +1455,15 @@ int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n) {
     std::unique_lock<RwLock> xl(s->mu);
     if (s->rows == 0) continue;
     HIPCHK(hipSetDevice(s->device));
-    int64_t *d_ids = nullptr;
-    HIPCHK(hipMalloc(&d_ids, (size_t)n * sizeof(int64_t)));
+    if (n > s->del_ids_cap) {  // kept between calls (deletes arrive in small batches, journal flush by journal flush)
+      hipFree(s->d_del_ids);
+      s->d_del_ids = nullptr;
+      s->del_ids_cap = 0;
+      const int64_t want = std::max<int64_t>(round_up(n, 1024), 4096);
+      HIPCHK(hipMalloc(&s->d_del_ids, (size_t)want * sizeof(int64_t)));
+      s->del_ids_cap = want;
+    }
+    int64_t *d_ids = s->d_del_ids;
     hipStream_t st = s->ingest_stream;
     hipError_t e = hipMemcpyAsync(d_ids, ids, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(s->d_tmp_u32, 0, 4, st);
@@ -1625,7 +1474,6 @@ int32_t tsh_index_set_deleted(tsh_index *idx, const int64_t *ids, int64_t n) {
     uint32_t cleared = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&cleared, s->d_tmp_u32, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d_ids);
     if (e != hipSuccess) return set_err(TSH_E_HIP, "set_deleted: %s", hipGetErrorString(e));
     s->deleted += cleared;
     if (cleared) s->all_live = false;
@@ -1651,7 +1499,7 @@ int64_t tsh_index_size(tsh_index *idx) {
   if (!idx) return 0;
   int64_t m = 0;
   for (auto &s : idx->shards) {
-    std::shared_lock<RwLock> sl(s->mu);
+    std::shared_lock<RwLock> sl = share(idx, s.get());
     if (s->rows > 0) m = std::max(m, s->row_base + s->rows);
   }
   return m;
@@ -1701,7 +1549,7 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
 
   auto run = [&](size_t g) {
     Shard *s = idx->shards[g].get();
-    std::shared_lock<RwLock> sl(s->mu);
+    std::shared_lock<RwLock> sl = share(idx, s);
     if (s->rows == 0) return;
     active[g] = 1;
     blocks[g] = idx->take_blocks(bb * (size_t)nq, &block_caps[g]);
@@ -1732,9 +1580,13 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
   if (ns == 1) {
     run(0);
   } else {
-    std::vector<std::thread> th;
-    for (size_t g = 0; g < ns; ++g) th.emplace_back(run, g);
-    for (auto &t : th) t.join();
+    const std::function<void(size_t)> frun = run;
+    if (!idx->workers || !idx->workers->run(frun)) {  // the workers are busy with a concurrent call: own threads
+      std::vector<std::thread> th;
+      for (size_t g = 1; g < ns; ++g) th.emplace_back(run, g);
+      run(0);
+      for (auto &t : th) t.join();
+    }
   }
   for (size_t g = 0; g < ns; ++g)
     if (rcs[g]) {
@@ -1781,9 +1633,19 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
   t->jobs.resize(idx->shards.size());
   t->locks.resize(idx->shards.size());
   int rc = TSH_OK;
+  // The handle stays share-locked from submit to wait.  A caller that already has tickets open must not queue
+  // behind a waiting append / delete (it would never reach the wait that lets the writer in): it is told to
+  // drain its tickets first, which also keeps a caller that always has one open from starving the writer.
+  const bool holding = idx->tickets_open.load() > 0;
+  if (holding)
+    for (auto &sp : idx->shards)
+      if (sp->mu.writer_pending())
+        return set_err(TSH_E_BUSY, "an append / delete is waiting for this handle's open asynchronous searches: "
+                                   "wait for them, then submit again");
   for (size_t g = 0; g < idx->shards.size() && rc == TSH_OK; ++g) {
     Shard *s = idx->shards[g].get();
-    t->locks[g] = std::shared_lock<RwLock>(s->mu);
+    s->mu.lock_shared_gate(holding);
+    t->locks[g] = std::shared_lock<RwLock>(s->mu, std::adopt_lock);
     if (s->rows == 0) continue;
     // Contexts held by synchronous callers come back on their own, so wait for one -- unless the
     // un-waited tickets alone could hold them all: waiting would then never end for a caller that
@@ -1884,7 +1746,7 @@ int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32
   if (nq <= 0 || !queries || !d_out_blocks || k <= 0 || entries < 1)
     return set_err(TSH_E_BAD_ARG, "bad nq / k / entries / pointers");
   Shard *s = idx->shards[0].get();
-  std::shared_lock<RwLock> sl(s->mu);
+  std::shared_lock<RwLock> sl = share(idx, s);
   size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   if (s->rows == 0) {  // an empty shard contributes empty blocks
     HIPCHK(hipSetDevice(s->device));
@@ -1949,7 +1811,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
   memset(out, 0, sizeof *out);
   for (auto &sp : idx->shards) {
     Shard *s = sp.get();
-    std::shared_lock<RwLock> sl(s->mu);
+    std::shared_lock<RwLock> sl = share(idx, s);
     if (s->rows > 0) out->rows = std::max(out->rows, s->row_base + s->rows);
     out->deleted_rows += s->deleted;
     out->searches = std::max<int64_t>(out->searches, s->c_searches.load());
@@ -1978,7 +1840,7 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   if (!idx || idx->shards.size() != 1 || !query || iters <= 0 || !out_avg_us)
     return set_err(TSH_E_BAD_ARG, "bad arguments");
   Shard *s = idx->shards[0].get();
-  std::shared_lock<RwLock> sl(s->mu);
+  std::shared_lock<RwLock> sl = share(idx, s);
   if (s->rows == 0) return set_err(TSH_E_BAD_ARG, "empty index");
   Ctx *c = ctx_acquire(s, true);
   struct Rel {
@@ -2036,7 +1898,7 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
   if (!idx || idx->shards.size() != 1 || !queries || nq <= 0 || k <= 0 || iters <= 0 || !out_avg_gemm_us)
     return set_err(TSH_E_BAD_ARG, "bad arguments");
   Shard *s = idx->shards[0].get();
-  std::shared_lock<RwLock> sl(s->mu);
+  std::shared_lock<RwLock> sl = share(idx, s);
   if (s->rows == 0) return set_err(TSH_E_BAD_ARG, "empty index");
   if (s->safe_mode()) return set_err(TSH_E_BAD_ARG, "index is in safe mode: no batched path");
   int32_t entries = tsh_default_block_entries(k);

@@ -2,7 +2,10 @@
 // lib/src/handler/hip_vector_backend.dart to route vectorSearch() through
 // libtostore_hip.so (include/tostore_hip.h).
 //
-// NOT compiled or tested in this repository: the build image has no Dart SDK.
+// NOT compiled in this repository: the build image has no Dart SDK.  What CAN be
+// checked without one is: tests/test_dart_bridge.py parses every `typedef ...C`
+// below, the symbol each one is looked up as, and the TshNghInfo struct, and
+// compares arity, argument widths and field layout with include/tostore_hip.h.
 // It is a mechanical mapping of the C-ABI, written in the style of the
 // reference's only existing FFI user, lib/src/handler/system_ffi_helper.dart
 // (DynamicLibrary.open + lookupFunction, int32 status with 0 = success,
@@ -48,9 +51,9 @@ typedef _SearchC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, D
 typedef _SearchD = int Function(Pointer<Void>, Pointer<Float>, int, int, double,
     Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
 typedef _OpenNghC = Int32 Function(
-    Pointer<Utf8>, Int32, Int32, Pointer<Pointer<Void>>, Pointer<Void>);
+    Pointer<Utf8>, Int32, Int32, Pointer<Pointer<Void>>, Pointer<TshNghInfo>);
 typedef _OpenNghD = int Function(
-    Pointer<Utf8>, int, int, Pointer<Pointer<Void>>, Pointer<Void>);
+    Pointer<Utf8>, int, int, Pointer<Pointer<Void>>, Pointer<TshNghInfo>);
 typedef _PqEncodeC = Int32 Function(
     Pointer<Void>, Int64, Int64, Pointer<Float>, Int32, Int32, Pointer<Uint8>);
 typedef _PqEncodeD = int Function(
@@ -59,6 +62,41 @@ typedef _PqTrainC = Int32 Function(Int32, Pointer<Float>, Int64, Int32, Int32, I
     Pointer<Int32>, Pointer<Float>);
 typedef _PqTrainD = int Function(int, Pointer<Float>, int, int, int, int, int,
     Pointer<Int32>, Pointer<Float>);
+
+/// `tsh_ngh_info` (include/tostore_hip.h): what tsh_index_open_ngh found.  Field order and
+/// widths are checked against the header by tests/test_dart_bridge.py.
+final class TshNghInfo extends Struct {
+  @Int32()
+  external int dimensions;
+  @Int32()
+  external int metric;
+  @Int32()
+  external int precision;
+  @Int32()
+  external int pageSize;
+  @Int32()
+  external int maxDegree;
+  @Int32()
+  external int reserved;
+  @Int64()
+  external int nextNodeId;
+  @Int64()
+  external int totalVectors;
+  @Int64()
+  external int deletedCount;
+  @Int64()
+  external int maxPartitionFileSize;
+  @Int64()
+  external int rowsLoaded;
+  @Int64()
+  external int tombstones;
+  @Int64()
+  external int filesRead;
+  @Int64()
+  external int pagesAbsent;
+  @Int64()
+  external int filesAbsent;
+}
 
 /// One device-resident copy of an NGH index's raw-vector column.
 ///
@@ -152,17 +190,29 @@ final class HipVectorBackend {
       {int devices = 1}) {
     if (!available) return null;
     final out = calloc<Pointer<Void>>();
+    final info = calloc<TshNghInfo>();
     final p = nghDir.toNativeUtf8();
     try {
-      final rc = _openNgh(p, maxEntriesPerDir, devices, out, nullptr);
+      final rc = _openNgh(p, maxEntriesPerDir, devices, out, info);
       if (rc != 0) {
         Logger.warn('tsh_index_open_ngh failed ($rc): ${_errorText()}',
             label: 'HipVectorBackend');
         return null;
       }
+      // Raw-vector pages that are not on disk load as ABSENT rows: the exhaustive path would
+      // silently never return those nodes, so an index with holes stays on the Dart path.
+      if (info.ref.pagesAbsent != 0 || info.ref.rowsLoaded != meta.nextNodeId) {
+        Logger.warn(
+            'device index of $nghDir not used: ${info.ref.pagesAbsent} raw-vector pages absent, '
+            '${info.ref.rowsLoaded} of ${meta.nextNodeId} rows loaded',
+            label: 'HipVectorBackend');
+        _destroy(out.value);
+        return null;
+      }
       return HipVectorBackend._(out.value, meta.dimensions, meta.distanceMetric);
     } finally {
       calloc.free(p);
+      calloc.free(info);
       calloc.free(out);
     }
   }

@@ -123,10 +123,7 @@ class ShardedSearcher:
         dist = np.full((nq, kk), np.nan, dtype=np.float64)
         cnt = np.zeros(nq, dtype=np.int32)
         entries = _ffi.lib().tsh_default_block_entries(int(k))
-        mp = None
-        if row_mask is not None:
-            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
-            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        row_mask, mp = self.index.mask_arg(row_mask)  # GLOBAL mask: one bit per row id below this shard's end
         spans = [(s, min(nq, s + group)) for s in range(0, nq, group)]
         if not spans:
             return ids, dist, cnt
@@ -163,10 +160,7 @@ class ShardedSearcher:
         nq = q.shape[0]
         L = _ffi.lib()
         entries = L.tsh_default_block_entries(int(k))
-        mp = None
-        if row_mask is not None:
-            row_mask = np.ascontiguousarray(row_mask, dtype=np.uint8)
-            mp = row_mask.ctypes.data_as(_ffi.p_u8)
+        row_mask, mp = self.index.mask_arg(row_mask)  # GLOBAL mask: one bit per row id below this shard's end
         for _attempt in range(3):
             self._scan(q, k, mp, entries, 0)
             try:
