@@ -160,8 +160,10 @@ class HipVectorIndex:
         if q.shape[1] != self.dim:
             raise ValueError(f"queries must be nq x {self.dim}")
         nq, kk = q.shape[0], max(int(k), 0)
-        ids = np.full((nq, max(kk, 1)), -1, dtype=np.int64)
-        dist = np.full((nq, max(kk, 1)), np.nan, dtype=np.float64)
+        # (the library fills the slots past a query's count with -1 / NaN itself: pre-filling 1.6 MB here cost a
+        # 1024-query call 0.3 ms)
+        ids = np.empty((nq, max(kk, 1)), dtype=np.int64)
+        dist = np.empty((nq, max(kk, 1)), dtype=np.float64)
         cnt = np.zeros(nq, dtype=np.int32)
         thr = math.nan if distance_threshold is None else float(distance_threshold)
         row_mask, mp = self.mask_arg(row_mask)

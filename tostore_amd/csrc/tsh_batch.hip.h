@@ -61,6 +61,7 @@ struct BatchArgs {
   int32_t hchunks;        // ceil(dim / 32)
   int32_t tile_m;         // workgroup tile (queries = rows): 128 or 256 (host-side dispatch only)
   float dot_scale;        // f16 variant: 2^-(eq + ev), undoes the power-of-two operand scales (0 = unused)
+  int32_t dbg;            // f16 kernel probe (TSH_F16_DBG): 4 = no epilogue (results are wrong)
 };
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of

@@ -1,0 +1,386 @@
+// tsh_batch_f16.hip.h -- the fp16 pre-filter key kernel of the batched path (TSH_OPT_BATCH_KERNEL = 2 / auto),
+// second generation.  Same contract as batch_score_bf16x3_kernel<MODE = 1> in tsh_batch.hip.h (operands rounded to
+// fp16 after an exact power-of-two scaling, ONE v_mfma_f32_32x32x16_f16 per product, key transform + per-query
+// threshold filter fused into the epilogue); different machine mapping:
+//
+//   * workgroup = 8 waves (2 x 4), each a 128 x 64 patch (4 x 2 MFMA 32x32 blocks, 128 accumulator registers) of a
+//     256 x 256 (queries x rows) tile -- 0.75 KB of LDS reads per MFMA instead of 1 KB (first generation: sixteen
+//     64 x 64 waves) -- or, for calls of up to 128 queries, a 64 x 64 patch of a 128 x 256 tile.  Every SIMD holds
+//     two waves of the workgroup, and the two take their turns in OPPOSITE order within a K-step: waves 0-3 issue
+//     their share of the next chunk's loads first and multiply afterwards, waves 4-7 multiply first and issue
+//     afterwards, so that on each SIMD one wave feeds the matrix pipe while the other one sits in the ~100 cycles
+//     each load instruction takes to issue.
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.
+//     The DMA writes a wave's 64 x 16 B linearly, so the bank swizzle the fragment reads need is baked into the
+//     GLOBAL layout of the planes ("plane32" below): a tile's K-chunk is a contiguous run of 8 KB blocks that are
+//     byte for byte the LDS image.
+//   * K-chunk = 32 (64 B per row), ring of four 32 KB stages, ONE s_barrier per K-step: a wave waits for its own
+//     DMA pieces of chunk kc with a COUNTED s_waitcnt vmcnt (the pieces of chunk kc + 1 stay in flight across the
+//     barrier), passes the barrier, issues the pieces of chunk kc + 2 into the stage chunk kc - 1 has just left,
+//     and multiplies chunk kc.  The DMA is issued from inline asm, so the compiler's own s_waitcnt insertion does
+//     not see it (it would drain it before every LDS read); the counts are kept by hand.
+//   * survivors of the filter are collected in a per-wave LDS list without atomics (slot = running scalar count +
+//     mbcnt of the hit mask) and flushed once per tile: one returning global atomic per survivor, all in flight
+//     together, instead of one wait per hit site.
+//
+// Plane layout "plane32": rows in groups of 128; per group and K-chunk of 32 one 8 KB block;
+//   16-byte piece(row, kc, p) at  (((row / 128) * KC + kc) * 128 + row % 128) * 4 + (p ^ ((row >> 2) & 3))
+// where piece p holds k = 32 kc + 8 p .. + 7 as fp16.  ds_read_b128 of a fragment (lane = row % 32, piece fixed)
+// then touches 16 distinct 16-byte bank groups per 16-lane service group (MI355X_MICROARCH.md, LDS table).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsh_batch.hip.h"
+
+namespace tsh {
+
+constexpr int F16_KC = 32;        // k per chunk
+constexpr int F16_GROUP = 128;    // rows per plane block
+constexpr int F16_BLOCK_PIECES = F16_GROUP * 4;  // 16-byte pieces per (group, chunk) block = 8 KB
+
+__host__ __device__ __forceinline__ int64_t plane32_piece(int64_t row, int kc, int p, int kchunks) {
+  return (((row / F16_GROUP) * kchunks + kc) * F16_GROUP + row % F16_GROUP) * 4 + (p ^ (int)((row >> 2) & 3));
+}
+
+struct Half32Args {
+  const float *rows;      // n x ld f32
+  const float *inv_norm;  // nullable: multiply each row by its 1/|row| first (cosine corpus)
+  u32x4 *out;             // plane32 layout
+  int64_t ld;
+  int64_t first, n;
+  int32_t dim, kchunks;   // kchunks = ceil(dim / 32)
+  float scale;            // power of two
+};
+
+// one thread = 8 consecutive k of one row = one 16-byte piece
+__global__ void __launch_bounds__(256) half_rows32_kernel(Half32Args a) {
+  const int64_t per_row = (int64_t)a.kchunks * 4;
+  const int64_t total = a.n * per_row, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = a.first + i / per_row;
+    const int pp = (int)(i % per_row), kc = pp >> 2, p = pp & 3;
+    const int k0 = kc * 32 + p * 8;
+    const float *src = a.rows + row * a.ld + k0;
+    const float mul = a.inv_norm ? a.inv_norm[row] * a.scale : a.scale;
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)(k0 + e < a.dim ? src[e] * mul : 0.f);  // round to nearest even
+    a.out[plane32_piece(row, kc, p, a.kchunks)] = __builtin_bit_cast(u32x4, h);
+  }
+}
+
+// one wave's 64 x 16 B from global (per-lane address) into LDS at lds_dst + 16 * lane (wave-uniform base in M0).
+// Invisible to the compiler's s_waitcnt bookkeeping: completion is counted by hand (f16_wait_dma).
+__device__ __forceinline__ void f16_dma16(const void *gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void f16_wait_dma() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+constexpr int F16_HITS = 128;  // per-wave survivor list of one tile (two per lane); fuller tiles take the slow walk
+
+// PERSISTENT: launch with gridDim.x = min(tiles, CUs) workgroups of 512 threads (one per CU); workgroup b takes tiles
+// b, b + gridDim.x, ... of batch_tile_of's XCD-aware order.  The K-chunks of a workgroup's tiles form ONE stream
+// through the ring: the first chunks of tile t + 1 are in flight while tile t's epilogue runs, and the global
+// atomics that reserve list slots for tile t's survivors are only waited for at the end of tile t + 1.
+template <int METRIC, bool DENSE, int MI>
+__global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
+  static_assert(MI == 4 || MI == 2, "wave patch 32 MI x 64; 8 waves as 2 x 4");
+  constexpr int WN = 4, TM = 64 * MI, TN = 256;
+  constexpr int STAGE = (TM + TN) * 64;            // bytes: [queries TM x 64 B][rows TN x 64 B] = 32 / 24 KB
+  constexpr int NST = 4, AHEAD = NST - 1;          // ring stages; chunks in flight ahead of the multiply
+  constexpr int P = STAGE / 1024 / 8;              // 1 KB DMA pieces per wave per stage = 4 / 3
+  constexpr bool IPLIKE = METRIC != METRIC_L2;     // cosine planes hold unit rows: its key is -dot, as for IP
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[NST * STAGE];
+  __shared__ __attribute__((aligned(16))) float s_thr[TM];
+  __shared__ __attribute__((aligned(16))) float s_qsq[TM];
+  __shared__ uint2 s_hits[8][F16_HITS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const bool load_first = wave < 4;  // (waves w and w + 4 share a SIMD: MI355X_MICROARCH.md, LDS section)
+  const int KC = a.hchunks;
+  const int G = (int)gridDim.x, total_tiles = a.q_tiles * a.n_tiles;
+
+  // ---- issue stream: the chunks of my tiles in order, AHEAD steps in front of the multiply ------------------------
+  // the stage image is (TM + TN) / 128 blocks of 8 KB; wave w moves 1 KB pieces P w .. P w + P - 1 of every stage.
+  // The stream never runs dry: past the last chunk it re-reads the last tile (into stages nobody reads any more),
+  // so that the number of pieces in flight -- which the hand-kept vmcnt counts rely on -- is the same at every step.
+  const u32x4 *src[P];
+  int i_tile = (int)blockIdx.x;
+  auto set_src = [&](int tile) {
+    int qt, nt;
+    batch_tile_of(a, tile, &qt, &nt);
+    const int qb = qt * TM, nb = a.row0 + nt * TN;  // row0 is a multiple of the tile (host)
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int piece = wave * P + u;
+      const int blk = piece >> 3, sub = piece & 7;  // block of the stage, 1 KB part of the block
+      const bool is_q = blk < TM / F16_GROUP;
+      const int64_t group = is_q ? (qb / F16_GROUP + blk) : (nb / F16_GROUP + (blk - TM / F16_GROUP));
+      src[u] = (is_q ? a.Qs : a.Vs) + (group * KC) * F16_BLOCK_PIECES + sub * 64 + lane;
+    }
+  };
+  const uint32_t my_dst = (uint32_t)(uintptr_t)ring + (uint32_t)wave * (P * 1024);
+  // rows past the end of the corpus: the planes are allocated in whole 256-row groups, so the loads stay inside
+  // the allocation; what they return is discarded by the epilogue (col_ok)
+  auto issue = [&](auto SIDX) {  // the next chunk of the stream -> ring stage SIDX (compile-time)
+    constexpr int ST = decltype(SIDX)::value;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      f16_dma16(src[u], my_dst + (uint32_t)(ST * STAGE + u * 1024));
+      src[u] += F16_BLOCK_PIECES;
+    }
+  };
+  auto next_tile_src = [&]() {  // the stream moves on to my next tile (or stays on the last one)
+    if (i_tile + G < total_tiles) i_tile += G;
+    set_src(i_tile);
+  };
+
+  // fragment addresses: row = 32 i + (lane & 31) (+ patch base), logical piece 2 s + (lane >> 5), slot = piece ^ sw
+  const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 2) & 3;
+  const int a_off = (wm * 32 * MI + l31) * 64, b_off = TM * 64 + (wn * 64 + l31) * 64;
+  const int slot0 = ((0 + half) ^ sw) * 16, slot1 = ((2 + half) ^ sw) * 16;
+  f32x16 acc[MI][2];
+  // Fragments of the two k16 slabs of a chunk, double-buffered ACROSS the barrier: while slab 0 of chunk g is
+  // multiplied, slab 1 is read; while slab 1 is multiplied, slab 0 of chunk g + 1 is read -- which is legal because
+  // a step's barrier already guarantees chunk g + 1 (see the K loop).  After a barrier the matrix pipe starts at
+  // once instead of after all eight waves' LDS reads.
+  f16x8 fa[2][MI], fb[2][2];
+  auto read_slab = [&](auto SIDX, int sl) {
+    constexpr int ST = decltype(SIDX)::value;
+    const unsigned char *st = ring + ST * STAGE;
+    const int so = sl == 0 ? slot0 : slot1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[sl][i] = *reinterpret_cast<const f16x8 *>(st + a_off + i * 2048 + so);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[sl][j] = *reinterpret_cast<const f16x8 *>(st + b_off + j * 2048 + so);
+  };
+  auto mfma_slab = [&](int sl) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc[i][j], 0, 0, 0);
+  };
+
+  // survivors whose list slots have been asked for but not yet answered (two per lane: F16_HITS = 128)
+  uint2 pend_e[2] = {uint2{0u, 0u}, uint2{0u, 0u}};
+  uint32_t pend_p[2] = {0u, 0u}, pend_n = 0;
+  int pend_qbase = 0, pend_nbase = 0;
+  auto ask = [&](int qb, int qrow) -> uint32_t {  // reserve one slot in the query's candidate list
+    int q = qb + qrow;
+    asm volatile("" : "+v"(q));  // keeps the 64 list addresses of a patch from being precomputed (and spilled)
+    return atomicAdd(&a.cand_cnt[(int64_t)q * CC_STRIDE], 1u);
+  };
+  auto store = [&](int qb, int nb, uint32_t e_key, uint32_t e_loc, uint32_t p) {
+    if (p < (uint32_t)a.cand_cap) {
+      const int64_t o = (int64_t)(qb + (int)(e_loc >> 16)) * a.cand_cap + p;
+      a.cand_key[o] = e_key;
+      a.cand_row[o] = (uint32_t)(nb + (int)(e_loc & 0xFFFFu));
+    }
+  };
+  auto settle = [&]() {  // the answers have had a whole tile's time to arrive
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if ((uint32_t)(lane + 64 * h) < pend_n) store(pend_qbase, pend_nbase, pend_e[h].x, pend_e[h].y, pend_p[h]);
+    pend_n = 0;
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  set_src(i_tile);
+  int cur_q_tile = -1;
+  // KC is a multiple of four (host) and at least four: every tile starts in ring stage 0
+  issue(S0{});
+  issue(S1{});
+  issue(S2{});
+  f16_wait_dma<2 * P>();  // my pieces of chunk 0
+  __builtin_amdgcn_s_barrier();
+  read_slab(S0{}, 0);
+
+  for (int tile = (int)blockIdx.x; tile < total_tiles; tile += G) {
+    int n_tile, q_tile;
+    batch_tile_of(a, tile, &q_tile, &n_tile);
+    const int qbase = q_tile * TM, nbase = a.row0 + n_tile * TN;
+    if (q_tile != cur_q_tile) {
+      // Per-query thresholds of this workgroup's query tile: with gridDim.x a multiple of 8 q_tiles a workgroup keeps
+      // its query tile for all its tiles, so this runs once (and in the ragged tail of the tile order).  The
+      // compiler waits for these loads with vmcnt(0), which also drains the DMA in flight: not in the K loop.
+      __syncthreads();  // (nobody still reads the old thresholds)
+      for (int t = tid; t < TM; t += 512) {
+        const int q = qbase + t;
+        float th = -__builtin_inff();  // dense mode / padding rows: nothing passes
+        if (!DENSE && q < a.nq) th = a.thr[q];
+        if (IPLIKE) th = -th / a.dot_scale;  // key = -(acc * scale) <= thr  <=>  acc >= -thr / scale (power of two: exact)
+        s_thr[t] = th;
+        s_qsq[t] = METRIC == METRIC_L2 ? a.qsq[q] : 0.f;
+      }
+      cur_q_tile = q_tile;  // (the K loop's barriers order these stores before the epilogue's reads)
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- K loop: one barrier per step, four steps (one turn of the ring) per iteration ---------------------------
+    // On entry to a step: slab 0 of its chunk is in registers; the three chunks after it have been issued.  Stage
+    // indices are compile-time constants and the stream's bookkeeping is a pointer increment, because everything a
+    // wave does between the barrier and its first MFMA is matrix-pipe idle time: both waves of a SIMD do it at the
+    // same moment (a first version with run-time stages and counters spent ~100 instructions there: 67 % MFMA busy
+    // with the loads and the epilogue switched off).
+    auto step = [&](auto CUR, auto NXT, auto FILL, auto SWITCH) {
+      f16_wait_dma<P>();             // my pieces of the NEXT chunk have landed (the one after it may still fly)
+      __builtin_amdgcn_s_barrier();  // everybody's have; and everybody is done reading the chunk before this one
+      if (decltype(SWITCH)::value) next_tile_src();
+      if (load_first) issue(FILL);   // chunk + 3, into the stage the previous chunk has just left
+      // (the sched_barriers pin the order reads -> multiply -> reads -> multiply: left alone the scheduler sinks
+      // every read to just before its first use to save registers, and the wave then waits out the LDS latency)
+      read_slab(CUR, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_slab(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_slab(NXT, 0);  // legal: this step's barrier already covers the next chunk
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_slab(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!load_first) issue(FILL);
+    };
+    using No = std::false_type;
+    using Yes = std::true_type;
+    for (int kq = 0; kq < KC / 4 - 1; ++kq) {
+      step(S0{}, S1{}, S3{}, No{});
+      step(S1{}, S2{}, S0{}, No{});
+      step(S2{}, S3{}, S1{}, No{});
+      step(S3{}, S0{}, S2{}, No{});
+    }
+    step(S0{}, S1{}, S3{}, No{});   // issues my last chunk
+    step(S1{}, S2{}, S0{}, Yes{});  // ... and from here on the first three chunks of my next tile
+    step(S2{}, S3{}, S1{}, No{});
+    step(S3{}, S0{}, S2{}, No{});
+    if (a.dbg & 4) continue;
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane & 31 (corpus row), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query).
+    // The 16 MI (block, register) sites are unrolled (accumulators are registers), so a site's code is kept
+    // minimal: compare, ballot, and -- only when a lane of the wave passes -- an append to the wave's LDS list at
+    // n_hits + mbcnt(mask); no atomics, nothing to wait for.  At the end every listed survivor asks for its slot
+    // (one returning global atomic each, all in flight together); the answers are used one tile later (settle).
+    // A tile with more survivors than the list holds (ties, duplicated rows) is walked a second time with one
+    // atomic per survivor straight from the registers.
+    if (!DENSE) settle();  // the previous tile's
+    uint32_t n_hits = 0;   // wave-uniform
+    uint2 *my_hits = s_hits[wave];
+    // (opaque per tile: everything the epilogue derives from the lane id is invariant across the tiles of the
+    // persistent loop, and the compiler would hoist all 16 MI site constants out of it -- and spill them)
+    int half_t = half, l31_t = l31;
+    asm volatile("" : "+v"(half_t), "+v"(l31_t));
+    // per column block j: the corpus row this lane holds, and whether it may be returned
+    int cl[2];
+    bool col_ok[2];
+    float vsq[2];
+    uint64_t alive_m[2];
+    bool alive_l[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      cl[j] = wn * 64 + j * 32 + l31_t;  // row within the tile
+      const int col = nbase + cl[j];
+      col_ok[j] = col < a.row1;
+      bool alive = col_ok[j];
+      vsq[j] = 0.f;
+      if (col_ok[j]) {
+        if (METRIC == METRIC_L2) vsq[j] = a.sqnorm[col];
+        if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
+        if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+      }
+      alive_l[j] = alive;
+      alive_m[j] = __ballot(alive);
+    }
+    auto walk = [&](auto DIRECT) {
+      constexpr bool direct = decltype(DIRECT)::value;
+      // (the second walk must not share values with the first: the compiler would keep all of the first walk's
+      // 16 MI keys and list entries alive for it -- in scratch)
+      float scale_w = a.dot_scale;
+      int half_w = half_t;
+      asm volatile("" : "+s"(scale_w), "+v"(half_w));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rbase = wm * 32 * MI + i * 32 + 4 * half_w;  // tile row (query) of reg 0
+        f32x4 th[4], qq[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          th[gq] = *reinterpret_cast<const f32x4 *>(&s_thr[rbase + 8 * gq]);
+          if (METRIC == METRIC_L2) qq[gq] = *reinterpret_cast<const f32x4 *>(&s_qsq[rbase + 8 * gq]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qrow = rbase + (r & 3) + 8 * (r >> 2);
+            auto key_of = [&]() -> float {
+              if (IPLIKE) return -(acc[i][j][r] * scale_w);
+              const float dot = acc[i][j][r] * scale_w;
+              return qq[r >> 2][r & 3] + vsq[j] - 2.f * dot;
+            };
+            if (DENSE) {
+              if (col_ok[j])
+                a.dense[(int64_t)(qbase + qrow) * a.dense_ld + (nbase + cl[j] - a.row0)] = alive_l[j] ? key_of() : __builtin_nanf("");
+            } else {
+              // a site without survivors costs a compare and a branch on vcc; the key, the live / mask bits and
+              // the list slot are only worked out behind the branch
+              const bool pass = IPLIKE ? acc[i][j][r] >= th[r >> 2][r & 3] : key_of() <= th[r >> 2][r & 3];
+              const uint64_t m0 = __ballot(pass);
+              if (m0) {  // wave-uniform
+                const uint64_t m = m0 & alive_m[j];
+                if (m) {
+                  const bool mine = (m >> lane) & 1ull;
+                  const float key = key_of();
+                  if (direct) {
+                    if (mine) store(qbase, nbase, __float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j], ask(qbase, qrow));
+                  } else {
+                    const uint32_t slot = n_hits + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (mine && slot < (uint32_t)F16_HITS) my_hits[slot] = uint2{__float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j]};
+                    n_hits += (uint32_t)__popcll(m);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    };
+    walk(std::false_type{});
+    if (!DENSE) {
+      if (n_hits > (uint32_t)F16_HITS) {
+        walk(std::true_type{});
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if ((uint32_t)(lane + 64 * h) < n_hits) {
+            pend_e[h] = my_hits[lane + 64 * h];
+            pend_p[h] = ask(qbase, (int)(pend_e[h].y >> 16));
+          }
+        pend_n = n_hits;
+        pend_qbase = qbase;
+        pend_nbase = nbase;
+      }
+    }
+  }
+  if (!DENSE) settle();
+  f16_wait_dma<0>();  // the stream's surplus pieces must have landed before this workgroup's LDS is handed on
+}
+
+}  // namespace tsh

@@ -76,20 +76,21 @@ template <int METRIC>
 void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
   int grid = a.q_tiles * a.n_tiles;
   if (grid <= 0) return;
-  if (a.dot_scale != 0.f) {  // f16 variant
-    // 256 x 256 tile: sixteen waves of 64 x 64 (four per SIMD) hide the LDS / barrier waits better than eight of
-    // 128 x 64: f16 pass 2.09-2.13 -> 1.95-2.00 ms.  (bf16x3 with its three MFMAs per fragment pair is LDS-read
-    // bound that way: 6.3 vs 4.85 ms, so it keeps eight waves.)  TSH_BATCH_F16_WAVES8=1 selects the old shape.
-    static const bool many_waves = getenv("TSH_BATCH_F16_WAVES8") == nullptr;
-    if (a.tile_m == 256 && many_waves) {
-      if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 64, 0, 1><<<grid, 1024, 0, st>>>(a);
-      else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 64, 0, 1><<<grid, 1024, 0, st>>>(a);
-    } else if (a.tile_m == 256) {
-      if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
-      else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128, 0, 1><<<grid, 512, 0, st>>>(a);
+  if (a.dot_scale != 0.f) {  // f16 variant: tsh_batch_f16.hip.h (persistent: one 8-wave workgroup per CU)
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (cus <= 0) cus = 256;
+    }
+    const int pgrid = std::min(grid, cus);
+    if (a.tile_m == 256) {
+      if (dense) batch_score_f16_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
+      else batch_score_f16_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
     } else {
-      if (dense) batch_score_bf16x3_kernel<METRIC, true, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
-      else batch_score_bf16x3_kernel<METRIC, false, 128, 128, 64, 0, 1><<<grid, BT_THREADS, 0, st>>>(a);
+      if (dense) batch_score_f16_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
+      else batch_score_f16_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
     }
     return;
   }
@@ -177,7 +178,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   HIPCHK(hipSetDevice(s->device));
   const int64_t rows = s->rows, ld = s->ld;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  // bf16x3 kernel: 256 x 256 tiles for batches of more than 128 queries, 128 x 128 otherwise
+  // Workgroup tile (queries x rows).  f32 MFMA: 128 x 128.  bf16x3: 256 x 256 for batches of more than 128 queries,
+  // 128 x 128 otherwise.  f16: 256 x 256 resp. 128 x 256.  Which key kernel runs is decided below (it needs the
+  // scale of the rows); the padding of the batch only depends on the query side of the tile.
   static const int forced_tile = getenv("TSH_BATCH_TILE") ? atoi(getenv("TSH_BATCH_TILE")) : 0;  // experiments
   const int32_t tile = (forced_tile == 128 || forced_tile == 256) && s->batch_kernel != 0
                            ? forced_tile
@@ -227,9 +230,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   s->batch_kernel_last = kern;
   const bool use_bf16 = kern == 1, use_f16 = kern == 2, use_planes = use_bf16 || use_f16;
-  const int32_t hchunks = use_f16 ? (int32_t)((s->dim + 63) / 64) : (int32_t)((s->dim + 31) / 32);
+  // K-chunks of 32 for both plane formats; the f16 kernel walks its ring of four stages in whole turns, so its
+  // planes are zero-padded to a multiple of four chunks
+  const int32_t hchunks = use_f16 ? (int32_t)round_up((s->dim + 31) / 32, 4) : (int32_t)((s->dim + 31) / 32);
+  // rows per workgroup tile: the f16 kernel's tile is 256 x 256 / 128 x 256 (tsh_batch_f16.hip.h), the others' square
+  const int32_t tile_n = use_f16 ? 256 : tile;
   if (use_planes) {
-    const int64_t row_bytes = (int64_t)hchunks * 128;
+    const int64_t row_bytes = (int64_t)hchunks * (use_f16 ? 64 : 128);  // fp16: 2 B per element, bf16 hi + lo: 4 B
     if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
     if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
       if (s->d_split) hipFree(s->d_split);
@@ -247,7 +254,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     s->split_mode = kern;
     s->split_exp = v_exp;
     if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, round_up(nq_pad, PLANE_GROUP) * hchunks * 8, &b->bytes)))
-      return rc;
+      return rc;  // (sized for the bf16 hi + lo planes; the fp16 ones are half of it)
   }
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
@@ -362,7 +369,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.hchunks = hchunks;
     } else if (use_f16) {
       auto half = [&](const float *src, const float *inv, int64_t first, int64_t n, u32x4 *dst, int e) {
-        HalfArgs ha{};
+        Half32Args ha{};
         ha.rows = src;
         ha.inv_norm = inv;
         ha.out = dst;
@@ -370,10 +377,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         ha.first = first;
         ha.n = n;
         ha.dim = s->dim;
-        ha.hchunks = hchunks;
+        ha.kchunks = hchunks;
         ha.scale = std::ldexp(1.0f, e);
-        const int64_t total = n * hchunks * 8;
-        half_rows_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
+        const int64_t total = n * hchunks * 4;
+        half_rows32_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
       };
       if (s->split_valid < rows) {
         half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, s->split_valid,
@@ -385,6 +392,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.Vs = s->d_split;
       a.hchunks = hchunks;
       a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
+      static const int f16_dbg = getenv("TSH_F16_DBG") ? atoi(getenv("TSH_F16_DBG")) : 0;  // probes: results are wrong
+      a.dbg = f16_dbg;
     }
     a.Q = b->d_Q;
     a.V = s->d_rows;
@@ -409,7 +418,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     // B0: dense keys of the sample rows
     a.row0 = 0;
     a.row1 = (int32_t)n_sample;
-    a.n_tiles = (int32_t)((n_sample + tile - 1) / tile);
+    a.n_tiles = (int32_t)((n_sample + tile_n - 1) / tile_n);
     HIPCHK(hipEventRecord(b->e0, st));
     launch_batch_score_m(s->metric, a, true, st);
     HIPCHK(hipEventRecord(b->e1, st));
@@ -437,7 +446,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if (rows > n_sample) {
       a.row0 = (int32_t)n_sample;
       a.row1 = (int32_t)rows;
-      a.n_tiles = (int32_t)((rows - n_sample + tile - 1) / tile);
+      a.n_tiles = (int32_t)((rows - n_sample + tile_n - 1) / tile_n);
       launch_batch_score_m(s->metric, a, false, st);
     }
     HIPCHK(hipEventRecord(b->e3, st));
@@ -511,12 +520,17 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HostPool::get().stay_awake_until(t_enq + b->last_wait_us * 1.1 + 50.0);
   std::vector<char> skip((size_t)nq, 0);
   double t_gpu = 0;
-  std::unique_ptr<HostPool::Hold> hold;  // from the first chunk on the pool gets a job every few hundred microseconds
+  // From the end of the key passes on the pool gets a job every few dozen microseconds (one per chunk of the tail):
+  // the long wait blocks, then the workers are woken and poll until the call is over
+  std::unique_ptr<HostPool::Hold> hold;
+  if (out->on_chunk && nq >= 64) {
+    HIPCHK(hipEventSynchronize(b->e3));
+    hold.reset(new HostPool::Hold());
+  }
   for (int c = 0; c < n_chunks; ++c) {
     const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
     HIPCHK(hipEventSynchronize(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done));
     if (c == 0) b->last_wait_us = now_us() - t_enq;
-    if (c == 0 && out->on_chunk && n_chunks > 1) hold.reset(new HostPool::Hold());
     if (c + 1 == n_chunks) {
       HIPCHK(hipGetLastError());
       t_gpu = now_us();

@@ -122,7 +122,17 @@ class HostPool {
   // call in which jobs follow each other closely.
   class Hold {
    public:
-    Hold() { get().holders_.fetch_add(1, std::memory_order_acq_rel); }
+    Hold() {
+      HostPool &p = get();
+      p.holders_.fetch_add(1, std::memory_order_acq_rel);
+      if (p.parked_.load(std::memory_order_acquire) > 0) {  // wake the parked workers: they find no open job and poll
+        {
+          std::lock_guard<std::mutex> lk(p.m_);
+          p.gen_.fetch_add(1, std::memory_order_release);
+        }
+        p.cv_.notify_all();
+      }
+    }
     ~Hold() { get().holders_.fetch_sub(1, std::memory_order_acq_rel); }
     Hold(const Hold &) = delete;
     Hold &operator=(const Hold &) = delete;

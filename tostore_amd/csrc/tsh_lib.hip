@@ -31,6 +31,7 @@
 
 #include "../../include/tostore_hip.h"
 #include "tsh_batch.hip.h"
+#include "tsh_batch_f16.hip.h"
 #include "tsh_host_sync.h"
 #include "tsh_kernels.hip.h"
 #include "tsh_pq.hip.h"
@@ -146,6 +147,10 @@ int32_t finalize_query(int metric, int dim, const float *query, int32_t k, doubl
   for (size_t i = 0; i < r; ++i) {
     out_ids[i] = hits[i].id;
     out_dist[i] = hits[i].dist;
+  }
+  for (size_t i = r; i < (size_t)std::max(k, 0); ++i) {  // unused slots read as "no row" (callers need not pre-fill)
+    out_ids[i] = -1;
+    out_dist[i] = std::nan("");
   }
   return (int32_t)r;
 }
