@@ -818,25 +818,15 @@ struct RerankBatchArgs {
 // One wave = up to 64 candidates of ONE query, one candidate per lane.  The exact sums must
 // add their terms strictly in dimension order -- a serial chain per candidate -- so 64 chains
 // run side by side and nothing crosses lanes: each lane streams its own row (16 B at a time,
-// 8 loads in flight, the next 32 dimensions prefetched while the current ones are added) and
+// 8 loads in flight, the next RB_CH dimensions prefetched while the current ones are added) and
 // the query values are wave-uniform (scalar loads).
 constexpr int RB_CH = 64;  // dimensions per step (two register buffers of RB_CH floats per lane)
 
-__global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
+// rp: this lane's row (any valid row for idle lanes), qp: the query (wave-uniform); ld: floats per row, multiple of
+// 4; rows and queries are zero beyond dim.  Identical arithmetic to rerank_kernel (tsh_kernels.hip.h).
+__device__ __forceinline__ void rerank_lane_sums(const float *__restrict__ rp, const float *__restrict__ qp, int dim,
+                                                 int ld, int metric, double *out_s0, double *out_s1) {
 #pragma clang fp contract(off)
-  const int lane = threadIdx.x, q = a.q0 + (int)blockIdx.y;
-  uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
-  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
-  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
-  const uint32_t c0 = blockIdx.x * 64u;
-  if (c0 >= count) return;
-  const bool mine = c0 + lane < count;
-  BlockEntry *out = reinterpret_cast<BlockEntry *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader));
-  const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;
-  const uint32_t row = mine ? a.final_rows[(int64_t)q * a.entries + c0 + lane] : 0u;
-  const float *__restrict__ rp = a.rows + (int64_t)row * a.ld;
-  const bool cosine = a.metric == METRIC_COS, l2 = a.metric == METRIC_L2;
-  const int ld = (int)a.ld;  // multiple of 4; rows and queries are zero beyond dim
   double s0 = 0.0, s1 = 0.0;
   f32x4 cur[RB_CH / 4], nxt[RB_CH / 4];
   // No branch around any load (offsets past the row are clamped to its last 16 bytes and never used) and none in
@@ -849,7 +839,7 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
       dst[j] = *reinterpret_cast<const f32x4 *>(rp + o);
     }
   };
-  const int nfull = a.dim / RB_CH;  // whole steps; the remaining dim % RB_CH elements follow
+  const int nfull = dim / RB_CH;  // whole steps; the remaining dim % RB_CH elements follow
   auto run = [&](auto METRIC) {  // the metric is a compile-time constant inside: no per-element branches
     constexpr int M = decltype(METRIC)::value;
     auto term = [&](float qf, float bf) {
@@ -875,20 +865,36 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
 #pragma unroll
       for (int j = 0; j < RB_CH / 4; ++j) cur[j] = nxt[j];
     }
-    const int base = nfull * RB_CH, m = a.dim - base;  // wave-uniform
+    const int base = nfull * RB_CH, m = dim - base;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < RB_CH / 4; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (4 * j + e < m) term(qp[base + 4 * j + e], cur[j][e]);
   };
-  if (l2) run(std::integral_constant<int, METRIC_L2>{});
-  else if (cosine) run(std::integral_constant<int, METRIC_COS>{});
+  if (metric == METRIC_L2) run(std::integral_constant<int, METRIC_L2>{});
+  else if (metric == METRIC_COS) run(std::integral_constant<int, METRIC_COS>{});
   else run(std::integral_constant<int, METRIC_IP>{});
+  *out_s0 = s0;
+  *out_s1 = metric == METRIC_COS ? s1 : 0.0;
+}
+
+__global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
+  const int lane = threadIdx.x, q = a.q0 + (int)blockIdx.y;
+  uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
+  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
+  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
+  const uint32_t c0 = blockIdx.x * 64u;
+  if (c0 >= count) return;
+  const bool mine = c0 + lane < count;
+  BlockEntry *out = reinterpret_cast<BlockEntry *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader));
+  const uint32_t row = mine ? a.final_rows[(int64_t)q * a.entries + c0 + lane] : 0u;
+  double s0, s1;
+  rerank_lane_sums(a.rows + (int64_t)row * a.ld, a.Q + (int64_t)q * a.ld, a.dim, (int)a.ld, a.metric, &s0, &s1);
   if (mine) {
     out[c0 + lane].id = a.row_base + (int64_t)row;
     out[c0 + lane].s0 = s0;
-    out[c0 + lane].s1 = cosine ? s1 : 0.0;
+    out[c0 + lane].s1 = s1;
   }
 }
 

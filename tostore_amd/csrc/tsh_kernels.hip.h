@@ -495,7 +495,7 @@ __device__ __forceinline__ uint32_t band_of(uint32_t tau_key, float eps_rel, flo
 //  (d) band = tau widened by the f32 error model; tiles with minimum <= band
 //  (e) only those tiles' keys are re-read; keys <= band are the candidates
 template <int NT, bool IN_REGS>
-__global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
+__device__ __forceinline__ void select_body(const SelectArgs &a) {
   static_assert(NT == 1024 || NT == 256, "thread minima are bisected by one wave as 16 or 4 per lane");
   constexpr int SEL_THREADS = NT;  // shadows the namespace constant inside this kernel
   __shared__ uint32_t s_lm[2 * SEL_THREADS];
@@ -759,6 +759,11 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
     *a.hdr = hv;
     if (a.hdr_host) *a.hdr_host = hv;
   }
+}
+
+template <int NT, bool IN_REGS>
+__global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
+  select_body<NT, IN_REGS>(a);
 }
 
 // K3a: one pass of a radix select over the WHOLE key array (fallback path, k beyond what the tile-minimum

@@ -32,6 +32,7 @@
 #include "../../include/tostore_hip.h"
 #include "tsh_batch.hip.h"
 #include "tsh_batch_f16.hip.h"
+#include "tsh_fused.hip.h"
 #include "tsh_host_sync.h"
 #include "tsh_kernels.hip.h"
 #include "tsh_pq.hip.h"
@@ -76,6 +77,8 @@ constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgrou
 constexpr int SUBMIT_THREADS = 1;     // host threads that submit a multi-query call (more did not help: the pipeline is GPU-bound)
 constexpr int MAX_DIM_SCAN = 4096;    // register-resident query (NCH <= 16; the reference's f32 pages hold d <= 4073)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
+// TSH_FUSED=1 (experiment): scans that read at most this many bytes go out as ONE dispatch (tsh_fused.hip.h)
+constexpr int64_t FUSED_MAX_SCAN_BYTES = 96ll << 20;
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -269,6 +272,7 @@ struct Ctx {
   uint32_t *d_keys = nullptr;
   uint32_t *d_gmin = nullptr;
   uint32_t *d_hist = nullptr;  // radix select of the fallback path (256 bins)
+  uint32_t *d_ticket = nullptr;  // fused single-dispatch path: workgroups done so far (zero between launches)
   int64_t tiles_cap = 0;
   uint8_t *d_block = nullptr;  // header + entries
   uint8_t *h_block = nullptr;  // pinned
@@ -355,7 +359,7 @@ struct Shard {
   std::vector<Ctx *> ctx_free;
   std::atomic<uint64_t> mask_epoch_src{1};
 
-  std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
+  std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0}, c_fused{0};
   double scan_us_sum = 0;  // guarded by ctx_mu
   int64_t scan_us_samples = 0;
   int64_t bytes = 0;
@@ -618,6 +622,7 @@ void ctx_free_all(Ctx *c) {
   hipFree(c->d_keys);
   hipFree(c->d_gmin);
   hipFree(c->d_hist);
+  hipFree(c->d_ticket);
   hipFree(c->d_block);
   hipHostFree(c->h_block);
   hipHostFree(c->h_quar);
@@ -637,6 +642,8 @@ int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
     HIPCHK(hipMalloc(&c->d_query, (size_t)s->ld * sizeof(float)));
     HIPCHK(hipHostMalloc(&c->h_query, (size_t)s->ld * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipMalloc(&c->d_big_count, 64));
+    HIPCHK(hipMalloc(&c->d_ticket, 64));
+    HIPCHK(hipMemset(c->d_ticket, 0, 64));
     c->bytes += s->ld * 4;
   }
   int64_t tiles = s->cap / 64;
@@ -803,6 +810,16 @@ void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
   else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
 }
 
+// one dispatch for scan + select + re-rank (tsh_fused.hip.h)
+template <int NT>
+void launch_fused_nt(const FusedArgsQ &fa, int metric, bool masked, int grid, hipStream_t st) {
+#define TSH_FU(M, MK) fused_query_kernel<NT, M, MK><<<grid, NT, 0, st>>>(fa)
+  if (metric == TSH_METRIC_L2) { if (masked) TSH_FU(METRIC_L2, true); else TSH_FU(METRIC_L2, false); }
+  else if (metric == TSH_METRIC_IP) { if (masked) TSH_FU(METRIC_IP, true); else TSH_FU(METRIC_IP, false); }
+  else { if (masked) TSH_FU(METRIC_COS, true); else TSH_FU(METRIC_COS, false); }
+#undef TSH_FU
+}
+
 // shard mode: the quarantined rows go into the job's device block
 void launch_quarantine_append(Shard *s, Ctx *c, Job *j, hipStream_t st) {
   QuarAppendArgs qa{};
@@ -914,6 +931,61 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
     if (!inline_q)
       HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
+    // EXPERIMENT, off unless TSH_FUSED=1: short scans as ONE dispatch, the last workgroup to finish its tiles selects
+    // and re-ranks (tsh_fused.hip.h).  Exact, but measured SLOWER than the three launches it replaces (C1: 45 vs
+    // 37 us per call; keep-1 % masks: 11.8 k vs 23.8 k queries/s): the release / acquire pair between the scan and
+    // the tail costs what the two launch boundaries did, the generic scan has no read-ahead across 8-row batches,
+    // and a fused query's tail no longer overlaps the next query's scan on the reserved CUs.
+    static const bool use_fused = getenv("TSH_FUSED") != nullptr && getenv("TSH_FUSED")[0] == '1';
+    const int64_t tiles_read_f = rows_est > 0 ? std::min<int64_t>(n_tiles, (rows_est + 63) / 64) : n_tiles;
+    const bool fused = use_fused && n_tiles <= SEL_VPT * SEL_THREADS && k <= 1024 && s->ld / 4 <= FUSED_MAX_D4 &&
+                       tiles_read_f * 64 * s->ld * 4 <= FUSED_MAX_SCAN_BYTES;
+    if (fused) {
+      static thread_local FusedArgsQ fa;  // 3.3 KiB: keep it off the stack of deep callers
+      fa.a.scan = sa.a;
+      fa.a.sel = se;
+      fa.a.rr = ra;
+      fa.a.ticket = c->d_ticket;
+      const bool inline_f = s->ld <= FUSED_Q_INLINE;
+      if (inline_f) {
+        memcpy(fa.q, qdst, (size_t)s->ld * sizeof(float));
+        fa.a.scan.query = nullptr;
+        fa.a.scan.query_out = c->d_query;
+      } else {  // the query goes through the context's device copy
+        if (inline_q) {
+          memcpy(c->h_query, qdst, (size_t)s->ld * sizeof(float));
+          HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
+        }
+        fa.a.scan.query = c->d_query;
+        fa.a.scan.query_out = nullptr;
+      }
+      const bool small_sel = n_tiles <= 512 && k <= 256;
+      const int wpb = small_sel ? 4 : 16;
+      const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + wpb - 1) / wpb, 4096));
+      if (small_sel) launch_fused_nt<256>(fa, s->metric, j->masked, grid, ps);
+      else launch_fused_nt<SEL_THREADS>(fa, s->metric, j->masked, grid, ps);
+      j->timed = false;
+      if (!j->quar_sel.empty() && dev_target) {
+        launch_quarantine_append(s, c, j, ps);
+      } else if (!j->quar_sel.empty()) {
+        QuarArgs qa{};
+        qa.rows = s->d_rows;
+        qa.Q = c->d_query;
+        qa.list = s->d_quar;
+        qa.out = c->h_quar_dev;
+        qa.ld = s->ld;
+        qa.ldq = s->ld;
+        qa.row_base = s->row_base;
+        qa.dim = s->dim;
+        qa.cap = (int32_t)QUARANTINE_MAX;
+        qa.metric = s->metric;
+        quarantine_kernel<<<dim3((unsigned)((s->quar_ids.size() + 63) / 64), 1), 64, 0, ps>>>(qa);
+      }
+      HIPCHK(hipEventRecord(c->ev_done, ps));
+      s->c_scans++;
+      s->c_fused++;
+      return TSH_OK;
+    }
     j->timed = (s->c_scans.load() & 3) == 0;  // sample every 4th scan with timing events
     LaunchEv ev;  // start / stop ride on the scan's own packet: no barrier packets between scans
     if (j->timed) {
@@ -1187,8 +1259,10 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
     mask_words.resize((size_t)n_tiles);
     slice_mask(s, mask, mask_words.data(), n_tiles);
     epoch = s->mask_epoch_src.fetch_add(1);
-    if (nq > 1)  // one pass over the mask per call: how long will each scan be?
-      for (uint64_t w : mask_words) rows_est += __builtin_popcountll(w);
+    // one pass over the mask per call: how long will each scan be?  (decides one- or two-stream pipelining and
+    // whether a query goes out as one fused dispatch)
+    for (uint64_t w : mask_words) rows_est += __builtin_popcountll(w);
+    if (rows_est == 0) rows_est = 1;
   }
   const uint64_t *mw = mask ? mask_words.data() : nullptr;
   const int T = std::min(SUBMIT_THREADS, nq / 8);
@@ -1835,6 +1909,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     out->bytes_resident += b;
     if (s->safe_mode()) out->safe_mode = 1;
     out->quarantined_rows += (int32_t)s->quar_ids.size();
+    out->fused_launches += s->c_fused.load();
     out->device_id = s->device;
   }
   return TSH_OK;
