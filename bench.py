@@ -85,6 +85,10 @@ def parse(argv=None):
     ap.add_argument("--side", default="c5,c1,c3", help="side legs to run, comma separated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets several ranks share one GPU in tests)")
+    ap.add_argument("--exchange", choices=["torch", "capi"], default="torch",
+                    help="N > 1: who all-gathers the candidate blocks -- torch.distributed (default), or the library's "
+                         "own RCCL entry points (tsh_comm_*, what a host without torch uses; the id travels by "
+                         "torch broadcast here)")
     ap.add_argument("--ranks-share-gpu", action="store_true", help="testing: every rank uses cuda:0")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the N>1 code path (process group, all-gather, merge) even with one rank")
@@ -233,8 +237,12 @@ class Env:
     def searcher(self, idx):
         if self.dist is None:
             return None
-        from tostore_amd.sharded import ShardedSearcher
+        from tostore_amd.sharded import CommSearcher, ShardedSearcher
 
+        if self.a.exchange == "capi":
+            box = [CommSearcher.unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(box, src=0)
+            return CommSearcher(idx, self.world, self.rank, box[0], self.local_rank)
         return ShardedSearcher(idx)
 
     def max_inflight(self):
@@ -660,7 +668,7 @@ def run_bench(a, env=None):
                        else sharded_group(a.group, a.steps),
                        "note": "every query scans the whole corpus on its own (HBM-bound kernel, no matrix-core "
                                "batching); independent queries are handed over in groups and pipelined",
-                       "sharding": "row-range x%d, RCCL all-gather of top-k candidates" % world
+                       "sharding": "row-range x%d, RCCL all-gather of top-k candidates (%s)" % (world, a.exchange)
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

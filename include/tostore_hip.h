@@ -45,7 +45,9 @@ extern "C" {
 #define TSH_E_OVERFLOW (-6) /* a candidate block was too small; retry with more entries */
 #define TSH_E_IO (-7)
 #define TSH_E_FORMAT (-8)
-#define TSH_E_BUSY (-9) /* tsh_max_inflight() asynchronous searches are already un-waited on the handle: wait for one */
+#define TSH_E_BUSY (-9) /* tsh_search_submit: tsh_max_inflight() asynchronous searches are already un-waited on the
+                           handle, or an append / delete is waiting for the open ones: wait for them, then submit again */
+#define TSH_E_RCCL (-10) /* librccl could not be loaded, or a collective failed */
 
 /* metric = enum order of VectorDistanceMetric, lib/src/model/table_schema.dart:2511-2531 */
 #define TSH_METRIC_L2 0
@@ -288,6 +290,26 @@ int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries,
                              const void *blocks, int32_t n_blocks, int32_t entries,
                              int64_t *out_ids, double *out_dist, int32_t *out_count,
                              int32_t *needed_entries);
+
+/* ---- the same exchange from a host without torch (a Dart process per GPU) ------------------------------------
+ * RCCL all-gather of the per-shard candidate blocks over xGMI + host merge, behind plain C.  librccl is loaded
+ * with dlopen on first use.  One communicator per rank:
+ *   rank 0:     tsh_comm_unique_id(id)  -> ship the 128 bytes to the other ranks (any channel the host has)
+ *   every rank: tsh_comm_create(id, world, rank, device, &comm)      (collective: returns when all ranks called)
+ *   every rank: tsh_search_sharded(shard, comm, queries, ...)        (collective: same queries / k on every rank;
+ *               each rank scans its shard, the blocks are all-gathered, every rank merges and gets the full
+ *               answer -- identical to tsh_search on one un-sharded index over the same rows)
+ *   every rank: tsh_comm_destroy(comm)
+ * row_mask is GLOBAL.  No reference counterpart (the reference has no distributed compute). */
+typedef struct tsh_comm tsh_comm;
+#define TSH_COMM_ID_BYTES 128
+int32_t tsh_comm_unique_id(void *out_id);
+int32_t tsh_comm_create(const void *id, int32_t world, int32_t rank, int32_t device, tsh_comm **out);
+int32_t tsh_comm_destroy(tsh_comm *comm);
+int32_t tsh_comm_world(tsh_comm *comm);
+int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
+                           double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,
+                           int32_t *out_count);
 
 int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out);
 

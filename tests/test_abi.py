@@ -48,6 +48,19 @@ def test_no_device_is_an_error_not_a_fallback():
     assert e.value.code == _ffi.TSH_E_NO_DEVICE
 
 
+def test_comm_entry_points_without_a_device():
+    from tostore_amd import _ffi
+
+    L = _ffi.lib()
+    if L.tsh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    buf = ctypes.create_string_buffer(128)
+    assert L.tsh_comm_unique_id(buf) in (_ffi.TSH_E_NO_DEVICE, _ffi.TSH_E_RCCL)
+    c = ctypes.c_void_p()
+    assert L.tsh_comm_create(buf, 1, 0, 0, ctypes.byref(c)) in (_ffi.TSH_E_NO_DEVICE, _ffi.TSH_E_RCCL)
+    assert not c and L.tsh_comm_destroy(None) == 0 and L.tsh_comm_world(None) == 0
+
+
 def test_argument_validation():
     from tostore_amd import _ffi
 

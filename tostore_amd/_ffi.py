@@ -24,6 +24,7 @@ TSH_E_OVERFLOW = -6
 TSH_E_IO = -7
 TSH_E_FORMAT = -8
 TSH_E_BUSY = -9
+TSH_E_RCCL = -10
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 
@@ -83,6 +84,11 @@ SIGNATURES = {
     "tsh_search_shard": (c_i32, [p_void, p_f32, c_i32, c_i32, p_u8, c_i32, p_void, p_void]),
     "tsh_merge_candidates": (c_i32, [c_i32, c_i32, p_f32, c_i32, c_i32, c_f64, p_void, c_i32, c_i32,
                                      p_i64, p_f64, p_i32, p_i32]),
+    "tsh_comm_unique_id": (c_i32, [p_void]),
+    "tsh_comm_create": (c_i32, [p_void, c_i32, c_i32, c_i32, ctypes.POINTER(p_void)]),
+    "tsh_comm_destroy": (c_i32, [p_void]),
+    "tsh_comm_world": (c_i32, [p_void]),
+    "tsh_search_sharded": (c_i32, [p_void, p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
     "tsh_get_counters": (c_i32, [p_void, ctypes.POINTER(TshCounters)]),
     "tsh_bench_scan": (c_i32, [p_void, p_f32, c_i32, p_u8, p_f64]),
     "tsh_bench_batch": (c_i32, [p_void, p_f32, c_i32, c_i32, c_i32, p_f64, p_f64]),

@@ -11,9 +11,9 @@ CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libtostore_hip.so")
 SOURCES = ["tsh_lib.hip"]
 HEADERS = ["tsh_kernels.hip.h", "tsh_batch.hip.h", "tsh_batch_f16.hip.h", "tsh_fused.hip.h", "tsh_host_sync.h", "tsh_pq.hip.h", "tsh_host_batch.inl.h", "tsh_host_coldstart.inl.h",
-           "tsh_host_pq.inl.h", os.path.join("..", "..", "include", "tostore_hip.h")]
+           "tsh_host_pq.inl.h", "tsh_host_comm.inl.h", os.path.join("..", "..", "include", "tostore_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wno-unused-value", "-Wno-unused-result", "-ldl"]
 
 
 def _stale() -> bool:

@@ -2001,3 +2001,4 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
 
 #include "tsh_host_coldstart.inl.h"  // raw-vector file loader, tsh_index_open_ngh
 #include "tsh_host_pq.inl.h"         // tsh_pq_train, tsh_index_pq_encode
+#include "tsh_host_comm.inl.h"       // tsh_comm_*, tsh_search_sharded (RCCL)

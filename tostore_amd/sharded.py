@@ -170,3 +170,59 @@ class ShardedSearcher:
                     raise
                 entries = int(e.needed_entries)  # identical on every rank: all saw the same headers
         raise RuntimeError("candidate blocks kept overflowing")
+
+
+class CommSearcher:
+    """The same exchange through the library's OWN RCCL entry points (include/tostore_hip.h: tsh_comm_*,
+    tsh_search_sharded) -- what a host without torch (one Dart process per GPU) calls.  Rank 0 makes the 128-byte id
+    with `CommSearcher.unique_id()`, the host ships it to the other ranks over whatever channel it has, every rank
+    constructs its searcher (collective) and then calls `search` with the same queries (collective)."""
+
+    def __init__(self, shard_index, world: int, rank: int, unique_id: bytes, device: int = -1):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of tsh_comm_unique_id")
+        self.index = shard_index
+        self.world = world
+        self._c = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _ffi.check(_ffi.lib().tsh_comm_create(buf, world, rank, device, ctypes.byref(self._c)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _ffi.check(_ffi.lib().tsh_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self) -> None:
+        if self._c:
+            _ffi.lib().tsh_comm_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, kk = q.shape[0], max(int(k), 0)
+        ids = np.empty((nq, max(kk, 1)), dtype=np.int64)
+        dist = np.empty((nq, max(kk, 1)), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        thr = math.nan if distance_threshold is None else float(distance_threshold)
+        row_mask, mp = self.index.mask_arg(row_mask)
+        _ffi.check(_ffi.lib().tsh_search_sharded(self.index._h, self._c, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, mp,
+                                                 ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
+                                                 cnt.ctypes.data_as(_ffi.p_i32)))
+        return ids[:, :kk], dist[:, :kk], cnt
+
+    def search_many(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None, group: int = 64):
+        """Groups of `group` queries per collective (same signature as ShardedSearcher.search_many)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        parts = [self.search(q[s:s + group], k, distance_threshold, row_mask) for s in range(0, q.shape[0], group)]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
