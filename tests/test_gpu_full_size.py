@@ -1,0 +1,137 @@
+"""GPU: BASELINE.json's configurations at their FULL sizes (the other GPU tests use corpora the oracle finishes in
+seconds for hundreds of queries).  1 M x 768 rows are generated on the device; the oracle (all host cores) answers
+a sample of the queries, the rest is held to size-independent properties: every path of the library gives the same
+answer for the same query, a stored row finds itself first, masked and unmasked answers nest.
+  C2  1M x 768 f32, L2, k = 100, single queries        (HBM-bound scan)
+  C3  1M x 768 f32, cosine, k = 100, 1024-query batch   (matrix-core path)
+  C5  1M x 768 f32 + device-side row bitmask"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, D, K = 1_000_000, 768, 100
+
+
+@pytest.fixture(scope="module")
+def corpora(hip_lib):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260612)
+    x = torch.empty((N, D), dtype=torch.float32, device=dev)
+    for s in range(0, N, 131072):
+        e = min(N, s + 131072)
+        t = torch.randn((e - s, D), generator=g, device=dev)
+        t /= t.norm(dim=1, keepdim=True)
+        x[s:e] = t
+    scale = torch.rand((N, 1), generator=g, device=dev) * 1.5 + 0.5
+    torch.cuda.synchronize()
+    host_unit = x.cpu().numpy()
+    yield {"dev_unit": x, "scale": scale, "host_unit": host_unit}
+
+
+def _index(metric, dev_rows):
+    import torch
+
+    from tostore_amd import HipVectorIndex
+
+    idx = HipVectorIndex(D, metric, capacity_rows=N, shard_device=0, row_base=0)
+    torch.cuda.synchronize()
+    idx.append_device(0, N, dev_rows.data_ptr())
+    torch.cuda.synchronize()
+    return idx
+
+
+def _queries(oracle, nq, metric, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, D)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    if metric == 2:
+        q = np.stack([oracle.normalize_f32(v) for v in q])
+    return np.ascontiguousarray(q)
+
+
+def _same(a, b):
+    return (np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+            and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64)))
+
+
+def test_c2_single_queries_full_size(corpora, oracle_mod):
+    import torch
+
+    rows_dev = corpora["dev_unit"] * corpora["scale"]  # L2 / IP corpora: norms in [0.5, 2)
+    torch.cuda.synchronize()
+    host = rows_dev.cpu().numpy()
+    qs = _queries(oracle_mod, 24, 0, 1)
+    with _index(0, rows_dev) as idx:
+        del rows_dev
+        idx.set_batch_min_nq(0)  # every query scans on its own
+        got = idx.search(qs, K)
+        ref = oracle_mod.search_heap_many_mt(host, qs[:12], 0, K)
+        assert _same(tuple(x[:12] for x in got), ref), "pipelined single-query scans vs oracle"
+        one = idx.search(qs[13], K)  # a lone query (no pipelining) gives the same answer as inside a group
+        assert np.array_equal(one[0][0], got[0][13]) and np.array_equal(one[1][0], got[1][13])
+        pend = [idx.submit(qs[i], K) for i in range(14, 18)]  # asynchronous form
+        for i, t in zip(range(14, 18), pend):
+            ids, dist = idx.wait(t)
+            assert np.array_equal(ids, got[0][i]) and np.array_equal(dist, got[1][i])
+        # a stored row finds itself first, at distance 0
+        probe = host[[0, 499_999, N - 1]]
+        ids, dist, cnt = idx.search(probe, 5)
+        assert ids[:, 0].tolist() == [0, 499_999, N - 1] and not dist[:, 0].any()
+        # the batched path answers the same queries identically
+        idx.set_batch_min_nq(2)
+        assert _same(idx.search(qs, K), got), "matrix-core batch vs single-query scans (L2)"
+        c = idx.counters()
+        assert c["fallback_searches"] == 0 and c["batch_launches"] > 0 and c["safe_mode"] == 0
+
+
+def test_c3_batch_of_1024_full_size(corpora, oracle_mod):
+    host = corpora["host_unit"]
+    qs = _queries(oracle_mod, 1024, 2, 2)
+    with _index(2, corpora["dev_unit"]) as idx:
+        got = idx.search(qs, K)  # one call: matrix-core path (auto = fp16 keys for cosine)
+        assert idx.counters()["batch_kernel_last"] == 2 and idx.counters()["batch_launches"] == 1
+        sample = np.r_[0:16, 500:516, 1008:1024]
+        ref = oracle_mod.search_heap_many_mt(host, qs[sample], 2, K)
+        assert _same(tuple(x[sample] for x in got), ref), "1024-query batch vs oracle (48 sampled queries)"
+        assert (got[2] == K).all()
+        # every key kernel, and the single-query pipeline, give the batch's answer bit for bit
+        for kern in (1, 0):
+            idx.set_batch_kernel(kern)
+            part = idx.search(qs[256:512], K)
+            assert _same(part, tuple(x[256:512] for x in got)), "key kernel %d" % kern
+        idx.set_batch_kernel(3)
+        idx.set_batch_min_nq(0)
+        assert _same(idx.search(qs[600:632], K), tuple(x[600:632] for x in got)), "single-query scans vs batch (cosine)"
+        assert idx.counters()["fallback_searches"] == 0
+
+
+@pytest.mark.parametrize("keep", [0.01, 0.5])
+def test_c5_row_mask_full_size(corpora, oracle_mod, keep):
+    import torch
+
+    rows_dev = corpora["dev_unit"] * corpora["scale"]
+    torch.cuda.synchronize()
+    host = rows_dev.cpu().numpy()
+    rng = np.random.default_rng(int(keep * 100))
+    bits = rng.random(N) < keep
+    mask = np.packbits(bits, bitorder="little")
+    qs = _queries(oracle_mod, 40, 0, 3)
+    with _index(0, rows_dev) as idx:
+        del rows_dev
+        idx.set_batch_min_nq(0)
+        got = idx.search(qs, K, None, mask)  # masked scans: bytes read scale with the mask
+        ref = oracle_mod.search_heap_many_mt(host, qs[:8], 0, K, None, mask)
+        assert _same(tuple(x[:8] for x in got), ref), "masked single-query scans vs oracle"
+        assert bits[got[0]].all(), "a masked-out row came back"
+        idx.set_batch_min_nq(2)  # the same calls through the matrix-core path (mask applied in its epilogue)
+        assert _same(idx.search(qs, K, None, mask), got), "masked batch vs masked scans"
+        # nesting: the unmasked top-k restricted to kept rows is a prefix-subsequence of the masked answer
+        full = idx.search(qs[:4], K)
+        for i in range(4):
+            kept_of_full = [r for r in full[0][i].tolist() if bits[r]]
+            assert kept_of_full == got[0][i][:len(kept_of_full)].tolist()
+        assert idx.counters()["fallback_searches"] == 0
