@@ -61,7 +61,8 @@ struct BatchArgs {
   int32_t hchunks;        // ceil(dim / 32)
   int32_t tile_m;         // workgroup tile (queries = rows): 128 or 256 (host-side dispatch only)
   float dot_scale;        // f16 variant: 2^-(eq + ev), undoes the power-of-two operand scales (0 = unused)
-  int32_t dbg;            // f16 kernel probe (TSH_F16_DBG): 4 = no epilogue (results are wrong)
+  int32_t dbg;            // f16 kernel probe (TSH_F16_DBG): 4 = no epilogue (results are wrong), 32 = timestamps
+  uint64_t *dbg_buf;      // TSH_F16_DBG & 32: [wave 0 / wave 4 of workgroup 0][step][point] shader-clock stamps
 };
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of

@@ -108,7 +108,15 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const bool load_first = wave < 4;  // (waves w and w + 4 share a SIMD: MI355X_MICROARCH.md, LDS section)
+  // (waves w and w + 4 share a SIMD: MI355X_MICROARCH.md, LDS section.)  Step timeline of the two waves of a SIMD,
+  // TSH_F16_DBG=32: with waves 0-3 loading first a step lasts ~1800 cycles for 1024 cycles of MFMA -- the load-first
+  // wave issues its 4 pieces in 230-520 cycles, multiplies in ~700 and then waits ~540 at the barrier; its partner
+  // multiplies for 1200-1400 (it loses the pipe to the older wave) and issues its pieces after that, pipe idle.
+  // Tried against that: s_setprio 1 for the multiply-first waves (the other wave's 4 DMA pieces then take 750-1500
+  // cycles to issue; 1.78-1.84 ms instead of 1.73-1.76) and swapped roles, older wave multiplying first (DMA issue
+  // 500-1400 cycles beside the partner's MFMAs; 1.79-1.82 ms): issuing LDS-DMA beside a partner that streams MFMAs
+  // is slow whichever wave does it.  Kept: the first arrangement.
+  const bool load_first = wave < 4;
   const int KC = a.hchunks;
   const int G = (int)gridDim.x, total_tiles = a.q_tiles * a.n_tiles;
 
@@ -200,6 +208,13 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   using S3 = std::integral_constant<int, 3>;
+  // probe (TSH_F16_DBG & 32): shader-clock stamps of waves 0 and 4 of workgroup 0 over their first 96 steps
+  int dbg_step = 0;
+  const bool dbg_on = (a.dbg & 32) && blockIdx.x == 0 && (wave == 0 || wave == 4);
+  auto stamp = [&](int point) {
+    if (dbg_on && dbg_step < 96 && lane == 0)
+      a.dbg_buf[((wave >> 2) * 96 + dbg_step) * 8 + point] = __builtin_amdgcn_s_memtime();
+  };
   set_src(i_tile);
   int cur_q_tile = -1;
   // KC is a multiple of four (host) and at least four: every tile starts in ring stage 0
@@ -243,10 +258,14 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
     // same moment (a first version with run-time stages and counters spent ~100 instructions there: 67 % MFMA busy
     // with the loads and the epilogue switched off).
     auto step = [&](auto CUR, auto NXT, auto FILL, auto SWITCH) {
+      stamp(0);
       f16_wait_dma<P>();             // my pieces of the NEXT chunk have landed (the one after it may still fly)
+      stamp(1);
       __builtin_amdgcn_s_barrier();  // everybody's have; and everybody is done reading the chunk before this one
+      stamp(2);
       if (decltype(SWITCH)::value) next_tile_src();
       if (load_first) issue(FILL);   // chunk + 3, into the stage the previous chunk has just left
+      stamp(3);
       // (the sched_barriers pin the order reads -> multiply -> reads -> multiply: left alone the scheduler sinks
       // every read to just before its first use to save registers, and the wave then waits out the LDS latency)
       read_slab(CUR, 1);
@@ -257,7 +276,10 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       mfma_slab(1);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(4);
       if (!load_first) issue(FILL);
+      stamp(5);
+      ++dbg_step;
     };
     using No = std::false_type;
     using Yes = std::true_type;
@@ -281,6 +303,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
     // (one returning global atomic each, all in flight together); the answers are used one tile later (settle).
     // A tile with more survivors than the list holds (ties, duplicated rows) is walked a second time with one
     // atomic per survivor straight from the registers.
+    stamp(6);
     if (!DENSE) settle();  // the previous tile's
     uint32_t n_hits = 0;   // wave-uniform
     uint2 *my_hits = s_hits[wave];

@@ -2,6 +2,7 @@
 // Part of the single translation unit tsh_lib.hip (textually included there; not compiled alone).
 
 // ---- batched (matrix-core) path ---------------------------------------------------
+static uint64_t *g_f16_dbg_buf = nullptr;  // TSH_F16_DBG & 32 probe
 struct BatchCtx {
   std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
   float *d_Q = nullptr, *h_Q = nullptr;
@@ -394,6 +395,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
       static const int f16_dbg = getenv("TSH_F16_DBG") ? atoi(getenv("TSH_F16_DBG")) : 0;  // probes: results are wrong
       a.dbg = f16_dbg;
+      static uint64_t *d_dbg = nullptr;
+      if ((f16_dbg & 32) && !d_dbg) HIPCHK(hipMalloc(&d_dbg, 2 * 96 * 8 * sizeof(uint64_t)));
+      if (f16_dbg & 32) HIPCHK(hipMemsetAsync(d_dbg, 0, 2 * 96 * 8 * sizeof(uint64_t), st));
+      a.dbg_buf = d_dbg;
+      g_f16_dbg_buf = d_dbg;
     }
     a.Q = b->d_Q;
     a.V = s->d_rows;
@@ -565,6 +571,19 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     hipStream_t us = out->user_stream ? out->user_stream : s->batch_stream;
     HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
     HIPCHK(hipStreamSynchronize(us));
+  }
+  if (g_f16_dbg_buf && nq >= 1024) {  // probe: step timeline of two waves of workgroup 0 (main pass: the last launch)
+    std::vector<uint64_t> hb(2 * 96 * 8);
+    HIPCHK(hipMemcpy(hb.data(), g_f16_dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
+    for (int w = 0; w < 2; ++w) {
+      fprintf(stderr, "[f16 dbg] wave %d: per step: wait vmcnt | barrier | early issue | reads+mfma | late issue | (to next step)\n", w * 4);
+      for (int st2 = 20; st2 < 52; ++st2) {
+        const uint64_t *t = &hb[(size_t)(w * 96 + st2) * 8], *tn = &hb[(size_t)(w * 96 + st2 + 1) * 8];
+        fprintf(stderr, "[f16 dbg]   step %2d: %5lld %5lld %5lld %5lld %5lld | %5lld   (epilogue stamp %lld)\n", st2, (long long)(t[1] - t[0]),
+                (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]), (long long)(t[5] - t[4]),
+                (long long)(tn[0] - t[5]), (long long)(t[6] ? t[6] - t[5] : 0));
+      }
+    }
   }
   if (trace_batch())
     fprintf(stderr, "[tsh batch] nq=%d prep %.0f us, enqueue %.0f us, gpu wait %.0f us, post %.0f us (gemm %.0f us)\n", nq,
