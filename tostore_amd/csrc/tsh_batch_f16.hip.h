@@ -6,10 +6,9 @@
 //   * workgroup = 8 waves (2 x 4), each a 128 x 64 patch (4 x 2 MFMA 32x32 blocks, 128 accumulator registers) of a
 //     256 x 256 (queries x rows) tile -- 0.75 KB of LDS reads per MFMA instead of 1 KB (first generation: sixteen
 //     64 x 64 waves) -- or, for calls of up to 128 queries, a 64 x 64 patch of a 128 x 256 tile.  Every SIMD holds
-//     two waves of the workgroup, and the two take their turns in OPPOSITE order within a K-step: waves 0-3 issue
-//     their share of the next chunk's loads first and multiply afterwards, waves 4-7 multiply first and issue
-//     afterwards, so that on each SIMD one wave feeds the matrix pipe while the other one sits in the ~100 cycles
-//     each load instruction takes to issue.
+//     two waves of the workgroup.  Waves 0-3 -- the older wave of each SIMD, which wins the matrix pipe and would
+//     otherwise sit at the barrier waiting for its partner -- also issue ALL the loads, one 8 KB block of the stage
+//     each, one 1 KB piece behind every pair of their MFMAs; waves 4-7 only read fragments and multiply.
 //   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.
 //     The DMA writes a wave's 64 x 16 B linearly, so the bank swizzle the fragment reads need is baked into the
 //     GLOBAL layout of the planes ("plane32" below): a tile's K-chunk is a contiguous run of 8 KB blocks that are
@@ -81,6 +80,20 @@ __device__ __forceinline__ void f16_dma16(const void *gsrc, uint32_t lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// the same with a wave-uniform base in an SGPR pair and one per-lane byte offset shared by all pieces of the wave
+__device__ __forceinline__ void f16_dma16_s(const void *sbase_any, uint32_t voff, uint32_t lds_dst) {
+  // (the base is wave-uniform by construction; where the compiler has lost track of that it holds it in VGPRs, and the
+  // "s" constraint fails to assemble: readfirstlane is free when the value already sits in SGPRs)
+  const uint64_t pb = (uint64_t)sbase_any;
+  const void *sbase = reinterpret_cast<const void *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) |
+                                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pb));
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void f16_wait_dma() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -98,7 +111,6 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   constexpr int WN = 4, TM = 64 * MI, TN = 256;
   constexpr int STAGE = (TM + TN) * 64;            // bytes: [queries TM x 64 B][rows TN x 64 B] = 32 / 24 KB
   constexpr int NST = 4, AHEAD = NST - 1;          // ring stages; chunks in flight ahead of the multiply
-  constexpr int P = STAGE / 1024 / 8;              // 1 KB DMA pieces per wave per stage = 4 / 3
   constexpr bool IPLIKE = METRIC != METRIC_L2;     // cosine planes hold unit rows: its key is -dot, as for IP
   __shared__ __attribute__((aligned(1024))) unsigned char ring[NST * STAGE];
   __shared__ __attribute__((aligned(16))) float s_thr[TM];
@@ -108,52 +120,51 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  // (waves w and w + 4 share a SIMD: MI355X_MICROARCH.md, LDS section.)  Step timeline of the two waves of a SIMD,
-  // TSH_F16_DBG=32: with waves 0-3 loading first a step lasts ~1800 cycles for 1024 cycles of MFMA -- the load-first
-  // wave issues its 4 pieces in 230-520 cycles, multiplies in ~700 and then waits ~540 at the barrier; its partner
-  // multiplies for 1200-1400 (it loses the pipe to the older wave) and issues its pieces after that, pipe idle.
-  // Tried against that: s_setprio 1 for the multiply-first waves (the other wave's 4 DMA pieces then take 750-1500
-  // cycles to issue; 1.78-1.84 ms instead of 1.73-1.76) and swapped roles, older wave multiplying first (DMA issue
-  // 500-1400 cycles beside the partner's MFMAs; 1.79-1.82 ms): issuing LDS-DMA beside a partner that streams MFMAs
-  // is slow whichever wave does it.  Kept: the first arrangement.
-  const bool load_first = wave < 4;
   const int KC = a.hchunks;
   const int G = (int)gridDim.x, total_tiles = a.q_tiles * a.n_tiles;
 
   // ---- issue stream: the chunks of my tiles in order, AHEAD steps in front of the multiply ------------------------
-  // the stage image is (TM + TN) / 128 blocks of 8 KB; wave w moves 1 KB pieces P w .. P w + P - 1 of every stage.
+  // The stage image is NBLK = (TM + TN) / 128 blocks of 8 KB, each one contiguous in the planes.  Waves 0 .. NBLK - 1
+  // move one block each (eight 1 KB pieces per step: scalar base + lane * 16); waves NBLK .. 7 issue nothing.  The
+  // issuing waves are the ones that otherwise wait at the barrier (step timeline, TSH_F16_DBG=32: ~540 of 1800
+  // cycles) for partners whose own share of the issue came after their multiply, with the matrix pipe idle.
   // The stream never runs dry: past the last chunk it re-reads the last tile (into stages nobody reads any more),
   // so that the number of pieces in flight -- which the hand-kept vmcnt counts rely on -- is the same at every step.
-  const u32x4 *src[P];
+  constexpr int NBLK = STAGE / 8192;
+  const bool issuer = wave < NBLK;
+  const unsigned char *blk_src = nullptr;  // wave-uniform: this wave's block of the next chunk of the stream
   int i_tile = (int)blockIdx.x;
   auto set_src = [&](int tile) {
     int qt, nt;
     batch_tile_of(a, tile, &qt, &nt);
     const int qb = qt * TM, nb = a.row0 + nt * TN;  // row0 is a multiple of the tile (host)
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int piece = wave * P + u;
-      const int blk = piece >> 3, sub = piece & 7;  // block of the stage, 1 KB part of the block
-      const bool is_q = blk < TM / F16_GROUP;
-      const int64_t group = is_q ? (qb / F16_GROUP + blk) : (nb / F16_GROUP + (blk - TM / F16_GROUP));
-      src[u] = (is_q ? a.Qs : a.Vs) + (group * KC) * F16_BLOCK_PIECES + sub * 64 + lane;
-    }
+    const bool is_q = wave < TM / F16_GROUP;
+    const int64_t group = is_q ? (qb / F16_GROUP + wave) : (nb / F16_GROUP + (wave - TM / F16_GROUP));
+    const uint64_t p = (uint64_t)(reinterpret_cast<const unsigned char *>(is_q ? a.Qs : a.Vs) + (group * KC) * 8192);
+    // (wave-uniform by construction; said explicitly so that the DMA's scalar base operand always gets SGPRs)
+    blk_src = reinterpret_cast<const unsigned char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(p >> 32)) << 32) |
+                                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)p));
   };
-  const uint32_t my_dst = (uint32_t)(uintptr_t)ring + (uint32_t)wave * (P * 1024);
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const uint32_t my_dst = (uint32_t)(uintptr_t)ring + (uint32_t)wave * 8192u;
   // rows past the end of the corpus: the planes are allocated in whole 256-row groups, so the loads stay inside
   // the allocation; what they return is discarded by the epilogue (col_ok)
-  auto issue = [&](auto SIDX) {  // the next chunk of the stream -> ring stage SIDX (compile-time)
+  auto issue_piece = [&](auto SIDX, int u) {  // 1 KB piece u of this wave's block of the next chunk -> ring stage SIDX
     constexpr int ST = decltype(SIDX)::value;
+    f16_dma16_s(blk_src + u * 1024, lane_off, my_dst + (uint32_t)(ST * STAGE + u * 1024));
+  };
+  auto issue = [&](auto SIDX) {  // the whole block at once (prologue)
+    if (issuer) {
 #pragma unroll
-    for (int u = 0; u < P; ++u) {
-      f16_dma16(src[u], my_dst + (uint32_t)(ST * STAGE + u * 1024));
-      src[u] += F16_BLOCK_PIECES;
+      for (int u = 0; u < 8; ++u) issue_piece(SIDX, u);
+      blk_src += 8192;
     }
   };
   auto next_tile_src = [&]() {  // the stream moves on to my next tile (or stays on the last one)
     if (i_tile + G < total_tiles) i_tile += G;
     set_src(i_tile);
   };
+  constexpr int P = 8;  // pieces an issuing wave has in flight per chunk (vmcnt bookkeeping; the others have none)
 
   // fragment addresses: row = 32 i + (lane & 31) (+ patch base), logical piece 2 s + (lane >> 5), slot = piece ^ sw
   const int half = lane >> 5, l31 = lane & 31, sw = (l31 >> 2) & 3;
@@ -174,11 +185,23 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) fb[sl][j] = *reinterpret_cast<const f16x8 *>(st + b_off + j * 2048 + so);
   };
-  auto mfma_slab = [&](int sl) {
+  // One slab's MFMAs; an issuing wave puts one DMA piece of the next chunk behind every pair of them.  (All eight
+  // pieces in one go at the top of the step held the LDS / VMEM issue path for ~430 cycles, and the SIMD partner,
+  // which has to issue its fragment reads right then, sat blocked in front of its first slab for ~850 cycles:
+  // step timeline, TSH_F16_DBG=32.)
+  // (Two more wave-uniform tests per pair in here cost 0.16 ms of 1.31; two compile-time copies of the loop, one per
+  // role, were no faster than this one test: 1.36 vs 1.31 ms.)
+  auto mfma_slab = [&](int sl, auto FILL) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sl][i], fb[sl][j], acc[i][j], 0, 0, 0);
+      if (issuer) {
+        constexpr int PER = 8 / (2 * MI);  // pieces behind each pair: 1 (MI = 4) or 2 (MI = 2)
+#pragma unroll
+        for (int e = 0; e < PER; ++e) issue_piece(FILL, (sl * MI + i) * PER + e);
+      }
+    }
   };
 
   // survivors whose list slots have been asked for but not yet answered (two per lane: F16_HITS = 128)
@@ -264,20 +287,20 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
       __builtin_amdgcn_s_barrier();  // everybody's have; and everybody is done reading the chunk before this one
       stamp(2);
       if (decltype(SWITCH)::value) next_tile_src();
-      if (load_first) issue(FILL);   // chunk + 3, into the stage the previous chunk has just left
       stamp(3);
       // (the sched_barriers pin the order reads -> multiply -> reads -> multiply: left alone the scheduler sinks
       // every read to just before its first use to save registers, and the wave then waits out the LDS latency)
       read_slab(CUR, 1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_slab(0);
+      mfma_slab(0, FILL);  // (+ the first half of chunk + 3, into the stage the previous chunk has just left)
       __builtin_amdgcn_sched_barrier(0);
+      stamp(7);
       read_slab(NXT, 0);  // legal: this step's barrier already covers the next chunk
       __builtin_amdgcn_sched_barrier(0);
-      mfma_slab(1);
+      mfma_slab(1, FILL);
+      if (issuer) blk_src += 8192;
       __builtin_amdgcn_sched_barrier(0);
       stamp(4);
-      if (!load_first) issue(FILL);
       stamp(5);
       ++dbg_step;
     };

@@ -576,11 +576,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     std::vector<uint64_t> hb(2 * 96 * 8);
     HIPCHK(hipMemcpy(hb.data(), g_f16_dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
     for (int w = 0; w < 2; ++w) {
-      fprintf(stderr, "[f16 dbg] wave %d: per step: wait vmcnt | barrier | early issue | reads+mfma | late issue | (to next step)\n", w * 4);
+      fprintf(stderr, "[f16 dbg] wave %d: per step: wait vmcnt | barrier | DMA issue | reads + slab 0 + reads + slab 1 | - | (to next step)\n", w * 4);
       for (int st2 = 20; st2 < 52; ++st2) {
         const uint64_t *t = &hb[(size_t)(w * 96 + st2) * 8], *tn = &hb[(size_t)(w * 96 + st2 + 1) * 8];
-        fprintf(stderr, "[f16 dbg]   step %2d: %5lld %5lld %5lld %5lld %5lld | %5lld   (epilogue stamp %lld)\n", st2, (long long)(t[1] - t[0]),
-                (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]), (long long)(t[5] - t[4]),
+        fprintf(stderr, "[f16 dbg]   step %2d: %5lld %5lld %5lld %5lld+%5lld %5lld | %5lld   (epilogue stamp %lld)\n", st2, (long long)(t[1] - t[0]),
+                (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[7] - t[3]), (long long)(t[4] - t[7]), (long long)(t[5] - t[4]),
                 (long long)(tn[0] - t[5]), (long long)(t[6] ? t[6] - t[5] : 0));
       }
     }
