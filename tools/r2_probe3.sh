@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r2p3
 rm -rf $O && mkdir -p $O
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $O/tests.txt
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" > $O/tests.txt
 cat $O/tests.txt
 timeout 300 python bench.py --batch 1024 --metric cosine --steps 20 --warmup 3 > $O/c3.json 2> $O/c3.err
 python -c "import json; j=json.load(open('$O/c3.json')); print('C3', round(j['value']), j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernel_us'], j.get('ids_and_distances_bit_exact'), j.get('checked_queries'), j['counters'])"

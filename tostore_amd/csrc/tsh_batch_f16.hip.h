@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   const bool dbg_on = (a.dbg & 32) && blockIdx.x == 0 && (wave == 0 || wave == 4);
   auto stamp = [&](int point) {
     if (dbg_on && dbg_step < 96 && lane == 0)
-      a.dbg_buf[((wave >> 2) * 96 + dbg_step) * 8 + point] = __builtin_amdgcn_s_memtime();
+      a.dbg_buf[((wave >> 2) * 96 + dbg_step) * 12 + point] = __builtin_amdgcn_s_memtime();
   };
   set_src(i_tile);
   int cur_q_tile = -1;
@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
     // atomic per survivor straight from the registers.
     stamp(6);
     if (!DENSE) settle();  // the previous tile's
+    stamp(8);
     uint32_t n_hits = 0;   // wave-uniform
     uint2 *my_hits = s_hits[wave];
     // (opaque per tile: everything the epilogue derives from the lane id is invariant across the tiles of the
@@ -374,32 +375,47 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int qrow = rbase + (r & 3) + 8 * (r >> 2);
-            auto key_of = [&]() -> float {
+          for (int g4 = 0; g4 < 4; ++g4) {  // the four registers of one group of consecutive query rows
+            auto key_of = [&](int r) -> float {
               if (IPLIKE) return -(acc[i][j][r] * scale_w);
               const float dot = acc[i][j][r] * scale_w;
               return qq[r >> 2][r & 3] + vsq[j] - 2.f * dot;
             };
             if (DENSE) {
-              if (col_ok[j])
-                a.dense[(int64_t)(qbase + qrow) * a.dense_ld + (nbase + cl[j] - a.row0)] = alive_l[j] ? key_of() : __builtin_nanf("");
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e, qrow = rbase + e + 8 * g4;
+                if (col_ok[j])
+                  a.dense[(int64_t)(qbase + qrow) * a.dense_ld + (nbase + cl[j] - a.row0)] = alive_l[j] ? key_of(r) : __builtin_nanf("");
+              }
             } else {
-              // a site without survivors costs a compare and a branch on vcc; the key, the live / mask bits and
-              // the list slot are only worked out behind the branch
-              const bool pass = IPLIKE ? acc[i][j][r] >= th[r >> 2][r & 3] : key_of() <= th[r >> 2][r & 3];
-              const uint64_t m0 = __ballot(pass);
-              if (m0) {  // wave-uniform
-                const uint64_t m = m0 & alive_m[j];
-                if (m) {
-                  const bool mine = (m >> lane) & 1ull;
-                  const float key = key_of();
-                  if (direct) {
-                    if (mine) store(qbase, nbase, __float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j], ask(qbase, qrow));
-                  } else {
-                    const uint32_t slot = n_hits + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (mine && slot < (uint32_t)F16_HITS) my_hits[slot] = uint2{__float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j]};
-                    n_hits += (uint32_t)__popcll(m);
+              // Four compares into four scalar masks, ONE test and branch for the four sites; keys, live / mask bits
+              // and list slots are only worked out behind the branch, which four groups in nine take (four sites in
+              // five have no survivor).  The walk takes ~10 k cycles per tile (epilogue stamps of TSH_F16_DBG=32)
+              // whichever way it is written: one compare + branch per site, inline or out of line, this grouped form,
+              // or margins reduced with v_max3 in the vector unit and branch-free appends (that one: 14 k).
+              uint64_t m0[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const bool pass = IPLIKE ? acc[i][j][r] >= th[g4][e] : key_of(r) <= th[g4][e];
+                m0[e] = __ballot(pass);
+              }
+              if (__builtin_expect((m0[0] | m0[1] | m0[2] | m0[3]) != 0, 0)) {  // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const uint64_t m = m0[e] & alive_m[j];
+                  if (m) {
+                    const int r = 4 * g4 + e, qrow = rbase + e + 8 * g4;
+                    const bool mine = (m >> lane) & 1ull;
+                    const float key = key_of(r);
+                    if (direct) {
+                      if (mine) store(qbase, nbase, __float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j], ask(qbase, qrow));
+                    } else {
+                      const uint32_t slot = n_hits + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                      if (mine && slot < (uint32_t)F16_HITS) my_hits[slot] = uint2{__float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j]};
+                      n_hits += (uint32_t)__popcll(m);
+                    }
                   }
                 }
               }
@@ -409,6 +425,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
       }
     };
     walk(std::false_type{});
+    stamp(9);
     if (!DENSE) {
       if (n_hits > (uint32_t)F16_HITS) {
         walk(std::true_type{});
@@ -424,6 +441,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
         pend_nbase = nbase;
       }
     }
+    stamp(10);
   }
   if (!DENSE) settle();
   f16_wait_dma<0>();  // the stream's surplus pieces must have landed before this workgroup's LDS is handed on

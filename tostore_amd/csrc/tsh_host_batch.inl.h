@@ -396,8 +396,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       static const int f16_dbg = getenv("TSH_F16_DBG") ? atoi(getenv("TSH_F16_DBG")) : 0;  // probes: results are wrong
       a.dbg = f16_dbg;
       static uint64_t *d_dbg = nullptr;
-      if ((f16_dbg & 32) && !d_dbg) HIPCHK(hipMalloc(&d_dbg, 2 * 96 * 8 * sizeof(uint64_t)));
-      if (f16_dbg & 32) HIPCHK(hipMemsetAsync(d_dbg, 0, 2 * 96 * 8 * sizeof(uint64_t), st));
+      if ((f16_dbg & 32) && !d_dbg) HIPCHK(hipMalloc(&d_dbg, 2 * 96 * 12 * sizeof(uint64_t)));
+      if (f16_dbg & 32) HIPCHK(hipMemsetAsync(d_dbg, 0, 2 * 96 * 12 * sizeof(uint64_t), st));
       a.dbg_buf = d_dbg;
       g_f16_dbg_buf = d_dbg;
     }
@@ -573,15 +573,17 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipStreamSynchronize(us));
   }
   if (g_f16_dbg_buf && nq >= 1024) {  // probe: step timeline of two waves of workgroup 0 (main pass: the last launch)
-    std::vector<uint64_t> hb(2 * 96 * 8);
+    std::vector<uint64_t> hb(2 * 96 * 12);
     HIPCHK(hipMemcpy(hb.data(), g_f16_dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
     for (int w = 0; w < 2; ++w) {
       fprintf(stderr, "[f16 dbg] wave %d: per step: wait vmcnt | barrier | DMA issue | reads + slab 0 + reads + slab 1 | - | (to next step)\n", w * 4);
       for (int st2 = 20; st2 < 52; ++st2) {
-        const uint64_t *t = &hb[(size_t)(w * 96 + st2) * 8], *tn = &hb[(size_t)(w * 96 + st2 + 1) * 8];
+        const uint64_t *t = &hb[(size_t)(w * 96 + st2) * 12], *tn = &hb[(size_t)(w * 96 + st2 + 1) * 12];
         fprintf(stderr, "[f16 dbg]   step %2d: %5lld %5lld %5lld %5lld+%5lld %5lld | %5lld   (epilogue stamp %lld)\n", st2, (long long)(t[1] - t[0]),
                 (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[7] - t[3]), (long long)(t[4] - t[7]), (long long)(t[5] - t[4]),
                 (long long)(tn[0] - t[5]), (long long)(t[6] ? t[6] - t[5] : 0));
+        if (t[6]) fprintf(stderr, "[f16 dbg]     epilogue before this step: settle %lld, walk %lld, list -> atomics %lld, to the step %lld\n",
+                          (long long)(t[8] - t[6]), (long long)(t[9] - t[8]), (long long)(t[10] - t[9]), (long long)(t[0] - t[10]));
       }
     }
   }
