@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char ring[NST * STAGE];
   __shared__ __attribute__((aligned(16))) float s_thr[TM];
   __shared__ __attribute__((aligned(16))) float s_qsq[TM];
-  __shared__ uint2 s_hits[8][F16_HITS];
+  __shared__ uint2 s_hits[8][F16_HITS + 64];  // + one spare slot per lane
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -391,15 +391,18 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
             } else {
               // Four compares into four scalar masks, ONE test and branch for the four sites; keys, live / mask bits
               // and list slots are only worked out behind the branch, which four groups in nine take (four sites in
-              // five have no survivor).  The walk takes ~10 k cycles per tile (epilogue stamps of TSH_F16_DBG=32)
-              // whichever way it is written: one compare + branch per site, inline or out of line, this grouped form,
-              // or margins reduced with v_max3 in the vector unit and branch-free appends (that one: 14 k).
+              // five have no survivor).  The walk takes ~10 k cycles per tile (epilogue stamps of TSH_F16_DBG=32):
+              // 4.3 k for the compares and branches of the 128 sites, 6.4 k for the ~14 visits behind the branch --
+              // instruction issue at ~4.5 cycles per instruction and wave with two waves per SIMD, nothing else
+              // (one compare + branch per site, inline or out of line, took the same; margins reduced with v_max3
+              // in the vector unit plus branch-free appends took 14 k).
               uint64_t m0[4];
+              bool pass_l[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g4 + e;
-                const bool pass = IPLIKE ? acc[i][j][r] >= th[g4][e] : key_of(r) <= th[g4][e];
-                m0[e] = __ballot(pass);
+                pass_l[e] = IPLIKE ? acc[i][j][r] >= th[g4][e] : key_of(r) <= th[g4][e];
+                m0[e] = __ballot(pass_l[e]);
               }
               if (__builtin_expect((m0[0] | m0[1] | m0[2] | m0[3]) != 0, 0)) {  // wave-uniform
 #pragma unroll
@@ -407,13 +410,19 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
                   const uint64_t m = m0[e] & alive_m[j];
                   if (m) {
                     const int r = 4 * g4 + e, qrow = rbase + e + 8 * g4;
-                    const bool mine = (m >> lane) & 1ull;
+                    const bool mine = pass_l[e] && alive_l[j];  // (a lane mask to the compiler: no bit arithmetic)
                     const float key = key_of(r);
                     if (direct) {
                       if (mine) store(qbase, nbase, __float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j], ask(qbase, qrow));
                     } else {
-                      const uint32_t slot = n_hits + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                      if (mine && slot < (uint32_t)F16_HITS) my_hits[slot] = uint2{__float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j]};
+                      // Kept SMALL (this block exists 128 times per patch and each copy runs once in a few tiles:
+                      // its instructions come from L2, not from the instruction cache -- ~460 cycles per visit with
+                      // the first, larger form): no exec games, no capacity test; a lane that does not pass, or
+                      // whose slot is beyond the list, writes to its own spare slot behind it.
+                      const uint32_t slot = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                      const uint32_t spare = (uint32_t)F16_HITS + (uint32_t)lane;
+                      const uint32_t at = mine ? (slot < spare ? slot : spare) : spare;
+                      my_hits[at] = uint2{__float_as_uint(key), ((uint32_t)qrow << 16) | (uint32_t)cl[j]};
                       n_hits += (uint32_t)__popcll(m);
                     }
                   }
