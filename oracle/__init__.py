@@ -197,7 +197,7 @@ def search_heap(rows, query, metric: int, k: int, threshold=None, keep=None):
 
 def search_heap_mt(rows, query, metric: int, k: int, threshold=None, keep=None, threads=0):
     return _search(lib_mt().vso_search_heap_mt, rows, query, metric, k, threshold, keep,
-                   int(threads))
+                   int(threads) if threads > 0 else mt_max_threads())
 
 
 def search_heap_many_mt(rows, queries, metric: int, k: int, threshold=None, keep=None, threads=0):
@@ -214,14 +214,29 @@ def search_heap_many_mt(rows, queries, metric: int, k: int, threshold=None, keep
         keep = np.ascontiguousarray(keep, dtype=np.uint8)
         kp = _p(keep, _c_u8p)
     rc = lib_mt().vso_search_heap_many_mt(_p(rows, _c_f32p), n, d, metric, _p(queries, _c_f32p), nq, int(k), thr, kp,
-                                          int(threads), _p(ids, _c_i64p), _p(dist, _c_f64p), _p(cnt, _c_i64p))
+                                          int(threads) if threads > 0 else mt_max_threads(), _p(ids, _c_i64p), _p(dist, _c_f64p), _p(cnt, _c_i64p))
     if rc != 0:
         raise MemoryError("oracle allocation failed")
     return ids[:, :k], dist[:, :k], cnt
 
 
+def cpu_quota() -> int:
+    """CPUs the container may actually use (cgroup v2 cpu.max), 0 when unlimited or unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(quota) > 0 and int(period) > 0:
+            return max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    return 0
+
+
 def mt_max_threads() -> int:
-    return lib_mt().vso_mt_max_threads()
+    """Threads of the multi-threaded checker: OpenMP's default, capped by the container's CPU quota (256
+    runnable threads on a 16-CPU quota spend most of their time throttled and would be reported as 256 cores)."""
+    t = lib_mt().vso_mt_max_threads()
+    q = cpu_quota()
+    return min(t, q) if q > 0 else t
 
 
 def pq_encode(codebook, subspaces: int, centroids: int, sub_dim: int, vectors) -> np.ndarray:

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -143,10 +144,23 @@ class HostPool {
     // one process per GPU shares the cores with its peers (torchrun exports LOCAL_WORLD_SIZE); TSH_HOST_THREADS
     // overrides
     unsigned hw = std::thread::hardware_concurrency();
+    // A container's CPU quota (cgroup v2 cpu.max) can be far below the core count it shows (16 of 256 on the
+    // MI355X boxes measured here), and a process that runs past it is frozen for the rest of the 100 ms period
+    // -- seen as one 60 ms stall every few hundred calls with 63 polling workers.  Workers only poll while a
+    // call holds them (Hold, ~20 % of a 1024-query call), so twice the quota is the limit that stayed clear of it.
+    unsigned quota = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long q = 0, period = 0;
+      if (fscanf(f, "%lld %lld", &q, &period) == 2 && q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
+      fclose(f);
+    }
+    if (quota) hw = std::min(hw, 2 * quota);
     const char *peers_s = getenv("LOCAL_WORLD_SIZE");
     const unsigned peers = peers_s && atoi(peers_s) > 0 ? (unsigned)atoi(peers_s) : 1u;
     hw = std::max(1u, hw / peers);
-    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 64 ? 31 : 15);
+    // (a 256-query chunk of a batch's tail is ~1.5 ms of single-thread finalisation: 32 threads take 45-55 us
+    // over it, as fast as the GPU delivers chunks)
+    int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 32 ? 31 : 15);
     if (const char *forced = getenv("TSH_HOST_THREADS")) nt = std::max(0, std::min(atoi(forced) - 1, 63));
     if (const char *spin = getenv("TSH_HOST_SPIN_US")) spin_us_ = std::max(0.0, atof(spin));
     for (int i = 0; i < nt; ++i) {
