@@ -603,9 +603,35 @@ struct KthScratch {
   uint32_t lm[BS_GROUPS];
   uint32_t list[BS_LIST];
   uint32_t n_list, U, tau;
+  RadixSelScratch rs;
 };
 
 __device__ __forceinline__ uint32_t fkey_or_dead(float f) { return f != f ? KEY_DEAD : f2key(f); }
+
+// fn(value, index) over keys[0, n), a workgroup's threads striding over 16-byte vectors (n4 = n / 4 when keys is
+// 16-byte aligned, else 0), EIGHT loads in flight per thread: with an atomic append in fn the compiler issues one
+// load per iteration and waits for it (batch_sample_select_kernel over 33 k-entry sample rows: 100 -> 91 us).
+template <int THREADS, typename F>
+__device__ __forceinline__ void for_each_key(const float *keys, int n, int n4, int tid, F fn) {
+  const f32x4 *keys4 = reinterpret_cast<const f32x4 *>(keys);
+  constexpr int U = 8;
+  int i = tid;
+  for (; i + (U - 1) * THREADS < n4; i += U * THREADS) {
+    f32x4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = keys4[i + u * THREADS];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fn(f[u][e], 4 * (i + u * THREADS) + e);
+  }
+  for (; i < n4; i += THREADS) {
+    const f32x4 f = keys4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fn(f[e], 4 * i + e);
+  }
+  for (int j = 4 * n4 + tid; j < n; j += THREADS) fn(keys[j], j);
+}
 
 template <int THREADS>
 __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc) {
@@ -655,44 +681,32 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
 #pragma unroll
   for (int u = 0; u < BS_GPT; ++u) sc->lm[u * THREADS + tid] = lmin[u];
   __syncthreads();
-  if (narrow && wave == 0) {
-    uint32_t v[BS_GROUPS / 64];
-#pragma unroll
-    for (int i = 0; i < BS_GROUPS / 64; ++i) v[i] = sc->lm[lane + 64 * i];
-    uint32_t U = wave_kth_bisect<BS_GROUPS / 64>(v, k);
-    if (lane == 0) sc->U = U;
+  if (narrow) {  // (workgroup-uniform)
+    const uint32_t U = block_kth_radix<THREADS>(sc->lm, (uint32_t)BS_GROUPS, k, &sc->rs);
+    if (tid == 0) sc->U = U;
   }
   __syncthreads();
   const uint32_t U = sc->U;
-  auto offer = [&](float f) {
+  for_each_key<THREADS>(keys, n, n4, tid, [&](float f, int) {
     uint32_t x = fkey_or_dead(f);
     if (x <= U && x != KEY_DEAD) {
       uint32_t p = atomicAdd(&sc->n_list, 1u);
       if (p < BS_LIST) sc->list[p] = x;
     }
-  };
-  for (int i = tid; i < n4; i += THREADS) {
-    const f32x4 f = keys4[i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) offer(f[e]);
-  }
-  for (int i = 4 * n4 + tid; i < n; i += THREADS) offer(keys[i]);
+  });
   __syncthreads();
-  if (wave == 0) {
-    const uint32_t m = sc->n_list;
+  {
+    const uint32_t m = sc->n_list;  // (workgroup-uniform)
     uint32_t tau;
     if (m < k) {
       tau = KEY_NAN;  // fewer than k live entries
     } else if (m > BS_LIST) {
       tau = U == KEY_DEAD ? KEY_NAN : U;  // flooded by ties: U is a valid, looser bound
     } else {
-      uint32_t v[BS_LIST / 64];
-#pragma unroll
-      for (int i = 0; i < BS_LIST / 64; ++i)
-        v[i] = (uint32_t)(lane + 64 * i) < m ? sc->list[lane + 64 * i] : KEY_DEAD;
-      tau = wave_kth_bisect<BS_LIST / 64>(v, k);
+      tau = block_kth_radix<THREADS>(sc->list, m, k, &sc->rs);
     }
-    if (lane == 0) sc->tau = tau;
+    __syncthreads();
+    if (tid == 0) sc->tau = tau;
   }
   __syncthreads();
   return sc->tau;
@@ -729,7 +743,8 @@ __global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelA
     s_cnt = 0;
   }
   __syncthreads();
-  auto offer = [&](float f, int i) {
+  const int n4 = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? a.n_sample >> 2 : 0;
+  for_each_key<THREADS>(keys, a.n_sample, n4, tid, [&](float f, int i) {
     if (f <= thr) {  // NaN (dead) never passes
       uint32_t p = atomicAdd(&s_cnt, 1u);
       if (p < (uint32_t)a.cand_cap) {
@@ -737,14 +752,7 @@ __global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelA
         a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)(a.row0 + i);
       }
     }
-  };
-  const int n4 = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? a.n_sample >> 2 : 0;
-  for (int i = tid; i < n4; i += THREADS) {
-    const f32x4 f = reinterpret_cast<const f32x4 *>(keys)[i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) offer(f[e], 4 * i + e);
-  }
-  for (int i = 4 * n4 + tid; i < a.n_sample; i += THREADS) offer(keys[i], i);
+  });
   __syncthreads();
   if (tid == 0) a.cand_cnt[(int64_t)q * CC_STRIDE] = s_cnt;
 }
@@ -776,12 +784,14 @@ __global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArg
   float band = band_float(tau, a.delta2[q]);
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += THREADS) {
-    if (keys[i] <= band) {
+  // (the candidate lists start at multiples of cand_cap entries: 16-byte aligned)
+  const int n4 = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? n >> 2 : 0;
+  for_each_key<THREADS>(keys, n, n4, tid, [&](float f, int i) {
+    if (f <= band) {
       uint32_t p = atomicAdd(&s_cnt, 1u);
       if (p < (uint32_t)a.entries) a.final_rows[(int64_t)q * a.entries + p] = rows[i];
     }
-  }
+  });
   __syncthreads();
   if (tid == 0) {
     BlockHeader hv;
@@ -880,23 +890,140 @@ __device__ __forceinline__ void rerank_lane_sums(const float *__restrict__ rp, c
   *out_s1 = metric == METRIC_COS ? s1 : 0.0;
 }
 
+// K4 over a batch.  One wave = RG candidates of ONE query.  The chains are serial per candidate, so a candidate
+// still belongs to one lane -- but a lane that streams its own row keeps only two 128-byte lines in flight and
+// waits out HBM latency a dozen times in a row (57 us per 256-query chunk; its 100 MB need 22).  Here the WAVE
+// loads: one instruction brings 1 KiB of one candidate's row (64 lanes x 16 B, coalesced), RG of them are in
+// flight, an LDS tile turns "lane = column" into "lane = candidate", and while lanes 0..RG-1 walk their chains
+// over the tile the next RG KiB are already on their way.  Eight times as many waves per chunk as with 64
+// candidates per wave, so the chunk's traffic is spread over the whole chip.  (f64 add / mul / fma / cvt all
+// issue at one per ~4.5 cycles whatever the number of active lanes -- tools/micro/f64_rate.hip -- so the chain
+// costs what its instruction count says: it is kept to cvt + fma per term, with the query converted once.)
+//
+// Arithmetic, bit for bit that of rerank_kernel / the oracle (vs_exact_sums): every term is added in dimension
+// order with one rounding per addition.  For IP and cosine the product of two f32 values is exact in f64 (24 + 24
+// significand bits), so fma(q, b, s) rounds exactly what s + q * b rounds; L2's (q - b)^2 is not exact and keeps its
+// separate multiply.
+constexpr int RG = 16;              // candidates per wave
+constexpr int RG_BLK = 256;         // floats of a row per load instruction
+constexpr int RG_LD = RG_BLK + 4;   // LDS row stride in floats: rows 4 banks apart, RG rows cover the 64 banks
+
 __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float tile[RG * RG_LD];
+  __shared__ __attribute__((aligned(16))) double s_q[RG_BLK];  // the query's current block, as f64
+  __shared__ uint32_t stage[6 * RG];
   const int lane = threadIdx.x, q = a.q0 + (int)blockIdx.y;
   uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
   uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
   if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
-  const uint32_t c0 = blockIdx.x * 64u;
+  const uint32_t c0 = blockIdx.x * (uint32_t)RG;
   if (c0 >= count) return;
-  const bool mine = c0 + lane < count;
-  BlockEntry *out = reinterpret_cast<BlockEntry *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader));
-  const uint32_t row = mine ? a.final_rows[(int64_t)q * a.entries + c0 + lane] : 0u;
-  double s0, s1;
-  rerank_lane_sums(a.rows + (int64_t)row * a.ld, a.Q + (int64_t)q * a.ld, a.dim, (int)a.ld, a.metric, &s0, &s1);
-  if (mine) {
-    out[c0 + lane].id = a.row_base + (int64_t)row;
-    out[c0 + lane].s0 = s0;
-    out[c0 + lane].s1 = s1;
+  const uint32_t left = count - c0;  // >= 1
+  // lane j < RG holds candidate c0 + j (idle lanes and slots past the list repeat the last candidate)
+  const uint32_t slot = (uint32_t)(lane & (RG - 1)) < left ? (uint32_t)(lane & (RG - 1)) : left - 1u;
+  const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
+  const float *rbase[RG];
+#pragma unroll
+  for (int j = 0; j < RG; ++j)
+    rbase[j] = a.rows + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_row, j) * a.ld;  // wave-uniform
+  const float *qp = a.Q + (int64_t)q * a.ld;
+  const int ld = (int)a.ld, dim = a.dim;
+  const int nblk = (dim + RG_BLK - 1) / RG_BLK;
+
+  f32x4 in[RG], qin;
+  auto fetch = [&](int b) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
+    const int o = b * RG_BLK + 4 * lane < ld - 4 ? b * RG_BLK + 4 * lane : ld - 4;
+#pragma unroll
+    for (int j = 0; j < RG; ++j) in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase[j] + o));
+    qin = *reinterpret_cast<const f32x4 *>(qp + o);
+  };
+  double s0 = 0.0, s1 = 0.0;
+  const float *trow = tile + (lane & (RG - 1)) * RG_LD;
+  auto chain = [&](auto METRIC, int b) {
+    constexpr int M = decltype(METRIC)::value;
+    const int m = dim - b * RG_BLK < RG_BLK ? dim - b * RG_BLK : RG_BLK;  // wave-uniform
+    auto term = [&](double qd, float bf) {
+      const double bd = (double)bf;
+      if (M == METRIC_L2) {
+        const double diff = qd - bd;
+        s0 = s0 + diff * diff;
+      } else {
+        s0 = __builtin_fma(qd, bd, s0);
+        if (M == METRIC_COS) s1 = __builtin_fma(bd, bd, s1);
+      }
+    };
+    // groups of 8 terms, the next group's LDS reads issued before this group's arithmetic
+    f32x4 v[2], nv[2];
+    double qd[8], nqd[8];
+    auto read = [&](f32x4 (&dv)[2], double (&dq)[8], int g) {
+      const int o = 8 * g < RG_BLK - 8 ? 8 * g : RG_BLK - 8;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) dv[u] = *reinterpret_cast<const f32x4 *>(trow + o + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const __attribute__((ext_vector_type(2))) double t =
+            *reinterpret_cast<const __attribute__((ext_vector_type(2))) double *>(s_q + o + 2 * u);
+        dq[2 * u] = t[0];
+        dq[2 * u + 1] = t[1];
+      }
+    };
+    const int ng = m >> 3;
+    read(v, qd, 0);
+    for (int g = 0; g < ng; ++g) {
+      read(nv, nqd, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) term(qd[4 * u + e], v[u][e]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) v[u] = nv[u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) qd[u] = nqd[u];
+    }
+    for (int i = 8 * ng; i < m; ++i) term(s_q[i], trow[i]);
+  };
+  fetch(0);
+  for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+    for (int j = 0; j < RG; ++j) *reinterpret_cast<f32x4 *>(tile + j * RG_LD + 4 * lane) = in[j];
+    {
+      __attribute__((ext_vector_type(2))) double d01, d23;
+      d01[0] = (double)qin[0], d01[1] = (double)qin[1], d23[0] = (double)qin[2], d23[1] = (double)qin[3];
+      *reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(s_q + 4 * lane) = d01;
+      *reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(s_q + 4 * lane + 2) = d23;
+    }
+    fetch(b + 1);  // (past the last block: clamped re-reads of cached lines)
+    asm volatile("" ::: "memory");  // (one wave, LDS in program order: only the compiler must not reorder)
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
+    if (lane < RG) {
+      if (a.metric == METRIC_L2) chain(std::integral_constant<int, METRIC_L2>{}, b);
+      else if (a.metric == METRIC_COS) chain(std::integral_constant<int, METRIC_COS>{}, b);
+      else chain(std::integral_constant<int, METRIC_IP>{}, b);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
+  // entries: 24 bytes each, RG of them contiguous -- staged in LDS and stored as whole dwords side by side (the
+  // entries usually live in pinned host memory: three strided 8-byte stores per lane cost 12 us per chunk)
+  if (lane < RG) {
+    const int64_t id = a.row_base + (int64_t)my_row;
+    const double e1 = a.metric == METRIC_COS ? s1 : 0.0;
+    stage[6 * lane + 0] = (uint32_t)id;
+    stage[6 * lane + 1] = (uint32_t)((uint64_t)id >> 32);
+    stage[6 * lane + 2] = (uint32_t)__double2loint(s0);
+    stage[6 * lane + 3] = (uint32_t)__double2hiint(s0);
+    stage[6 * lane + 4] = (uint32_t)__double2loint(e1);
+    stage[6 * lane + 5] = (uint32_t)__double2hiint(e1);
+  }
+  asm volatile("" ::: "memory");
+  static_assert(sizeof(BlockEntry) == 24, "entry layout");
+  uint32_t *outw = reinterpret_cast<uint32_t *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader)) + 6 * (int64_t)c0;
+  const uint32_t nw = 6u * (left < (uint32_t)RG ? left : (uint32_t)RG);
+  if ((uint32_t)lane < nw) outw[lane] = stage[lane];
+  if ((uint32_t)lane + 64u < nw) outw[lane + 64] = stage[lane + 64];
 }
 
 }  // namespace tsh

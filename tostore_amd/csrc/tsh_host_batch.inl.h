@@ -489,13 +489,15 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     rb.dim = s->dim;
     rb.entries = entries;
     rb.metric = s->metric;
-    // the tail runs in chunks of queries: while the GPU re-ranks chunk c + 1 and copies it out, the host already
-    // finalises chunk c (out->on_chunk)
+    // the tail runs in chunks of queries: while the GPU re-ranks chunk c + 1, the host already finalises chunk c
+    // (out->on_chunk).  (One launch over all chunks, each reporting through a pinned word when its last workgroup
+    // has stored its entries, was tried: 167 us against 4 x 48 -- no overlap to speak of -- and the waits for the
+    // host-memory stores to land doubled it.)
     n_chunks = !out->on_chunk ? 1 : (nq >= 512 ? 4 : (nq >= 256 ? 2 : 1));  // (256 queries: 1.00 -> 0.94 ms; 128: no gain)
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
       rb.q0 = q0;
-      rerank_batch_kernel<<<dim3((unsigned)((entries + 63) / 64), (unsigned)(q1 - q0)), 64, 0, st>>>(rb);
+      rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64, 0, st>>>(rb);
       if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
         QuarAppendArgs qa{};
         qa.rows = s->d_rows;

@@ -467,6 +467,75 @@ __device__ uint32_t wave_kth_bisect(const uint32_t (&v)[VPT], uint32_t k) {
   return X;
 }
 
+// k-th smallest (k = 1 .. m) of m 32-bit keys in LDS, by the WHOLE workgroup: four rounds over one byte of the
+// key each, most significant first -- a 256-bin histogram of the keys that still match the prefix found so far
+// (LDS atomics, every thread taking its share of the keys), then wave 0 scans the bins and names the one holding
+// the k-th key.  wave_kth_bisect above has ONE wave walk up to 32 bits x all keys while the others wait: 13 us
+// for 2048 keys and 30 us for a 4096-entry list (measured with s_memtime inside batch_sample_select_kernel, where
+// the two of them were half the kernel); this takes 2-3 us whatever the key distribution.
+// Every thread of the workgroup must call it (it contains barriers).  rs: scratch in LDS.
+struct RadixSelScratch {
+  uint32_t hist[256];
+  uint32_t bin, k;
+};
+template <int THREADS>
+__device__ uint32_t block_kth_radix(const uint32_t *v, uint32_t m, uint32_t k, RadixSelScratch *rs) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 256; i += THREADS) rs->hist[i] = 0u;
+  uint32_t prefix = 0u;
+  __syncthreads();
+#pragma unroll 1
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (uint32_t i0 = 0; i0 < m; i0 += THREADS) {  // (workgroup-uniform trip count: the ballots below see whole waves)
+      const uint32_t i = i0 + tid;
+      const uint32_t x = i < m ? v[i] : 0u;
+      const bool in = i < m && (shift == 24 || (x >> (shift + 8)) == (prefix >> (shift + 8)));
+      const uint32_t b = (x >> shift) & 255u;
+      // keys that agree in this byte (close keys: the usual case in the upper rounds) would queue up on one bin:
+      // a wave whose matching lanes all name the same bin adds its count once
+      const uint64_t act = __ballot(in);
+      if (act) {
+        const uint32_t b0 = (uint32_t)__shfl((int)b, __builtin_ctzll(act));
+        if (__ballot(in && b == b0) == act) {
+          if (lane == (int)__builtin_ctzll(act)) atomicAdd(&rs->hist[b0], (uint32_t)__popcll(act));
+        } else if (in) {
+          atomicAdd(&rs->hist[b], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: lane l owns bins 4l .. 4l+3 (and clears them for the next round)
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = rs->hist[4 * lane + j];
+        rs->hist[4 * lane + j] = 0u;
+      }
+      const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
+      }
+      uint32_t below = incl - mine;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k > below && k <= below + c[j]) {  // exactly one (lane, j): 1 <= k <= number of matching keys
+          rs->bin = (uint32_t)(4 * lane + j);
+          rs->k = k - below;
+        }
+        below += c[j];
+      }
+    }
+    __syncthreads();
+    prefix |= rs->bin << shift;
+    k = rs->k;
+  }
+  __syncthreads();  // (rs may be reused by the caller right away)
+  return prefix;
+}
+
 // tau widened by the f32 error band, rounded UP to the next float
 __device__ __forceinline__ uint32_t band_of(uint32_t tau_key, float eps_rel, float delta_abs) {
   if (tau_key >= KEY_NAN) return KEY_NAN;
