@@ -166,6 +166,37 @@ def test_merge_orders_like_double_compare_to(oracle_mod):
             assert (math.isnan(g) and math.isnan(vals[i])) or (g == vals[i] and math.copysign(1, g) == math.copysign(1, vals[i]))
 
 
+def test_merge_sort_of_clustered_distances(oracle_mod):
+    """the finaliser's counting-bucket sort on what a query's candidates look like -- distances that share their
+    leading bits, exact ties (id order), a few far outliers -- at list lengths either side of its small-list and
+    long-run fallbacks"""
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    rng = np.random.default_rng(33)
+    for n in (23, 24, 25, 100, 127, 128, 300, 511):
+        for spread in (1e-3, 1e-9, 0.0, 10.0):
+            base = 0.9 + spread * rng.random(n)
+            vals = [float(x) for x in base]
+            for _ in range(n // 6):  # exact ties
+                vals[int(rng.integers(n))] = vals[int(rng.integers(n))]
+            if n > 30 and spread == 1e-3:
+                vals[3], vals[7], vals[11] = -1e300, 1e300, math.nan
+            cands = [(int(i), -v, 0.0) for i, v in zip(rng.permutation(10 * n)[:n], vals)]  # IP: dist = -s0 = v
+            blk = _block(512, cands, n, IP)
+            ids, dist, cnt = merge_candidate_blocks(IP, 4, np.zeros(4, np.float32), n, None,
+                                                    np.frombuffer(blk, np.uint8), 1, 512)
+            key = lambda c: (math.isnan(c[1]), -c[1] if not math.isnan(c[1]) else 0.0, c[0])  # noqa: E731
+            want = sorted(cands, key=key)
+            assert cnt[0] == n and ids[0].tolist() == [c[0] for c in want], (n, spread)
+            for g, c in zip(dist[0], want):
+                assert (math.isnan(g) and math.isnan(c[1])) or g == -c[1]
+            # the cut: the k smallest of the same list
+            k = max(1, n // 3)
+            ids2, _, cnt2 = merge_candidate_blocks(IP, 4, np.zeros(4, np.float32), k, None,
+                                                   np.frombuffer(_block(512, cands, k, IP), np.uint8), 1, 512)
+            assert cnt2[0] == k and ids2[0].tolist() == [c[0] for c in want[:k]]
+
+
 def test_merge_reports_truncated_blocks(oracle_mod):
     from tostore_amd import _ffi
     from tostore_amd.sharded import merge_candidate_blocks

@@ -27,6 +27,7 @@ struct BatchCtx {
   int64_t bytes = 0;
   double last_gemm_us = 0, last_flops = 0;
   double last_wait_us = 0;  // how long the previous call waited for the GPU after enqueueing
+  std::vector<double> mag_a;  // per query of the current call: sum of q[i]^2 in element order
 };
 
 void batch_free(BatchCtx *b) {
@@ -124,7 +125,8 @@ int64_t batch_sample_rows(int64_t rows, int32_t k) {
 }
 
 // 2 * (error bound of the f32 MFMA key), absolute, per query
-bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2, float *out_qsq, float *out_qmax) {
+bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2, float *out_qsq, float *out_qmax,
+                  double *out_qn2 = nullptr) {
   double qn2 = 0;
   float qmax = 0.f;
   for (int i = 0; i < s->dim; ++i) {
@@ -134,6 +136,7 @@ bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2,
     qn2 += (double)q[i] * (double)q[i];
   }
   if (out_qmax) *out_qmax = qmax;
+  if (out_qn2) *out_qn2 = qn2;  // == query_mag_a(q): same terms, same order, one rounding per addition
   const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
   const double u2 = 1.1920928955078125e-07;        // 2^-23
   double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
@@ -262,12 +265,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
   std::vector<char> bad((size_t)nq, 0);
   std::vector<float> qmax((size_t)nq_pad, 0.f);
+  b->mag_a.resize((size_t)nq);  // the finaliser's sum of q[i]^2 (cosine), a by-product of the band computation
   parallel_for(nq_pad, [&](int32_t q) {
     float *dst = b->h_Q + (size_t)q * ld;
     if (q < nq) {
       memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
       for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
-      if (!batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q])) {
+      if (!batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q], &b->mag_a[(size_t)q])) {
         qmax[(size_t)q] = 0.f;
         bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
         memset(dst, 0, (size_t)ld * sizeof(float));
@@ -558,7 +562,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       }
     }
     const double t_c0 = now_us();
-    if (out->on_chunk) out->on_chunk(q0, q1, skip.data(), b->h_blocks);  // finalised straight from the pinned buffer
+    if (out->on_chunk) out->on_chunk(q0, q1, skip.data(), b->h_blocks, b->mag_a.data());  // finalised straight from the pinned buffer
     if (trace_batch()) fprintf(stderr, "[tsh batch]   chunk %d: event at %.0f us, finalised in %.0f us\n", c, t_c0 - t_enq, now_us() - t_c0);
     else if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
   }
@@ -627,8 +631,8 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
     part.extra = out->extra;
     part.q_base = out->q_base + q0;
     if (out->on_chunk)  // indices of the callback are the caller's: shift this part's
-      part.on_chunk = [out, q0, bb](int32_t a, int32_t b2, const char *skip, const uint8_t *base) {
-        out->on_chunk(q0 + a, q0 + b2, skip - q0, base - (size_t)q0 * bb);
+      part.on_chunk = [out, q0, bb](int32_t a, int32_t b2, const char *skip, const uint8_t *base, const double *mag_a) {
+        out->on_chunk(q0 + a, q0 + b2, skip - q0, base - (size_t)q0 * bb, mag_a - q0);
       };
     std::vector<int32_t> r;
     int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);

@@ -95,24 +95,100 @@ inline uint64_t dart_order_key(double d) {
 struct Hit {
   uint64_t key;  // dart_order_key(distance)
   int64_t id;
-  double dist;
 };
 inline bool hit_less(const Hit &a, const Hit &b) { return a.key != b.key ? a.key < b.key : a.id < b.id; }
-
-// Final per-candidate arithmetic of ngh_graph_engine.dart:908-946 given the
-// exact f64 sums; mag_a = sum q[i]*q[i] accumulated in element order.
-inline double final_distance(int metric, double s0, double s1, double mag_a) {
-  switch (metric) {
-    case TSH_METRIC_L2:
-      return std::sqrt(s0);  // :926
-    case TSH_METRIC_IP:
-      return -s0;  // :914
-    default: {
-      double denom = std::sqrt(mag_a) * std::sqrt(s1);  // :944
-      double sim = denom > 0 ? s0 / denom : 0;          // :945
-      return 1.0 - sim;                                 // :916
-    }
+// Ascending by (key, id).  A query's candidates are k plus a band's worth of rows whose distances share their
+// leading bits, and std::sort spends 3-4 us on 127 of them (two thirds of a query's finalisation, mostly
+// mispredicted branches): one counting pass over 512 buckets of the key RANGE (a shift, so the bucket is monotone in
+// the key) leaves runs of a few entries to put in order -- 1 us.  Ties, NaNs or a wild range only mean longer runs.
+inline void sort_hits(Hit *h, size_t n) {
+  constexpr int BITS = 9, NB = 1 << BITS;
+  if (n < 24 || n > 60000) {
+    std::sort(h, h + n, hit_less);
+    return;
   }
+  static thread_local std::vector<Hit> tmp;
+  static thread_local std::vector<uint16_t> bucket;
+  if (tmp.size() < n) {
+    tmp.resize(n);
+    bucket.resize(n);
+  }
+  uint64_t kmin = ~0ull, kmax = 0;
+  for (size_t i = 0; i < n; ++i) {
+    kmin = std::min(kmin, h[i].key);
+    kmax = std::max(kmax, h[i].key);
+  }
+  const uint64_t range = kmax - kmin;
+  const int shift = range < (uint64_t)NB ? 0 : (64 - __builtin_clzll(range)) - BITS;  // (range >> shift) < NB
+  uint16_t pos[NB + 1];
+  memset(pos, 0, sizeof(pos));
+  for (size_t i = 0; i < n; ++i) {
+    const uint16_t b = (uint16_t)((h[i].key - kmin) >> shift);
+    bucket[i] = b;
+    pos[b + 1]++;
+  }
+  for (int b = 0; b < NB; ++b) pos[b + 1] += pos[b];
+  for (size_t i = 0; i < n; ++i) tmp[pos[bucket[i]]++] = h[i];
+  size_t start = 0;
+  for (size_t i = 1; i <= n; ++i) {
+    if (i < n && ((tmp[i].key - kmin) >> shift) == ((tmp[start].key - kmin) >> shift)) continue;
+    const size_t len = i - start;  // a bucket's run
+    if (len > 12) {
+      std::sort(tmp.begin() + start, tmp.begin() + i, hit_less);
+    } else {
+      for (size_t a = start + 1; a < i; ++a) {
+        const Hit x = tmp[a];
+        size_t j = a;
+        for (; j > start && hit_less(x, tmp[j - 1]); --j) tmp[j] = tmp[j - 1];
+        tmp[j] = x;
+      }
+    }
+    start = i;
+  }
+  memcpy(h, tmp.data(), n * sizeof(Hit));
+}
+// the distance an order key stands for (every NaN comes back as the one quiet NaN)
+inline double dart_order_key_to_double(uint64_t key) {
+  if (key == ~0ull) return std::nan("");
+  const uint64_t b = (key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+
+// Final per-candidate arithmetic of ngh_graph_engine.dart:908-946 given the exact f64 sums (L2 :926 sqrt(s0);
+// IP :914 -s0; cosine :944-945,:916 1 - s0 / (sqrt(mag_a) * sqrt(s1)), similarity 0 when the denominator is not
+// positive), mag_a = sum q[i]*q[i] accumulated in element order --
+// over a whole list: a plain loop over arrays, so the compiler's vector square roots and
+// divisions (IEEE-exact, like the scalar ones; no contraction: -ffp-contract=off) do four or eight at a time on
+// hosts that have AVX2 / AVX-512 -- the square root and the division were a third of a query's finalisation.
+#define TSH_FINAL_KEYS_BODY                                                                   \
+  for (uint32_t i = 0; i < n; ++i) {                                                          \
+    const double s0 = e[i].s0, s1 = e[i].s1;                                                  \
+    double d;                                                                                 \
+    if (metric == TSH_METRIC_L2) {                                                            \
+      d = std::sqrt(s0);                                                                      \
+    } else if (metric == TSH_METRIC_IP) {                                                     \
+      d = -s0;                                                                                \
+    } else {                                                                                  \
+      const double denom = sqrt_mag_a * std::sqrt(s1);                                        \
+      const double sim = denom > 0 ? s0 / denom : 0;                                          \
+      d = 1.0 - sim;                                                                          \
+    }                                                                                         \
+    dist[i] = d;                                                                              \
+  }
+__attribute__((target("avx2"))) void final_distances_avx2(int metric, const BlockEntry *e, uint32_t n, double sqrt_mag_a,
+                                                          double *dist) {
+  TSH_FINAL_KEYS_BODY
+}
+void final_distances_base(int metric, const BlockEntry *e, uint32_t n, double sqrt_mag_a, double *dist) {
+  TSH_FINAL_KEYS_BODY
+}
+#undef TSH_FINAL_KEYS_BODY
+inline void final_distances(int metric, const BlockEntry *e, uint32_t n, double sqrt_mag_a, double *dist) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) final_distances_avx2(metric, e, n, sqrt_mag_a, dist);
+  else final_distances_base(metric, e, n, sqrt_mag_a, dist);
 }
 
 double query_mag_a(const float *q, int dim) {
@@ -123,39 +199,54 @@ double query_mag_a(const float *q, int dim) {
 }
 
 // threshold + order + cut of ngh_graph_engine.dart:127,133-134 over candidate
-// entries from any number of blocks
-int32_t finalize_query(int metric, int dim, const float *query, int32_t k, double thr,
-                       const std::vector<std::pair<const BlockEntry *, uint32_t>> &lists,
-                       int64_t *out_ids, double *out_dist) {
-  double mag_a = metric == TSH_METRIC_COSINE ? query_mag_a(query, dim) : 0.0;
+// entries from any number of blocks.  mag_a: query_mag_a(query) when the caller has it already (the batched path
+// computes it while it prepares the queries), else nullptr.
+typedef std::pair<const BlockEntry *, uint32_t> EntryList;
+int32_t finalize_query(int metric, int dim, const float *query, int32_t k, double thr, const EntryList *lists_p,
+                       size_t n_lists, int64_t *out_ids, double *out_dist, const double *mag_a_known = nullptr) {
+  struct {
+    const EntryList *b, *e;
+    const EntryList *begin() const { return b; }
+    const EntryList *end() const { return e; }
+  } lists{lists_p, lists_p + n_lists};
+  const double mag_a = metric != TSH_METRIC_COSINE ? 0.0 : (mag_a_known ? *mag_a_known : query_mag_a(query, dim));
+  const double sqrt_mag_a = std::sqrt(mag_a);
   static thread_local std::vector<Hit> hits;  // (one allocation per thread, not per query)
+  static thread_local std::vector<double> dist;
   hits.clear();
   size_t total = 0;
   for (auto &l : lists) total += l.second;
   hits.reserve(total);
-  for (auto &l : lists)
+  const bool has_thr = !std::isnan(thr);
+  for (auto &l : lists) {
+    if (dist.size() < l.second) dist.resize(l.second);
+    final_distances(metric, l.first, l.second, sqrt_mag_a, dist.data());
     for (uint32_t i = 0; i < l.second; ++i) {
-      const BlockEntry &e = l.first[i];
-      double d = final_distance(metric, e.s0, e.s1, mag_a);
-      if (!std::isnan(thr) && d > thr) continue;
-      hits.push_back({dart_order_key(d), e.id, d});
+      const double d = dist[i];
+      if (has_thr && d > thr) continue;
+      hits.push_back({dart_order_key(d), l.first[i].id});
     }
+  }
   size_t r = std::min<size_t>(hits.size(), (size_t)std::max(k, 0));
-  if (hits.size() <= 4 * r) {  // the usual case (k + a band's worth of candidates): one plain sort is cheapest
-    std::sort(hits.begin(), hits.end(), hit_less);
+  if (hits.size() <= 4 * r) {  // the usual case (k + a band's worth of candidates): one sort is cheapest
+    sort_hits(hits.data(), hits.size());
   } else {
     std::nth_element(hits.begin(), hits.begin() + r, hits.end(), hit_less);
     std::sort(hits.begin(), hits.begin() + r, hit_less);
   }
   for (size_t i = 0; i < r; ++i) {
     out_ids[i] = hits[i].id;
-    out_dist[i] = hits[i].dist;
+    out_dist[i] = dart_order_key_to_double(hits[i].key);
   }
   for (size_t i = r; i < (size_t)std::max(k, 0); ++i) {  // unused slots read as "no row" (callers need not pre-fill)
     out_ids[i] = -1;
     out_dist[i] = std::nan("");
   }
   return (int32_t)r;
+}
+inline int32_t finalize_query(int metric, int dim, const float *query, int32_t k, double thr,
+                              const std::vector<EntryList> &lists, int64_t *out_ids, double *out_dist) {
+  return finalize_query(metric, dim, query, k, thr, lists.data(), lists.size(), out_ids, out_dist);
 }
 
 // ---- kernel dispatch ---------------------------------------------------------
@@ -1190,7 +1281,8 @@ struct SearchOut {
   // still re-ranks the next chunk; query q's block is at base + q * block bytes (the batch's own pinned buffer:
   // valid during the call only -- with a callback the blocks are NOT copied to h_blocks); skip[q] != 0 marks
   // queries the single-query path will redo (those do land in h_blocks)
-  std::function<void(int32_t q0, int32_t q1, const char *skip, const uint8_t *base)> on_chunk;
+  // (mag_a[q]: query_mag_a of query q, computed while the queries were prepared)
+  std::function<void(int32_t q0, int32_t q1, const char *skip, const uint8_t *base, const double *mag_a)> on_chunk;
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1639,17 +1731,17 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
     so.spill = &spills[g];
     so.extra = &extras[g];
     if (ns == 1)  // batched path: finalise a chunk of queries while the GPU still works on the next one
-      so.on_chunk = [&](int32_t q0, int32_t q1, const char *skip, const uint8_t *base) {
+      so.on_chunk = [&](int32_t q0, int32_t q1, const char *skip, const uint8_t *base, const double *mag_a) {
         parallel_for_range(q0, q1, [&](int32_t q) {
           if (skip[q]) return;
           const uint8_t *b = base + (size_t)q * bb;
           const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b);
-          std::vector<std::pair<const BlockEntry *, uint32_t>> one{
-              {reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)), std::min(h->count, h->entries)}};
           const std::vector<BlockEntry> &ex = extras[0][(size_t)q];
-          if (!ex.empty()) one.push_back({ex.data(), (uint32_t)ex.size()});
-          out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, one,
-                                        out_ids + (size_t)q * k, out_dist + (size_t)q * k);
+          const EntryList two[2] = {
+              {reinterpret_cast<const BlockEntry *>(b + sizeof(BlockHeader)), std::min(h->count, h->entries)},
+              {ex.data(), (uint32_t)ex.size()}};
+          out_count[q] = finalize_query(idx->metric, idx->dim, queries + (size_t)q * idx->dim, k, thr, two,
+                                        ex.empty() ? 1 : 2, out_ids + (size_t)q * k, out_dist + (size_t)q * k, mag_a + q);
           finalized[(size_t)q] = 1;
         });
       };
