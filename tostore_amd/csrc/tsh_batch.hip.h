@@ -890,56 +890,65 @@ __device__ __forceinline__ void rerank_lane_sums(const float *__restrict__ rp, c
   *out_s1 = metric == METRIC_COS ? s1 : 0.0;
 }
 
-// K4 over a batch.  One wave = RG candidates of ONE query.  The chains are serial per candidate, so a candidate
-// still belongs to one lane -- but a lane that streams its own row keeps only two 128-byte lines in flight and
-// waits out HBM latency a dozen times in a row (57 us per 256-query chunk; its 100 MB need 22).  Here the WAVE
-// loads: one instruction brings 1 KiB of one candidate's row (64 lanes x 16 B, coalesced), RG of them are in
-// flight, an LDS tile turns "lane = column" into "lane = candidate", and while lanes 0..RG-1 walk their chains
-// over the tile the next RG KiB are already on their way.  Eight times as many waves per chunk as with 64
-// candidates per wave, so the chunk's traffic is spread over the whole chip.  (f64 add / mul / fma / cvt all
-// issue at one per ~4.5 cycles whatever the number of active lanes -- tools/micro/f64_rate.hip -- so the chain
-// costs what its instruction count says: it is kept to cvt + fma per term, with the query converted once.)
+// K4 over a batch.  One workgroup (four waves) = RG candidates of ONE query.  The chains are serial per candidate,
+// so a candidate still belongs to one lane -- but a lane that streams its own row keeps only two 128-byte lines in
+// flight and waits out HBM latency a dozen times in a row.  Here the WAVES load: one instruction brings 1 KiB of
+// one candidate's row (64 lanes x 16 B, coalesced), each wave keeps 16 of them in flight, an LDS tile turns
+// "lane = column" into "lane = candidate", and while wave 0 walks the 64 chains over the tile (all 64 lanes busy)
+// the next 64 KiB are already on their way.
+// Measured per 256-query chunk of config C3 (32.5 k candidates, 100 MB of rows): a lane per row 57 us; this shape
+// 55 us, of which the loads alone take 22, the chains ~14 per workgroup (4.8 us per 256-float block: two LDS reads
+// of the tile and four of the query per eight terms keep the one chain wave waiting), the entries' stores to pinned
+// host memory ~13.  (f64 add / mul / fma / cvt issue at one per ~4.5 cycles whatever the number of active lanes --
+// tools/micro/f64_rate.hip -- so 16 candidates per chain wave cost four times the instructions: 60 us.  The query
+// as f64 scalar operands from global memory instead of LDS: 89 us, the scalar cache misses.)
 //
 // Arithmetic, bit for bit that of rerank_kernel / the oracle (vs_exact_sums): every term is added in dimension
 // order with one rounding per addition.  For IP and cosine the product of two f32 values is exact in f64 (24 + 24
 // significand bits), so fma(q, b, s) rounds exactly what s + q * b rounds; L2's (q - b)^2 is not exact and keeps its
 // separate multiply.
-constexpr int RG = 16;              // candidates per wave
+constexpr int RG = 64;              // candidates per workgroup
+constexpr int RG_WAVES = 4;         // loading waves (16 rows each); wave 0 also walks the chains
+constexpr int RG_ROWS = RG / RG_WAVES;
 constexpr int RG_BLK = 256;         // floats of a row per load instruction
-constexpr int RG_LD = RG_BLK + 4;   // LDS row stride in floats: rows 4 banks apart, RG rows cover the 64 banks
+constexpr int RG_LD = RG_BLK + 4;   // LDS row stride in floats: rows 4 banks apart, 16 rows cover the 64 banks
 
-__global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
+__global__ void __launch_bounds__(64 * RG_WAVES) rerank_batch_kernel(RerankBatchArgs a) {
 #pragma clang fp contract(off)
   __shared__ __attribute__((aligned(16))) float tile[RG * RG_LD];
   __shared__ __attribute__((aligned(16))) double s_q[RG_BLK];  // the query's current block, as f64
   __shared__ uint32_t stage[6 * RG];
-  const int lane = threadIdx.x, q = a.q0 + (int)blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = a.q0 + (int)blockIdx.y;
   uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
   uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
   if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
   const uint32_t c0 = blockIdx.x * (uint32_t)RG;
   if (c0 >= count) return;
   const uint32_t left = count - c0;  // >= 1
-  // lane j < RG holds candidate c0 + j (idle lanes and slots past the list repeat the last candidate)
-  const uint32_t slot = (uint32_t)(lane & (RG - 1)) < left ? (uint32_t)(lane & (RG - 1)) : left - 1u;
+  // lane c of a wave holds candidate c0 + c (slots past the list repeat the last candidate)
+  const uint32_t slot = (uint32_t)lane < left ? (uint32_t)lane : left - 1u;
   const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
-  const float *rbase[RG];
+  const float *rbase[RG_ROWS];  // this wave's rows (wave-uniform)
 #pragma unroll
-  for (int j = 0; j < RG; ++j)
-    rbase[j] = a.rows + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_row, j) * a.ld;  // wave-uniform
+  for (int j = 0; j < RG_ROWS; ++j) {
+    const uint32_t r = (uint32_t)__shfl((int)my_row, wave * RG_ROWS + j);
+    rbase[j] = a.rows + (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)r) * a.ld;
+  }
   const float *qp = a.Q + (int64_t)q * a.ld;
   const int ld = (int)a.ld, dim = a.dim;
   const int nblk = (dim + RG_BLK - 1) / RG_BLK;
 
-  f32x4 in[RG], qin;
+  f32x4 in[RG_ROWS], qin;
   auto fetch = [&](int b) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
     const int o = b * RG_BLK + 4 * lane < ld - 4 ? b * RG_BLK + 4 * lane : ld - 4;
 #pragma unroll
-    for (int j = 0; j < RG; ++j) in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase[j] + o));
+    for (int j = 0; j < RG_ROWS; ++j) in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase[j] + o));
     qin = *reinterpret_cast<const f32x4 *>(qp + o);
   };
   double s0 = 0.0, s1 = 0.0;
-  const float *trow = tile + (lane & (RG - 1)) * RG_LD;
+  const float *trow = tile + lane * RG_LD;
   auto chain = [&](auto METRIC, int b) {
     constexpr int M = decltype(METRIC)::value;
     const int m = dim - b * RG_BLK < RG_BLK ? dim - b * RG_BLK : RG_BLK;  // wave-uniform
@@ -953,9 +962,10 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
         if (M == METRIC_COS) s1 = __builtin_fma(bd, bd, s1);
       }
     };
-    // groups of 8 terms, the next group's LDS reads issued before this group's arithmetic
-    f32x4 v[2], nv[2];
-    double qd[8], nqd[8];
+    // groups of 8 terms, the next group's LDS reads issued before this group's arithmetic; two register sets
+    // take turns (copying one into the other doubled the chain's instruction count)
+    f32x4 va[2], vb[2];
+    double qa[8], qb[8];
     auto read = [&](f32x4 (&dv)[2], double (&dq)[8], int g) {
       const int o = 8 * g < RG_BLK - 8 ? 8 * g : RG_BLK - 8;
 #pragma unroll
@@ -968,47 +978,52 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
         dq[2 * u + 1] = t[1];
       }
     };
-    const int ng = m >> 3;
-    read(v, qd, 0);
-    for (int g = 0; g < ng; ++g) {
-      read(nv, nqd, g + 1);
-      __builtin_amdgcn_sched_barrier(0);
+    auto terms = [&](const f32x4 (&dv)[2], const double (&dq)[8]) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) term(qd[4 * u + e], v[u][e]);
+        for (int e = 0; e < 4; ++e) term(dq[4 * u + e], dv[u][e]);
+    };
+    const int ng = m >> 3;
+    read(va, qa, 0);
+    int g = 0;
+    for (; g + 1 < ng; g += 2) {
+      read(vb, qb, g + 1);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) v[u] = nv[u];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) qd[u] = nqd[u];
+      terms(va, qa);
+      __builtin_amdgcn_sched_barrier(0);
+      read(va, qa, g + 2);  // (past the block: a clamped re-read, unused)
+      __builtin_amdgcn_sched_barrier(0);
+      terms(vb, qb);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (g < ng) terms(va, qa);
     for (int i = 8 * ng; i < m; ++i) term(s_q[i], trow[i]);
   };
   fetch(0);
   for (int b = 0; b < nblk; ++b) {
 #pragma unroll
-    for (int j = 0; j < RG; ++j) *reinterpret_cast<f32x4 *>(tile + j * RG_LD + 4 * lane) = in[j];
-    {
+    for (int j = 0; j < RG_ROWS; ++j)
+      *reinterpret_cast<f32x4 *>(tile + (wave * RG_ROWS + j) * RG_LD + 4 * lane) = in[j];
+    if (wave == 0) {
       __attribute__((ext_vector_type(2))) double d01, d23;
       d01[0] = (double)qin[0], d01[1] = (double)qin[1], d23[0] = (double)qin[2], d23[1] = (double)qin[3];
       *reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(s_q + 4 * lane) = d01;
       *reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(s_q + 4 * lane + 2) = d23;
     }
     fetch(b + 1);  // (past the last block: clamped re-reads of cached lines)
-    asm volatile("" ::: "memory");  // (one wave, LDS in program order: only the compiler must not reorder)
-    __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
-    if (lane < RG) {
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the barrier and the chains, not sunk below them
+    __syncthreads();
+    if (wave == 0) {
       if (a.metric == METRIC_L2) chain(std::integral_constant<int, METRIC_L2>{}, b);
       else if (a.metric == METRIC_COS) chain(std::integral_constant<int, METRIC_COS>{}, b);
       else chain(std::integral_constant<int, METRIC_IP>{}, b);
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // the tile is free again
   }
-  // entries: 24 bytes each, RG of them contiguous -- staged in LDS and stored as whole dwords side by side (the
-  // entries usually live in pinned host memory: three strided 8-byte stores per lane cost 12 us per chunk)
-  if (lane < RG) {
+  if (wave != 0) return;
+  // entries: 24 bytes each, RG of them contiguous -- staged in LDS and stored as whole dwords side by side
+  {
     const int64_t id = a.row_base + (int64_t)my_row;
     const double e1 = a.metric == METRIC_COS ? s1 : 0.0;
     stage[6 * lane + 0] = (uint32_t)id;
@@ -1018,12 +1033,13 @@ __global__ void __launch_bounds__(64) rerank_batch_kernel(RerankBatchArgs a) {
     stage[6 * lane + 4] = (uint32_t)__double2loint(e1);
     stage[6 * lane + 5] = (uint32_t)__double2hiint(e1);
   }
-  asm volatile("" ::: "memory");
+  asm volatile("" ::: "memory");  // (one wave, LDS in program order: only the compiler must not reorder)
   static_assert(sizeof(BlockEntry) == 24, "entry layout");
   uint32_t *outw = reinterpret_cast<uint32_t *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader)) + 6 * (int64_t)c0;
   const uint32_t nw = 6u * (left < (uint32_t)RG ? left : (uint32_t)RG);
-  if ((uint32_t)lane < nw) outw[lane] = stage[lane];
-  if ((uint32_t)lane + 64u < nw) outw[lane + 64] = stage[lane + 64];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if ((uint32_t)(lane + 64 * i) < nw) outw[lane + 64 * i] = stage[lane + 64 * i];
 }
 
 }  // namespace tsh

@@ -501,7 +501,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
       rb.q0 = q0;
-      rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64, 0, st>>>(rb);
+      rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64 * RG_WAVES, 0, st>>>(rb);
       if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
         QuarAppendArgs qa{};
         qa.rows = s->d_rows;
