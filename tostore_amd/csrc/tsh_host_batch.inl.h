@@ -327,6 +327,15 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
 
   const double t_prep = now_us();
   int n_chunks = 1;
+  // chunk c of the tail = queries [chunk_q(c), chunk_q(c + 1)): the last chunk is the small one -- its finalisation
+  // is all that is left to do on the host once the GPU is done
+  auto chunk_q = [&](int c) -> int32_t {
+    static const int cut4[5] = {0, 31, 62, 87, 100}, cut2[3] = {0, 60, 100};
+    if (c <= 0) return 0;
+    if (c >= n_chunks) return nq;
+    const int pct = n_chunks == 4 ? cut4[c] : (n_chunks == 2 ? cut2[c] : 100 * c / n_chunks);
+    return (int32_t)((int64_t)nq * pct / 100);
+  };
   // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
   {
     hipStream_t st = s->batch_stream;
@@ -499,7 +508,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     // host-memory stores to land doubled it.)
     n_chunks = !out->on_chunk ? 1 : (nq >= 512 ? 4 : (nq >= 256 ? 2 : 1));  // (256 queries: 1.00 -> 0.94 ms; 128: no gain)
     for (int c = 0; c < n_chunks; ++c) {
-      const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
+      const int32_t q0 = chunk_q(c), q1 = chunk_q(c + 1);
       rb.q0 = q0;
       rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64 * RG_WAVES, 0, st>>>(rb);
       if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
@@ -540,7 +549,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     hold.reset(new HostPool::Hold());
   }
   for (int c = 0; c < n_chunks; ++c) {
-    const int32_t q0 = (int32_t)((int64_t)nq * c / n_chunks), q1 = (int32_t)((int64_t)nq * (c + 1) / n_chunks);
+    const int32_t q0 = chunk_q(c), q1 = chunk_q(c + 1);
     HIPCHK(hipEventSynchronize(c + 1 < n_chunks ? b->e_chunk[c] : b->e_done));
     if (c == 0) b->last_wait_us = now_us() - t_enq;
     if (c + 1 == n_chunks) {
