@@ -1091,6 +1091,9 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       ts = s->tail_stream;
       HIPCHK(hipStreamWaitEvent(ts, ev.stop, 0));
     }
+    // (short rows and lists, config C1: K2 + K4 as ONE dispatch, the selecting workgroup re-ranking its dozen
+    // candidates a lane each, was tried -- 17 us against 9 + 4.4 for the two launches: the lone workgroup waits out
+    // count -> candidate ids -> rows one after the other, which the second launch's ramp-up hides)
     launch_select(se, n_tiles, ts);
     rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
     if (!j->quar_sel.empty() && dev_target) {
