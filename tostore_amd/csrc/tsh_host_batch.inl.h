@@ -544,7 +544,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // From the end of the key passes on the pool gets a job every few dozen microseconds (one per chunk of the tail):
   // the long wait blocks, then the workers are woken and poll until the call is over
   std::unique_ptr<HostPool::Hold> hold;
-  if (out->on_chunk && nq >= 64) {
+  if (out->on_chunk && nq >= 24) {
     HIPCHK(hipEventSynchronize(b->e3));
     hold.reset(new HostPool::Hold());
   }

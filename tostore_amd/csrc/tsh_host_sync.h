@@ -230,7 +230,7 @@ class HostPool {
 
 template <typename F>
 void parallel_for(int32_t n, F fn) {
-  if (n >= 64) {
+  if (n >= 24) {  // (below that the calling thread is done before the workers are up)
     std::function<void(int32_t)> f = fn;
     if (HostPool::get().run(n, f)) return;
   }

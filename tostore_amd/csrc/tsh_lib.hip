@@ -1768,7 +1768,9 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
       return rcs[g];
     }
   const double t_shards = now_us();
-  parallel_for(nq, [&](int32_t q) {
+  // (the batched path's chunk callback has usually done everything: waking the pool for nothing cost 30-50 us)
+  const bool all_done = std::find(finalized.begin(), finalized.end(), (char)0) == finalized.end();
+  if (!all_done) parallel_for(nq, [&](int32_t q) {
     if (finalized[(size_t)q]) return;
     std::vector<std::pair<const BlockEntry *, uint32_t>> lists;
     for (size_t g = 0; g < ns; ++g) {
