@@ -571,9 +571,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       }
     }
     const double t_c0 = now_us();
-    if (out->on_chunk) out->on_chunk(q0, q1, skip.data(), b->h_blocks, b->mag_a.data());  // finalised straight from the pinned buffer
+    if (out->on_chunk) {
+      out->on_chunk(q0, q1, skip.data(), b->h_blocks, b->mag_a.data());  // finalised straight from the pinned buffer
+      // (queries the single-query path will redo write their blocks to out->h_blocks themselves)
+    } else if (out->h_blocks) {
+      memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
+    }
     if (trace_batch()) fprintf(stderr, "[tsh batch]   chunk %d: event at %.0f us, finalised in %.0f us\n", c, t_c0 - t_enq, now_us() - t_c0);
-    else if (out->h_blocks) memcpy(out->h_blocks + (size_t)q0 * bb, b->h_blocks + (size_t)q0 * bb, (size_t)(q1 - q0) * bb);
   }
   float ms0 = 0.f, ms1 = 0.f;
   HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
