@@ -384,7 +384,7 @@ struct Ctx {
 struct DeviceStreams {
   hipStream_t ingest = nullptr;
   hipStream_t scan = nullptr, scan2 = nullptr;  // pipeline streams (240-CU mask when cu_split)
-  hipStream_t tail = nullptr;                   // the other 16 CUs
+  hipStream_t tail = nullptr, tail2 = nullptr;  // the other 16 CUs (two queues: the tails of consecutive queries overlap)
   hipStream_t batch = nullptr;                  // unmasked: matrix-core batches
   hipStream_t aux = nullptr;                    // rare synchronous work (fallback filter, bench hooks)
   bool cu_split = false;
@@ -437,7 +437,8 @@ struct Shard {
   // When several queries are in flight, a query's select + rerank run here, on
   // CUs the scan stream's CU mask leaves free (2 per XCD), so they overlap the
   // next query's scan without queueing behind its loads on the same CU.
-  hipStream_t tail_stream = nullptr;
+  hipStream_t tail_stream = nullptr, tail_stream2 = nullptr;
+  uint64_t tail_seq = 0;  // guarded by scan_mu
   bool cu_split = false;
   hipStream_t batch_stream = nullptr;  // matrix-core batches: compute-bound, so all CUs (no mask)
   std::mutex *scan_mu = nullptr;  // the device's (DeviceStreams): streams are shared by its shards
@@ -487,7 +488,7 @@ static void destroy_masked_streams_at_exit() {
   for (auto &kv : *g_stream_sets) {
     DeviceStreams *ds = kv.second;
     if (!ds->cu_split || hipSetDevice(kv.first) != hipSuccess) continue;
-    for (hipStream_t *st : {&ds->scan, &ds->scan2, &ds->tail})
+    for (hipStream_t *st : {&ds->scan, &ds->scan2, &ds->tail, &ds->tail2})
       if (*st) {
         (void)hipStreamSynchronize(*st);
         (void)hipStreamDestroy(*st);
@@ -527,13 +528,15 @@ DeviceStreams *device_streams(int device) {
     tail_mask[0] = 0x0000FFFFu;
     if (hipExtStreamCreateWithCUMask(&ds->scan, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
         hipExtStreamCreateWithCUMask(&ds->scan2, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
-        hipExtStreamCreateWithCUMask(&ds->tail, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
+        hipExtStreamCreateWithCUMask(&ds->tail, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess &&
+        hipExtStreamCreateWithCUMask(&ds->tail2, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
       ds->cu_split = true;
     } else {
       if (ds->scan) (void)hipStreamDestroy(ds->scan);
       if (ds->scan2) (void)hipStreamDestroy(ds->scan2);
       if (ds->tail) (void)hipStreamDestroy(ds->tail);
-      ds->scan = ds->scan2 = ds->tail = nullptr;
+      if (ds->tail2) (void)hipStreamDestroy(ds->tail2);
+      ds->scan = ds->scan2 = ds->tail = ds->tail2 = nullptr;
       (void)hipGetLastError();
     }
   }
@@ -552,6 +555,7 @@ int shard_init(Shard *s) {
   s->scan_stream = ds->scan;
   s->scan_stream2 = ds->scan2;
   s->tail_stream = ds->tail;
+  s->tail_stream2 = ds->tail2;
   s->batch_stream = ds->batch;
   s->aux_stream = ds->aux;
   s->cu_split = ds->cu_split;
@@ -1088,7 +1092,10 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     launch_scan(sa, s->nch, s->metric, j->masked, ps, ev);
     hipStream_t ts = ps;
     if (overlap) {
-      ts = s->tail_stream;
+      // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
+      // scans -- selective masks, small shards -- were then limited by)
+      static const bool one_tail = getenv("TSH_ONE_TAIL") != nullptr && getenv("TSH_ONE_TAIL")[0] == '1';
+      ts = (!one_tail && s->tail_stream2 && (s->tail_seq++ & 1)) ? s->tail_stream2 : s->tail_stream;
       HIPCHK(hipStreamWaitEvent(ts, ev.stop, 0));
     }
     // (short rows and lists, config C1: K2 + K4 as ONE dispatch, the selecting workgroup re-ranking its dozen
