@@ -1367,7 +1367,11 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
     if (rows_est == 0) rows_est = 1;
   }
   const uint64_t *mw = mask ? mask_words.data() : nullptr;
-  const int T = std::min(SUBMIT_THREADS, nq / 8);
+  // short scans (small shards, selective masks) are bound by the submitting thread's ~25 us per query: two threads
+  const int64_t scan_bytes = (rows_est > 0 ? rows_est : s->rows) * s->ld * 4;
+  static const int forced_threads = getenv("TSH_SUBMIT_THREADS") ? atoi(getenv("TSH_SUBMIT_THREADS")) : 0;
+  const int want = forced_threads > 0 ? forced_threads : (scan_bytes <= (160ll << 20) ? 2 : SUBMIT_THREADS);
+  const int T = std::min(want, nq / 8);
   if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est);
   std::vector<int> rcs((size_t)T, TSH_OK);
   std::vector<std::string> errs((size_t)T);
