@@ -142,6 +142,28 @@ def test_batched_mixed_bad_query_and_small_index(hip_lib, oracle_mod):
         assert idx.counters()["batch_launches"] == 0
 
 
+@pytest.mark.parametrize("metric", [L2, COS])
+@pytest.mark.parametrize("k", [1, 2, 63, 64, 65, 255])
+def test_batched_clustered_keys_and_k_edges(hip_lib, oracle_mod, metric, k):
+    """rows drawn around a few dozen centres: the pre-filter keys of a query bunch into a few narrow groups (the
+    workgroup-wide radix select of the sample / final select kernels sees bytes where nearly every key agrees and
+    bytes where they spread), at k either side of the wave and list sizes those kernels step through"""
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq = 40, 30000, 24
+    rng = np.random.default_rng(77 + k)
+    centres = rng.standard_normal((48, d)).astype(np.float32)
+    rows = (centres[rng.integers(0, 48, n)] + 2e-3 * rng.standard_normal((n, d))).astype(np.float32)
+    rows[::997] = centres[0]  # a sprinkle of exact duplicates
+    qs = _queries(oracle_mod, nq, d, 78, metric)
+    qs[:8] = (centres[:8] + 1e-3 * rng.standard_normal((8, d))).astype(np.float32)  # queries inside a cluster
+    if metric == COS:
+        qs = np.stack([oracle_mod.normalize_f32(q) for q in qs])
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        _check_batch(oracle_mod, idx, rows, qs, metric, k, tag=f"clustered k{k}")
+
+
 @pytest.mark.parametrize("k", [300, 1000])
 def test_batched_large_k(hip_lib, oracle_mod, k):
     """k above the thread count of the per-query select kernels (group minima, 4 per thread)."""
