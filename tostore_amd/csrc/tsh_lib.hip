@@ -1102,7 +1102,15 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     // candidates a lane each, was tried -- 17 us against 9 + 4.4 for the two launches: the lone workgroup waits out
     // count -> candidate ids -> rows one after the other, which the second launch's ramp-up hides)
     launch_select(se, n_tiles, ts);
-    rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
+    // the completion event rides on the re-rank's own dispatch packet unless more kernels follow (a separate
+    // hipEventRecord is one more runtime call and one more barrier packet per query)
+    bool done_recorded = false;
+    if (j->quar_sel.empty()) {
+      hipExtLaunchKernelGGL(rerank_kernel, dim3((unsigned)std::min(entries, 1024)), dim3(64), 0, ts, nullptr, c->ev_done, 0, ra);
+      done_recorded = true;
+    } else {
+      rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
+    }
     if (!j->quar_sel.empty() && dev_target) {
       launch_quarantine_append(s, c, j, ts);
     } else if (!j->quar_sel.empty()) {
@@ -1119,7 +1127,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       qa.metric = s->metric;
       quarantine_kernel<<<dim3((unsigned)((s->quar_ids.size() + 63) / 64), 1), 64, 0, ts>>>(qa);
     }
-    HIPCHK(hipEventRecord(c->ev_done, ts));
+    if (!done_recorded) HIPCHK(hipEventRecord(c->ev_done, ts));
   }
   s->c_scans++;
   return TSH_OK;
