@@ -135,3 +135,73 @@ def test_c5_row_mask_full_size(corpora, oracle_mod, keep):
             kept_of_full = [r for r in full[0][i].tolist() if bits[r]]
             assert kept_of_full == got[0][i][:len(kept_of_full)].tolist()
         assert idx.counters()["fallback_searches"] == 0
+
+
+def test_c4_two_of_eight_shards_at_size(hip_lib, oracle_mod):
+    """C4 (10 M x 1536 f32, inner product, k = 100, rows split over 8 GPUs): TWO of the eight row-range shards at
+    their real size (1.25 M x 1536 each, 7.7 GB), both on the one GPU of the test box, through the entry points a
+    rank uses -- tsh_index_create_shard with global row ids, tsh_search_shard into device candidate blocks,
+    tsh_merge_candidates over the concatenated blocks (what the all-gather delivers).  The oracle answers a few
+    queries over the 2.5 M rows; the rest is held to: pipelined scans == matrix-core batch, bit for bit."""
+    import ctypes
+
+    import torch
+
+    from tostore_amd import HipVectorIndex, _ffi
+    from tostore_amd.sharded import merge_candidate_blocks
+
+    L = _ffi.lib()
+    d, per, k, ip = 1536, 1_250_000, 100, 1
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260614)
+    shards, hosts = [], []
+    try:
+        for r in range(2):
+            x = torch.empty((per, d), dtype=torch.float32, device=dev)
+            for s in range(0, per, 65536):
+                e = min(per, s + 65536)
+                t = torch.randn((e - s, d), generator=g, device=dev)
+                t /= t.norm(dim=1, keepdim=True)
+                t *= torch.rand((e - s, 1), generator=g, device=dev) * 1.5 + 0.5
+                x[s:e] = t
+            torch.cuda.synchronize()
+            idx = HipVectorIndex(d, ip, capacity_rows=per, shard_device=0, row_base=r * per)
+            torch.cuda.synchronize()
+            idx.append_device(r * per, per, x.data_ptr())
+            torch.cuda.synchronize()
+            shards.append(idx)
+            hosts.append(x.cpu().numpy())
+            del x
+            torch.cuda.empty_cache()
+        rng = np.random.default_rng(3)
+        nq = 12
+        qs = rng.standard_normal((nq, d)).astype(np.float32)
+        qs /= np.linalg.norm(qs, axis=1, keepdims=True).astype(np.float32)
+        qs[0] = hosts[1][per - 1]  # the last row of the second shard: finds itself first (largest inner product
+        qs[0] *= np.float32(4.0)   # with itself among unit-direction rows of norm < 2 needs a long query: scaled)
+        entries = L.tsh_default_block_entries(k)
+        bb = L.tsh_candidate_block_bytes(entries)
+
+        def answer(batch_min_nq):
+            bufs = []
+            for idx in shards:
+                idx.set_batch_min_nq(batch_min_nq)
+                buf = torch.empty(nq * bb, dtype=torch.uint8, device="cuda")
+                _ffi.check(L.tsh_search_shard(idx._h, qs.ctypes.data_as(_ffi.p_f32), nq, k, None, entries,
+                                              ctypes.c_void_p(buf.data_ptr()), None))
+                bufs.append(buf)
+            return merge_candidate_blocks(ip, d, qs, k, None, torch.cat(bufs).cpu().numpy(), 2, entries)
+
+        scans = answer(0)    # every query its own HBM scan of each shard
+        batch = answer(2)    # all twelve in one matrix-core pass per shard
+        assert _same(scans, batch), "pipelined scans vs batched path over two shards"
+        assert shards[0].counters()["batch_launches"] >= 1
+        rows = np.concatenate(hosts)
+        del hosts
+        ref = oracle_mod.search_heap_many_mt(rows, qs[:4], ip, k)
+        assert _same(tuple(x[:4] for x in scans), ref), "two merged shards vs oracle over 2.5 M x 1536"
+        assert scans[0][0][0] == 2 * per - 1  # global id of the stored row, from the shard with row_base = 1.25 M
+    finally:
+        for idx in shards:
+            idx.close()
