@@ -645,45 +645,46 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   // 2048 strided groups (8 per thread): k distinct groups hold an entry <= the k-th
   // smallest group minimum, so that minimum bounds the k-th smallest entry; about
   // G ln(G / (G - k)) entries lie at or below it (1420 at k = 1024)
-  uint32_t lmin[BS_GPT];
-#pragma unroll
-  for (int u = 0; u < BS_GPT; ++u) lmin[u] = KEY_DEAD;
   // 16-byte loads when the list is 16-byte aligned (the dense sample rows and the candidate lists are): four
   // consecutive entries then share a group, which is as good a partition as any
   const bool vec = (reinterpret_cast<uintptr_t>(keys) & 15) == 0;
   const int n4 = vec ? n >> 2 : 0;
   const f32x4 *keys4 = reinterpret_cast<const f32x4 *>(keys);
-  for (int base = 0; base < n4; base += BS_GROUPS) {
+  // a list that fits the LDS list whole (B2's candidate lists, small samples) needs no bound first: no first pass
+  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_GROUPS / 2 && n > BS_LIST;
+  if (narrow) {  // (workgroup-uniform)
+    uint32_t lmin[BS_GPT];
 #pragma unroll
-    for (int u = 0; u < BS_GPT; ++u) {
-      int i = base + u * THREADS + tid;
-      if (i < n4) {
-        const f32x4 f = keys4[i];
+    for (int u = 0; u < BS_GPT; ++u) lmin[u] = KEY_DEAD;
+    for (int base = 0; base < n4; base += BS_GROUPS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t x = fkey_or_dead(f[e]);
+      for (int u = 0; u < BS_GPT; ++u) {
+        int i = base + u * THREADS + tid;
+        if (i < n4) {
+          const f32x4 f = keys4[i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t x = fkey_or_dead(f[e]);
+            lmin[u] = x < lmin[u] ? x : lmin[u];
+          }
+        }
+      }
+    }
+    for (int base = 4 * n4; base < n; base += BS_GROUPS) {
+#pragma unroll
+      for (int u = 0; u < BS_GPT; ++u) {
+        int i = base + u * THREADS + tid;
+        if (i < n) {
+          uint32_t x = fkey_or_dead(keys[i]);
           lmin[u] = x < lmin[u] ? x : lmin[u];
         }
       }
     }
-  }
-  for (int base = 4 * n4; base < n; base += BS_GROUPS) {
 #pragma unroll
-    for (int u = 0; u < BS_GPT; ++u) {
-      int i = base + u * THREADS + tid;
-      if (i < n) {
-        uint32_t x = fkey_or_dead(keys[i]);
-        lmin[u] = x < lmin[u] ? x : lmin[u];
-      }
-    }
-  }
-  const bool narrow = (uint32_t)n >= k && k <= (uint32_t)BS_GROUPS / 2 && n > BS_LIST;
-#pragma unroll
-  for (int u = 0; u < BS_GPT; ++u) sc->lm[u * THREADS + tid] = lmin[u];
-  __syncthreads();
-  if (narrow) {  // (workgroup-uniform)
-    const uint32_t U = block_kth_radix<THREADS>(sc->lm, (uint32_t)BS_GROUPS, k, &sc->rs);
-    if (tid == 0) sc->U = U;
+    for (int u = 0; u < BS_GPT; ++u) sc->lm[u * THREADS + tid] = lmin[u];
+    __syncthreads();
+    const uint32_t Ub = block_kth_radix<THREADS>(sc->lm, (uint32_t)BS_GROUPS, k, &sc->rs);
+    if (tid == 0) sc->U = Ub;
   }
   __syncthreads();
   const uint32_t U = sc->U;
