@@ -223,9 +223,17 @@ def search_heap_many_mt(rows, queries, metric: int, k: int, threshold=None, keep
 def cpu_quota() -> int:
     """CPUs the container may actually use (cgroup v2 cpu.max), 0 when unlimited or unknown."""
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
         if quota != "max" and int(quota) > 0 and int(period) > 0:
             return max(1, int(quota) // int(period))
+        return 0
+    except (OSError, ValueError):
+        pass
+    try:  # cgroup v1 (-1 = unlimited)
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            return max(1, quota // period)
     except (OSError, ValueError):
         pass
     return 0

@@ -149,10 +149,19 @@ class HostPool {
     // -- seen as one 60 ms stall every few hundred calls with 63 polling workers.  Workers only poll while a
     // call holds them (Hold, ~20 % of a 1024-query call), so twice the quota is the limit that stayed clear of it.
     unsigned quota = 0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
       long long q = 0, period = 0;
       if (fscanf(f, "%lld %lld", &q, &period) == 2 && q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
       fclose(f);
+    } else if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1 (-1 = unlimited)
+      long long q = 0, period = 0;
+      if (fscanf(fq, "%lld", &q) != 1) q = 0;
+      fclose(fq);
+      if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (fscanf(fp, "%lld", &period) != 1) period = 0;
+        fclose(fp);
+      }
+      if (q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
     }
     if (quota) hw = std::min(hw, 2 * quota);
     const char *peers_s = getenv("LOCAL_WORLD_SIZE");
