@@ -505,7 +505,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     // the tail runs in chunks of queries: while the GPU re-ranks chunk c + 1, the host already finalises chunk c
     // (out->on_chunk).  (One launch over all chunks, each reporting through a pinned word when its last workgroup
     // has stored its entries, was tried: 167 us against 4 x 48 -- no overlap to speak of -- and the waits for the
-    // host-memory stores to land doubled it.)
+    // host-memory stores to land doubled it.  Consecutive chunks on two streams: no change, a chunk's 512 workgroups of
+    // 70 KB LDS fill every CU and the next chunk's only start as they leave.)
     n_chunks = !out->on_chunk ? 1 : (nq >= 512 ? 4 : (nq >= 256 ? 2 : 1));  // (256 queries: 1.00 -> 0.94 ms; 128: no gain)
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = chunk_q(c), q1 = chunk_q(c + 1);
