@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define TSH_ABI_VERSION 1
+/* 2: tsh_counters grew (fused_launches) and tsh_ngh_info grew (pages_absent, files_absent) after version 1 shipped; a
+ * host built against the version-1 structs would be written past its buffers, so the number changed with them.
+ * tsh_comm_create_host / tsh_comm_set_group and TSH_E_PEER came with version 2 as well. */
+#define TSH_ABI_VERSION 2
 
 /* status codes */
 #define TSH_OK 0
@@ -48,6 +51,8 @@ extern "C" {
 #define TSH_E_BUSY (-9) /* tsh_search_submit: tsh_max_inflight() asynchronous searches are already un-waited on the
                            handle, or an append / delete is waiting for the open ones: wait for them, then submit again */
 #define TSH_E_RCCL (-10) /* librccl could not be loaded, or a collective failed */
+#define TSH_E_PEER (-11) /* tsh_search_sharded: another rank of the collective failed (its own call returned the real
+                            error); nothing was written on this rank.  The communicator stays usable. */
 
 /* metric = enum order of VectorDistanceMetric, lib/src/model/table_schema.dart:2511-2531 */
 #define TSH_METRIC_L2 0
@@ -258,6 +263,11 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
 int32_t tsh_max_inflight(void);
 int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const uint8_t *row_mask,
                           int32_t *out_ticket);
+/* 1 = the ticket's kernels have finished (tsh_search_wait will not wait for the GPU), 0 = still running, < 0 =
+ * error.  Never blocks: a single-threaded host (a Dart isolate, whose yield budget is 8 ms on clients and 50 ms on
+ * servers: lib/src/model/data_store_config.dart:225-230, core/yield_controller.dart:110-169) submits, returns to
+ * its event loop, and waits once this says 1. */
+int32_t tsh_search_ready(tsh_index *idx, int32_t ticket);
 int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double distance_threshold, int64_t *out_ids,
                         double *out_dist, int32_t *out_count);
 
@@ -296,17 +306,36 @@ int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries,
  * with dlopen on first use.  One communicator per rank:
  *   rank 0:     tsh_comm_unique_id(id)  -> ship the 128 bytes to the other ranks (any channel the host has)
  *   every rank: tsh_comm_create(id, world, rank, device, &comm)      (collective: returns when all ranks called)
- *   every rank: tsh_search_sharded(shard, comm, queries, ...)        (collective: same queries / k on every rank;
- *               each rank scans its shard, the blocks are all-gathered, every rank merges and gets the full
- *               answer -- identical to tsh_search on one un-sharded index over the same rows)
+ *   every rank: tsh_search_sharded(shard, comm, queries, ...)        (collective: same queries / nq / k / threshold
+ *               on every rank; identical answer on every rank -- the one tsh_search gives on one un-sharded
+ *               index over the same rows)
  *   every rank: tsh_comm_destroy(comm)
+ * Inside one call the queries travel in groups: while a group's candidate blocks are all-gathered (device to
+ * device) and merged, a helper thread already scans the next group on this rank's shard.  Of every group each
+ * rank copies back and merges only its own slice of the queries (world blocks per query); a second, small
+ * all-gather hands every slice's final ids / distances to every rank.
+ * Failures: a rank whose own part fails (bad handle, TSH_E_BUSY, a HIP error in its shard search, an allocation)
+ * STAYS in the collective, contributes blocks that say so, and returns its error; the other ranks return
+ * TSH_E_PEER; the communicator remains usable.  Only a failing all-gather / stream operation (TSH_E_RCCL,
+ * TSH_E_HIP from the exchange itself) leaves the ranks out of step: destroy the communicator then.
  * row_mask is GLOBAL.  No reference counterpart (the reference has no distributed compute). */
 typedef struct tsh_comm tsh_comm;
 #define TSH_COMM_ID_BYTES 128
 int32_t tsh_comm_unique_id(void *out_id);
 int32_t tsh_comm_create(const void *id, int32_t world, int32_t rank, int32_t device, tsh_comm **out);
+/* The same protocol over a transport the host brings (ranks on several nodes, a host without RCCL, tests with
+ * several ranks on one GPU): `allgather(user, send, recv, bytes)` must place every rank's `bytes` at
+ * recv + rank * bytes on every rank (host memory, synchronous; 0 = ok) -- the one callback in this ABI; it is
+ * invoked on the thread that called tsh_search_sharded, never after that call returned.  The candidate blocks
+ * then travel device -> host -> callback instead of device -> device. */
+typedef int32_t (*tsh_allgather_fn)(void *user, const void *send, void *recv, int64_t bytes);
+int32_t tsh_comm_create_host(int32_t world, int32_t rank, int32_t device, tsh_allgather_fn allgather, void *user,
+                             tsh_comm **out);
 int32_t tsh_comm_destroy(tsh_comm *comm);
 int32_t tsh_comm_world(tsh_comm *comm);
+/* queries per exchange of tsh_search_sharded; 0 (default) = by the size of the call (a quarter of it, 8..64; 256 for
+ * calls of 512 queries and more).  Same value on every rank. */
+int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
                            double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,
                            int32_t *out_count);

@@ -144,11 +144,36 @@ static void test_shard_workers() {
   puts("ok shard_workers");
 }
 
+// the sharded search's look-ahead thread: jobs run one at a time, in order, wait() covers the last one
+static void test_one_worker() {
+  OneWorker w;
+  std::vector<int> seen;
+  for (int i = 0; i < 500; ++i) {
+    w.post([&seen, i] { seen.push_back(i); });
+    if (i % 7 == 0) w.wait();
+  }
+  w.wait();
+  if (seen.size() != 500) fail("a job was lost");
+  for (int i = 0; i < 500; ++i)
+    if (seen[(size_t)i] != i) fail("jobs ran out of order");
+  std::atomic<bool> ran{false};
+  {
+    OneWorker w2;
+    w2.post([&] {
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      ran = true;
+    });
+  }  // the destructor lets a posted job finish
+  if (!ran) fail("destructor dropped a posted job");
+  puts("ok one_worker");
+}
+
 int main() {
   test_ticket_holder_passes_waiting_writer();
   test_rwlock_exclusion_stress();
   test_pool_runs_every_item_once();
   test_pool_parks_when_idle();
   test_shard_workers();
+  test_one_worker();
   return 0;
 }

@@ -18,135 +18,8 @@ if ROOT not in sys.path:
 import bench  # noqa: E402
 
 
-class FakeIndex:
-    def __init__(self, oracle, d, metric, rows, lo):
-        self.o, self.dim, self.metric, self.rows, self.lo = oracle, d, metric, np.ascontiguousarray(rows), lo
-        self.c = {"searches": 0, "scan_launches": 0, "batch_launches": 0, "fallback_searches": 0,
-                  "candidates_total": 0, "scan_us_sum": 0.0, "scan_us_samples": 0, "batch_kernel_last": -1}
-        self.min_nq, self.kernel, self.closed = 1, 3, False
-        self.pending, self.next_ticket = {}, 0
-
-    @property
-    def size(self):
-        return self.lo + len(self.rows)
-
-    def _mask(self, row_mask):
-        if row_mask is None:
-            return None
-        assert len(row_mask) >= (self.size + 7) // 8
-        bits = np.unpackbits(np.asarray(row_mask, np.uint8), bitorder="little")[self.lo:self.lo + len(self.rows)]
-        return np.packbits(bits, bitorder="little")
-
-    def search(self, queries, k, thr=None, row_mask=None):
-        assert not self.closed
-        q = np.ascontiguousarray(queries, np.float32)
-        if q.ndim == 1:
-            q = q[None, :]
-        assert q.shape[1] == self.dim and q.shape[0] >= 1
-        ids, dist, cnt = self.o.search_heap_many_mt(self.rows, q, self.metric, k, thr, self._mask(row_mask), threads=2)
-        ids = np.where(ids >= 0, ids + self.lo, ids)
-        self.c["searches"] += len(q)
-        self.c["candidates_total"] += int(cnt.sum())
-        if len(q) > 1 and self.min_nq >= 1:
-            self.c["batch_launches"] += 2
-            self.c["batch_kernel_last"] = 2 if self.kernel == 3 else self.kernel
-        else:
-            self.c["scan_launches"] += len(q)
-            self.c["scan_us_sum"] += 10.0 * ((len(q) + 3) // 4)
-            self.c["scan_us_samples"] += (len(q) + 3) // 4
-        return ids, dist, cnt
-
-    def submit(self, q, k, row_mask=None):
-        t, self.next_ticket = self.next_ticket, self.next_ticket + 1
-        self.pending[t] = self.search(q, k, None, row_mask)
-        return (t, k)
-
-    def wait(self, ticket, thr=None):
-        ids, dist, cnt = self.pending.pop(ticket[0])
-        return ids[0, :cnt[0]], dist[0, :cnt[0]]
-
-    def counters(self):
-        return dict(self.c)
-
-    def bench_scan(self, q, iters=20, row_mask=None):
-        return 10.0
-
-    def bench_batch(self, qs, k, iters=3):
-        return 100.0, 2.0 * len(qs) * len(self.rows) * self.dim
-
-    def set_batch_min_nq(self, v):
-        self.min_nq = v
-
-    def set_batch_kernel(self, v):
-        self.kernel = v
-
-    def close(self):
-        self.closed = True
-
-
-class FakeSearcher:
-    """Stands for ShardedSearcher: answers over the WHOLE corpus, as the merge of all ranks would."""
-
-    def __init__(self, whole):
-        self.whole = whole
-        self.groups = []
-
-    def search(self, q, k, thr=None, row_mask=None):
-        return self.whole.search(q, k, thr, row_mask)
-
-    def search_many(self, qs, k, thr=None, row_mask=None, group=8):
-        assert group >= 1 and len(qs) >= 1
-        self.groups.append((len(qs), group))
-        return self.whole.search(qs, k, thr, row_mask)
-
-
-class FakeEnv:
-    def __init__(self, oracle, world=1):
-        self.o, self.world, self.rank = oracle, world, 0
-        self.fences = 0
-        self.made = []
-        self.last_searcher = None
-
-    def corpus(self, n, d, metric):
-        rng = np.random.default_rng(7 + metric)
-        x = rng.standard_normal((n, d)).astype(np.float32)
-        x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
-        if metric != 2:
-            x *= (rng.random((n, 1)) * 1.5 + 0.5).astype(np.float32)
-        return x
-
-    def corpus_host(self, c):
-        return c
-
-    def release(self, c):
-        pass
-
-    def make_index(self, d, metric, corpus, lo, hi):
-        idx = FakeIndex(self.o, d, metric, corpus[lo:hi], lo)
-        self.made.append(idx)
-        self._whole = FakeIndex(self.o, d, metric, corpus, 0)
-        return idx
-
-    def searcher(self, idx):
-        if self.world == 1:
-            return None
-        self.last_searcher = FakeSearcher(self._whole)
-        return self.last_searcher
-
-    def max_inflight(self):
-        return 8
-
-    def fence(self):
-        self.fences += 1
-
-    def reduce_max(self, x):
-        return float(x)
-
-    def bcast_int(self, x):
-        return int(x)
-
-    def finish(self):
-        pass
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fake_bench_env import FakeEnv  # noqa: E402
 
 
 def _args(*extra):

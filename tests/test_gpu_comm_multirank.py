@@ -1,0 +1,51 @@
+"""GPU: the library's own sharded search with MORE THAN ONE rank.  RCCL refuses two ranks on one device and a test
+box has one GPU, so the ranks exchange over the host transport (tsh_comm_create_host + gloo): the protocol of
+tsh_search_sharded -- groups, look-ahead scans on a helper thread, per-rank query slices, the result all-gather,
+the overflow retry every rank takes alike, a failing rank staying in the collective -- runs exactly as it does over
+RCCL, only the all-gather call differs.  And `python bench.py --gpus 2` as the driver would start it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_over_host_transport(hip_lib, world):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "tests", "_comm_worker.py"), "40003"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0, out[-4000:]
+    assert "MISMATCH" not in out, out[-4000:]
+    assert out.count(" ok\n") == world * (2 * 8 + 1), out[-4000:]
+
+
+def test_bench_gpus_2_plain_command(hip_lib):
+    """Exactly what a driver without a launcher runs: two ranks share this box's GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks-share-gpu", "--backend",
+                        "gloo", "--steps", "20", "--warmup", "5", "--rows", "200000", "--cpu-seconds", "3"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True and out["recall_queries"] >= 2
+    assert "tsh_search_sharded" in out["config"]["sharding"]
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == 100000 * 768 * 4

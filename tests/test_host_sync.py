@@ -19,4 +19,4 @@ def test_host_sync_cpp(tmp_path):
     sys.stdout.write(r.stdout)
     sys.stderr.write(r.stderr)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.count("ok ") == 5
+    assert r.stdout.count("ok ") == 6

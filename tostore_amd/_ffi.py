@@ -25,6 +25,8 @@ TSH_E_IO = -7
 TSH_E_FORMAT = -8
 TSH_E_BUSY = -9
 TSH_E_RCCL = -10
+TSH_E_PEER = -11
+ABI_VERSION = 2
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 
@@ -78,6 +80,7 @@ SIGNATURES = {
     "tsh_search": (c_i32, [p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
     "tsh_max_inflight": (c_i32, []),
     "tsh_search_submit": (c_i32, [p_void, p_f32, c_i32, p_u8, p_i32]),
+    "tsh_search_ready": (c_i32, [p_void, c_i32]),
     "tsh_search_wait": (c_i32, [p_void, c_i32, c_f64, p_i64, p_f64, p_i32]),
     "tsh_candidate_block_bytes": (c_i64, [c_i32]),
     "tsh_default_block_entries": (c_i32, [c_i32]),
@@ -86,7 +89,9 @@ SIGNATURES = {
                                      p_i64, p_f64, p_i32, p_i32]),
     "tsh_comm_unique_id": (c_i32, [p_void]),
     "tsh_comm_create": (c_i32, [p_void, c_i32, c_i32, c_i32, ctypes.POINTER(p_void)]),
+    "tsh_comm_create_host": (c_i32, [c_i32, c_i32, c_i32, p_void, p_void, ctypes.POINTER(p_void)]),
     "tsh_comm_destroy": (c_i32, [p_void]),
+    "tsh_comm_set_group": (c_i32, [p_void, c_i32]),
     "tsh_comm_world": (c_i32, [p_void]),
     "tsh_search_sharded": (c_i32, [p_void, p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
     "tsh_get_counters": (c_i32, [p_void, ctypes.POINTER(TshCounters)]),
@@ -94,6 +99,10 @@ SIGNATURES = {
     "tsh_bench_batch": (c_i32, [p_void, p_f32, c_i32, c_i32, c_i32, p_f64, p_f64]),
     "tsh_index_set_option": (c_i32, [p_void, c_i32, c_i64]),
 }
+
+
+# tsh_allgather_fn: int32 (*)(void *user, const void *send, void *recv, int64 bytes)
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_i32, p_void, p_void, p_void, c_i64)
 
 
 class TshError(RuntimeError):
@@ -119,7 +128,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.tsh_abi_version() != 1:
+        if L.tsh_abi_version() != ABI_VERSION:
             raise RuntimeError("libtostore_hip.so ABI version mismatch")
         _lib = L
     return _lib

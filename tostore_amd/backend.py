@@ -183,6 +183,13 @@ class HipVectorIndex:
                                                 ctypes.byref(t)))
         return (t.value, int(k))
 
+    def ready(self, ticket: tuple) -> bool:
+        """True once the ticket's kernels have finished (wait() will not block on the GPU).  Never blocks."""
+        rc = _ffi.lib().tsh_search_ready(self._h, ticket[0])
+        if rc < 0:
+            _ffi.check(rc)
+        return rc == 1
+
     def wait(self, ticket: tuple, distance_threshold: Optional[float] = None):
         t, k = ticket
         ids = np.empty(k, dtype=np.int64)

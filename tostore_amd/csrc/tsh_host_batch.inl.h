@@ -197,8 +197,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
     for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
-    HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming));
-    for (hipEvent_t &e : b->e_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0;
+    HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming | wait_flag));
+    for (hipEvent_t &e : b->e_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | wait_flag));
   }
   int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;

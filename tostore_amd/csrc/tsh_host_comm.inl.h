@@ -1,12 +1,27 @@
-// tsh_host_comm.inl.h -- the RCCL exchange of a row-sharded index, reachable from the C ABI (one process per GPU)
+// tsh_host_comm.inl.h -- the exchange of a row-sharded index, reachable from the C ABI (one process per GPU)
 // Part of the single translation unit tsh_lib.hip (textually included there; not compiled alone).
 //
 // BASELINE.json's north star: "the corpus shards by row-range across the 8 GPUs of one node with a RCCL
 // all-gather of per-shard (distance, row-id) top-k candidates over xGMI and a final host-side merge".  The Python
-// harness does that exchange with torch.distributed (tostore_amd/sharded.py); a Dart host has no torch, so the
-// same three steps -- shard scan into device blocks, ncclAllGather of the blocks, host merge -- are offered here
-// behind plain C entry points.  librccl is loaded with dlopen on first use: a process that never shards does not
-// pull it in, and a process that already holds a librccl (a torch host) gets that one.
+// harness can do that exchange with torch.distributed (tostore_amd/sharded.py); a Dart host has no torch, so the
+// same steps are offered here behind plain C entry points.  librccl is loaded with dlopen on first use: a
+// process that never shards does not pull it in, and a process that already holds a librccl (a torch host)
+// gets that one.
+//
+// One tsh_search_sharded call, nq queries, W ranks:
+//   * the queries go in GROUPS; a helper thread scans group g + 1 on this rank's shard (tsh_search_shard into
+//     device blocks) while the calling thread exchanges and merges group g;
+//   * exchange of a group: all-gather of every rank's candidate blocks (RCCL: device to device over xGMI);
+//     rank r then copies back and merges only ITS SLICE of the group's queries (W blocks per query), so the host
+//     work of a group is done once, spread over the ranks, not W times;
+//   * a second, small all-gather carries every slice's final (ids, distances, counts) plus a status word per
+//     rank, so every rank returns the full answer -- and the same verdict: a rank whose shard search failed
+//     contributes blocks that say so (it does not leave the collective), a truncated block makes every rank retry
+//     the group with the same larger entry count.
+// Buffers grow on the same calls on every rank (same arguments everywhere, by contract); a call that grows them
+// ends the growth with a tiny agreement all-gather, so an allocation failure on one rank fails the call on all.
+// What cannot be recovered: a failing all-gather / stream.  The call then returns TSH_E_RCCL or TSH_E_HIP and the
+// communicator must be destroyed (its peers may be blocked in the collective).
 #include <dlfcn.h>
 
 namespace {
@@ -57,16 +72,360 @@ int rccl_fail(const char *what, int rc) {
   return set_err(TSH_E_RCCL, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "?");
 }
 
+// header of one rank's result slice in the second all-gather
+struct ResHeader {
+  int32_t status;  // TSH_OK, or why this rank could not merge its slice (its own error, or TSH_E_PEER)
+  int32_t need;    // entries a truncated block of the slice asks for (0 = none)
+  int32_t pad[14];
+};
+static_assert(sizeof(ResHeader) == 64, "result header is 64 bytes");
+constexpr uint32_t FLAG_RANK_ERROR = 0x80000000u;  // BlockHeader.flags: this rank's shard search failed (pad[0] = rc)
+
+inline size_t res_rec_bytes(int32_t k) { return (size_t)k * 16 + 8; }  // k ids, k distances, count + pad
+
 }  // namespace
 
 struct tsh_comm {
-  void *comm = nullptr;  // ncclComm_t
+  void *comm = nullptr;  // ncclComm_t (RCCL transport)
+  tsh_allgather_fn host_fn = nullptr;  // host transport (tsh_comm_create_host)
+  void *host_user = nullptr;
   int32_t world = 1, rank = 0, device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
   std::mutex mu;  // collectives of one communicator are issued one call at a time
-  uint8_t *d_mine = nullptr, *d_all = nullptr, *h_all = nullptr;
-  size_t mine_cap = 0, all_cap = 0;
+  uint8_t *d_mine[2] = {nullptr, nullptr};  // this rank's blocks of the group being scanned / exchanged
+  size_t mine_cap[2] = {0, 0};
+  uint8_t *h_mine = nullptr;  // host transport: pinned copy of d_mine
+  size_t h_mine_cap = 0;
+  uint8_t *d_all = nullptr;  // RCCL: every rank's blocks of the group
+  size_t all_cap = 0;
+  uint8_t *h_slice = nullptr;  // pinned: RCCL -- W x (this rank's query slice) blocks; host transport -- W x group blocks
+  size_t slice_cap = 0;
+  uint8_t *h_res_mine = nullptr, *h_res_all = nullptr, *d_res_mine = nullptr, *d_res_all = nullptr;
+  size_t res_cap = 0;  // bytes of one rank's result slice
+  int32_t *d_agree = nullptr, *h_agree = nullptr;  // 1 + world words (allocated with the communicator)
+  int32_t group = 0;  // queries per exchange; 0 = by the size of the call
+  std::unique_ptr<OneWorker> helper;
+  int64_t c_groups = 0, c_retries = 0;
 };
+
+namespace {
+
+int comm_sync(tsh_comm *c) {  // the communicator's stream, without burning a core (event with blocking sync)
+  HIPCHK(hipEventRecord(c->ev, c->stream));
+  HIPCHK(hipEventSynchronize(c->ev));
+  return TSH_OK;
+}
+
+// all-gather of `bytes` per rank.  RCCL: device buffers on the communicator's stream (asynchronous);
+// host transport: host buffers, synchronous
+int comm_allgather_dev(tsh_comm *c, const void *d_send, void *d_recv, size_t bytes) {
+  int nrc = rccl()->AllGather(d_send, d_recv, bytes, /*ncclChar*/ 0, c->comm, c->stream);
+  if (nrc != 0) return rccl_fail("ncclAllGather", nrc);
+  return TSH_OK;
+}
+int comm_allgather_host(tsh_comm *c, const void *h_send, void *h_recv, size_t bytes) {
+  int32_t rc = c->host_fn(c->host_user, h_send, h_recv, (int64_t)bytes);
+  if (rc != 0) return set_err(TSH_E_RCCL, "the host's all-gather callback failed (%d)", rc);
+  return TSH_OK;
+}
+
+// every rank says whether its part of a step that may fail locally (allocations) worked; all ranks get the
+// same answer.  Collective.
+int comm_agree(tsh_comm *c, int local_rc) {
+  if (c->world == 1) return local_rc;
+  c->h_agree[0] = local_rc;
+  int32_t *all = c->h_agree + 1;
+  if (c->host_fn) {
+    int rc = comm_allgather_host(c, c->h_agree, all, 4);
+    if (rc) return rc;
+  } else {
+    HIPCHK(hipMemcpyAsync(c->d_agree, c->h_agree, 4, hipMemcpyHostToDevice, c->stream));
+    int rc = comm_allgather_dev(c, c->d_agree, c->d_agree + 1, 4);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(all, c->d_agree + 1, 4 * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    rc = comm_sync(c);
+    if (rc) return rc;
+  }
+  if (local_rc != TSH_OK) return local_rc;
+  for (int r = 0; r < c->world; ++r)
+    if (all[r] != TSH_OK) return set_err(TSH_E_PEER, "rank %d could not allocate its exchange buffers (%d)", r, all[r]);
+  return TSH_OK;
+}
+
+template <typename T>
+int grow_dev(T **p, size_t *cap, size_t want) {
+  if (want <= *cap) return TSH_OK;
+  hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(p), want));
+  *cap = want;
+  return TSH_OK;
+}
+template <typename T>
+int grow_host(T **p, size_t *cap, size_t want) {
+  if (want <= *cap) return TSH_OK;
+  hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(p), want, hipHostMallocDefault));
+  *cap = want;
+  return TSH_OK;
+}
+
+// buffers for groups of up to gq queries with `entries` entries per block.  *grew: anything was (re)allocated --
+// identical on every rank, since capacities only depend on the calls made so far
+int comm_reserve(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, bool *grew) {
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world;
+  const size_t slice_q = ((size_t)gq + W - 1) / W;
+  const size_t mine = bb * (size_t)gq, res = sizeof(ResHeader) + slice_q * res_rec_bytes(k);
+  const size_t slice = c->host_fn ? W * mine : W * slice_q * bb;
+  *grew = mine > c->mine_cap[0] || mine > c->mine_cap[1] || res > c->res_cap || slice > c->slice_cap ||
+          (c->host_fn ? mine > c->h_mine_cap : W * mine > c->all_cap);
+  if (!*grew) return TSH_OK;
+  int rc = TSH_OK;
+  for (int s = 0; s < 2 && !rc; ++s) rc = grow_dev(&c->d_mine[s], &c->mine_cap[s], mine);
+  if (!rc) rc = grow_host(&c->h_slice, &c->slice_cap, slice);
+  if (!rc && c->host_fn) rc = grow_host(&c->h_mine, &c->h_mine_cap, mine);
+  if (!rc && !c->host_fn) rc = grow_dev(&c->d_all, &c->all_cap, W * mine);
+  if (!rc && res > c->res_cap) {
+    hipHostFree(c->h_res_mine);
+    hipHostFree(c->h_res_all);
+    hipFree(c->d_res_mine);
+    hipFree(c->d_res_all);
+    c->h_res_mine = c->h_res_all = c->d_res_mine = c->d_res_all = nullptr;
+    c->res_cap = 0;
+    size_t cap = 0;
+    rc = grow_host(&c->h_res_mine, &cap, res);
+    cap = 0;
+    if (!rc) rc = grow_host(&c->h_res_all, &cap, W * res);
+    if (!rc && !c->host_fn) {
+      cap = 0;
+      rc = grow_dev(&c->d_res_mine, &cap, res);
+      cap = 0;
+      if (!rc) rc = grow_dev(&c->d_res_all, &cap, W * res);
+    }
+    if (!rc) c->res_cap = res;
+  }
+  return rc;
+}
+
+// after a growth some rank could not follow, every rank drops its buffers: capacities must stay identical on all
+// ranks, or the next call's "did anything grow" would differ from rank to rank
+void comm_drop_buffers(tsh_comm *c) {
+  for (int s = 0; s < 2; ++s) {
+    hipFree(c->d_mine[s]);
+    c->d_mine[s] = nullptr;
+    c->mine_cap[s] = 0;
+  }
+  hipHostFree(c->h_mine);
+  hipFree(c->d_all);
+  hipHostFree(c->h_slice);
+  hipHostFree(c->h_res_mine);
+  hipHostFree(c->h_res_all);
+  hipFree(c->d_res_mine);
+  hipFree(c->d_res_all);
+  c->h_mine = c->d_all = c->h_slice = c->h_res_mine = c->h_res_all = c->d_res_mine = c->d_res_all = nullptr;
+  c->h_mine_cap = c->all_cap = c->slice_cap = c->res_cap = 0;
+}
+int comm_reserve_agreed(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, bool *grew) {
+  int rc = comm_reserve(c, gq, entries, k, grew);
+  if (*grew) {
+    rc = comm_agree(c, rc);
+    if (rc) comm_drop_buffers(c);
+  }
+  return rc;
+}
+
+// this rank's blocks of a group, as error markers (its shard search failed with `rc`): the rank stays in the collective
+int comm_error_blocks(tsh_comm *c, int slot, int32_t gq, int32_t entries, int rc_local) {
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  std::vector<BlockHeader> h((size_t)gq);
+  memset(h.data(), 0, h.size() * sizeof(BlockHeader));
+  for (auto &x : h) {
+    x.entries = (uint32_t)entries;
+    x.flags = FLAG_RANK_ERROR;
+    x.pad[0] = (uint32_t)rc_local;
+  }
+  HIPCHK(hipMemcpy2D(c->d_mine[slot], bb, h.data(), sizeof(BlockHeader), sizeof(BlockHeader), (size_t)gq,
+                     hipMemcpyHostToDevice));
+  return TSH_OK;
+}
+
+struct GroupOut {
+  int32_t need = 0;  // > 0: every rank retries the group with this many entries
+};
+
+// Exchange + merge of one group whose blocks sit in d_mine[slot].  local_rc: what this rank's shard search said.
+// Collective; returns the same verdict class on every rank (own error / TSH_E_PEER / TSH_OK + need).
+int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, const float *queries, int32_t gq,
+                        int32_t k, double thr, int32_t entries, int64_t *out_ids, double *out_dist, int32_t *out_count,
+                        GroupOut *go) {
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world, mine = bb * (size_t)gq;
+  const int32_t slice_q = (int32_t)(((size_t)gq + W - 1) / W);
+  const int32_t a = std::min<int32_t>(gq, c->rank * slice_q), b = std::min<int32_t>(gq, a + slice_q);
+  const size_t rec = res_rec_bytes(k), res = sizeof(ResHeader) + (size_t)slice_q * rec;
+  int rc;
+  if (local_rc != TSH_OK) {
+    rc = comm_error_blocks(c, slot, gq, entries, local_rc);
+    if (rc) return rc;
+  }
+  // ---- 1. every rank's blocks of the group; this rank's query slice of them to the host -------------------
+  const uint8_t *slice_base;  // block (rank w, query a + i) at slice_base + w * slice_pitch + i * bb
+  size_t slice_pitch;
+  if (c->host_fn) {
+    HIPCHK(hipMemcpyAsync(c->h_mine, c->d_mine[slot], mine, hipMemcpyDeviceToHost, c->stream));
+    rc = comm_sync(c);
+    if (rc) return rc;
+    rc = comm_allgather_host(c, c->h_mine, c->h_slice, mine);
+    if (rc) return rc;
+    slice_base = c->h_slice + (size_t)a * bb;
+    slice_pitch = mine;
+  } else {
+    rc = comm_allgather_dev(c, c->d_mine[slot], c->d_all, mine);  // k' x 24 B per rank and query: latency-bound
+    if (rc) return rc;
+    if (b > a)
+      HIPCHK(hipMemcpy2DAsync(c->h_slice, (size_t)(b - a) * bb, c->d_all + (size_t)a * bb, mine, (size_t)(b - a) * bb, W,
+                              hipMemcpyDeviceToHost, c->stream));
+    rc = comm_sync(c);
+    if (rc) return rc;
+    slice_base = c->h_slice;
+    slice_pitch = (size_t)(b - a) * bb;
+  }
+  // ---- 2. merge the slice ---------------------------------------------------------------------------------
+  ResHeader *rh = reinterpret_cast<ResHeader *>(c->h_res_mine);
+  memset(rh, 0, sizeof *rh);
+  rh->status = local_rc;
+  uint8_t *recs = c->h_res_mine + sizeof(ResHeader);
+  if (local_rc == TSH_OK && b > a) {
+    uint32_t need = 0;
+    for (size_t w = 0; w < W && rh->status == TSH_OK; ++w)
+      for (int32_t i = 0; i < b - a; ++i) {
+        const BlockHeader *h = reinterpret_cast<const BlockHeader *>(slice_base + w * slice_pitch + (size_t)i * bb);
+        if (h->flags & FLAG_RANK_ERROR) {
+          rh->status = TSH_E_PEER;
+          rh->pad[0] = (int32_t)w;
+          rh->pad[1] = (int32_t)h->pad[0];
+          break;
+        }
+        if (h->entries != (uint32_t)entries) {
+          rh->status = TSH_E_FORMAT;
+          break;
+        }
+        if (h->count > h->entries) need = std::max(need, h->count);
+      }
+    if (rh->status == TSH_OK && need) rh->need = (int32_t)round_up(need, 64);
+    if (rh->status == TSH_OK && !need) {
+      const int metric = shard->metric, dim = shard->dim;
+      parallel_for(b - a, [&](int32_t i) {
+        EntryList lists[64];
+        std::vector<EntryList> big;
+        EntryList *lp = lists;
+        if (W > 64) {
+          big.resize(W);
+          lp = big.data();
+        }
+        for (size_t w = 0; w < W; ++w) {
+          const uint8_t *p = slice_base + w * slice_pitch + (size_t)i * bb;
+          lp[w] = {reinterpret_cast<const BlockEntry *>(p + sizeof(BlockHeader)),
+                   reinterpret_cast<const BlockHeader *>(p)->count};
+        }
+        uint8_t *r = recs + (size_t)i * rec;
+        int64_t *ids = reinterpret_cast<int64_t *>(r);
+        double *dd = reinterpret_cast<double *>(r + (size_t)k * 8);
+        int32_t *cnt = reinterpret_cast<int32_t *>(r + (size_t)k * 16);
+        cnt[0] = finalize_query(metric, dim, queries + (size_t)(a + i) * dim, k, thr, lp, W, ids, dd);
+        cnt[1] = 0;
+      });
+    }
+  }
+  // ---- 3. every slice's results + status to every rank ----------------------------------------------------
+  const uint8_t *all_res = c->h_res_mine;
+  if (W > 1) {
+    if (c->host_fn) {
+      rc = comm_allgather_host(c, c->h_res_mine, c->h_res_all, res);
+      if (rc) return rc;
+    } else {
+      HIPCHK(hipMemcpyAsync(c->d_res_mine, c->h_res_mine, res, hipMemcpyHostToDevice, c->stream));
+      rc = comm_allgather_dev(c, c->d_res_mine, c->d_res_all, res);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(c->h_res_all, c->d_res_all, W * res, hipMemcpyDeviceToHost, c->stream));
+      rc = comm_sync(c);
+      if (rc) return rc;
+    }
+    all_res = c->h_res_all;
+  }
+  int32_t need = 0;
+  for (size_t w = 0; w < W; ++w) {
+    const ResHeader *h = reinterpret_cast<const ResHeader *>(all_res + w * res);
+    if (h->status != TSH_OK) {
+      if (local_rc != TSH_OK) return local_rc;  // (this rank's own error text is still in place)
+      if (h->status == TSH_E_PEER)
+        return set_err(TSH_E_PEER, "rank %d's shard search failed (%d); this call is void on every rank", h->pad[0], h->pad[1]);
+      return set_err(h->status == TSH_E_FORMAT ? TSH_E_FORMAT : TSH_E_PEER, "rank %d could not merge its slice (%d)", (int)w,
+                     h->status);
+    }
+    need = std::max(need, h->need);
+  }
+  go->need = need;
+  if (need) return TSH_OK;
+  for (size_t w = 0; w < W; ++w) {
+    const int32_t wa = std::min<int32_t>(gq, (int32_t)w * slice_q), wb = std::min<int32_t>(gq, wa + slice_q);
+    const uint8_t *r = all_res + w * res + sizeof(ResHeader);
+    for (int32_t q = wa; q < wb; ++q, r += rec) {
+      memcpy(out_ids + (size_t)q * k, r, (size_t)k * 8);
+      memcpy(out_dist + (size_t)q * k, r + (size_t)k * 8, (size_t)k * 8);
+      out_count[q] = *reinterpret_cast<const int32_t *>(r + (size_t)k * 16);
+    }
+  }
+  return TSH_OK;
+}
+
+int comm_common_create(tsh_comm *c, int32_t world, int32_t rank, int32_t device) {
+  c->world = world;
+  c->rank = rank;
+  c->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming | hipEventBlockingSync));
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_agree), 4 * (size_t)(world + 1)));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_agree), 4 * (size_t)(world + 1), hipHostMallocDefault));
+  c->helper.reset(new OneWorker());
+  return TSH_OK;
+}
+
+void comm_free(tsh_comm *c) {
+  c->helper.reset();
+  hipSetDevice(c->device);
+  if (c->comm) rccl()->CommDestroy(c->comm);
+  hipFree(c->d_mine[0]);
+  hipFree(c->d_mine[1]);
+  hipHostFree(c->h_mine);
+  hipFree(c->d_all);
+  hipHostFree(c->h_slice);
+  hipHostFree(c->h_res_mine);
+  hipHostFree(c->h_res_all);
+  hipFree(c->d_res_mine);
+  hipFree(c->d_res_all);
+  hipFree(c->d_agree);
+  hipHostFree(c->h_agree);
+  if (c->ev) hipEventDestroy(c->ev);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int comm_check_create(const void *id_or_fn, int32_t world, int32_t rank, int32_t *device, tsh_comm **out) {
+  if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (!id_or_fn || world < 1 || rank < 0 || rank >= world) return set_err(TSH_E_BAD_ARG, "bad id / callback / world / rank");
+  if (device_count_cached() <= 0) return set_err(TSH_E_NO_DEVICE, "no HIP device available");
+  if (*device < 0 && hipGetDevice(device) != hipSuccess) *device = 0;
+  if (*device >= device_count_cached()) return set_err(TSH_E_BAD_ARG, "device %d not present", *device);
+  HIPCHK(hipSetDevice(*device));
+  return TSH_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -83,93 +442,143 @@ int32_t tsh_comm_unique_id(void *out_id) {
 }
 
 int32_t tsh_comm_create(const void *id, int32_t world, int32_t rank, int32_t device, tsh_comm **out) {
-  if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
-  *out = nullptr;
-  if (!id || world < 1 || rank < 0 || rank >= world) return set_err(TSH_E_BAD_ARG, "bad id / world / rank");
+  int rc = comm_check_create(id, world, rank, &device, out);
+  if (rc) return rc;
   RcclApi *r = rccl();
   if (!r->ok) return set_err(TSH_E_RCCL, "%s", r->err.c_str());
-  if (device_count_cached() <= 0) return set_err(TSH_E_NO_DEVICE, "no HIP device available");
-  if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
-  if (device >= device_count_cached()) return set_err(TSH_E_BAD_ARG, "device %d not present", device);
-  HIPCHK(hipSetDevice(device));
-  std::unique_ptr<tsh_comm> c(new tsh_comm());
-  c->world = world;
-  c->rank = rank;
-  c->device = device;
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  tsh_comm *c = new tsh_comm();
+  rc = comm_common_create(c, world, rank, device);
+  if (rc) {
+    comm_free(c);
+    return rc;
+  }
   RcclId uid;
   memcpy(&uid, id, sizeof uid);
-  int rc = r->CommInitRank(&c->comm, world, uid, rank);  // collective: every rank of the job calls it
-  if (rc != 0) {
-    hipStreamDestroy(c->stream);
-    return rccl_fail("ncclCommInitRank", rc);
+  int nrc = r->CommInitRank(&c->comm, world, uid, rank);  // collective: every rank of the job calls it
+  if (nrc != 0) {
+    c->comm = nullptr;
+    comm_free(c);
+    return rccl_fail("ncclCommInitRank", nrc);
   }
-  *out = c.release();
+  *out = c;
+  return TSH_OK;
+}
+
+int32_t tsh_comm_create_host(int32_t world, int32_t rank, int32_t device, tsh_allgather_fn allgather, void *user,
+                             tsh_comm **out) {
+  int rc = comm_check_create(reinterpret_cast<const void *>(allgather), world, rank, &device, out);
+  if (rc) return rc;
+  tsh_comm *c = new tsh_comm();
+  c->host_fn = allgather;
+  c->host_user = user;
+  rc = comm_common_create(c, world, rank, device);
+  if (rc) {
+    comm_free(c);
+    return rc;
+  }
+  *out = c;
   return TSH_OK;
 }
 
 int32_t tsh_comm_destroy(tsh_comm *c) {
   if (!c) return TSH_OK;
-  hipSetDevice(c->device);
-  if (c->comm) rccl()->CommDestroy(c->comm);
-  hipFree(c->d_mine);
-  hipFree(c->d_all);
-  hipHostFree(c->h_all);
-  if (c->stream) hipStreamDestroy(c->stream);
-  delete c;
+  comm_free(c);
   return TSH_OK;
 }
 
 int32_t tsh_comm_world(tsh_comm *c) { return c ? c->world : 0; }
 
+int32_t tsh_comm_set_group(tsh_comm *c, int32_t queries_per_exchange) {
+  if (!c || queries_per_exchange < 0 || queries_per_exchange > 65536) return set_err(TSH_E_BAD_ARG, "bad comm / group");
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->group = queries_per_exchange;
+  return TSH_OK;
+}
+
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, int32_t nq, int32_t k, double thr,
                            const uint8_t *row_mask, int64_t *out_ids, double *out_dist, int32_t *out_count) {
-  if (!shard || !c) return set_err(TSH_E_BAD_ARG, "shard / comm is NULL");
-  if (shard->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle (tsh_index_create_shard)");
+  // arguments that are the same on every rank by contract are answered locally ...
+  if (!c) return set_err(TSH_E_BAD_ARG, "comm is NULL");
   if (nq < 0) return set_err(TSH_E_BAD_ARG, "nq < 0");
   if (nq == 0) return TSH_OK;
   if (!queries || !out_count) return set_err(TSH_E_BAD_ARG, "queries / out_count is NULL");
   for (int32_t q = 0; q < nq; ++q) out_count[q] = 0;
   if (k <= 0) return TSH_OK;
+  if (k > (1 << 20)) return set_err(TSH_E_BAD_ARG, "k too large");
   if (!out_ids || !out_dist) return set_err(TSH_E_BAD_ARG, "out_ids / out_dist is NULL");
-  if (shard->shards[0]->device != c->device) return set_err(TSH_E_BAD_ARG, "shard and communicator sit on different devices");
+  // ... what can differ from rank to rank (the handle, its device, its search) travels through the exchange
+  int local_rc = TSH_OK;
+  if (!shard || shard->shards.size() != 1)
+    local_rc = set_err(TSH_E_BAD_ARG, "needs a single-shard handle (tsh_index_create_shard)");
+  else if (shard->shards[0]->device != c->device)
+    local_rc = set_err(TSH_E_BAD_ARG, "shard and communicator sit on different devices");
+  std::string local_err = g_err;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
+  // queries per exchange: enough groups for the look-ahead to matter, not so many that the two all-gathers of a
+  // group (some tens of microseconds each) show; big calls go to the matrix cores, which want big groups
+  int32_t G = c->group;
+  if (G <= 0) G = nq >= 512 ? 256 : std::max(8, std::min(64, (nq + 3) / 4));
+  G = std::min(G, nq);
   int32_t entries = tsh_default_block_entries(k);
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    const size_t bb = (size_t)tsh_candidate_block_bytes(entries), mine = bb * (size_t)nq, all = mine * (size_t)c->world;
-    if (mine > c->mine_cap) {
-      hipFree(c->d_mine);
-      c->d_mine = nullptr;
-      c->mine_cap = 0;
-      HIPCHK(hipMalloc(&c->d_mine, mine));
-      c->mine_cap = mine;
+  bool grew = false;
+  int rc = comm_reserve_agreed(c, G, entries, k, &grew);
+  if (rc) return rc;
+  const int32_t dim = local_rc == TSH_OK ? shard->dim : 0;
+  const int dev = c->device;
+  const int32_t n_groups = (nq + G - 1) / G;
+  std::vector<int> scan_rc((size_t)n_groups, TSH_OK);
+  std::vector<std::string> scan_err((size_t)n_groups);
+  auto scan = [&](int32_t g, int slot, int32_t ent) {
+    if (local_rc != TSH_OK) {
+      scan_rc[(size_t)g] = local_rc;
+      scan_err[(size_t)g] = local_err;
+      return;
     }
-    if (all > c->all_cap) {
-      hipFree(c->d_all);
-      hipHostFree(c->h_all);
-      c->d_all = c->h_all = nullptr;
-      c->all_cap = 0;
-      HIPCHK(hipMalloc(&c->d_all, all));
-      HIPCHK(hipHostMalloc(&c->h_all, all, hipHostMallocDefault));
-      c->all_cap = all;
+    (void)hipSetDevice(dev);
+    const int32_t q0 = g * G, gq = std::min(G, nq - q0);
+    scan_rc[(size_t)g] = tsh_search_shard(shard, queries + (size_t)q0 * dim, gq, k, row_mask, ent, c->d_mine[slot], nullptr);
+    if (scan_rc[(size_t)g]) scan_err[(size_t)g] = g_err;
+  };
+  const double t_in = now_us();
+  c->helper->post([&] { scan(0, 0, entries); });
+  for (int32_t g = 0; g < n_groups; ++g) {
+    const int32_t q0 = g * G, gq = std::min(G, nq - q0);
+    c->helper->wait();  // group g's blocks are in d_mine[g & 1]
+    if (g + 1 < n_groups) c->helper->post([&, g] { scan(g + 1, (g + 1) & 1, entries); });
+    if (scan_rc[(size_t)g]) g_err = scan_err[(size_t)g];
+    GroupOut go;
+    rc = comm_exchange_group(c, shard, g & 1, scan_rc[(size_t)g], queries + (size_t)q0 * dim, gq, k, thr, entries,
+                             out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0, &go);
+    c->c_groups++;
+    int32_t ent = entries;
+    bool lookahead_lost = false;
+    for (int attempt = 0; rc == TSH_OK && go.need > 0; ++attempt) {
+      // ties made a block overflow: every rank saw the same verdict and redoes this group with larger blocks.
+      // The look-ahead scan must be done first; if the buffers have to grow its blocks go with them and it is redone
+      if (attempt == 3) rc = set_err(TSH_E_OVERFLOW, "candidate blocks kept overflowing");
+      if (rc) break;
+      c->helper->wait();
+      ent = go.need;
+      c->c_retries++;
+      rc = comm_reserve_agreed(c, G, ent, k, &grew);
+      lookahead_lost |= grew;
+      if (rc) break;
+      scan(g, g & 1, ent);
+      if (scan_rc[(size_t)g]) g_err = scan_err[(size_t)g];
+      go = GroupOut();
+      rc = comm_exchange_group(c, shard, g & 1, scan_rc[(size_t)g], queries + (size_t)q0 * dim, gq, k, thr, ent,
+                               out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0, &go);
     }
-    // 1. this rank's shard: candidate blocks stay in device memory (host-synchronised on return)
-    int rc = tsh_search_shard(shard, queries, nq, k, row_mask, entries, c->d_mine, nullptr);
-    if (rc != TSH_OK) return rc;
-    // 2. all-gather over RCCL (xGMI between the GPUs of a node): k' x 24 B per rank and query -- latency-bound
-    int nrc = rccl()->AllGather(c->d_mine, c->d_all, mine, /*ncclChar*/ 0, c->comm, c->stream);
-    if (nrc != 0) return rccl_fail("ncclAllGather", nrc);
-    HIPCHK(hipMemcpyAsync(c->h_all, c->d_all, all, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    // 3. host merge; a truncated block (ties) asks every rank alike for a retry with more entries
-    int32_t need = entries;
-    rc = tsh_merge_candidates(shard->metric, shard->dim, queries, nq, k, thr, c->h_all, c->world, entries, out_ids, out_dist,
-                              out_count, &need);
-    if (rc != TSH_E_OVERFLOW) return rc;
-    entries = need;
+    if (rc == TSH_OK && lookahead_lost && g + 1 < n_groups) c->helper->post([&, g] { scan(g + 1, (g + 1) & 1, entries); });
+    if (rc) {
+      c->helper->wait();  // nothing of this call may still run when it returns
+      return rc;
+    }
   }
-  return set_err(TSH_E_OVERFLOW, "candidate blocks kept overflowing");
+  if (trace_batch())
+    fprintf(stderr, "[tsh sharded] rank %d nq=%d groups of %d: %.0f us\n", c->rank, nq, G, now_us() - t_in);
+  return TSH_OK;
 }
 
 }  // extern "C"

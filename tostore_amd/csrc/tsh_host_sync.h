@@ -69,6 +69,45 @@ class RwLock {
   bool writer_ = false;
 };
 
+// CPUs the container may use per scheduling period (cgroup v2 cpu.max, v1 cpu.cfs_quota_us); 0 = no limit known.
+// It can be far below the core count the box shows (16 of 256 on the MI355X boxes measured here), and a process
+// group that runs past it is frozen for the rest of the 100 ms period.
+inline unsigned cpu_quota_cpus() {
+  unsigned quota = 0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    long long q = 0, period = 0;
+    if (fscanf(f, "%lld %lld", &q, &period) == 2 && q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
+    fclose(f);
+  } else if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1 (-1 = unlimited)
+    long long q = 0, period = 0;
+    if (fscanf(fq, "%lld", &q) != 1) q = 0;
+    fclose(fq);
+    if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(fp, "%lld", &period) != 1) period = 0;
+      fclose(fp);
+    }
+    if (q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
+  }
+  return quota;
+}
+inline unsigned local_peers() {  // processes of this job on this node (one per GPU): torchrun / bench.py export it
+  const char *p = getenv("LOCAL_WORLD_SIZE");
+  return p && atoi(p) > 0 ? (unsigned)atoi(p) : 1u;
+}
+// How a thread waits for the GPU.  The HIP runtime's default is to spin: fine for one process on a box of its
+// own, but a rank per GPU spins in two or three threads (the caller, the sharded search's look-ahead, a submit
+// thread), and eight ranks then burn the whole CPU quota of a 16-CPU container while waiting -- the throttling
+// that follows freezes every rank for tens of milliseconds.  With fewer than three CPUs of quota per rank the
+// library's completion events block (interrupt) instead; TSH_BLOCKING_WAIT=0 / 1 overrides.
+inline bool blocking_wait() {
+  static const bool v = [] {
+    if (const char *e = getenv("TSH_BLOCKING_WAIT")) return e[0] == '1';
+    const unsigned q = cpu_quota_cpus(), peers = local_peers();
+    return peers > 1 && q > 0 && q < 3 * peers;
+  }();
+  return v;
+}
+
 // run fn(q) for q in [0,n) on a few host threads (per-query preparation / finalisation of a batch).  The
 // workers are created once and parked on a condition variable: spawning threads per call costs more than the
 // work itself (about 30 us per thread on a 128-core host).
@@ -97,7 +136,7 @@ class HostPool {
     grain_ = std::max(1, std::min(8, n / (4 * threads())));  // a 128-item job on 32 threads: items of one, not of eight
     done_items_.store(0, std::memory_order_relaxed);
     next_.store(0, std::memory_order_relaxed);
-    open_.store(true, std::memory_order_release);
+    open_.store(true, std::memory_order_seq_cst);
     {
       std::lock_guard<std::mutex> lk(m_);  // a worker between its last look at gen_ and cv_.wait must not miss this
       gen_.fetch_add(1, std::memory_order_release);
@@ -105,8 +144,10 @@ class HostPool {
     if (parked_.load(std::memory_order_acquire) > 0) cv_.notify_all();
     chunks();
     spin_until([&] { return done_items_.load(std::memory_order_acquire) >= n; });
-    open_.store(false, std::memory_order_release);
-    spin_until([&] { return active_.load(std::memory_order_acquire) == 0; });  // nobody still looks at fn_ / n_
+    // store-then-load on this side, add-then-load on the worker's (loop()): all four sequentially consistent, or
+    // this thread could read active_ == 0 while a late worker still reads open_ == true and walks into the next job
+    open_.store(false, std::memory_order_seq_cst);
+    spin_until([&] { return active_.load(std::memory_order_seq_cst) == 0; });  // nobody still looks at fn_ / n_
     fn_ = nullptr;
     return true;
   }
@@ -148,25 +189,9 @@ class HostPool {
     // MI355X boxes measured here), and a process that runs past it is frozen for the rest of the 100 ms period
     // -- seen as one 60 ms stall every few hundred calls with 63 polling workers.  Workers only poll while a
     // call holds them (Hold, ~20 % of a 1024-query call), so twice the quota is the limit that stayed clear of it.
-    unsigned quota = 0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
-      long long q = 0, period = 0;
-      if (fscanf(f, "%lld %lld", &q, &period) == 2 && q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
-      fclose(f);
-    } else if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1 (-1 = unlimited)
-      long long q = 0, period = 0;
-      if (fscanf(fq, "%lld", &q) != 1) q = 0;
-      fclose(fq);
-      if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-        if (fscanf(fp, "%lld", &period) != 1) period = 0;
-        fclose(fp);
-      }
-      if (q > 0 && period > 0) quota = (unsigned)std::max<long long>(1, q / period);
-    }
+    const unsigned quota = cpu_quota_cpus();
     if (quota) hw = std::min(hw, 2 * quota);
-    const char *peers_s = getenv("LOCAL_WORLD_SIZE");
-    const unsigned peers = peers_s && atoi(peers_s) > 0 ? (unsigned)atoi(peers_s) : 1u;
-    hw = std::max(1u, hw / peers);
+    hw = std::max(1u, hw / local_peers());
     // (a 256-query chunk of a batch's tail is ~1.5 ms of single-thread finalisation: 32 threads take 45-55 us
     // over it, as fast as the GPU delivers chunks)
     int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 32 ? 31 : 15);
@@ -219,8 +244,8 @@ class HostPool {
         parked_.fetch_sub(1, std::memory_order_acq_rel);
       }
       seen = gen_.load(std::memory_order_acquire);
-      active_.fetch_add(1, std::memory_order_acq_rel);
-      if (open_.load(std::memory_order_acquire)) chunks();  // closed: the job finished without this worker
+      active_.fetch_add(1, std::memory_order_seq_cst);
+      if (open_.load(std::memory_order_seq_cst)) chunks();  // closed: the job finished without this worker
       active_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
@@ -317,6 +342,53 @@ class ShardWorkers {
   };
   std::mutex owner_;
   std::vector<std::unique_ptr<Slot>> slots_;
+};
+
+// One persistent helper thread that runs one job at a time (the sharded search's look-ahead: group g + 1 is scanned
+// while the caller exchanges and merges group g).  post() hands it a job, wait() returns when that job is done.
+class OneWorker {
+ public:
+  OneWorker() : th_([this] { loop(); }) {}
+  ~OneWorker() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  void post(std::function<void()> fn) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !pending_; });
+    fn_ = std::move(fn);
+    pending_ = true;
+    lk.unlock();
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !pending_; });
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      cv_.wait(lk, [&] { return pending_ || stop_; });
+      if (!pending_) return;  // (a job posted before the destructor still runs)
+      std::function<void()> f = std::move(fn_);
+      lk.unlock();
+      f();
+      lk.lock();
+      pending_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> fn_;
+  bool pending_ = false, stop_ = false;
+  std::thread th_;  // last member: the thread starts with everything above constructed
 };
 
 }  // namespace tsh

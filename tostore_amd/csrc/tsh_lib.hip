@@ -732,7 +732,7 @@ int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
   if (!c->ev0) {
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming | (blocking_wait() ? hipEventBlockingSync : 0)));
     HIPCHK(hipEventCreateWithFlags(&c->ev_scanned, hipEventDisableTiming));
     HIPCHK(hipMalloc(&c->d_query, (size_t)s->ld * sizeof(float)));
     HIPCHK(hipHostMalloc(&c->h_query, (size_t)s->ld * sizeof(float), hipHostMallocDefault));
@@ -1887,6 +1887,22 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
   idx->tickets_open.fetch_add(1);
   *out_ticket = slot;
   return TSH_OK;
+}
+
+int32_t tsh_search_ready(tsh_index *idx, int32_t ticket) {
+  if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  std::lock_guard<std::mutex> lk(idx->tk_mu);
+  if (ticket < 0 || (size_t)ticket >= idx->tickets.size() || !idx->tickets[(size_t)ticket])
+    return set_err(TSH_E_BAD_ARG, "unknown ticket %d", ticket);
+  Ticket *t = idx->tickets[(size_t)ticket].get();
+  for (size_t g = 0; g < idx->shards.size(); ++g) {
+    if (!t->jobs[g].c) continue;
+    if (hipSetDevice(idx->shards[g]->device) != hipSuccess) return set_err(TSH_E_HIP, "hipSetDevice failed");
+    const hipError_t e = hipEventQuery(t->jobs[g].c->ev_done);
+    if (e == hipErrorNotReady) return 0;
+    if (e != hipSuccess) return set_err(TSH_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+  }
+  return 1;
 }
 
 int32_t tsh_search_wait(tsh_index *idx, int32_t ticket, double thr, int64_t *out_ids, double *out_dist,

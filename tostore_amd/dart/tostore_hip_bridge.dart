@@ -4,8 +4,10 @@
 //
 // NOT compiled in this repository: the build image has no Dart SDK.  What CAN be
 // checked without one is: tests/test_dart_bridge.py parses every `typedef ...C`
-// below, the symbol each one is looked up as, and the TshNghInfo struct, and
-// compares arity, argument widths and field layout with include/tostore_hip.h.
+// below, the symbol each one is looked up as, and the TshNghInfo / TshCounters
+// structs, and compares arity, argument widths and field layout with
+// include/tostore_hip.h; a header symbol that is neither bound here nor on that
+// test's short "not for a Dart host" list fails the test.
 // It is a mechanical mapping of the C-ABI, written in the style of the
 // reference's only existing FFI user, lib/src/handler/system_ffi_helper.dart
 // (DynamicLibrary.open + lookupFunction, int32 status with 0 = success,
@@ -13,6 +15,7 @@
 // The ctypes binding tostore_amd/_ffi.py exercises the same entry points with
 // the same argument meaning and IS tested (tests/test_abi.py, tests/test_gpu_*).
 
+import 'dart:async';
 import 'dart:ffi';
 import 'dart:math' show Random;
 import 'dart:typed_data';
@@ -62,6 +65,94 @@ typedef _PqTrainC = Int32 Function(Int32, Pointer<Float>, Int64, Int32, Int32, I
     Pointer<Int32>, Pointer<Float>);
 typedef _PqTrainD = int Function(int, Pointer<Float>, int, int, int, int, int,
     Pointer<Int32>, Pointer<Float>);
+
+typedef _CreateShardC = Int32 Function(Int32, Int32, Int64, Int32, Int64, Pointer<Pointer<Void>>);
+typedef _CreateShardD = int Function(int, int, int, int, int, Pointer<Pointer<Void>>);
+typedef _DimC = Int32 Function(Pointer<Void>);
+typedef _DimD = int Function(Pointer<Void>);
+typedef _MetricC = Int32 Function(Pointer<Void>);
+typedef _MetricD = int Function(Pointer<Void>);
+typedef _MaxInflightC = Int32 Function();
+typedef _MaxInflightD = int Function();
+typedef _SubmitC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Pointer<Uint8>, Pointer<Int32>);
+typedef _SubmitD = int Function(Pointer<Void>, Pointer<Float>, int, Pointer<Uint8>, Pointer<Int32>);
+typedef _ReadyC = Int32 Function(Pointer<Void>, Int32);
+typedef _ReadyD = int Function(Pointer<Void>, int);
+typedef _WaitC = Int32 Function(
+    Pointer<Void>, Int32, Double, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _WaitD = int Function(
+    Pointer<Void>, int, double, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _CountersC = Int32 Function(Pointer<Void>, Pointer<TshCounters>);
+typedef _CountersD = int Function(Pointer<Void>, Pointer<TshCounters>);
+typedef _SetOptionC = Int32 Function(Pointer<Void>, Int32, Int64);
+typedef _SetOptionD = int Function(Pointer<Void>, int, int);
+typedef _BlockBytesC = Int64 Function(Int32);
+typedef _BlockBytesD = int Function(int);
+typedef _BlockEntriesC = Int32 Function(Int32);
+typedef _BlockEntriesD = int Function(int);
+typedef _SearchShardC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, Pointer<Uint8>,
+    Int32, Pointer<Void>, Pointer<Void>);
+typedef _SearchShardD = int Function(Pointer<Void>, Pointer<Float>, int, int, Pointer<Uint8>,
+    int, Pointer<Void>, Pointer<Void>);
+typedef _MergeC = Int32 Function(Int32, Int32, Pointer<Float>, Int32, Int32, Double, Pointer<Void>,
+    Int32, Int32, Pointer<Int64>, Pointer<Double>, Pointer<Int32>, Pointer<Int32>);
+typedef _MergeD = int Function(int, int, Pointer<Float>, int, int, double, Pointer<Void>,
+    int, int, Pointer<Int64>, Pointer<Double>, Pointer<Int32>, Pointer<Int32>);
+typedef _CommIdC = Int32 Function(Pointer<Void>);
+typedef _CommIdD = int Function(Pointer<Void>);
+typedef _CommCreateC = Int32 Function(Pointer<Void>, Int32, Int32, Int32, Pointer<Pointer<Void>>);
+typedef _CommCreateD = int Function(Pointer<Void>, int, int, int, Pointer<Pointer<Void>>);
+/// `tsh_allgather_fn`: int32 (*)(void *user, const void *send, void *recv, int64 bytes)
+typedef TshAllgatherNative = Int32 Function(Pointer<Void>, Pointer<Void>, Pointer<Void>, Int64);
+typedef _CommCreateHostC = Int32 Function(Int32, Int32, Int32,
+    Pointer<NativeFunction<TshAllgatherNative>>, Pointer<Void>, Pointer<Pointer<Void>>);
+typedef _CommCreateHostD = int Function(int, int, int,
+    Pointer<NativeFunction<TshAllgatherNative>>, Pointer<Void>, Pointer<Pointer<Void>>);
+typedef _CommDestroyC = Int32 Function(Pointer<Void>);
+typedef _CommDestroyD = int Function(Pointer<Void>);
+typedef _CommWorldC = Int32 Function(Pointer<Void>);
+typedef _CommWorldD = int Function(Pointer<Void>);
+typedef _CommSetGroupC = Int32 Function(Pointer<Void>, Int32);
+typedef _CommSetGroupD = int Function(Pointer<Void>, int);
+typedef _SearchShardedC = Int32 Function(Pointer<Void>, Pointer<Void>, Pointer<Float>, Int32, Int32,
+    Double, Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _SearchShardedD = int Function(Pointer<Void>, Pointer<Void>, Pointer<Float>, int, int,
+    double, Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+
+/// `tsh_counters` (include/tostore_hip.h).  Field order and widths are checked against the header by
+/// tests/test_dart_bridge.py.
+final class TshCounters extends Struct {
+  @Int64()
+  external int rows;
+  @Int64()
+  external int deletedRows;
+  @Int64()
+  external int searches;
+  @Int64()
+  external int scanLaunches;
+  @Int64()
+  external int batchLaunches;
+  @Int64()
+  external int fallbackSearches;
+  @Int64()
+  external int candidatesTotal;
+  @Int64()
+  external int bytesResident;
+  @Int32()
+  external int safeMode;
+  @Int32()
+  external int deviceId;
+  @Double()
+  external double scanUsSum;
+  @Int64()
+  external int scanUsSamples;
+  @Int32()
+  external int batchKernelLast;
+  @Int32()
+  external int quarantinedRows;
+  @Int64()
+  external int fusedLaunches;
+}
 
 /// `tsh_ngh_info` (include/tostore_hip.h): what tsh_index_open_ngh found.  Field order and
 /// widths are checked against the header by tests/test_dart_bridge.py.
@@ -121,6 +212,29 @@ final class HipVectorBackend {
   static late final _OpenNghD _openNgh;
   static late final _PqEncodeD _pqEncode;
   static late final _PqTrainD _pqTrain;
+  static late final _CreateShardD _createShard;
+  static late final _DimD _dim;
+  static late final _MetricD _metric;
+  static late final _MaxInflightD _maxInflight;
+  static late final _SubmitD _submit;
+  static late final _ReadyD _ready;
+  static late final _WaitD _wait;
+  static late final _CountersD _counters;
+  static late final _SetOptionD _setOption;
+  static late final _BlockBytesD _blockBytes;
+  static late final _BlockEntriesD _blockEntries;
+  static late final _SearchShardD _searchShard;
+  static late final _MergeD _merge;
+  static late final _CommIdD _commId;
+  static late final _CommCreateD _commCreate;
+  static late final _CommCreateHostD _commCreateHost;
+  static late final _CommDestroyD _commDestroy;
+  static late final _CommWorldD _commWorld;
+  static late final _CommSetGroupD _commSetGroup;
+  static late final _SearchShardedD _searchSharded;
+
+  /// include/tostore_hip.h TSH_ABI_VERSION this file was written against.
+  static const int abiVersion = 2;
 
   /// True when libtostore_hip.so is loadable, ABI-compatible and sees a GPU.
   static bool get available {
@@ -142,7 +256,30 @@ final class HipVectorBackend {
       _openNgh = lib.lookupFunction<_OpenNghC, _OpenNghD>('tsh_index_open_ngh');
       _pqEncode = lib.lookupFunction<_PqEncodeC, _PqEncodeD>('tsh_index_pq_encode');
       _pqTrain = lib.lookupFunction<_PqTrainC, _PqTrainD>('tsh_pq_train');
-      if (_abiVersion() != 1 || _deviceCount() < 1) return false;
+      _createShard = lib.lookupFunction<_CreateShardC, _CreateShardD>('tsh_index_create_shard');
+      _dim = lib.lookupFunction<_DimC, _DimD>('tsh_index_dim');
+      _metric = lib.lookupFunction<_MetricC, _MetricD>('tsh_index_metric');
+      _maxInflight = lib.lookupFunction<_MaxInflightC, _MaxInflightD>('tsh_max_inflight');
+      _submit = lib.lookupFunction<_SubmitC, _SubmitD>('tsh_search_submit');
+      _ready = lib.lookupFunction<_ReadyC, _ReadyD>('tsh_search_ready');
+      _wait = lib.lookupFunction<_WaitC, _WaitD>('tsh_search_wait');
+      _counters = lib.lookupFunction<_CountersC, _CountersD>('tsh_get_counters');
+      _setOption = lib.lookupFunction<_SetOptionC, _SetOptionD>('tsh_index_set_option');
+      _blockBytes = lib.lookupFunction<_BlockBytesC, _BlockBytesD>('tsh_candidate_block_bytes');
+      _blockEntries = lib.lookupFunction<_BlockEntriesC, _BlockEntriesD>('tsh_default_block_entries');
+      _searchShard = lib.lookupFunction<_SearchShardC, _SearchShardD>('tsh_search_shard');
+      _merge = lib.lookupFunction<_MergeC, _MergeD>('tsh_merge_candidates');
+      _commId = lib.lookupFunction<_CommIdC, _CommIdD>('tsh_comm_unique_id');
+      _commCreate = lib.lookupFunction<_CommCreateC, _CommCreateD>('tsh_comm_create');
+      _commCreateHost =
+          lib.lookupFunction<_CommCreateHostC, _CommCreateHostD>('tsh_comm_create_host');
+      _commDestroy = lib.lookupFunction<_CommDestroyC, _CommDestroyD>('tsh_comm_destroy');
+      _commWorld = lib.lookupFunction<_CommWorldC, _CommWorldD>('tsh_comm_world');
+      _commSetGroup = lib.lookupFunction<_CommSetGroupC, _CommSetGroupD>('tsh_comm_set_group');
+      _searchSharded =
+          lib.lookupFunction<_SearchShardedC, _SearchShardedD>('tsh_search_sharded');
+      // the structs of this file are the version-2 layouts: any other library is not used
+      if (_abiVersion() != abiVersion || _deviceCount() < 1) return false;
       _lib = lib;
       return true;
     } catch (_) {
@@ -359,10 +496,258 @@ final class HipVectorBackend {
     }
   }
 
+  /// One shard of a row-range partitioned index (one Dart process per GPU): holds node ids
+  /// [rowBase, rowBase + rows) on `device`; reported ids are global.
+  static HipVectorBackend? tryCreateShard(NghIndexMeta meta, int device, int rowBase, int rows) {
+    if (!available) return null;
+    final out = calloc<Pointer<Void>>();
+    try {
+      final rc = _createShard(
+          meta.dimensions, meta.distanceMetric.index, rows, device, rowBase, out);
+      if (rc != 0) {
+        Logger.warn('tsh_index_create_shard failed ($rc): ${_errorText()}',
+            label: 'HipVectorBackend');
+        return null;
+      }
+      return HipVectorBackend._(out.value, meta.dimensions, meta.distanceMetric);
+    } finally {
+      calloc.free(out);
+    }
+  }
+
+  /// Searches that may be in flight per handle (tsh_max_inflight).
+  static int get maxInflight => available ? _maxInflight() : 0;
+
+  /// The asynchronous form of [search]: the query is enqueued (some 20 microseconds), the isolate goes back
+  /// to its event loop while the GPU scans, and the result is collected once tsh_search_ready says
+  /// so -- the isolate never blocks for longer than the final copy, whatever the corpus size, which
+  /// is what the reference's cooperative scheduling asks of everything on the main isolate (8 ms
+  /// client / 50 ms server budget: model/data_store_config.dart:225-230,
+  /// core/yield_controller.dart:110-169).  Up to [maxInflight] calls may overlap on one handle; their
+  /// scans run back to back and each query's select / re-rank hides behind the next scan.
+  /// Returns null on any native failure (TSH_E_BUSY included: the caller falls back to the
+  /// synchronous path or the Dart graph search).
+  Future<List<NghSearchResult>?> searchAsync(Float32List query, int topK,
+      {double? distanceThreshold, Uint8List? rowMask}) async {
+    if (topK <= 0 || size == 0) return const [];
+    final q = calloc<Float>(dimensions);
+    final ticket = calloc<Int32>();
+    Pointer<Uint8> mask = nullptr;
+    int t;
+    try {
+      q.asTypedList(dimensions).setAll(0, query);
+      if (rowMask != null) {
+        mask = calloc<Uint8>(rowMask.length);
+        mask.asTypedList(rowMask.length).setAll(0, rowMask);
+      }
+      final rc = _submit(_handle, q, topK, mask, ticket); // inputs are consumed before it returns
+      if (rc != 0) {
+        Logger.warn('tsh_search_submit failed ($rc): ${_errorText()}',
+            label: 'HipVectorBackend');
+        return null;
+      }
+      t = ticket.value;
+    } finally {
+      calloc.free(q);
+      calloc.free(ticket);
+      if (mask != nullptr) calloc.free(mask);
+    }
+    // every ticket must be waited exactly once: from here on nothing may return before _wait ran
+    while (_ready(_handle, t) == 0) {
+      await Future<void>.delayed(Duration.zero); // yield to the event loop, as YieldController does
+    }
+    final ids = calloc<Int64>(topK);
+    final dist = calloc<Double>(topK);
+    final cnt = calloc<Int32>();
+    try {
+      final rc = _wait(_handle, t, distanceThreshold ?? double.nan, ids, dist, cnt);
+      if (rc != 0) {
+        Logger.warn('tsh_search_wait failed ($rc): ${_errorText()}', label: 'HipVectorBackend');
+        return null;
+      }
+      final n = cnt.value;
+      return [
+        for (var i = 0; i < n; i++) NghSearchResult(nodeId: ids[i], distance: dist[i])
+      ];
+    } finally {
+      calloc.free(ids);
+      calloc.free(dist);
+      calloc.free(cnt);
+    }
+  }
+
+  /// Diagnostics for Logger (handler/logger.dart:8-60): rows, searches, candidates per query,
+  /// resident bytes, safe mode / quarantined rows.
+  Map<String, num>? counters() {
+    final c = calloc<TshCounters>();
+    try {
+      if (_counters(_handle, c) != 0) return null;
+      final r = c.ref;
+      return {
+        'rows': r.rows,
+        'deletedRows': r.deletedRows,
+        'searches': r.searches,
+        'scanLaunches': r.scanLaunches,
+        'batchLaunches': r.batchLaunches,
+        'fallbackSearches': r.fallbackSearches,
+        'candidatesTotal': r.candidatesTotal,
+        'bytesResident': r.bytesResident,
+        'safeMode': r.safeMode,
+        'deviceId': r.deviceId,
+        'quarantinedRows': r.quarantinedRows,
+      };
+    } finally {
+      calloc.free(c);
+    }
+  }
+
+  /// tsh_index_set_option: 1 = TSH_OPT_BATCH_MIN_NQ, 2 = TSH_OPT_BATCH_KERNEL.
+  bool setOption(int option, int value) => _setOption(_handle, option, value) == 0;
+
+  int get nativeDimensions => _dim(_handle);
+  int get nativeMetric => _metric(_handle);
+
+  /// Row-sharded deployments whose exchange the HOST does itself (any transport): this shard's
+  /// candidate blocks for `queries` into `deviceBlocks` (device memory of
+  /// nq * candidateBlockBytes(entries) bytes), to be gathered from all ranks and merged with
+  /// [mergeCandidates].  Hosts on one node use [HipShardComm] instead, which does all of it.
+  static int candidateBlockBytes(int entries) => _blockBytes(entries);
+  static int defaultBlockEntries(int k) => _blockEntries(k);
+  bool searchShard(Pointer<Float> queries, int nq, int topK, Pointer<Uint8> rowMask, int entries,
+          Pointer<Void> deviceBlocks) =>
+      _searchShard(_handle, queries, nq, topK, rowMask, entries, deviceBlocks, nullptr) == 0;
+
+  /// Host-side merge of `nBlocks` x nq gathered candidate blocks; false with `neededEntries`
+  /// set when a block was truncated (every rank retries with that many entries).
+  static bool mergeCandidates(int metric, int dim, Pointer<Float> queries, int nq, int topK,
+      double? distanceThreshold, Pointer<Void> blocks, int nBlocks, int entries,
+      Pointer<Int64> outIds, Pointer<Double> outDist, Pointer<Int32> outCount,
+      Pointer<Int32> neededEntries) {
+    return _merge(metric, dim, queries, nq, topK, distanceThreshold ?? double.nan, blocks, nBlocks,
+            entries, outIds, outDist, outCount, neededEntries) ==
+        0;
+  }
+
   void dispose() {
     if (_handle != nullptr) {
       _destroy(_handle);
       _handle = nullptr;
+    }
+  }
+}
+
+/// One rank of a row-sharded index: one Dart process per GPU, the library's own RCCL exchange
+/// (tsh_comm_* / tsh_search_sharded).  Rank 0 calls [uniqueId] and ships the 128 bytes to its peers over
+/// whatever channel the deployment has; every rank then constructs its communicator (collective) and
+/// calls [search] with the same queries (collective).  Every rank gets the full answer.
+final class HipShardComm {
+  Pointer<Void> _comm;
+  final HipVectorBackend shard;
+
+  HipShardComm._(this._comm, this.shard);
+
+  static Uint8List? uniqueId() {
+    if (!HipVectorBackend.available) return null;
+    final buf = calloc<Uint8>(128);
+    try {
+      if (HipVectorBackend._commId(buf.cast<Void>()) != 0) return null;
+      return Uint8List.fromList(buf.asTypedList(128));
+    } finally {
+      calloc.free(buf);
+    }
+  }
+
+  static HipShardComm? tryCreate(
+      HipVectorBackend shard, Uint8List id, int world, int rank, int device) {
+    if (!HipVectorBackend.available || id.length != 128) return null;
+    final buf = calloc<Uint8>(128);
+    final out = calloc<Pointer<Void>>();
+    try {
+      buf.asTypedList(128).setAll(0, id);
+      final rc = HipVectorBackend._commCreate(buf.cast<Void>(), world, rank, device, out);
+      if (rc != 0) {
+        Logger.warn('tsh_comm_create failed ($rc): ${HipVectorBackend._errorText()}',
+            label: 'HipShardComm');
+        return null;
+      }
+      return HipShardComm._(out.value, shard);
+    } finally {
+      calloc.free(buf);
+      calloc.free(out);
+    }
+  }
+
+  /// The same protocol over a transport the host brings (ranks on several nodes): `allgather` is a
+  /// `Pointer.fromFunction` / `NativeCallable.isolateLocal` of [TshAllgatherNative] that places every rank's
+  /// bytes at recv + rank * bytes on every rank.
+  static HipShardComm? tryCreateOverHost(HipVectorBackend shard, int world, int rank, int device,
+      Pointer<NativeFunction<TshAllgatherNative>> allgather) {
+    if (!HipVectorBackend.available) return null;
+    final out = calloc<Pointer<Void>>();
+    try {
+      final rc =
+          HipVectorBackend._commCreateHost(world, rank, device, allgather, nullptr, out);
+      if (rc != 0) return null;
+      return HipShardComm._(out.value, shard);
+    } finally {
+      calloc.free(out);
+    }
+  }
+
+  int get world => HipVectorBackend._commWorld(_comm);
+
+  /// Queries per exchange inside one [search] call (0 = by the size of the call).  Same on every rank.
+  bool setGroup(int queriesPerExchange) =>
+      HipVectorBackend._commSetGroup(_comm, queriesPerExchange) == 0;
+
+  /// Collective: same queries, topK and threshold on every rank.  null on failure -- this rank's own
+  /// (its error is logged) or another rank's (TSH_E_PEER = -11): every rank then takes the same
+  /// fallback, and the communicator stays usable.
+  List<List<NghSearchResult>>? search(List<Float32List> queries, int topK,
+      {double? distanceThreshold, Uint8List? rowMask}) {
+    final nq = queries.length, d = shard.dimensions;
+    if (nq == 0 || topK <= 0) return [for (var i = 0; i < nq; i++) const []];
+    final q = calloc<Float>(nq * d);
+    final ids = calloc<Int64>(nq * topK);
+    final dist = calloc<Double>(nq * topK);
+    final cnt = calloc<Int32>(nq);
+    Pointer<Uint8> mask = nullptr;
+    try {
+      final view = q.asTypedList(nq * d);
+      for (var i = 0; i < nq; i++) {
+        view.setRange(i * d, (i + 1) * d, queries[i]);
+      }
+      if (rowMask != null) {
+        mask = calloc<Uint8>(rowMask.length);
+        mask.asTypedList(rowMask.length).setAll(0, rowMask);
+      }
+      final rc = HipVectorBackend._searchSharded(shard._handle, _comm, q, nq, topK,
+          distanceThreshold ?? double.nan, mask, ids, dist, cnt);
+      if (rc != 0) {
+        Logger.warn('tsh_search_sharded failed ($rc): ${HipVectorBackend._errorText()}',
+            label: 'HipShardComm');
+        return null;
+      }
+      return [
+        for (var i = 0; i < nq; i++)
+          [
+            for (var j = 0; j < cnt[i]; j++)
+              NghSearchResult(nodeId: ids[i * topK + j], distance: dist[i * topK + j])
+          ]
+      ];
+    } finally {
+      calloc.free(q);
+      calloc.free(ids);
+      calloc.free(dist);
+      calloc.free(cnt);
+      if (mask != nullptr) calloc.free(mask);
+    }
+  }
+
+  void dispose() {
+    if (_comm != nullptr) {
+      HipVectorBackend._commDestroy(_comm);
+      _comm = nullptr;
     }
   }
 }

@@ -173,25 +173,69 @@ class ShardedSearcher:
 
 
 class CommSearcher:
-    """The same exchange through the library's OWN RCCL entry points (include/tostore_hip.h: tsh_comm_*,
-    tsh_search_sharded) -- what a host without torch (one Dart process per GPU) calls.  Rank 0 makes the 128-byte id
-    with `CommSearcher.unique_id()`, the host ships it to the other ranks over whatever channel it has, every rank
-    constructs its searcher (collective) and then calls `search` with the same queries (collective)."""
+    """The same exchange through the library's OWN entry points (include/tostore_hip.h: tsh_comm_*,
+    tsh_search_sharded) -- what a host without torch (one Dart process per GPU) calls.  The library pipelines the
+    call itself (groups of queries: a helper thread scans group g + 1 while group g is all-gathered and merged, each
+    rank merging its slice of the group's queries).
 
-    def __init__(self, shard_index, world: int, rank: int, unique_id: bytes, device: int = -1):
-        if len(unique_id) != 128:
-            raise ValueError("unique_id must be the 128 bytes of tsh_comm_unique_id")
+    RCCL transport: rank 0 makes the 128-byte id with `CommSearcher.unique_id()`, the host ships it to the other
+    ranks over whatever channel it has, every rank constructs its searcher (collective) and then calls `search`
+    with the same queries (collective).
+    Host transport (`allgather=`): a callable `(send: np.ndarray[uint8], recv: np.ndarray[uint8]) -> None` that
+    places every rank's bytes at recv[rank * len(send):]; `CommSearcher.over_torch(...)` builds one from a
+    torch.distributed group (gloo: several ranks may share one GPU)."""
+
+    python_groups = False  # search_many: the library forms the groups itself
+
+    def __init__(self, shard_index, world: int, rank: int, unique_id: Optional[bytes] = None, device: int = -1,
+                 allgather=None):
         self.index = shard_index
         self.world = world
+        self.rank = rank
         self._c = ctypes.c_void_p()
+        self._cb = None
+        self.callback_error = None
+        if allgather is not None:
+            def _cb(_user, send, recv, nbytes):
+                try:
+                    src = np.ctypeslib.as_array(ctypes.cast(send, _ffi.p_u8), shape=(nbytes,))
+                    dst = np.ctypeslib.as_array(ctypes.cast(recv, _ffi.p_u8), shape=(nbytes * world,))
+                    allgather(src, dst)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- must not unwind through the C frames
+                    self.callback_error = e
+                    return -1
+            self._cb = _ffi.ALLGATHER_FN(_cb)  # kept alive as long as the communicator
+            _ffi.check(_ffi.lib().tsh_comm_create_host(world, rank, device, ctypes.cast(self._cb, ctypes.c_void_p),
+                                                       None, ctypes.byref(self._c)))
+            return
+        if unique_id is None or len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of tsh_comm_unique_id")
         buf = ctypes.create_string_buffer(unique_id, 128)
         _ffi.check(_ffi.lib().tsh_comm_create(buf, world, rank, device, ctypes.byref(self._c)))
+
+    @classmethod
+    def over_torch(cls, shard_index, group=None, device: int = -1):
+        """Host transport over a torch.distributed process group (CPU tensors: gloo)."""
+        import torch
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def allgather(send, recv):
+            dist.all_gather_into_tensor(torch.from_numpy(recv), torch.from_numpy(send), group=group)
+
+        return cls(shard_index, world, rank, None, device, allgather=allgather)
 
     @staticmethod
     def unique_id() -> bytes:
         buf = ctypes.create_string_buffer(128)
         _ffi.check(_ffi.lib().tsh_comm_unique_id(buf))
         return buf.raw
+
+    def set_group(self, queries_per_exchange: int) -> None:
+        """Queries per exchange (0 = by the size of the call).  Same value on every rank."""
+        _ffi.check(_ffi.lib().tsh_comm_set_group(self._c, int(queries_per_exchange)))
 
     def close(self) -> None:
         if self._c:
@@ -204,7 +248,9 @@ class CommSearcher:
     def __exit__(self, *exc):
         self.close()
 
-    def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
+    def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None, shard=...):
+        """Collective.  `shard=None` (tests) passes a NULL handle: this rank fails locally and stays in the
+        collective."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
@@ -214,15 +260,19 @@ class CommSearcher:
         cnt = np.zeros(nq, dtype=np.int32)
         thr = math.nan if distance_threshold is None else float(distance_threshold)
         row_mask, mp = self.index.mask_arg(row_mask)
-        _ffi.check(_ffi.lib().tsh_search_sharded(self.index._h, self._c, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, mp,
+        h = self.index._h if shard is ... else shard
+        _ffi.check(_ffi.lib().tsh_search_sharded(h, self._c, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, mp,
                                                  ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
                                                  cnt.ctypes.data_as(_ffi.p_i32)))
         return ids[:, :kk], dist[:, :kk], cnt
 
-    def search_many(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None, group: int = 64):
-        """Groups of `group` queries per collective (same signature as ShardedSearcher.search_many)."""
-        q = np.ascontiguousarray(queries, dtype=np.float32)
-        if q.ndim == 1:
-            q = q[None, :]
-        parts = [self.search(q[s:s + group], k, distance_threshold, row_mask) for s in range(0, q.shape[0], group)]
-        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+    def search_many(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None, group: int = 0):
+        """One collective call; the library forms the groups itself (same signature as
+        ShardedSearcher.search_many; `group` > 0 overrides the library's choice)."""
+        if group:
+            self.set_group(group)
+        try:
+            return self.search(queries, k, distance_threshold, row_mask)
+        finally:
+            if group:
+                self.set_group(0)
