@@ -637,7 +637,10 @@ def run_bench(a, env=None):
     # ---- resident corpus: this rank generates and holds its own row range only -------
     per = (n + world - 1) // world
     lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
-    want_host = rank == 0 and world == 1 and not a.no_cpu_baseline  # for the CPU baseline / recall check only
+    # a host copy for the CPU baseline / recall check, unless the corpus is too big for one (C4: 61 GB): then the
+    # oracle sees it chunk by chunk, as in a sharded run
+    big = float(n) * d * 4 > 16e9
+    want_host = rank == 0 and world == 1 and not a.no_cpu_baseline and not big
     idx, host_rows = env.build_index(d, metric, n, lo, hi, keep_host=want_host)
 
     if a.batch > 0:
@@ -700,6 +703,7 @@ def run_bench(a, env=None):
     repeats = auto_repeats(a.steps, a.repeats)
     regions = []
     env.fence()
+    cg0, t_cg0 = cgroup_cpu_stat(), time.perf_counter()
     c0 = idx.counters()
     for r in range(repeats):
         env.fence()
@@ -708,6 +712,7 @@ def run_bench(a, env=None):
         env.fence()
         regions.append(env.reduce_max(time.perf_counter() - t0))
     c1 = idx.counters()
+    cg1, t_cg1 = cgroup_cpu_stat(), time.perf_counter()
     elapsed = float(np.median(regions))
 
     # single-query latency, one at a time (not the headline value).  Round 2's line carried p99 = 42.8 ms: one
@@ -759,13 +764,25 @@ def run_bench(a, env=None):
         t1 = time.perf_counter()
         ref = [oracle.search_heap(host_rows, queries[i % nqp], metric, k, None, row_mask) for i in range(n_cpu)]
         cpu_elapsed = time.perf_counter() - t1
-    elif rank == 0 and world > 1 and not a.no_cpu_baseline:
-        # sharded run: no rank holds the corpus.  Rank 0 regenerates it chunk by chunk (counter-based generator)
-        # and runs the exhaustive oracle on a few sampled queries -- a parity check, not a baseline
-        # (cpu_baseline is reported at N = 1 only)
+    elif rank == 0 and not a.no_cpu_baseline:
+        # sharded run (or a corpus too big for a host copy): no process holds the corpus.  Rank 0 regenerates it
+        # chunk by chunk (counter-based generator) and runs the exhaustive oracle on a few sampled queries -- a
+        # parity check; cpu_baseline is reported at N = 1 only
         n_cpu = max(2, min(8, int(a.cpu_seconds * 6e9 / (float(n) * d * 4))))
         r_ids, r_dist, r_cnt = oracle_topk_stream(env.oracle_chunks(n, d, metric), queries[:n_cpu], metric, k, row_mask)
         ref = [(r_ids[i, :r_cnt[i]], r_dist[i, :r_cnt[i]]) for i in range(n_cpu)]
+        if world == 1:  # big corpus on one GPU: the single-thread baseline on a bounded sample of its rows
+            import oracle
+
+            sample = np.concatenate([rows for _, rows in
+                                     (c for i, c in zip(range(8), env.oracle_chunks(n, d, metric)))])
+            smask = None if row_mask is None else row_mask[:(len(sample) + 7) // 8]
+            t1 = time.perf_counter()
+            m_cpu = 0
+            while m_cpu < 2 or (time.perf_counter() - t1 < a.cpu_seconds and m_cpu < 32):
+                oracle.search_heap(sample, queries[m_cpu % nqp], metric, k, None, smask)
+                m_cpu += 1
+            big_cpu = (m_cpu / (time.perf_counter() - t1) * len(sample) / n, m_cpu, len(sample))
     n_cpu = env.bcast_int(n_cpu)
     got = [one(i) for i in range(n_cpu)]
 
@@ -834,7 +851,7 @@ def run_bench(a, env=None):
             out["recall_at_k"] = hits / max(tot, 1)
             out["recall_queries"] = n_cpu
             out["ids_and_distances_bit_exact"] = exact
-            if world == 1 and a.recall_queries > n_cpu:
+            if world == 1 and a.recall_queries > n_cpu and host_rows is not None:
                 # recall@k over >= 1000 queries: the oracle's OpenMP form, same
                 # per-(query,row) arithmetic, against the GPU answers of the same queries; 100-query chunks
                 # until the time budget is used
@@ -857,7 +874,12 @@ def run_bench(a, env=None):
                 out["cpu_baseline_mt_batched"] = {"value": nr / t_or, "unit": "queries/s",
                                                   "cores": oracle.mt_max_threads(), "kind": "port",
                                                   "sample": "%d queries, OpenMP over query groups" % nr}
-            if world == 1:
+            if world == 1 and host_rows is None:
+                out["cpu_baseline"] = {
+                    "value": big_cpu[0], "unit": "queries/s", "cores": 1, "kind": "port",
+                    "sample": "%d of the same queries over the first %d of the %d rows, oracle/vs_oracle.c single "
+                              "thread, scaled by %d / %d (the scan is linear in the rows)" % (big_cpu[1], big_cpu[2], n, big_cpu[2], n)}
+            elif world == 1:
                 out["cpu_baseline"] = {
                     "value": n_cpu / cpu_elapsed, "unit": "queries/s", "cores": 1, "kind": "port",
                     "sample": "%d of the same queries over the full %dx%d corpus, oracle/vs_oracle.c "
@@ -877,6 +899,12 @@ def run_bench(a, env=None):
                                            "mean": float(lat.mean()), "queries": int(len(lat)),
                                            "harness_gc_collections_inside": len(gc_ms)}
         c = idx.counters()
+        if cg0 and cg1:  # host side of the timed regions, all ranks together: CPUs busy, and whether the quota throttled
+            out["host_cpu"] = {"cpus_busy": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 / max(t_cg1 - t_cg0, 1e-9),
+                               "throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                               "throttled_ms": (cg1.get("throttled_usec", cg1.get("throttled_time", 0)) -
+                                                cg0.get("throttled_usec", cg0.get("throttled_time", 0))) / 1e3,
+                               "wall_s": t_cg1 - t_cg0}
         out["counters"] = {"fallback_searches": c["fallback_searches"],
                            "candidates_per_query": c["candidates_total"] / max(c["searches"], 1)}
 
@@ -909,6 +937,20 @@ def run_bench(a, env=None):
     if idx is not None:
         idx.close()
     return dumps(out) if rank == 0 else None
+
+
+def cgroup_cpu_stat():
+    """cgroup cpu.stat of this container (usage_usec, nr_throttled, throttled_usec ...): all ranks share it."""
+    d = {}
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for ln in open(path):
+                key, v = ln.split()
+                d[key] = int(v)
+            break
+        except (OSError, ValueError):
+            pass
+    return d
 
 
 def free_port():

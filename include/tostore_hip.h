@@ -82,8 +82,7 @@ typedef struct tsh_counters {
   int32_t batch_kernel_last; /* TSH_OPT_BATCH_KERNEL variant the last batched search ran (0/1/2; -1 none yet) */
   int32_t quarantined_rows;  /* live rows outside the f32 error model (non-finite or > 1e15 elements; cosine: norm
                                 below 2^-50) that are kept out of the scan and re-ranked exactly on every search */
-  int64_t fused_launches;    /* single-query searches that went out as ONE dispatch (scan + select + re-rank fused:
-                                short scans -- small shards, selective row masks); counted in scan_launches too */
+  int64_t fused_launches;    /* reserved (0): counted a single-dispatch experiment of round 2 that was removed */
 } tsh_counters;
 
 int32_t tsh_abi_version(void);

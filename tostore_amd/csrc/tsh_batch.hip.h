@@ -295,7 +295,7 @@ struct SplitArgs {
 };
 
 // one thread = 8 consecutive k of one row: a 16-B hi piece and a 16-B lo piece
-__global__ void __launch_bounds__(256) split_rows_kernel(SplitArgs a) {
+static __global__ void __launch_bounds__(256) split_rows_kernel(SplitArgs a) {
   const int64_t per_row = (int64_t)a.hchunks * 4;
   const int64_t total = a.n * per_row, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -343,7 +343,7 @@ struct HalfArgs {
 };
 
 // one thread = 8 consecutive k of one row = one 16-B piece
-__global__ void __launch_bounds__(256) half_rows_kernel(HalfArgs a) {
+static __global__ void __launch_bounds__(256) half_rows_kernel(HalfArgs a) {
   const int64_t per_row = (int64_t)a.hchunks * 8;
   const int64_t total = a.n * per_row, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -920,7 +920,7 @@ constexpr int RG_ROWS = RG / RG_WAVES;
 constexpr int RG_BLK = 256;         // floats of a row per load instruction
 constexpr int RG_LD = RG_BLK + 4;   // LDS row stride in floats: rows 4 banks apart, 16 rows cover the 64 banks
 
-__global__ void __launch_bounds__(64 * RG_WAVES) rerank_batch_kernel(RerankBatchArgs a) {
+static __global__ void __launch_bounds__(64 * RG_WAVES) rerank_batch_kernel(RerankBatchArgs a) {
 #pragma clang fp contract(off)
   __shared__ __attribute__((aligned(16))) float tile[RG * RG_LD];
   __shared__ __attribute__((aligned(16))) double s_q[RG_BLK];  // the query's current block, as f64

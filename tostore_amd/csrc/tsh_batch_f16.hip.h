@@ -54,7 +54,7 @@ struct Half32Args {
 };
 
 // one thread = 8 consecutive k of one row = one 16-byte piece
-__global__ void __launch_bounds__(256) half_rows32_kernel(Half32Args a) {
+static __global__ void __launch_bounds__(256) half_rows32_kernel(Half32Args a) {
   const int64_t per_row = (int64_t)a.kchunks * 4;
   const int64_t total = a.n * per_row, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -232,12 +232,18 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
   using S2 = std::integral_constant<int, 2>;
   using S3 = std::integral_constant<int, 3>;
   // probe (TSH_F16_DBG & 32): shader-clock stamps of waves 0 and 4 of workgroup 0 over their first 96 steps
+  // Compiled in with -DTSH_PROBES only (tools/f16_probe.sh builds such a library): a release build cannot be
+  // switched into the no-epilogue mode, whose results are wrong, by an environment variable.
   int dbg_step = 0;
+#ifdef TSH_PROBES
   const bool dbg_on = (a.dbg & 32) && blockIdx.x == 0 && (wave == 0 || wave == 4);
   auto stamp = [&](int point) {
     if (dbg_on && dbg_step < 96 && lane == 0)
       a.dbg_buf[((wave >> 2) * 96 + dbg_step) * 12 + point] = __builtin_amdgcn_s_memtime();
   };
+#else
+  auto stamp = [](int) {};
+#endif
   set_src(i_tile);
   int cur_q_tile = -1;
   // KC is a multiple of four (host) and at least four: every tile starts in ring stage 0
@@ -316,7 +322,9 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16_kernel(BatchArgs a) {
     step(S1{}, S2{}, S0{}, Yes{});  // ... and from here on the first three chunks of my next tile
     step(S2{}, S3{}, S1{}, No{});
     step(S3{}, S0{}, S2{}, No{});
+#ifdef TSH_PROBES
     if (a.dbg & 4) continue;
+#endif
 
     // ---- epilogue ----------------------------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: col = lane & 31 (corpus row), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query).

@@ -2,7 +2,9 @@
 // Part of the single translation unit tsh_lib.hip (textually included there; not compiled alone).
 
 // ---- batched (matrix-core) path ---------------------------------------------------
-static uint64_t *g_f16_dbg_buf = nullptr;  // TSH_F16_DBG & 32 probe
+#ifdef TSH_PROBES
+static uint64_t *g_f16_dbg_buf = nullptr;  // TSH_F16_DBG & 32 probe (probe builds only: -DTSH_PROBES)
+#endif
 struct BatchCtx {
   std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
   float *d_Q = nullptr, *h_Q = nullptr;
@@ -67,54 +69,7 @@ int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
   return TSH_OK;
 }
 
-template <int METRIC>
-void launch_batch_score(const BatchArgs &a, bool dense, hipStream_t st) {
-  int grid = a.q_tiles * a.n_tiles;
-  if (grid <= 0) return;
-  if (dense) batch_score_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
-  else batch_score_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
-}
-template <int METRIC>
-void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
-  int grid = a.q_tiles * a.n_tiles;
-  if (grid <= 0) return;
-  if (a.dot_scale != 0.f) {  // f16 variant: tsh_batch_f16.hip.h (persistent: one 8-wave workgroup per CU)
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (cus <= 0) cus = 256;
-    }
-    const int pgrid = std::min(grid, cus);
-    if (a.tile_m == 256) {
-      if (dense) batch_score_f16_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
-      else batch_score_f16_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
-    } else {
-      if (dense) batch_score_f16_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
-      else batch_score_f16_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
-    }
-    return;
-  }
-  if (a.tile_m == 256) {  // 256 x 256 tiles, 8 waves (batches of more than 128 queries)
-    if (dense) batch_score_bf16x3_kernel<METRIC, true, 256, 256, 128><<<grid, 512, 0, st>>>(a);
-    else batch_score_bf16x3_kernel<METRIC, false, 256, 256, 128><<<grid, 512, 0, st>>>(a);
-    return;
-  }
-  if (dense) batch_score_bf16x3_kernel<METRIC, true><<<grid, BT_THREADS, 0, st>>>(a);
-  else batch_score_bf16x3_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
-}
-void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st) {
-  if (a.Vs) {
-    if (metric == TSH_METRIC_L2) launch_batch_score_bf16<METRIC_L2>(a, dense, st);
-    else if (metric == TSH_METRIC_IP) launch_batch_score_bf16<METRIC_IP>(a, dense, st);
-    else launch_batch_score_bf16<METRIC_COS>(a, dense, st);
-    return;
-  }
-  if (metric == TSH_METRIC_L2) launch_batch_score<METRIC_L2>(a, dense, st);
-  else if (metric == TSH_METRIC_IP) launch_batch_score<METRIC_IP>(a, dense, st);
-  else launch_batch_score<METRIC_COS>(a, dense, st);
-}
+// (launch_batch_score_m: tsh_batch_tu.hip -- the key kernels compile as a translation unit of their own)
 
 int64_t batch_sample_rows(int64_t rows, int32_t k) {
   if (rows <= 16384) return rows;
@@ -407,6 +362,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.Vs = s->d_split;
       a.hchunks = hchunks;
       a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
+#ifdef TSH_PROBES
       static const int f16_dbg = getenv("TSH_F16_DBG") ? atoi(getenv("TSH_F16_DBG")) : 0;  // probes: results are wrong
       a.dbg = f16_dbg;
       static uint64_t *d_dbg = nullptr;
@@ -414,6 +370,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       if (f16_dbg & 32) HIPCHK(hipMemsetAsync(d_dbg, 0, 2 * 96 * 12 * sizeof(uint64_t), st));
       a.dbg_buf = d_dbg;
       g_f16_dbg_buf = d_dbg;
+#endif
     }
     a.Q = b->d_Q;
     a.V = s->d_rows;
@@ -593,6 +550,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
     HIPCHK(hipStreamSynchronize(us));
   }
+#ifdef TSH_PROBES
   if (g_f16_dbg_buf && nq >= 1024) {  // probe: step timeline of two waves of workgroup 0 (main pass: the last launch)
     std::vector<uint64_t> hb(2 * 96 * 12);
     HIPCHK(hipMemcpy(hb.data(), g_f16_dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
@@ -608,6 +566,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       }
     }
   }
+#endif
   if (trace_batch())
     fprintf(stderr, "[tsh batch] nq=%d prep %.0f us, enqueue %.0f us, gpu wait %.0f us, post %.0f us (gemm %.0f us)\n", nq,
             t_prep - t_in, t_enq - t_prep, t_gpu - t_enq, now_us() - t_gpu, b->last_gemm_us);

@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
 // K3a: one pass of a radix select over the WHOLE key array (fallback path, k beyond what the tile-minimum
 // bound of K2 can serve): histogram of bits [shift, shift + 8) of the keys that share `prefix` above them.
 // Dead tiles are skipped through gmin (their keys are stale); dead rows inside live tiles carry KEY_DEAD.
-__global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
+static __global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
                                                          uint32_t prefix, int shift, uint32_t *hist) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *keys, c
 }
 
 // K3: whole-grid filter (fallback).  count accumulates in *out_count.
-__global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
+static __global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
                                                      uint32_t band, uint32_t *out_rows,
                                                      uint32_t *out_count, uint32_t cap) {
   const int lane = threadIdx.x & 63;
@@ -895,7 +895,7 @@ struct RerankArgs {
 };
 constexpr int RR_CHUNK = 1024;
 
-__global__ void __launch_bounds__(64) rerank_kernel(RerankArgs a) {
+static __global__ void __launch_bounds__(64) rerank_kernel(RerankArgs a) {
 #pragma clang fp contract(off)
   __shared__ __attribute__((aligned(16))) double t0[RR_CHUNK];
   __shared__ __attribute__((aligned(16))) double t1[RR_CHUNK];
@@ -986,7 +986,7 @@ __device__ __forceinline__ void quarantine_sums(const float *__restrict__ rp, co
   *o1 = cosine ? s1 : 0.0;
 }
 
-__global__ void __launch_bounds__(64) quarantine_kernel(QuarArgs a) {
+static __global__ void __launch_bounds__(64) quarantine_kernel(QuarArgs a) {
   uint32_t count = a.list[0];
   if (count > (uint32_t)a.cap) count = (uint32_t)a.cap;
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
@@ -1010,7 +1010,7 @@ struct QuarAppendArgs {
   int32_t dim, entries, metric;
 };
 
-__global__ void __launch_bounds__(64) quarantine_append_kernel(QuarAppendArgs a) {
+static __global__ void __launch_bounds__(64) quarantine_append_kernel(QuarAppendArgs a) {
   const uint32_t count = a.list[0];
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   if (c >= count) return;
@@ -1039,7 +1039,7 @@ struct IngestStats {
 // cannot cover (a non-finite or > 1e15 element; for cosine a norm below 2^-50).  Up to irr_cap of them are
 // listed (the host quarantines them: not live on the device, exact sums by quarantine_kernel) and stay out of the
 // statistics; the rest count as before and put the shard into safe mode.
-__global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t ld, int dim,
+static __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t ld, int dim,
                                                      int64_t first, int64_t n, float *inv_norm,
                                                      float *sqnorm, IngestStats *st, uint32_t *irr,
                                                      uint32_t irr_cap, int cosine) {
@@ -1118,7 +1118,7 @@ __global__ void __launch_bounds__(256) ingest_kernel(const float *rows, int64_t 
 }
 
 // set / clear bits of the live bitmap (word t bit r = row t*64+r)
-__global__ void live_range_kernel(uint64_t *live, int64_t first, int64_t n, int set) {
+static __global__ void live_range_kernel(uint64_t *live, int64_t first, int64_t n, int set) {
   int64_t w0 = first >> 6, w1 = (first + n - 1) >> 6;
   for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1;
        w += (int64_t)gridDim.x * blockDim.x) {
@@ -1134,12 +1134,12 @@ __global__ void live_range_kernel(uint64_t *live, int64_t first, int64_t n, int 
   }
 }
 
-__global__ void live_clear_u32_kernel(uint64_t *live, const uint32_t *ids, uint32_t n) {
+static __global__ void live_clear_u32_kernel(uint64_t *live, const uint32_t *ids, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     atomicAnd((unsigned long long *)&live[ids[i] >> 6], ~(1ull << (ids[i] & 63)));
 }
 
-__global__ void live_clear_ids_kernel(uint64_t *live, const int64_t *ids, int64_t n, int64_t row_base,
+static __global__ void live_clear_ids_kernel(uint64_t *live, const int64_t *ids, int64_t n, int64_t row_base,
                                       int64_t rows, uint32_t *n_cleared) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {

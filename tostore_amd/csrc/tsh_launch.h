@@ -1,0 +1,27 @@
+// tsh_launch.h -- launchers that live in translation units of their own (the kernels they instantiate take most
+// of the library's compile time: tsh_scan_tu.hip, tsh_batch_tu.hip), as seen by the host side in tsh_lib.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tsh_batch.hip.h"
+#include "tsh_kernels.hip.h"
+
+namespace tsh {
+
+constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgroups, two scan streams
+
+// Events that ride on the scan's own dispatch packet (hipExtLaunchKernel): a separate
+// hipEventRecord is a barrier packet of its own, and two or three of those between
+// consecutive scans were most of the gap between them.
+struct LaunchEv {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+
+// K1 for one query: picks the instantiation for the row width (nch), metric and mask, the grid shape for the
+// shard size.  tsh_scan_tu.hip
+void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev = LaunchEv());
+
+// batched key pass (f32 MFMA / bf16x3 / f16 by a.Vs and a.dot_scale).  tsh_batch_tu.hip
+void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st);
+
+}  // namespace tsh

@@ -32,9 +32,9 @@
 #include "../../include/tostore_hip.h"
 #include "tsh_batch.hip.h"
 #include "tsh_batch_f16.hip.h"
-#include "tsh_fused.hip.h"
 #include "tsh_host_sync.h"
 #include "tsh_kernels.hip.h"
+#include "tsh_launch.h"
 #include "tsh_pq.hip.h"
 
 using namespace tsh;
@@ -73,12 +73,9 @@ int device_count_cached() {
 constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
 constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
 constexpr uint32_t QUARANTINE_MAX = 1024;  // quarantined rows per shard; beyond that the shard goes to safe mode
-constexpr int SMALL_SHARD_TILES = 6 * 4 * 256;  // below this: one-wave workgroups, two scan streams
 constexpr int SUBMIT_THREADS = 1;     // host threads that submit a multi-query call (more did not help: the pipeline is GPU-bound)
 constexpr int MAX_DIM_SCAN = 4096;    // register-resident query (NCH <= 16; the reference's f32 pages hold d <= 4073)
 constexpr float BIG_ABS = 1.0e15f;    // beyond this f32 squares can overflow
-// TSH_FUSED=1 (experiment): scans that read at most this many bytes go out as ONE dispatch (tsh_fused.hip.h)
-constexpr int64_t FUSED_MAX_SCAN_BYTES = 96ll << 20;
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -258,96 +255,8 @@ inline int pick_nch(int d4) {
   return -1;
 }
 
-// (rows per group, min waves per SIMD) per row width: two register buffers of
-// R*NCH*4 VGPRs plus NCH*4 for the query must fit 512/MINW registers.
-template <int NCH, bool MASKED> struct ScanTune {
-  static constexpr int R = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 2 : 4) : 2);
-  static constexpr int MINW =
-      (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH <= 6 ? 3 : (NCH <= 8 ? 2 : 1))));
-};
-// Events that ride on the scan's own dispatch packet (hipExtLaunchKernel): a separate
-// hipEventRecord is a barrier packet of its own, and two or three of those between
-// consecutive scans were most of the gap between them.
-struct LaunchEv {
-  hipEvent_t start = nullptr, stop = nullptr;
-};
-#define TSH_LAUNCH(KERN, GRID, BLOCK, ST, EV, ARG)                                                       \
-  do {                                                                                                  \
-    if ((EV).start || (EV).stop)                                                                        \
-      hipExtLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), 0, ST, (EV).start,   \
-                            (EV).stop, 0, ARG);                                                         \
-    else                                                                                                \
-      KERN<<<(GRID), (BLOCK), 0, ST>>>(ARG);                                                            \
-  } while (0)
-
-template <int NCH, int METRIC, bool FULL, bool MASKED>
-void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s, const LaunchEv &ev) {
-  using T = ScanTune<NCH, MASKED>;
-  // grid > 0: 4-wave workgroups; grid < 0: -grid one-wave workgroups (small shards)
-  if (grid > 0) TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), grid, 256, s, ev, a);
-  else TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), -grid, 64, s, ev, a);
-}
-template <int NCH, int METRIC>
-void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
-  bool full = a.a.d4 == NCH * 64;
-  if (full) {
-    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s, ev);
-    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s, ev);
-  } else {
-    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s, ev);
-    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s, ev);
-  }
-}
-template <int NCH>
-void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
-  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s, ev);
-  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s, ev);
-  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s, ev);
-}
-template <int SPLIT>
-void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s,
-                   const LaunchEv &ev) {
-#define TSH_PK(M, MK) TSH_LAUNCH((scan_packed_kernel<SPLIT, M, MK, true>), grid, threads, s, ev, a)
-  if (metric == TSH_METRIC_L2) { if (masked) TSH_PK(METRIC_L2, true); else TSH_PK(METRIC_L2, false); }
-  else if (metric == TSH_METRIC_IP) { if (masked) TSH_PK(METRIC_IP, true); else TSH_PK(METRIC_IP, false); }
-  else { if (masked) TSH_PK(METRIC_COS, true); else TSH_PK(METRIC_COS, false); }
-#undef TSH_PK
-}
-
-void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev = LaunchEv()) {
-  int grid = (a.a.n_tiles + 3) / 4;
-  if (grid < 1) grid = 1;
-  if (a.a.ld == 128 || a.a.ld == 64 || a.a.ld == 32) {
-    // narrow rows: several whole rows per 1 KiB wave load (scan_packed_kernel)
-    int threads = 256;
-    if (a.a.n_tiles < SMALL_SHARD_TILES) {
-      grid = std::max(1, (int)a.a.n_tiles);
-      threads = 64;
-    }
-    if (a.a.ld == 128) launch_packed<1>(a, metric, masked, grid, threads, s, ev);
-    else if (a.a.ld == 64) launch_packed<2>(a, metric, masked, grid, threads, s, ev);
-    else launch_packed<3>(a, metric, masked, grid, threads, s, ev);
-    return;
-  }
-  // fewer than ~6 four-wave workgroups per CU: tile counts per CU differ by tens of
-  // percent; one tile per workgroup lets the dispatcher even them out
-  if (a.a.n_tiles < SMALL_SHARD_TILES) grid = -std::max(1, (int)a.a.n_tiles);
-  switch (nch) {
-    case 1: launch_scan_n<1>(a, metric, masked, grid, s, ev); break;
-    case 2: launch_scan_n<2>(a, metric, masked, grid, s, ev); break;
-    case 3: launch_scan_n<3>(a, metric, masked, grid, s, ev); break;
-    case 4: launch_scan_n<4>(a, metric, masked, grid, s, ev); break;
-    case 5: launch_scan_n<5>(a, metric, masked, grid, s, ev); break;
-    case 6: launch_scan_n<6>(a, metric, masked, grid, s, ev); break;
-    case 7: launch_scan_n<7>(a, metric, masked, grid, s, ev); break;
-    case 8: launch_scan_n<8>(a, metric, masked, grid, s, ev); break;
-    case 10: launch_scan_n<10>(a, metric, masked, grid, s, ev); break;
-    case 12: launch_scan_n<12>(a, metric, masked, grid, s, ev); break;
-    case 14: launch_scan_n<14>(a, metric, masked, grid, s, ev); break;
-    default: launch_scan_n<16>(a, metric, masked, grid, s, ev); break;
-  }
-}
-
+// the scan kernels' launchers live in their own translation unit (tsh_scan_tu.hip): 144 instantiations that
+// compile beside this file instead of in front of it
 // ---- per-search scratch: one context = one query in flight ---------------------
 struct Ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -363,7 +272,6 @@ struct Ctx {
   uint32_t *d_keys = nullptr;
   uint32_t *d_gmin = nullptr;
   uint32_t *d_hist = nullptr;  // radix select of the fallback path (256 bins)
-  uint32_t *d_ticket = nullptr;  // fused single-dispatch path: workgroups done so far (zero between launches)
   int64_t tiles_cap = 0;
   uint8_t *d_block = nullptr;  // header + entries
   uint8_t *h_block = nullptr;  // pinned
@@ -451,7 +359,7 @@ struct Shard {
   std::vector<Ctx *> ctx_free;
   std::atomic<uint64_t> mask_epoch_src{1};
 
-  std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0}, c_fused{0};
+  std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   double scan_us_sum = 0;  // guarded by ctx_mu
   int64_t scan_us_samples = 0;
   int64_t bytes = 0;
@@ -717,7 +625,6 @@ void ctx_free_all(Ctx *c) {
   hipFree(c->d_keys);
   hipFree(c->d_gmin);
   hipFree(c->d_hist);
-  hipFree(c->d_ticket);
   hipFree(c->d_block);
   hipHostFree(c->h_block);
   hipHostFree(c->h_quar);
@@ -737,8 +644,6 @@ int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
     HIPCHK(hipMalloc(&c->d_query, (size_t)s->ld * sizeof(float)));
     HIPCHK(hipHostMalloc(&c->h_query, (size_t)s->ld * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipMalloc(&c->d_big_count, 64));
-    HIPCHK(hipMalloc(&c->d_ticket, 64));
-    HIPCHK(hipMemset(c->d_ticket, 0, 64));
     c->bytes += s->ld * 4;
   }
   int64_t tiles = s->cap / 64;
@@ -905,16 +810,6 @@ void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
   else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
 }
 
-// one dispatch for scan + select + re-rank (tsh_fused.hip.h)
-template <int NT>
-void launch_fused_nt(const FusedArgsQ &fa, int metric, bool masked, int grid, hipStream_t st) {
-#define TSH_FU(M, MK) fused_query_kernel<NT, M, MK><<<grid, NT, 0, st>>>(fa)
-  if (metric == TSH_METRIC_L2) { if (masked) TSH_FU(METRIC_L2, true); else TSH_FU(METRIC_L2, false); }
-  else if (metric == TSH_METRIC_IP) { if (masked) TSH_FU(METRIC_IP, true); else TSH_FU(METRIC_IP, false); }
-  else { if (masked) TSH_FU(METRIC_COS, true); else TSH_FU(METRIC_COS, false); }
-#undef TSH_FU
-}
-
 // shard mode: the quarantined rows go into the job's device block
 void launch_quarantine_append(Shard *s, Ctx *c, Job *j, hipStream_t st) {
   QuarAppendArgs qa{};
@@ -1026,61 +921,9 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
     if (!inline_q)
       HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
-    // EXPERIMENT, off unless TSH_FUSED=1: short scans as ONE dispatch, the last workgroup to finish its tiles selects
-    // and re-ranks (tsh_fused.hip.h).  Exact, but measured SLOWER than the three launches it replaces (C1: 45 vs
-    // 37 us per call; keep-1 % masks: 11.8 k vs 23.8 k queries/s): the release / acquire pair between the scan and
-    // the tail costs what the two launch boundaries did, the generic scan has no read-ahead across 8-row batches,
-    // and a fused query's tail no longer overlaps the next query's scan on the reserved CUs.
-    static const bool use_fused = getenv("TSH_FUSED") != nullptr && getenv("TSH_FUSED")[0] == '1';
-    const int64_t tiles_read_f = rows_est > 0 ? std::min<int64_t>(n_tiles, (rows_est + 63) / 64) : n_tiles;
-    const bool fused = use_fused && n_tiles <= SEL_VPT * SEL_THREADS && k <= 1024 && s->ld / 4 <= FUSED_MAX_D4 &&
-                       tiles_read_f * 64 * s->ld * 4 <= FUSED_MAX_SCAN_BYTES;
-    if (fused) {
-      static thread_local FusedArgsQ fa;  // 3.3 KiB: keep it off the stack of deep callers
-      fa.a.scan = sa.a;
-      fa.a.sel = se;
-      fa.a.rr = ra;
-      fa.a.ticket = c->d_ticket;
-      const bool inline_f = s->ld <= FUSED_Q_INLINE;
-      if (inline_f) {
-        memcpy(fa.q, qdst, (size_t)s->ld * sizeof(float));
-        fa.a.scan.query = nullptr;
-        fa.a.scan.query_out = c->d_query;
-      } else {  // the query goes through the context's device copy
-        if (inline_q) {
-          memcpy(c->h_query, qdst, (size_t)s->ld * sizeof(float));
-          HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
-        }
-        fa.a.scan.query = c->d_query;
-        fa.a.scan.query_out = nullptr;
-      }
-      const bool small_sel = n_tiles <= 512 && k <= 256;
-      const int wpb = small_sel ? 4 : 16;
-      const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + wpb - 1) / wpb, 4096));
-      if (small_sel) launch_fused_nt<256>(fa, s->metric, j->masked, grid, ps);
-      else launch_fused_nt<SEL_THREADS>(fa, s->metric, j->masked, grid, ps);
-      j->timed = false;
-      if (!j->quar_sel.empty() && dev_target) {
-        launch_quarantine_append(s, c, j, ps);
-      } else if (!j->quar_sel.empty()) {
-        QuarArgs qa{};
-        qa.rows = s->d_rows;
-        qa.Q = c->d_query;
-        qa.list = s->d_quar;
-        qa.out = c->h_quar_dev;
-        qa.ld = s->ld;
-        qa.ldq = s->ld;
-        qa.row_base = s->row_base;
-        qa.dim = s->dim;
-        qa.cap = (int32_t)QUARANTINE_MAX;
-        qa.metric = s->metric;
-        quarantine_kernel<<<dim3((unsigned)((s->quar_ids.size() + 63) / 64), 1), 64, 0, ps>>>(qa);
-      }
-      HIPCHK(hipEventRecord(c->ev_done, ps));
-      s->c_scans++;
-      s->c_fused++;
-      return TSH_OK;
-    }
+    // (short scans as ONE dispatch -- every workgroup scans its tiles, the one drawing the last ticket selects and
+    // re-ranks -- were built in round 2 and measured slower than these three launches: C1 45 vs 37 us per call,
+    // keep-1 % masks 11.8 k vs 23.8 k queries/s.  Removed in round 3)
     j->timed = (s->c_scans.load() & 3) == 0;  // sample every 4th scan with timing events
     LaunchEv ev;  // start / stop ride on the scan's own packet: no barrier packets between scans
     if (j->timed) {
@@ -1369,8 +1212,7 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
     mask_words.resize((size_t)n_tiles);
     slice_mask(s, mask, mask_words.data(), n_tiles);
     epoch = s->mask_epoch_src.fetch_add(1);
-    // one pass over the mask per call: how long will each scan be?  (decides one- or two-stream pipelining and
-    // whether a query goes out as one fused dispatch)
+    // one pass over the mask per call: how long will each scan be?  (decides one- or two-stream pipelining)
     for (uint64_t w : mask_words) rows_est += __builtin_popcountll(w);
     if (rows_est == 0) rows_est = 1;
   }
@@ -2041,7 +1883,6 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     out->bytes_resident += b;
     if (s->safe_mode()) out->safe_mode = 1;
     out->quarantined_rows += (int32_t)s->quar_ids.size();
-    out->fused_launches += s->c_fused.load();
     out->device_id = s->device;
   }
   return TSH_OK;

@@ -86,7 +86,7 @@ struct PqTrainArgs {
   int32_t n, dim, subspaces, k, sub_dim;
 };
 
-__global__ void pq_train_init_kernel(PqTrainArgs a) {
+static __global__ void pq_train_init_kernel(PqTrainArgs a) {
   const int m = blockIdx.y, c = blockIdx.x, d = threadIdx.x;
   if (d < a.sub_dim)
     a.centroids[((int64_t)m * a.k + c) * a.sub_dim + d] =
@@ -97,7 +97,7 @@ __global__ void pq_train_init_kernel(PqTrainArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(256) pq_train_norms_kernel(PqTrainArgs a) {
+static __global__ void __launch_bounds__(256) pq_train_norms_kernel(PqTrainArgs a) {
 #pragma clang fp contract(off)
   const int m = blockIdx.x, c = threadIdx.x;
   if (!a.active[m]) return;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) pq_train_assign_kernel(PqTrainArgs a) {
 // One wave per (centroid, sub-space): lanes own dimensions, members are visited in
 // sample order (ballot over 64 samples at a time, then a bit scan), so each lane's
 // f32 running sum sees exactly the reference's sequence of additions.
-__global__ void __launch_bounds__(64) pq_train_update_kernel(PqTrainArgs a) {
+static __global__ void __launch_bounds__(64) pq_train_update_kernel(PqTrainArgs a) {
 #pragma clang fp contract(off)
   const int m = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
   if (!a.active[m]) return;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64) pq_train_update_kernel(PqTrainArgs a) {
   *cp = (float)nv;
 }
 
-__global__ void pq_train_flag_kernel(PqTrainArgs a) {
+static __global__ void pq_train_flag_kernel(PqTrainArgs a) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m < a.subspaces && a.active[m] && !a.changed[m]) a.active[m] = 0;
 }

@@ -1,0 +1,100 @@
+// tsh_scan_tu.hip -- the single-query scan kernels' instantiations and their launcher (K1, tsh_kernels.hip.h).
+// A translation unit of its own: the instantiations compile in parallel with the rest of the library.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+
+#include "../../include/tostore_hip.h"
+#include "tsh_launch.h"
+
+namespace tsh {
+namespace {
+
+// (rows per group, min waves per SIMD) per row width: two register buffers of
+// R*NCH*4 VGPRs plus NCH*4 for the query must fit 512/MINW registers.
+template <int NCH, bool MASKED> struct ScanTune {
+  static constexpr int R = (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 2 : 4) : 2);
+  static constexpr int MINW =
+      (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH <= 6 ? 3 : (NCH <= 8 ? 2 : 1))));
+};
+#define TSH_LAUNCH(KERN, GRID, BLOCK, ST, EV, ARG)                                                       \
+  do {                                                                                                  \
+    if ((EV).start || (EV).stop)                                                                        \
+      hipExtLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), 0, ST, (EV).start,   \
+                            (EV).stop, 0, ARG);                                                         \
+    else                                                                                                \
+      KERN<<<(GRID), (BLOCK), 0, ST>>>(ARG);                                                            \
+  } while (0)
+
+template <int NCH, int METRIC, bool FULL, bool MASKED>
+void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s, const LaunchEv &ev) {
+  using T = ScanTune<NCH, MASKED>;
+  // grid > 0: 4-wave workgroups; grid < 0: -grid one-wave workgroups (small shards)
+  if (grid > 0) TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), grid, 256, s, ev, a);
+  else TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), -grid, 64, s, ev, a);
+}
+template <int NCH, int METRIC>
+void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
+  bool full = a.a.d4 == NCH * 64;
+  if (full) {
+    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s, ev);
+    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s, ev);
+  } else {
+    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s, ev);
+    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s, ev);
+  }
+}
+template <int NCH>
+void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
+  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s, ev);
+  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s, ev);
+  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s, ev);
+}
+template <int SPLIT>
+void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s,
+                   const LaunchEv &ev) {
+#define TSH_PK(M, MK) TSH_LAUNCH((scan_packed_kernel<SPLIT, M, MK, true>), grid, threads, s, ev, a)
+  if (metric == TSH_METRIC_L2) { if (masked) TSH_PK(METRIC_L2, true); else TSH_PK(METRIC_L2, false); }
+  else if (metric == TSH_METRIC_IP) { if (masked) TSH_PK(METRIC_IP, true); else TSH_PK(METRIC_IP, false); }
+  else { if (masked) TSH_PK(METRIC_COS, true); else TSH_PK(METRIC_COS, false); }
+#undef TSH_PK
+}
+
+}  // namespace
+
+void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev) {
+  int grid = (a.a.n_tiles + 3) / 4;
+  if (grid < 1) grid = 1;
+  if (a.a.ld == 128 || a.a.ld == 64 || a.a.ld == 32) {
+    // narrow rows: several whole rows per 1 KiB wave load (scan_packed_kernel)
+    int threads = 256;
+    if (a.a.n_tiles < SMALL_SHARD_TILES) {
+      grid = std::max(1, (int)a.a.n_tiles);
+      threads = 64;
+    }
+    if (a.a.ld == 128) launch_packed<1>(a, metric, masked, grid, threads, s, ev);
+    else if (a.a.ld == 64) launch_packed<2>(a, metric, masked, grid, threads, s, ev);
+    else launch_packed<3>(a, metric, masked, grid, threads, s, ev);
+    return;
+  }
+  // fewer than ~6 four-wave workgroups per CU: tile counts per CU differ by tens of
+  // percent; one tile per workgroup lets the dispatcher even them out
+  if (a.a.n_tiles < SMALL_SHARD_TILES) grid = -std::max(1, (int)a.a.n_tiles);
+  switch (nch) {
+    case 1: launch_scan_n<1>(a, metric, masked, grid, s, ev); break;
+    case 2: launch_scan_n<2>(a, metric, masked, grid, s, ev); break;
+    case 3: launch_scan_n<3>(a, metric, masked, grid, s, ev); break;
+    case 4: launch_scan_n<4>(a, metric, masked, grid, s, ev); break;
+    case 5: launch_scan_n<5>(a, metric, masked, grid, s, ev); break;
+    case 6: launch_scan_n<6>(a, metric, masked, grid, s, ev); break;
+    case 7: launch_scan_n<7>(a, metric, masked, grid, s, ev); break;
+    case 8: launch_scan_n<8>(a, metric, masked, grid, s, ev); break;
+    case 10: launch_scan_n<10>(a, metric, masked, grid, s, ev); break;
+    case 12: launch_scan_n<12>(a, metric, masked, grid, s, ev); break;
+    case 14: launch_scan_n<14>(a, metric, masked, grid, s, ev); break;
+    default: launch_scan_n<16>(a, metric, masked, grid, s, ev); break;
+  }
+}
+
+}  // namespace tsh
