@@ -241,6 +241,8 @@ class Env:
         if torch.cuda.device_count() <= self.local_rank:
             raise RuntimeError("rank %d wants cuda:%d, this box has %d GPU(s) (one GPU: --ranks-share-gpu)"
                                % (self.rank, self.local_rank, torch.cuda.device_count()))
+        if self.world > 1:  # one rank of several: a share of the CPUs (see launch_ranks)
+            torch.set_num_threads(max(1, int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cpus() // self.world))
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.dist = None
@@ -953,6 +955,17 @@ def cgroup_cpu_stat():
     return d
 
 
+def host_cpus():
+    """CPUs this container may use: the cgroup quota when there is one, else the CPU count."""
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(q) // int(period))
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
 def free_port():
     import socket
 
@@ -972,6 +985,12 @@ def launch_ranks(a, argv, timeout):
     n = a.gpus
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                 MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", TSH_BENCH_RANK_PROCESS="1")
+    # torch sizes its CPU thread pool by the hardware threads it sees (256 on an MI355X box), not by the container's
+    # quota: N ranks waking 256 OpenMP threads each for every small host-side copy burn the whole quota and get the
+    # job throttled (tools/thread_cpu_probe.py: 300 threads per rank, 2.3 CPUs per rank doing nothing).
+    # torch.distributed.run sets OMP_NUM_THREADS=1 for the same reason.
+    if "OMP_NUM_THREADS" not in base:
+        base["OMP_NUM_THREADS"] = str(max(1, host_cpus() // n))
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
