@@ -353,6 +353,18 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters,
 int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_t k, int32_t iters,
                         double *out_avg_gemm_us, double *out_flops);
 
+/* Probes of the pre-filter keys (tests only: tests/test_gpu_bands.py holds every key kernel to the error bound the
+ * host claims for it, on rows built to err in one direction).  Single-shard handles.
+ * tsh_probe_scan_keys: the single-query scan kernel's f32 ranking key of every row (NaN = row not live) and the
+ * band the select step would apply: a row of the true top k has key <= tau * (1 + eps_rel) + delta_abs, where
+ * eps_rel = 3 eps and delta_abs = 2 delta * 1.0001 for the per-key bounds |key - exact| <= eps * exact (L2) resp.
+ * <= delta (inner product, cosine); exact = sum (q - v)^2, -q.v, -q.v / |v|.
+ * tsh_probe_batch_keys: the batched key kernel's (TSH_OPT_BATCH_KERNEL) keys of every row for nq queries, row-major
+ * nq x size, and per query 2 * 1.0001 * (the bound on |key - exact|); L2 keys are |q|^2 + |v|^2 - 2 q.v. */
+int32_t tsh_probe_scan_keys(tsh_index *idx, const float *query, float *out_keys, float *out_eps_rel, float *out_delta_abs);
+int32_t tsh_probe_batch_keys(tsh_index *idx, const float *queries, int32_t nq, int32_t k, float *out_keys,
+                             float *out_delta2);
+
 /* Tuning knobs (no reference counterpart).  TSH_OPT_BATCH_MIN_NQ: when tsh_search /
  * tsh_search_shard answer a multi-query call on the batched matrix-core path:
  * 0 = never; 1 (default) = whenever its estimated cost is below that of nq pipelined

@@ -1,0 +1,240 @@
+"""GPU: every pre-filter key kernel against the error bound the host claims for it, on ADVERSARIAL rows.
+
+The exhaustive path returns bit-exact ids because each candidate generator (the f32 scan, and the f32-MFMA /
+bf16x3 / fp16 batched key kernels) is paired with a proven bound D on |key - exact key| and everything within
+tau + 2 D of the k-th key is re-ranked in f64.  Gaussian test data never comes near those
+bounds.  Here, per kernel, metric and row width:
+
+  1. candidates: rows nearly parallel to the query (so sum |q_i v_i| ~ |q| |v|, the case the bounds are tight for),
+     all products of one sign, the operands sitting just below / just above the rounding midpoints of the format
+     the kernel rounds them to (fp16: 10 mantissa bits; bf16 hi + lo: 16) -- every operand rounding errs the same
+     way within a row -- and with exact keys spread over a few D around a boundary K;
+  2. the kernel's ACTUAL keys of all candidates are read back (tsh_probe_*_keys) and compared with the exact f64
+     keys: max |key - exact| / D must be <= 1, and is recorded -- a bound that only holds by luck would show as a
+     ratio near (or above) 1;
+  3. the worst cases are selected: G = the k rows truly better than K whose approximate keys look WORST, B = rows
+     truly worse than K whose approximate keys look BEST.  In a corpus of G + B + far-away filler rows the true top k is exactly G while
+     the approximate ranking prefers B -- the search must still return G, bit for bit, without any fallback.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+L2, IP, COS = 0, 1, 2
+SCAN = -1
+K = 50
+N_CAND = 8192
+RESULTS = []
+
+
+def _exact_keys(rows, q, metric):
+    r64, q64 = rows.astype(np.float64), q.astype(np.float64)
+    if metric == L2:
+        d = r64 - q64
+        return np.einsum("ij,ij->i", d, d)
+    dot = r64 @ q64
+    if metric == IP:
+        return -dot
+    return -dot / np.sqrt(np.einsum("ij,ij->i", r64, r64))
+
+
+def _patterned(rng, shape, path, up):
+    """Positive f32 values 2^e (1 + m), e in {0, -1}, whose low mantissa bits sit just below (up = False) or just
+    above (up = True) the rounding midpoint of the format `path` rounds operands to."""
+    e = rng.integers(-1, 1, size=shape)
+    if path == 2:  # fp16: 10 mantissa bits kept; bit 11 set = midpoint, -/+ 2^-21
+        j = rng.integers(200, 248, size=shape)  # (room for _nudge_to in both directions)
+        m = j * 2.0 ** -10 + 2.0 ** -11 + (2.0 ** -21 if up else -2.0 ** -21)
+    elif path == 1:  # bf16 hi + lo: 16 mantissa bits kept; low 7 bits 0b1000001 / 0b0111111
+        hi = rng.integers(0, 1 << 14, size=shape)  # a quarter of the range: values stay within [1, 1.25)
+        m = (hi * 128 + (0x41 if up else 0x3F)) * 2.0 ** -23
+    else:  # f32 operands are exact: only the accumulation rounds
+        m = rng.integers(0, 1 << 21, size=shape) * 2.0 ** -23
+    x = np.ldexp(1.0 + m, e)
+    assert np.array_equal(x.astype(np.float32).astype(np.float64), x)
+    return x.astype(np.float32)
+
+
+def _nudge_to(rows, q, metric, path, target, rng, passes=8):
+    """Move each row's exact key to target[i]: per pass one random element of the row takes as much of the remaining
+    difference as it can, in whole steps of the lowest mantissa bit ABOVE the bits that carry the rounding pattern
+    (so the pattern survives) and without leaving the pattern's value range."""
+    step_bit = {2: -10, 1: -16}.get(path, -23)
+    fmax = {2: 900.0, 1: float(1 << 14)}.get(path, float(1 << 23)) - 1.0  # mantissa field, in steps
+    rows = rows.copy()
+    n, d = rows.shape
+    for it in range(passes):
+        diff = target - _exact_keys(rows, q, metric)
+        if not np.any(diff):
+            break
+        if metric == COS:
+            r64 = rows.astype(np.float64)
+            dots, nrms = r64 @ q.astype(np.float64), np.sqrt(np.einsum("ij,ij->i", r64, r64))
+        for i in np.nonzero(diff)[0]:
+            c = int(rng.integers(0, d))
+            x = float(rows[i, c])
+            e = np.floor(np.log2(x))
+            unit = 2.0 ** (e + step_bit)
+            if metric == L2:  # (q - x - dx)^2 - (q - x)^2 = diff: the root of smaller size, or as close as x = q gets
+                a = float(q[c]) - x
+                disc = a * a + diff[i]
+                dx = a - np.copysign(np.sqrt(disc), a) if disc > 0 else a
+            elif metric == IP:  # d key / d x = -q
+                dx = diff[i] / -float(q[c])
+            else:  # key = -q.v / |v|: d key / d x = -(q_c - (q.v) x / |v|^2) / |v|  (small for v near q: many passes)
+                g = -(float(q[c]) - dots[i] * x / nrms[i] ** 2) / nrms[i]
+                if abs(g) < 1e-12:
+                    continue
+                dx = diff[i] / g
+            f = np.floor((x / 2.0 ** e - 1.0) / 2.0 ** step_bit)  # the field's current value
+            steps = np.clip(np.round(dx / unit), -f, fmax - f)
+            nx = x + steps * unit
+            rows[i, c] = np.float32(nx)
+            assert float(rows[i, c]) == nx
+    return rows
+
+
+def _candidates(rng, d, metric, path, delta_abs_guess, normalize):
+    """A query with four distinct values (a fixed random assignment to the positions), two base rows -- operands
+    just below / just above the rounding midpoints -- brought to the SAME exact key, and N_CAND rows that permute a
+    base row's elements among positions of equal query value: the exact key of a permuted row is the base row's (so
+    is its norm), what changes is how the kernel's roundings fall.  A last nudge spreads the exact keys over +-3 D."""
+    classes = rng.integers(0, 4, size=d)
+    q = _patterned(rng, 4, path, up=False)[classes]
+    if normalize is not None:
+        q = normalize(q)
+    v_dn, v_up = _patterned(rng, d, path, up=False), _patterned(rng, d, path, up=True)
+    kb = float(_exact_keys(v_dn[None, :], q, metric)[0])
+    v_up = _nudge_to(v_up[None, :], q, metric, path, np.array([kb]), rng, passes=3000)[0]
+    assert abs(float(_exact_keys(v_up[None, :], q, metric)[0]) - kb) < 0.05 * delta_abs_guess
+    cand = np.empty((N_CAND, d), np.float32)
+    members = [np.nonzero(classes == c)[0] for c in range(4)]
+    for i in range(N_CAND):
+        src = v_up if i & 1 else v_dn
+        for m in members:
+            cand[i, m] = src[rng.permutation(m)]
+    return q, _nudge_to(cand, q, metric, path, np.full(N_CAND, kb), rng), kb
+
+
+def _open(d, metric, rows, path):
+    from tostore_amd import HipVectorIndex
+
+    idx = HipVectorIndex(d, metric, capacity_rows=len(rows))
+    idx.append(0, rows)
+    if path != SCAN:
+        idx.set_batch_kernel(path)
+        idx.set_batch_min_nq(2)
+    else:
+        idx.set_batch_min_nq(0)
+    return idx
+
+
+def _keys_and_bound(idx, q, others, metric, path, exact):
+    """(approximate keys of the first query, per-key bound D as an absolute number per row)"""
+    if path == SCAN:
+        keys, eps_rel, delta_abs = idx.probe_scan_keys(q)
+        if metric == L2:  # relative bound: eps_rel = 3 eps, |key - s| <= eps s
+            return keys.astype(np.float64), (eps_rel / 3.0) * np.abs(exact) + delta_abs
+        return keys.astype(np.float64), np.full(len(exact), delta_abs / 2.0 / 1.0001)
+    keys, d2 = idx.probe_batch_keys(np.stack([q] + list(others)), K)
+    return keys[0].astype(np.float64), np.full(len(exact), float(d2[0]) / 2.0 / 1.0001)
+
+
+@pytest.mark.parametrize("d", [768, 1536])
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("path", [SCAN, 0, 1, 2])
+def test_band_holds_on_adversarial_rows(hip_lib, oracle_mod, path, metric, d):
+    rng = np.random.default_rng(1000 * (path + 2) + 10 * metric + d)
+    # a first look at the bound's size for this shape (any patterned rows will do)
+    q0 = _patterned(rng, d, path, up=False)
+    some = np.stack([_patterned(rng, d, path, up=False) for _ in range(4096)])
+    if metric == COS:
+        q0 = oracle_mod.normalize_f32(q0)
+    with _open(d, metric, some, path) as idx:
+        _, bound = _keys_and_bound(idx, q0, [some[1], some[2], some[3]], metric, path, _exact_keys(some, q0, metric))
+    guess = float(np.median(bound))
+
+    # ---- 1. candidates around a boundary, 2. the kernel's actual keys of all of them --------------------------
+    q, cand, kb = _candidates(rng, d, metric, path, guess, oracle_mod.normalize_f32 if metric == COS else None)
+    others = [_patterned(rng, d, path, up=True) for _ in range(3)]
+    if metric == COS:
+        others = [oracle_mod.normalize_f32(o) for o in others]
+    # a first reading with every candidate AT the boundary tells how large this kernel's errors really are; the exact
+    # keys are then spread over just that much, so that the approximate ranking around K is decided by the errors
+    with _open(d, metric, cand, path) as idx:
+        keys0, bound0 = _keys_and_bound(idx, q, others, metric, path, _exact_keys(cand, q, metric))
+    emax = float(np.max(np.abs(keys0 - _exact_keys(cand, q, metric))))
+    spread = min(1.9 * float(np.median(bound0)), max(1.5 * emax, 1e-3 * float(np.median(bound0))))
+    cand = _nudge_to(cand, q, metric, path, kb + rng.uniform(-1.0, 1.0, size=N_CAND) * spread, rng)
+    exact = _exact_keys(cand, q, metric)
+    with _open(d, metric, cand, path) as idx:
+        keys, bound = _keys_and_bound(idx, q, others, metric, path, exact)
+    err = keys - exact
+    ratio = np.abs(err) / bound
+    assert np.all(np.isfinite(keys))
+    assert ratio.max() <= 1.0, "a key is further from the exact value than the claimed bound: ratio %.3f" % ratio.max()
+
+    # ---- 3. the worst cases around the boundary: G truly better but looking worst, B truly worse but looking best
+    better = np.nonzero((exact < kb) & (exact > kb - spread))[0]
+    worse = np.nonzero((exact > kb) & (exact < kb + spread))[0]
+    assert len(better) >= 4 * K and len(worse) >= 4 * K, (len(better), len(worse))
+    g = better[np.argsort(-keys[better])[:K]]  # truly better than K, with the WORST-looking approximate keys
+    b = worse[np.argsort(keys[worse])[:2 * K]]  # truly worse than K, with the BEST-looking approximate keys
+    n_total, n_sample = 40960, 8192
+    filler = np.stack([_patterned(rng, d, path, up=bool(i & 1)) for i in range(1024)])
+    filler = np.tile(filler, (n_total // 1024, 1))[:n_total] * rng.choice([-1.0, 1.0], size=(n_total, d)).astype(np.float32)
+    rows = filler
+    # half of G and B inside the sample the batched path draws its threshold from, half in the filtered pass
+    pos_g = np.concatenate([rng.choice(n_sample, K // 2, replace=False), n_sample + rng.choice(n_total - n_sample, K - K // 2, replace=False)])
+    left = np.setdiff1d(np.arange(n_total), pos_g)
+    pos_b = rng.choice(left, len(b), replace=False)
+    rows[pos_g] = cand[g]
+    rows[pos_b] = cand[b]
+    ex_all = _exact_keys(rows, q, metric)
+    true_top = set(np.argsort(ex_all, kind="stable")[:K].tolist())
+    assert true_top == set(pos_g.tolist())  # the construction: G is the true top k
+    queries = np.stack([q] + others)
+    with _open(d, metric, rows, path) as idx:
+        c0 = idx.counters()
+        keys_all, bound_all = _keys_and_bound(idx, q, others, metric, path, ex_all)
+        tau = np.sort(keys_all)[K - 1]  # k-th smallest APPROXIMATE key over all rows
+        usage = float(np.max((keys_all[pos_g] - tau) / (2.0 * bound_all[pos_g])))
+        looks_better = int(np.sum(keys_all[pos_b] < np.max(keys_all[pos_g])))
+        if path == SCAN:
+            got = [idx.search(x, K) for x in queries]
+            ids = np.concatenate([x[0] for x in got])
+            dist = np.concatenate([x[1] for x in got])
+            cnt = np.concatenate([x[2] for x in got])
+        else:
+            ids, dist, cnt = idx.search(queries, K)
+        c1 = idx.counters()
+    e_ids, e_dist, e_cnt = oracle_mod.search_heap_many_mt(rows, queries, metric, K)
+    assert np.array_equal(cnt, e_cnt) and np.array_equal(ids, e_ids), "ids differ from the oracle's"
+    assert np.array_equal(dist.view(np.uint64), e_dist.view(np.uint64)), "distances differ from the oracle's"
+    assert set(ids[0].tolist()) == set(pos_g.tolist())
+    assert c1["fallback_searches"] == c0["fallback_searches"], "a query took the wide-band fallback"
+    if path != SCAN:
+        assert c1["batch_launches"] > c0["batch_launches"] and c1["batch_kernel_last"] == path
+    # the adversity was real: rows outside the top k out-ranked rows inside it by their approximate keys,
+    # and the true neighbours sat inside the band, not at its edge by luck
+    assert looks_better > 0 or ratio.max() < 0.02, "the construction did not invert any approximate ranking"
+    assert usage <= 1.0, "a true neighbour lies outside tau + 2 D: band usage %.3f" % usage
+    RESULTS.append({"path": {SCAN: "f32 scan", 0: "f32 MFMA", 1: "bf16x3", 2: "fp16"}[path],
+                    "metric": ["l2", "ip", "cosine"][metric], "dim": d, "max_abs_err_over_bound": float(ratio.max()),
+                    "band_usage_of_true_neighbours": usage, "outsiders_ranked_above_a_true_neighbour": looks_better,
+                    "candidates_per_query": (c1["candidates_total"] - c0["candidates_total"]) / max(c1["searches"] - c0["searches"], 1)})
+
+
+def test_write_band_report():
+    """(runs last in this file) the measured ratios, for profiles/: gpurun_out/band_ratios.json"""
+    if not RESULTS:
+        pytest.skip("no band case ran in this process")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "band_ratios.json"), "w") as f:
+        json.dump(RESULTS, f, indent=1)
+    worst = max(r["max_abs_err_over_bound"] for r in RESULTS)
+    assert worst <= 1.0

@@ -97,6 +97,8 @@ SIGNATURES = {
     "tsh_get_counters": (c_i32, [p_void, ctypes.POINTER(TshCounters)]),
     "tsh_bench_scan": (c_i32, [p_void, p_f32, c_i32, p_u8, p_f64]),
     "tsh_bench_batch": (c_i32, [p_void, p_f32, c_i32, c_i32, c_i32, p_f64, p_f64]),
+    "tsh_probe_scan_keys": (c_i32, [p_void, p_f32, p_f32, p_f32, p_f32]),
+    "tsh_probe_batch_keys": (c_i32, [p_void, p_f32, c_i32, c_i32, p_f32, p_f32]),
     "tsh_index_set_option": (c_i32, [p_void, c_i32, c_i64]),
 }
 

@@ -218,6 +218,24 @@ class HipVectorIndex:
                                               ctypes.byref(us), ctypes.byref(fl)))
         return us.value, fl.value
 
+    def probe_scan_keys(self, query):
+        """(f32 key of every row from the scan kernel, eps_rel, delta_abs): tests of the error model."""
+        q = _f32c(query).reshape(-1)
+        keys = np.empty(self.size - self.row_base, dtype=np.float32)
+        er, da = ctypes.c_float(0), ctypes.c_float(0)
+        _ffi.check(_ffi.lib().tsh_probe_scan_keys(self._h, q.ctypes.data_as(_ffi.p_f32), keys.ctypes.data_as(_ffi.p_f32),
+                                                  ctypes.byref(er), ctypes.byref(da)))
+        return keys, er.value, da.value
+
+    def probe_batch_keys(self, queries, k: int):
+        """(keys[nq, rows] of the batched key kernel in use, delta2[nq]): tests of the error model."""
+        q = _f32c(queries)
+        keys = np.empty((q.shape[0], self.size - self.row_base), dtype=np.float32)
+        d2 = np.empty(q.shape[0], dtype=np.float32)
+        _ffi.check(_ffi.lib().tsh_probe_batch_keys(self._h, q.ctypes.data_as(_ffi.p_f32), q.shape[0], int(k),
+                                                   keys.ctypes.data_as(_ffi.p_f32), d2.ctypes.data_as(_ffi.p_f32)))
+        return keys, d2
+
     def bench_scan(self, query, iters: int = 20, row_mask=None) -> float:
         q = _f32c(query)
         out = ctypes.c_double(0)

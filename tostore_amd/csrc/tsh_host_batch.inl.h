@@ -28,6 +28,8 @@ struct BatchCtx {
   int64_t quar_cap = 0;
   int64_t bytes = 0;
   double last_gemm_us = 0, last_flops = 0;
+  int64_t last_nq = 0, last_nq_pad = 0, last_sample = 0;  // shape of d_dense / h_qaux after the last call (tsh_probe_batch_keys)
+  int32_t last_sample_force = 0;  // tsh_probe_batch_keys: the next call's dense sample covers every row
   double last_wait_us = 0;  // how long the previous call waited for the GPU after enqueueing
   std::vector<double> mag_a;  // per query of the current call: sum of q[i]^2 in element order
 };
@@ -147,7 +149,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t nq_pad = (int32_t)round_up(nq, tile);
   // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
-  const int64_t n_sample = batch_sample_rows(rows, k);
+  const int64_t n_sample = b->last_sample_force ? rows : batch_sample_rows(rows, k);
   const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
@@ -543,6 +545,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
   b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
   b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  b->last_nq = nq;
+  b->last_nq_pad = nq_pad;
+  b->last_sample = n_sample;
   s->c_batches++;
   s->c_searches += nq - (int64_t)redo->size();
   if (out->d_blocks) {

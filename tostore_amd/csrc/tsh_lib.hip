@@ -1970,6 +1970,68 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
   return TSH_OK;
 }
 
+// ---- probes of the pre-filter keys (tests/test_gpu_bands.py): what the kernels actually computed, next to the
+// error bound the host claimed for it
+int32_t tsh_probe_scan_keys(tsh_index *idx, const float *query, float *out_keys, float *out_eps_rel, float *out_delta_abs) {
+  if (!idx || idx->shards.size() != 1 || !query || !out_keys || !out_eps_rel || !out_delta_abs)
+    return set_err(TSH_E_BAD_ARG, "bad arguments");
+  Shard *s = idx->shards[0].get();
+  std::shared_lock<RwLock> sl = share(idx, s);
+  if (s->rows == 0) return set_err(TSH_E_BAD_ARG, "empty index");
+  Ctx *c = ctx_acquire(s, true);
+  struct Rel {
+    Shard *s;
+    Ctx *c;
+    ~Rel() { ctx_release(s, c); }
+  } rel{s, c};
+  int rc = ctx_prepare(s, c, tsh_default_block_entries(100), false);
+  if (rc) return rc;
+  hipStream_t st = s->aux_stream;
+  memcpy(c->h_query, query, (size_t)s->dim * sizeof(float));
+  for (int64_t j = s->dim; j < s->ld; ++j) c->h_query[j] = 0.f;
+  const Band band = compute_band(s, c->h_query);
+  if (band.force_all) return set_err(TSH_E_BAD_ARG, "the query / index is outside the error model (no band)");
+  HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, st));
+  static thread_local ScanArgsQ sa;
+  const bool masked = !s->all_live;
+  fill_scan_args(s, c, masked, false, &sa);
+  launch_scan(sa, s->nch, s->metric, masked, st);
+  std::vector<uint32_t> keys((size_t)s->rows);
+  HIPCHK(hipMemcpyAsync(keys.data(), c->d_keys, keys.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  for (int64_t i = 0; i < s->rows; ++i) out_keys[i] = keys[(size_t)i] >= KEY_NAN ? std::nanf("") : h_key2f(keys[(size_t)i]);
+  *out_eps_rel = band.eps_rel;
+  *out_delta_abs = band.delta_abs;
+  return TSH_OK;
+}
+
+int32_t tsh_probe_batch_keys(tsh_index *idx, const float *queries, int32_t nq, int32_t k, float *out_keys, float *out_delta2) {
+  if (!idx || idx->shards.size() != 1 || !queries || nq <= 0 || k <= 0 || !out_keys || !out_delta2)
+    return set_err(TSH_E_BAD_ARG, "bad arguments");
+  Shard *s = idx->shards[0].get();
+  std::shared_lock<RwLock> sl = share(idx, s);
+  if (s->rows == 0 || s->safe_mode()) return set_err(TSH_E_BAD_ARG, "empty index, or safe mode: no batched path");
+  if ((int64_t)nq * s->rows > (1ll << 28)) return set_err(TSH_E_BAD_ARG, "nq x rows too large for a dense key matrix");
+  const int32_t entries = tsh_default_block_entries(k);
+  std::vector<uint8_t> blocks((size_t)tsh_candidate_block_bytes(entries) * (size_t)nq);
+  SearchOut so;
+  so.h_blocks = blocks.data();
+  std::vector<int32_t> redo;
+  BatchCtx *b = s->batch;
+  b->last_sample_force = 1;  // (read under b->mu by the call below; probes are not run concurrently)
+  int rc = shard_search_batch(s, b, queries, nq, k, nullptr, entries, &so, &redo);
+  b->last_sample_force = 0;
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(b->mu);
+  if (b->last_sample != s->rows || b->last_nq != nq) return set_err(TSH_E_BUSY, "another batched call ran in between");
+  HIPCHK(hipSetDevice(s->device));
+  HIPCHK(hipMemcpy2D(out_keys, (size_t)s->rows * 4, b->d_dense, (size_t)b->last_sample * 4, (size_t)s->rows * 4, (size_t)nq,
+                     hipMemcpyDeviceToHost));
+  memcpy(out_delta2, b->h_qaux + b->last_nq_pad, (size_t)nq * sizeof(float));
+  return TSH_OK;
+}
+
 }  // extern "C"
 
 #include "tsh_host_coldstart.inl.h"  // raw-vector file loader, tsh_index_open_ngh
