@@ -633,8 +633,10 @@ __device__ __forceinline__ void for_each_key(const float *keys, int n, int n4, i
   for (int j = 4 * n4 + tid; j < n; j += THREADS) fn(keys[j], j);
 }
 
+// k_pick <= k: which order statistic to return -- the k_pick-th smallest -- once the k smallest are known to be in
+// the list (the sample select's estimated threshold; everybody else passes k)
 template <int THREADS>
-__device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc) {
+__device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc, uint32_t k_pick) {
   constexpr int BS_GPT = BS_GROUPS / THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
@@ -707,7 +709,7 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
     } else if (m > BS_LIST) {
       tau = U == KEY_DEAD ? KEY_NAN : U;  // flooded by ties: U is a valid, looser bound
     } else {
-      tau = block_kth_radix<THREADS>(sc->list, m, k, &sc->rs);
+      tau = block_kth_radix<THREADS>(sc->list, m, k_pick, &sc->rs);
     }
     __syncthreads();
     if (tid == 0) sc->tau = tau;
@@ -727,13 +729,23 @@ struct SampleSelArgs {
   const float *dense;    // nq_pad x dense_ld
   const float *delta2;   // per query: 2 * error bound of the key
   float *thr;            // out: per-query filter threshold (key space)
+  uint32_t *tau_est;     // out: the sample key the threshold was derived from (key encoding; KEY_NAN = no threshold)
   uint32_t *cand_key, *cand_row, *cand_cnt;
   int64_t dense_ld;
   int32_t n_sample, k, cand_cap, row0;
+  int32_t k_est;         // which order statistic of the sample the threshold comes from (<= k; k = the proven bound)
 };
 
-// B0s: one workgroup per query.  thr[q] = band(k-th smallest sample key); the
-// sample rows at or below it open the query's candidate list.
+// B0s: one workgroup per query.  thr[q] = band(tau), tau = the k_est-th smallest sample key; the sample rows at
+// or below it open the query's candidate list.
+// k_est = k: tau bounds the k-th smallest key of the WHOLE row set by construction (k sample rows lie at or below it).
+// k_est < k: tau is an ESTIMATE of that bound, verified after the fact.  The sample is 1 / R of the rows, so with
+// k_est = k the filtered pass lets ~k R rows per query through (3200 at k = 100, R = 32), and every survivor costs the
+// key kernel's epilogue an append -- two thirds of its epilogue time.  The k smallest keys of the whole set fall
+// into the sample Binomial(k, 1 / R) at a time (3.1 on average): the p-th smallest SAMPLE key is below the k-th
+// smallest key overall only if p or more of them did, which for p = 14 happens once in a million queries -- and
+// then B2 sees it (its list holds fewer than k keys at or below tau) and hands the query to the single-query path.
+// Survivors per query: ~p R = 450.
 // (A variant that keeps the query's sample keys in registers and so reads them once instead of three times was
 // measured: 1024 queries 88 us against 71 -- at 181 registers only two workgroups share a CU and their serial phases
 // no longer hide behind each other; 16 queries 17.7 against 20.3 us.  Not kept.)
@@ -743,10 +755,11 @@ __global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelA
   __shared__ uint32_t s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float *keys = a.dense + (int64_t)q * a.dense_ld;
-  uint32_t tau = block_kth_of_floats<THREADS>(keys, a.n_sample, (uint32_t)a.k, &sc);
+  uint32_t tau = block_kth_of_floats<THREADS>(keys, a.n_sample, (uint32_t)a.k, &sc, (uint32_t)a.k_est);
   float thr = band_float(tau, a.delta2[q]);
   if (tid == 0) {
     a.thr[q] = thr;
+    a.tau_est[q] = thr == __builtin_inff() ? KEY_NAN : tau;  // (no threshold: nothing to verify)
     s_cnt = 0;
   }
   __syncthreads();
@@ -767,6 +780,7 @@ __global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelA
 struct FinalSelArgs {
   const uint32_t *cand_key, *cand_row, *cand_cnt;
   const float *delta2;
+  const uint32_t *tau_est;  // per query: the sample key the filter threshold came from (KEY_NAN: everything passed)
   uint8_t *blocks;       // nq blocks (BlockHeader + entries), device
   uint8_t *blocks_host;  // nullable: the same blocks in pinned host memory (headers are stored to both)
   uint32_t *final_rows;  // nq x entries
@@ -787,8 +801,13 @@ __global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArg
   const int n = (int)(over_in ? (uint32_t)a.cand_cap : total);
   const float *keys = reinterpret_cast<const float *>(a.cand_key + (int64_t)q * a.cand_cap);
   const uint32_t *rows = a.cand_row + (int64_t)q * a.cand_cap;
-  uint32_t tau = block_kth_of_floats<THREADS>(keys, n, (uint32_t)a.k, &sc);
+  uint32_t tau = block_kth_of_floats<THREADS>(keys, n, (uint32_t)a.k, &sc, (uint32_t)a.k);
   float band = band_float(tau, a.delta2[q]);
+  // The list holds every row with key <= tau_est + band.  It holds the whole top k only if the k-th smallest key
+  // overall is <= tau_est, i.e. if at least k of its entries are: tau (their k-th smallest) <= tau_est.  An estimated
+  // threshold (SampleSelArgs::k_est < k) that turns out too tight fails exactly this test.
+  const uint32_t te = a.tau_est[q];
+  const bool unverified = te < KEY_NAN && (tau >= KEY_NAN || tau > te);
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   // (the candidate lists start at multiples of cand_cap entries: 16-byte aligned)
@@ -802,13 +821,13 @@ __global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArg
   __syncthreads();
   if (tid == 0) {
     BlockHeader hv;
-    const bool over = over_in || s_cnt > (uint32_t)a.entries;
+    const bool over = over_in || unverified || s_cnt > (uint32_t)a.entries;
     hv.count = over ? 0u : s_cnt;
     hv.entries = (uint32_t)a.entries;
     hv.tau_key = tau;
     hv.band_key = f2key(band);
     hv.tiles_hit = total;
-    hv.flags = over ? FLAG_LIST_OVERFLOW : 0u;
+    hv.flags = (over ? FLAG_LIST_OVERFLOW : 0u) | (unverified ? FLAG_TAU_UNVERIFIED : 0u);
     hv.k = (uint32_t)a.k;
     hv.metric = (uint32_t)a.metric;
     hv.row_base = a.row_base;

@@ -28,6 +28,8 @@ struct BatchCtx {
   int64_t quar_cap = 0;
   int64_t bytes = 0;
   double last_gemm_us = 0, last_flops = 0;
+  int32_t est_backoff = 0;  // calls left during which the estimated threshold stays off (it failed too often)
+  int64_t est_unverified = 0;  // queries whose estimated threshold turned out too tight (redone exactly)
   int64_t last_nq = 0, last_nq_pad = 0, last_sample = 0;  // shape of d_dense / h_qaux after the last call (tsh_probe_batch_keys)
   int32_t last_sample_force = 0;  // tsh_probe_batch_keys: the next call's dense sample covers every row
   double last_wait_us = 0;  // how long the previous call waited for the GPU after enqueueing
@@ -72,6 +74,30 @@ int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
 }
 
 // (launch_batch_score_m: tsh_batch_tu.hip -- the key kernels compile as a translation unit of their own)
+
+// Which order statistic of the sample the filter threshold is taken from (SampleSelArgs::k_est, tsh_batch.hip.h).
+// The k smallest keys of all `rows` rows fall into the n_sample sample rows Binomial(k, n_sample / rows) at a time
+// when rows are exchangeable; the p-th smallest sample key fails as a bound on the k-th smallest key overall only if
+// p or more of them did.  p = the smallest value that makes this rarer than 1e-6 per query; B2 detects the failure
+// and the query is redone, so a corpus that is NOT exchangeable (rows clustered by insertion time) costs time, never
+// correctness -- and a call that sees more than a few failures switches the estimate off for the next calls.
+int32_t batch_k_est(BatchCtx *b, int32_t k, int64_t rows, int64_t n_sample) {
+  static const bool off = getenv("TSH_BATCH_PROVEN_TAU") != nullptr && getenv("TSH_BATCH_PROVEN_TAU")[0] == '1';
+  if (off || n_sample >= rows || k <= 8 || b->est_backoff > 0) return k;
+  const double pr = (double)n_sample / (double)rows;
+  // tail P(Binomial(k, pr) >= p) from p = k downwards
+  std::vector<double> pmf((size_t)k + 1);
+  const double lq = std::log1p(-pr), lp = std::log(pr);
+  for (int i = 0; i <= k; ++i)
+    pmf[(size_t)i] = std::exp(std::lgamma(k + 1.0) - std::lgamma(i + 1.0) - std::lgamma(k - i + 1.0) + i * lp + (k - i) * lq);
+  double tail = 0;
+  int p = k;
+  for (; p >= 1; --p) {
+    tail += pmf[(size_t)p];
+    if (tail > 1e-6) break;
+  }
+  return std::min(k, std::max(p + 1, 4));
+}
 
 int64_t batch_sample_rows(int64_t rows, int32_t k) {
   if (rows <= 16384) return rows;
@@ -151,6 +177,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
   const int64_t n_sample = b->last_sample_force ? rows : batch_sample_rows(rows, k);
   const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
+  const int32_t k_est = batch_k_est(b, k, rows, n_sample);
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
     for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
@@ -160,7 +187,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
-  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 3, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 4, &b->bytes))) return rc;  // + tau_est
   if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
   {
     int64_t want = (int64_t)nq * cand_cap, c1 = b->cand_total, c2 = b->cand_total;
@@ -317,6 +344,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
                             hipMemcpyDeviceToHost, st));
     }
     float *d_qsq = b->d_qaux, *d_d2 = b->d_qaux + nq_pad, *d_thr = b->d_qaux + 2 * (size_t)nq_pad;
+    uint32_t *d_tau_est = reinterpret_cast<uint32_t *>(b->d_qaux + 3 * (size_t)nq_pad);
     BatchArgs a{};
     if (use_bf16) {
       auto split = [&](const float *src, int64_t first, int64_t n, u32x4 *dst) {
@@ -412,6 +440,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     ss.dense_ld = n_sample;
     ss.n_sample = (int32_t)n_sample;
     ss.k = k;
+    ss.k_est = k_est;
+    ss.tau_est = d_tau_est;
     ss.cand_cap = cand_cap;
     ss.row0 = 0;
     // one workgroup per query: a small batch leaves most CUs empty, so its workgroups get sixteen waves instead of
@@ -435,6 +465,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     fs.cand_row = b->d_cr;
     fs.cand_cnt = b->d_cc;
     fs.delta2 = d_d2;
+    fs.tau_est = d_tau_est;
     // host mode: headers and re-ranked entries are stored straight into pinned host memory (only the `count`
     // valid entries cross PCIe, and no copy sits between the last kernel and the host)
     const bool zero_copy = out->d_blocks == nullptr;
@@ -501,6 +532,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if (out->on_chunk && b->last_wait_us > 0 && b->last_wait_us < 900.0)
     HostPool::get().stay_awake_until(t_enq + b->last_wait_us * 1.1 + 50.0);
   std::vector<char> skip((size_t)nq, 0);
+  int32_t n_unverified = 0;
   double t_gpu = 0;
   // From the end of the key passes on the pool gets a job every few dozen microseconds (one per chunk of the tail):
   // the long wait blocks, then the workers are woken and poll until the call is over
@@ -520,6 +552,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     for (int32_t q = q0; q < q1; ++q) {
       const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
       if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) {
+        if (h->flags & FLAG_TAU_UNVERIFIED) ++n_unverified;
         redo->push_back(q);
         skip[(size_t)q] = 1;
       } else {
@@ -545,6 +578,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
   b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
   b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  b->est_unverified += n_unverified;
+  if (b->est_backoff > 0) --b->est_backoff;
+  else if (n_unverified > std::max(1, nq / 64)) b->est_backoff = 64;  // the sample does not represent these rows
   b->last_nq = nq;
   b->last_nq_pad = nq_pad;
   b->last_sample = n_sample;

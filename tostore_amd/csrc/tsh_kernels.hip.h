@@ -408,6 +408,8 @@ struct BlockEntry {
 static_assert(sizeof(BlockEntry) == 24, "entry is 24 bytes");
 constexpr uint32_t FLAG_LIST_OVERFLOW = 1u;
 constexpr uint32_t FLAG_TAU_REFINED = 2u;  // informational: select step (f) ran
+constexpr uint32_t FLAG_TAU_UNVERIFIED = 4u;  // batched path: the estimated filter threshold was too tight (set with
+                                              // FLAG_LIST_OVERFLOW: the query is redone by the single-query path)
 
 struct SelectArgs {
   const uint32_t *gmin;
