@@ -12,7 +12,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtostore_hip.so")
+# (TSH_LIB_PATH: a development override -- tools/build_variants.py links probe variants of the library side by side)
+LIB_PATH = os.environ.get("TSH_LIB_PATH") or os.path.join(_HERE, "libtostore_hip.so")
 
 TSH_OK = 0
 TSH_E_BAD_ARG = -1

@@ -41,6 +41,7 @@ struct BatchArgs {
   const float *sqnorm;    // L2: |v|^2
   const float *qsq;       // L2: |q|^2 per query (nq_pad)
   const float *thr;       // filter mode: per-query band (float, key space); nq_pad
+  const float *kmax;      // f16 ping-pong kernel, IP / cosine: the largest key a row can have for this query (nq_pad)
   const uint64_t *live;   // nullable: bit = row present & not deleted
   const uint64_t *mask;   // nullable: caller keep mask
   float *dense;           // dense mode: nq_pad x dense_ld keys of rows [row0,row1)

@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/tostore_hip.h"
 #include "tsh_launch.h"
 #include "tsh_batch_f16.hip.h"
+#include "tsh_batch_f16pp.hip.h"
 
 namespace tsh {
 namespace {
@@ -32,6 +34,19 @@ void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
       if (cus <= 0) cus = 256;
     }
     const int pgrid = std::min(grid, cus);
+    // IP / cosine: third generation (ping-pong phases, tsh_batch_f16pp.hip.h) unless TSH_F16_GEN=2 asks for the
+    // second; L2 (a per-row term in the key: no sign test) stays on the second
+    static const bool gen2 = getenv("TSH_F16_GEN") != nullptr && getenv("TSH_F16_GEN")[0] == '2';
+    if constexpr (METRIC != METRIC_L2) if (!gen2) {
+      if (a.tile_m == 256) {
+        if (dense) batch_score_f16pp_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
+        else batch_score_f16pp_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
+      } else {
+        if (dense) batch_score_f16pp_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
+        else batch_score_f16pp_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
+      }
+      return;
+    }
     if (a.tile_m == 256) {
       if (dense) batch_score_f16_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
       else batch_score_f16_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);

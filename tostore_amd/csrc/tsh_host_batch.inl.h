@@ -134,7 +134,10 @@ bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2,
     // sit >= 27 binades under the largest operand value after the power-of-two scaling
     const double hld = (double)round_up(s->dim, 64);
     // (a query is only batched when its largest element is within 2^8 of the batch's, see top_q)
-    gam = (hld + 8.0) * u2 * (1.0 + 0.001) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
+    // The filtered IP / cosine pass starts its accumulators at -theta (|theta| <= |q| max|v| (1 + 1e-3), capped by
+    // BatchArgs::kmax) instead of zero: the chain carries twice the magnitude, and the key is formed from the
+    // accumulator by one more subtraction and one multiplication by a power of two (tsh_batch_f16pp.hip.h)
+    gam = 2.0 * (hld + 10.0) * u2 * (1.0 + 0.002) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
           std::sqrt(hld) * 9.3e-10;
   }
   double delta;
@@ -187,7 +190,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
-  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 4, &b->bytes))) return rc;  // + tau_est
+  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 5, &b->bytes))) return rc;  // + thr, tau_est, kmax
   if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
   {
     int64_t want = (int64_t)nq * cand_cap, c1 = b->cand_total, c2 = b->cand_total;
@@ -247,7 +250,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
-  float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad;
+  float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad, *h_kmax = b->h_qaux + 4 * (size_t)nq_pad;
+  // the largest key a row can have (IP: -dot <= |q| max|v|; cosine planes hold unit rows): caps the thresholds
+  const double kmax_v = s->metric == TSH_METRIC_COSINE ? 1.0 : (double)s->max_norm;
   std::vector<char> bad((size_t)nq, 0);
   std::vector<float> qmax((size_t)nq_pad, 0.f);
   b->mag_a.resize((size_t)nq);  // the finaliser's sum of q[i]^2 (cosine), a by-product of the band computation
@@ -256,7 +261,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if (q < nq) {
       memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
       for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
-      if (!batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q], &b->mag_a[(size_t)q])) {
+      h_kmax[q] = 0.f;
+      if (batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q], &b->mag_a[(size_t)q])) {
+        const double km = std::sqrt(b->mag_a[(size_t)q]) * kmax_v * 1.001 + 1e-30;
+        h_kmax[q] = km < 3e38 ? (float)km : 3e38f;
+      } else {
         qmax[(size_t)q] = 0.f;
         bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
         memset(dst, 0, (size_t)ld * sizeof(float));
@@ -267,6 +276,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       memset(dst, 0, (size_t)ld * sizeof(float));
       h_d2[q] = 0.f;
       h_qsq[q] = 0.f;
+      h_kmax[q] = 0.f;
     }
   });
   // f16: one power-of-two scale for the whole batch; queries much smaller than the largest one would sit
@@ -326,6 +336,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     hipStream_t st = s->batch_stream;
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * sizeof(float), hipMemcpyHostToDevice, st));
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
     if (!quar_sel.empty() && !out->d_blocks) {
       QuarArgs qa{};
@@ -396,8 +407,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       static const int f16_dbg = getenv("TSH_F16_DBG") ? atoi(getenv("TSH_F16_DBG")) : 0;  // probes: results are wrong
       a.dbg = f16_dbg;
       static uint64_t *d_dbg = nullptr;
-      if ((f16_dbg & 32) && !d_dbg) HIPCHK(hipMalloc(&d_dbg, 2 * 96 * 12 * sizeof(uint64_t)));
-      if (f16_dbg & 32) HIPCHK(hipMemsetAsync(d_dbg, 0, 2 * 96 * 12 * sizeof(uint64_t), st));
+      if ((f16_dbg & 32) && !d_dbg) HIPCHK(hipMalloc(&d_dbg, (4 * 96 * 12 + 16) * sizeof(uint64_t)));
+      if (f16_dbg & 32) HIPCHK(hipMemsetAsync(d_dbg, 0, (4 * 96 * 12 + 16) * sizeof(uint64_t), st));
       a.dbg_buf = d_dbg;
       g_f16_dbg_buf = d_dbg;
 #endif
@@ -408,6 +419,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.sqnorm = s->d_sqnorm;
     a.qsq = d_qsq;
     a.thr = d_thr;
+    a.kmax = b->d_qaux + 4 * (size_t)nq_pad;
     a.live = s->all_live ? nullptr : s->d_live;
     a.mask = mask ? b->d_mask : nullptr;
     a.dense = b->d_dense;
@@ -593,8 +605,24 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
 #ifdef TSH_PROBES
   if (g_f16_dbg_buf && nq >= 1024) {  // probe: step timeline of two waves of workgroup 0 (main pass: the last launch)
-    std::vector<uint64_t> hb(2 * 96 * 12);
+    std::vector<uint64_t> hb(4 * 96 * 12 + 16);
     HIPCHK(hipMemcpy(hb.data(), g_f16_dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[pp cnt] wave tiles %llu, crowded %llu, more than two per lane %llu, hit blocks %llu\n", (unsigned long long)hb[4 * 96 * 12],
+            (unsigned long long)hb[4 * 96 * 12 + 1], (unsigned long long)hb[4 * 96 * 12 + 2], (unsigned long long)hb[4 * 96 * 12 + 3]);
+    static const bool raw = getenv("TSH_F16_GEN") == nullptr || getenv("TSH_F16_GEN")[0] != '2';
+    if (raw) {  // ping-pong kernel: raw stamps relative to the wave's first, one line per chunk (points 0-9)
+      const int wv[4] = {0, 4, 1, 5};
+      for (int w = 0; w < 4; ++w) {
+        const uint64_t *b0 = &hb[(size_t)(w * 96) * 12];
+        fprintf(stderr, "[pp dbg] wave %d hw_id 0x%llx simd %llu\n", wv[w], (unsigned long long)b0[11], (unsigned long long)((b0[11] >> 4) & 3));
+        for (int st2 = 0; st2 < 60; ++st2) {
+          const uint64_t *t = &hb[(size_t)(w * 96 + st2) * 12];
+          fprintf(stderr, "[pp dbg]  w%d c%02d:", wv[w], st2);
+          for (int pt = 0; pt < 12; ++pt) fprintf(stderr, " %7lld", t[pt] ? (long long)(t[pt] - hb[0]) : -1ll);
+          fprintf(stderr, "\n");
+        }
+      }
+    } else
     for (int w = 0; w < 2; ++w) {
       fprintf(stderr, "[f16 dbg] wave %d: per step: wait vmcnt | barrier | DMA issue | reads + slab 0 + reads + slab 1 | - | (to next step)\n", w * 4);
       for (int st2 = 20; st2 < 52; ++st2) {
