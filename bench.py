@@ -585,6 +585,33 @@ def side_c1(env, with_oracle):
                 oracle.search_heap(host_rows, qs[i], metric, k)
             out["cpu_baseline"] = {"value": 20 / (time.perf_counter() - t1), "unit": "queries/s", "cores": 1,
                                    "kind": "port", "sample": "20 queries, oracle/vs_oracle.c single thread"}
+            # context: what the reference's OWN search -- the approximate NGH graph walk this
+            # build replaces -- returns on the same rows and queries.  A restatement (oracle/ngh_ann.c), not the
+            # reference: its PQ training draws come from NumPy instead of Dart's Random(42), nothing here was produced
+            # by a Dart VM, so the numbers are properties of the restatement and must not be quoted as ToStore's.
+            try:
+                t1 = time.perf_counter()
+                ann = oracle.NghAnnIndex(d, metric, host_rows[:2500])
+                for b0 in range(2500, n, 2500):
+                    ann.insert_batch(host_rows[b0:b0 + 2500])
+                t_build = time.perf_counter() - t1
+                nqa = 200
+                ann.counters()
+                t1 = time.perf_counter()
+                found = [ann.search(qs[i], k)[0] for i in range(nqa)]
+                t_search = time.perf_counter() - t1
+                ctr = ann.counters()
+                hit = sum(len(np.intersect1d(found[i], ref[0][i][:k])) for i in range(nqa))
+                out["reference_ann_restated"] = {
+                    "label": "restatement of the reference's NGH graph search (PQ/ADC beam search + exact re-rank), CPU, "
+                             "1 thread, in memory; unverifiable here: Dart's PRNG differs, no Dart VM in the image",
+                    "recall_at_k": hit / float(nqa * k), "ms_per_query": 1e3 * t_search / nqa, "queries": nqa,
+                    "build_seconds": t_build, "adc_evaluations_per_query": ctr["adc_evaluations"] / nqa,
+                    "hops_per_query": ctr["hops"] / nqa,
+                    "defaults": "M=%d K=%d R=64 efSearch=64 efConstruction=128 alpha=1.2" % (ann.subspaces, ann.centroids)}
+                ann.close()
+            except Exception as e:  # context only: never fails the line
+                out["reference_ann_restated"] = {"error": repr(e)}
         return out
     finally:
         idx.close()

@@ -80,6 +80,9 @@ def lib() -> ctypes.CDLL:
         L.vso_pq_train_subspace.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_int32), _c_f32p]
         L.vso_pq_train_subspace.restype = None
+        L.vso_pq_train_subspace_pp.argtypes = [_c_f32p, _c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int32,
+                                               _c_f64p, _c_f32p]
+        L.vso_pq_train_subspace_pp.restype = None
         L.vso_crc32.argtypes = [_c_u8p, ctypes.c_size_t]
         L.vso_crc32.restype = ctypes.c_uint32
         L.vso_vectors_per_raw_page.argtypes = [ctypes.c_int] * 3
@@ -271,6 +274,24 @@ def pq_train(samples, subspaces: int, k: int, iterations: int, init_index) -> np
     return out
 
 
+def pq_train_pp(samples, subspaces: int, k: int, iterations: int, first_index, draws) -> np.ndarray:
+    """Codebook (subspaces x k x subDim) trained like VectorQuantizer.train -- the k-means++ trainer the reference
+    uses when the first batch holds fewer than 100 vectors (ref: core/vector_quantizer.dart:81-350).  Dart's
+    Random(42) is not reproducible here: `first_index[m]` stands for its nextInt(n) and `draws[m][c - 1]` for the
+    nextDouble() that picks centroid c of sub-space m."""
+    s = _f32(samples)
+    n, dim = s.shape
+    sd = dim // subspaces
+    first = np.ascontiguousarray(first_index, dtype=np.int32).reshape(subspaces)
+    u = np.ascontiguousarray(draws, dtype=np.float64).reshape(subspaces, max(k - 1, 0))
+    out = np.empty((subspaces, k, sd), dtype=np.float32)
+    for m in range(subspaces):
+        sub = np.ascontiguousarray(s[:, m * sd:(m + 1) * sd])
+        um = np.ascontiguousarray(u[m]) if k > 1 else np.zeros(1)
+        lib().vso_pq_train_subspace_pp(_p(sub, _c_f32p), n, sd, k, iterations, int(first[m]), _p(um, _c_f64p), _p(out[m], _c_f32p))
+    return out
+
+
 def crc32(data: bytes) -> int:
     buf = np.frombuffer(data, dtype=np.uint8)
     return lib().vso_crc32(_p(buf, _c_u8p), buf.shape[0])
@@ -350,8 +371,8 @@ def _ann():
 class NghAnnIndex:
     """The reference's index as it builds and searches it (NghGraphEngine + VectorQuantizer), restated on
     the CPU for context numbers only.  `first_batch` plays the first writeChanges call: its first <= 2500
-    rows train the codebook (trainPqSubspace per sub-space, seeds from `seed` because Dart's PRNG is not
-    reproducible here).  ref: core/vector_index_manager.dart:300-420,725-850, core/ngh_graph_engine.dart."""
+    rows train the codebook (100 or more: trainPqSubspace per sub-space; fewer: VectorQuantizer.train with
+    k-means++ seeding; random draws from `seed` because Dart's PRNG is not reproducible here).  ref: core/vector_index_manager.dart:300-420,725-850, core/ngh_graph_engine.dart."""
 
     def __init__(self, dim: int, metric: int, first_batch, *, subspaces: Optional[int] = None, max_degree: int = 64,
                  ef_search: int = 64, ef_construction: int = 128, prune_alpha: float = 1.2, seed: int = 42):
@@ -360,12 +381,17 @@ class NghAnnIndex:
         self.subspaces = subspaces or min(max(dim // 8, 8), 128)  # NghIndexMeta.autoPqSubspaces
         samples = fb[:2500]
         n = samples.shape[0]
-        if n < 100:
-            raise ValueError("the restated path covers the >= 100-sample training branch only")
+        if n < 1:
+            raise ValueError("an empty first batch trains nothing (vector_index_manager.dart:739)")
         self.centroids = min(256, n)
         rng = np.random.default_rng(seed)
-        init = rng.integers(0, n, size=(self.subspaces, self.centroids)).astype(np.int32)
-        self.codebook = pq_train(samples, self.subspaces, self.centroids, 10, init)
+        if n >= 100:  # isolate tasks, one per sub-space (vector_index_manager.dart:744-841)
+            init = rng.integers(0, n, size=(self.subspaces, self.centroids)).astype(np.int32)
+            self.codebook = pq_train(samples, self.subspaces, self.centroids, 10, init)
+        else:  # VectorQuantizer.train: k-means++ seeding, k = n centroids (vector_index_manager.dart:842-849)
+            first = rng.integers(0, n, size=self.subspaces).astype(np.int32)
+            draws = rng.random((self.subspaces, max(self.centroids - 1, 0)))
+            self.codebook = pq_train_pp(samples, self.subspaces, self.centroids, 10, first, draws)
         cb = np.ascontiguousarray(self.codebook.reshape(-1), dtype=np.float32)
         self._h = _ann().vso_ann_create(dim, metric, self.subspaces, self.centroids, max_degree, ef_search,
                                         ef_construction, prune_alpha, _p(cb, _c_f32p))

@@ -230,6 +230,76 @@ def pq_train_subspace(data, k: int, iterations: int, init_index) -> np.ndarray:
 
 
 # ---- A7 page framing ------------------------------------------------------
+def pq_train_subspace_pp(data, k: int, iterations: int, first: int, draws) -> np.ndarray:
+    """N3. ref: core/vector_quantizer.dart:81-350 (VectorQuantizer.train, one sub-space): k-means++ seeding, then
+    Lloyd iterations on squared distances.  `first` / `draws` stand for Dart's Random(42) (nextInt, nextDouble)."""
+    data = np.asarray(data, np.float32)
+    n, sd = data.shape
+    f32, f64 = np.float32, np.float64
+    simd = sd % 4 == 0
+    d64 = data.astype(f64)
+
+    def dists(cvec):  # squared distance of every sample to one centre, widths as in the Dart text
+        acc = np.zeros(n, f64)
+        if simd:
+            for d in range(0, sd, 4):
+                m = []
+                for u in range(4):
+                    diff = (data[:, d + u] - f32(cvec[d + u])).astype(f32)
+                    m.append((diff * diff).astype(f32).astype(f64))
+                acc = acc + (((m[0] + m[1]) + m[2]) + m[3])
+        else:
+            c64 = cvec.astype(f64)
+            for d in range(sd):
+                diff = d64[:, d] - c64[d]
+                acc = acc + diff * diff
+        return acc
+
+    cent = np.zeros((k, sd), f32)
+    cent[0] = data[first]
+    with np.errstate(all="ignore"):
+        min_d = np.full(n, np.inf)
+        for c in range(1, k):
+            min_d = np.minimum(min_d, dists(cent[c - 1]))
+            total = 0.0
+            for i in range(n):
+                total += float(min_d[i])
+            selected = n - 1
+            if total > 0:
+                thr = float(draws[c - 1]) * total
+                for i in range(n):
+                    thr -= float(min_d[i])
+                    if thr <= 0:
+                        selected = i
+                        break
+            cent[c] = data[selected]
+        for _ in range(iterations):
+            dm = np.stack([dists(cent[c]) for c in range(k)], axis=1)
+            best = np.full(n, np.inf)
+            assign = np.zeros(n, np.int64)
+            for c in range(k):
+                lt = dm[:, c] < best
+                best = np.where(lt, dm[:, c], best)
+                assign = np.where(lt, c, assign)
+            sums = np.zeros((k, sd), f32)
+            counts = np.zeros(k, np.int64)
+            for i in range(n):
+                c = assign[i]
+                counts[c] += 1
+                sums[c] = (sums[c].astype(f64) + d64[i]).astype(f32)
+            changed = False
+            for c in range(k):
+                if counts[c] == 0:
+                    continue
+                new = sums[c].astype(f64) * (1.0 / counts[c])
+                if (np.abs(cent[c].astype(f64) - new) > 1e-6).any():
+                    changed = True
+                cent[c] = new.astype(f32)
+            if not changed:
+                break
+    return cent
+
+
 def crc32(data: bytes) -> int:
     """ref: core/btree_page.dart:61-89 (IEEE CRC-32; same as zlib.crc32)."""
     import zlib

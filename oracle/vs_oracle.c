@@ -348,6 +348,102 @@ void vso_pq_train_subspace(const float *data, int64_t n, int sub_dim, int k, int
   free(norms);
 }
 
+/* ---- N3: the reference's OTHER trainer, for first batches of fewer than 100 vectors.
+ * ref: core/vector_quantizer.dart:81-350 (VectorQuantizer.train), chosen at core/vector_index_manager.dart:744,842-849.
+ * One sub-space: k-means++ seeding, then Lloyd iterations with squared distances (the isolate trainer above ranks by
+ * dot - |c|^2 / 2 and starts from k random samples instead).  Dart's Random(42) -- one stream shared by all
+ * sub-spaces, nextInt(n) then k - 1 nextDouble() per sub-space -- is not reproducible without a Dart runtime, so the
+ * caller supplies the draws: first = the nextInt result, u[c - 1] = the nextDouble that picks centroid c.
+ * Arithmetic widths as in the Dart text: Float32x4 lanes subtract and multiply in f32 and are summed as doubles
+ * (:143-146); the scalar path (sub_dim % 4 != 0) subtracts the widened values in f64 (:262-266). */
+static double vso_pp_dist(const float *a, const float *b, int sub_dim, int use_simd) {
+  double dist = 0;
+  int d;
+  if (use_simd) {
+    for (d = 0; d < sub_dim; d += 4) {
+      float dx = a[d] - b[d], dy = a[d + 1] - b[d + 1], dz = a[d + 2] - b[d + 2], dw = a[d + 3] - b[d + 3];
+      float mx = dx * dx, my = dy * dy, mz = dz * dz, mw = dw * dw;
+      dist += (((double)mx + (double)my) + (double)mz) + (double)mw;
+    }
+  } else {
+    for (d = 0; d < sub_dim; d++) {
+      double diff = (double)a[d] - (double)b[d];
+      dist += diff * diff;
+    }
+  }
+  return dist;
+}
+
+void vso_pq_train_subspace_pp(const float *data, int64_t n, int sub_dim, int k, int iterations, int32_t first,
+                              const double *u, float *centroids) {
+  int32_t *assign = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  int32_t *counts = (int32_t *)malloc((size_t)k * sizeof(int32_t));
+  float *sums = (float *)malloc((size_t)k * sub_dim * sizeof(float));
+  double *min_d = (double *)malloc((size_t)n * sizeof(double));
+  int use_simd = (sub_dim % 4 == 0), iter, c, d;
+  int64_t i;
+  for (d = 0; d < sub_dim; d++) centroids[d] = data[(int64_t)first * sub_dim + d]; /* :126-130 */
+  for (i = 0; i < n; i++) min_d[i] = INFINITY;
+  for (c = 1; c < k; c++) { /* :135-172 */
+    double total = 0;
+    int64_t selected = n - 1;
+    for (i = 0; i < n; i++) {
+      double dist = vso_pp_dist(data + i * sub_dim, centroids + (int64_t)(c - 1) * sub_dim, sub_dim, use_simd);
+      if (dist < min_d[i]) min_d[i] = dist;
+      total += min_d[i];
+    }
+    if (total > 0) {
+      double threshold = u[c - 1] * total;
+      for (i = 0; i < n; i++) {
+        threshold -= min_d[i];
+        if (threshold <= 0) {
+          selected = i;
+          break;
+        }
+      }
+    }
+    for (d = 0; d < sub_dim; d++) centroids[(int64_t)c * sub_dim + d] = data[selected * sub_dim + d];
+  }
+  for (iter = 0; iter < iterations; iter++) { /* :180-232 */
+    int changed = 0;
+    for (i = 0; i < n; i++) {
+      int best_idx = 0;
+      double best = INFINITY;
+      for (c = 0; c < k; c++) {
+        double dist = vso_pp_dist(data + i * sub_dim, centroids + (int64_t)c * sub_dim, sub_dim, use_simd);
+        if (dist < best) {
+          best = dist;
+          best_idx = c;
+        }
+      }
+      assign[i] = best_idx;
+    }
+    memset(sums, 0, (size_t)k * sub_dim * sizeof(float));
+    memset(counts, 0, (size_t)k * sizeof(int32_t));
+    for (i = 0; i < n; i++) {
+      c = assign[i];
+      counts[c]++;
+      for (d = 0; d < sub_dim; d++)
+        sums[c * sub_dim + d] = (float)((double)sums[c * sub_dim + d] + (double)data[i * sub_dim + d]);
+    }
+    for (c = 0; c < k; c++) {
+      double inv;
+      if (counts[c] == 0) continue;
+      inv = 1.0 / (double)counts[c];
+      for (d = 0; d < sub_dim; d++) {
+        double new_val = (double)sums[c * sub_dim + d] * inv;
+        if (fabs((double)centroids[c * sub_dim + d] - new_val) > 1e-6) changed = 1;
+        centroids[c * sub_dim + d] = (float)new_val;
+      }
+    }
+    if (!changed) break;
+  }
+  free(assign);
+  free(counts);
+  free(sums);
+  free(min_d);
+}
+
 /* ---- A7: CRC32.  ref: core/btree_page.dart:61-89 ------------------------ */
 uint32_t vso_crc32(const uint8_t *data, size_t len) {
   static uint32_t table[256];

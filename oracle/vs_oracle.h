@@ -101,6 +101,10 @@ void vso_pq_encode(const float *codebook, int subspaces, int centroids, int sub_
  * sub_samples n x sub_dim; init_index k; out_centroids k x sub_dim. */
 void vso_pq_train_subspace(const float *sub_samples, int64_t n, int sub_dim, int k, int iterations,
                            const int32_t *init_index, float *out_centroids);
+/* N3: the k-means++ trainer the reference uses for first batches of fewer than 100 vectors
+ * (ref: core/vector_quantizer.dart:81-350); `first` and u[k - 1] stand for Dart's Random(42) draws */
+void vso_pq_train_subspace_pp(const float *sub_samples, int64_t n, int sub_dim, int k, int iterations, int32_t first,
+                              const double *u, float *centroids);
 
 /* A7  page framing.  ref: core/btree_page.dart:61-89 (CRC32 IEEE, reflected,
  * poly 0xEDB88320), :132-234 (20-byte 'TPG2' header) */

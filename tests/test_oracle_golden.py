@@ -257,6 +257,31 @@ def test_pq_train_restatements_agree(oracle_mod, n, sd, k):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,sd,k", [(60, 8, 60), (99, 4, 99), (37, 6, 37), (50, 3, 20), (5, 4, 1)])
+def test_pq_train_kmeanspp_restatements_agree(oracle_mod, n, sd, k):
+    """N3: the trainer for first batches of fewer than 100 vectors (VectorQuantizer.train, ref
+    core/vector_quantizer.dart:81-350: k-means++ seeding + Lloyd on squared distances): the C and the NumPy
+    restatement, written separately, agree bit for bit -- Float32x4 path (sd % 4 == 0) and scalar path."""
+    from oracle import np_oracle as npo
+
+    rng = np.random.default_rng(1000 + n)
+    data = (rng.standard_normal((n, sd)) + rng.integers(0, 4, (n, 1)) * 3.0).astype(np.float32)
+    data[n // 2] = data[0]  # a duplicated sample: a zero distance inside the seeding
+    first = int(rng.integers(0, n))
+    draws = rng.random(max(k - 1, 0))
+    for iters in (1, 10):
+        a = oracle_mod.pq_train_pp(data, 1, k, iters, [first], draws)[0]
+        b = npo.pq_train_subspace_pp(data, k, iters, first, draws)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # hand-checkable: k = n well separated points, draws that walk the cumulative distances -> every sample is chosen once
+    pts = (np.arange(6, dtype=np.float32)[:, None] * 10.0 + np.zeros((6, 4), np.float32))
+    c = oracle_mod.pq_train_pp(pts, 1, 6, 10, [0], np.full(5, 0.999999))[0]
+    assert sorted(c[:, 0].tolist()) == [0.0, 10.0, 20.0, 30.0, 40.0, 50.0]
+    # all samples identical: total distance 0 -> the last sample is selected every time (:160-169)
+    same = np.ones((4, 4), np.float32)
+    assert np.array_equal(oracle_mod.pq_train_pp(same, 1, 4, 3, [2], np.full(3, 0.5))[0], same)
+
+
 def test_ngh_directory_writer_reader_round_trip(oracle_mod, tmp_path):
     """N1 fixtures: the directory writer restatement (oracle/ngh_dir.py) and the reader restatement agree,
     across partition files and dir_N buckets, for every stored precision."""

@@ -56,6 +56,25 @@ def test_restated_reference_ann_result_count_rules(oracle_mod):
     thr = float(dist[len(dist) // 2])
     idt, dt = ann.search(q, 100, ef_search=400, threshold=thr)
     assert len(idt) > 0 and dt.max() <= thr and np.array_equal(idt, ids[:len(idt)])
+    ann.close()
+
+
+def test_restated_reference_ann_small_first_batch(oracle_mod):
+    """A first batch of fewer than 100 vectors trains with VectorQuantizer.train (k-means++ seeding, k = n centroids:
+    ref core/vector_index_manager.dart:842-849, core/vector_quantizer.dart:81-350); later batches are encoded with that
+    codebook.  With k = n every training vector is its own centroid in every sub-space it is distinct in, so the ADC
+    distance of a first-batch vector to itself is 0 and it comes back first."""
+    d = 16
+    x = _data(900, d, 11)
+    ann = oracle_mod.NghAnnIndex(d, L2, x[:60])
+    assert ann.centroids == 60 and ann.codebook.shape == (ann.subspaces, 60, d // ann.subspaces)
+    ann.insert_batch(x[60:])
+    assert ann.size == 900
+    hits = 0
+    for i in range(0, 60, 7):
+        ids, dist = ann.search(x[i], 5, ef_search=200)
+        hits += int(len(ids) > 0 and ids[0] == i and dist[0] == 0.0)
+    assert hits >= 8  # (9 probes; the graph walk is approximate)
     with pytest.raises(ValueError):
-        oracle_mod.NghAnnIndex(d, L2, x[:50])  # < 100 samples: the k-means++ branch is not restated
+        oracle_mod.NghAnnIndex(d, L2, x[:0])
     ann.close()
