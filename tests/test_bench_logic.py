@@ -53,6 +53,9 @@ def test_single_gpu_line(oracle_mod, steps, warmup):
     for keep in ("keep_1%", "keep_10%", "keep_50%"):
         assert side["C5"][keep]["ids_and_distances_bit_exact"] is True, side["C5"]
     assert side["C1"]["ids_and_distances_bit_exact"] is True and side["C1"]["latency_us"]["p50"] > 0
+    ann = side["C1"]["reference_ann_restated"]  # context only, labelled as a restatement
+    assert "error" not in ann and 0.0 <= ann["recall_at_k"] <= 1.0 and ann["ms_per_query"] > 0
+    assert "restatement" in ann["label"] and "unverifiable" in ann["label"]
     if steps == 20:
         c3 = side["C3"]
         assert c3["ids_and_distances_bit_exact"] is True and c3["checked_queries"] == 128
