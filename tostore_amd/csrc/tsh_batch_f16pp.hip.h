@@ -35,6 +35,12 @@
 // issued (LOAD phase, between the MFMAs, any split), whether their data is L2- or L1-hot, and whether anybody waits
 // for them makes no difference: a K-step pays ~8 cycles per DMA instruction and ~14 cycles per KB written into LDS,
 // on top of the matrix time -- the LDS side of this tile shape, not the memory side.
+// Tried on top of that and dropped: the corpus rows' fragments straight from the plane into registers (buffer loads,
+// three chunks ahead, four register sets; only the queries through the DMA ring -- half the LDS writes).  With
+// nobody waiting for those loads the K loop runs in 1.19 ms (PP_ISSUE=4); with the MFMAs actually consuming them
+// 1.38-1.44 (1.31 with a plane layout that makes each load a contiguous 1 KB, 1.27 with the rows L2-hot) against
+// 1.32-1.34 for the ring: a load that misses L2 now stalls a COMPUTE phase directly, and 256 registers leave no room
+// for a deeper prefetch.  768-byte DMA pieces (global_load_lds_dwordx3): no faster.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -122,7 +128,19 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
   // (one piece: the K loop spreads a chunk's pieces over the LOAD and the COMPUTE phase)
   auto issue_one = [&](auto SIDX, int u) {
     constexpr int ST = decltype(SIDX)::value;
+#if defined(TSH_PROBES) && defined(PP_ISSUE) && PP_ISSUE == 1    // probe: 4 B per lane into LDS
+    f16_dma4_s(src[u], lane_off, my_dst + (uint32_t)(ST * STAGE + piece_off(u)));
+#elif defined(TSH_PROBES) && defined(PP_ISSUE) && PP_ISSUE == 2  // probe: 16 B per lane into registers
+    f16_load16_s(src[u], lane_off, &dbg_sink);
+#elif defined(TSH_PROBES) && defined(PP_ISSUE) && PP_ISSUE == 3  // probe: no loads
+#elif defined(TSH_PROBES) && defined(PP_ISSUE) && PP_ISSUE == 4  // probe: what "rows straight into registers" would cost
+    // at best: the query half of the stage by DMA as shipped, the row half not at all; instead EVERY wave loads 4 KB
+    // (its own 64 rows' chunk) into registers, 16 B per lane, and nobody waits for them (results are wrong)
+    if (wave * PPW + u < (TM / F16_GROUP) * 8) f16_dma16_s(src[u], lane_off, my_dst + (uint32_t)(ST * STAGE + piece_off(u)));
+    f16_load16_s(src[u], lane_off, &dbg_sink);
+#else
     f16_dma16_s(src[u], lane_off, my_dst + (uint32_t)(ST * STAGE + piece_off(u)));
+#endif
     src[u] += 8192;
   };
   auto issue = [&](auto SIDX) {  // a whole chunk (prologue)

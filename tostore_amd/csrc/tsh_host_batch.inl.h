@@ -101,7 +101,8 @@ int32_t batch_k_est(BatchCtx *b, int32_t k, int64_t rows, int64_t n_sample) {
 
 int64_t batch_sample_rows(int64_t rows, int32_t k) {
   if (rows <= 16384) return rows;
-  int64_t n = std::max<int64_t>(rows / 32, (int64_t)k * rows / 3000);
+  static const int64_t div = getenv("TSH_SAMPLE_DIV") ? std::max(4, atoi(getenv("TSH_SAMPLE_DIV"))) : 32;  // experiments
+  int64_t n = std::max<int64_t>(rows / div, (int64_t)k * rows / (3000 * div / 32));
   n = std::max<int64_t>(round_up(n, 256), 8192);  // whole row tiles of either tile shape
   n = std::max<int64_t>(n, round_up((int64_t)k * 4, 256));
   return std::min(n, rows);
