@@ -34,25 +34,37 @@ void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
       if (cus <= 0) cus = 256;
     }
     const int pgrid = std::min(grid, cus);
-    // IP / cosine: third generation (ping-pong phases, tsh_batch_f16pp.hip.h) unless TSH_F16_GEN=2 asks for the
-    // second; L2 (a per-row term in the key: no sign test) stays on the second
-    static const bool gen2 = getenv("TSH_F16_GEN") != nullptr && getenv("TSH_F16_GEN")[0] == '2';
-    if constexpr (METRIC != METRIC_L2) if (!gen2) {
-      if (a.tile_m == 256) {
-        if (dense) batch_score_f16pp_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
-        else batch_score_f16pp_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
-      } else {
-        if (dense) batch_score_f16pp_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
-        else batch_score_f16pp_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
+    // IP / cosine: third generation (ping-pong phases, tsh_batch_f16pp.hip.h); L2 (a per-row term in the key: no sign
+    // test) stays on the second.  Probe builds (-DTSH_PROBES) keep the second generation for IP / cosine as well,
+    // TSH_F16_GEN=2 selects it there (tools/r3_ab.sh)
+    if constexpr (METRIC != METRIC_L2) {
+#ifdef TSH_PROBES
+      static const bool gen2 = getenv("TSH_F16_GEN") != nullptr && getenv("TSH_F16_GEN")[0] == '2';
+#else
+      constexpr bool gen2 = false;
+#endif
+      if (!gen2) {
+        if (a.tile_m == 256) {
+          if (dense) batch_score_f16pp_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
+          else batch_score_f16pp_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
+        } else {
+          if (dense) batch_score_f16pp_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
+          else batch_score_f16pp_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
+        }
+        return;
       }
-      return;
     }
-    if (a.tile_m == 256) {
-      if (dense) batch_score_f16_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
-      else batch_score_f16_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
-    } else {
-      if (dense) batch_score_f16_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
-      else batch_score_f16_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
+#ifndef TSH_PROBES
+    if constexpr (METRIC == METRIC_L2)
+#endif
+    {
+      if (a.tile_m == 256) {
+        if (dense) batch_score_f16_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
+        else batch_score_f16_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
+      } else {
+        if (dense) batch_score_f16_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
+        else batch_score_f16_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
+      }
     }
     return;
   }
