@@ -7,8 +7,8 @@ from tostore_amd import HipVectorIndex, _ffi
 L=_ffi.lib()
 "
 try() { # name, code
-  timeout 120 rocprofv3 --kernel-trace -d gpurun_out/exitcheck/$1 -o x -- python -c "$PRE$2" > gpurun_out/exitcheck/$1.log 2>&1
-  echo "$1 rc=$? segv=$(grep -c SIGSEGV gpurun_out/exitcheck/$1.log)"
+  timeout -k 5 120 rocprofv3 --kernel-trace -d gpurun_out/exitcheck/$1 -o x -- python -c "$PRE$2" > gpurun_out/exitcheck/$1.log 2>&1
+  echo "$1 rc=$? segv=$(grep -c SIGSEGV gpurun_out/exitcheck/$1.log) abrt=$(grep -c "caught signal 6" gpurun_out/exitcheck/$1.log)"
 }
 try count "print(L.tsh_device_count())"
 try create "idx = HipVectorIndex(64, 0); idx.close()"

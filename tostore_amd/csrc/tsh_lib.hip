@@ -299,8 +299,11 @@ struct DeviceStreams {
   std::mutex scan_mu;                           // one enqueue sequence (scan + hand-off + tail) at a time
   int rc = TSH_OK;
   std::string err;
+  int users = 0;                                // shards alive on this device (device_streams / device_streams_release)
+  int cus = 0;
 };
 DeviceStreams *device_streams(int device);  // defined after set_err / HIPCHK users below
+void device_streams_release(int device);
 
 struct Shard {
   int device = 0;
@@ -314,6 +317,7 @@ struct Shard {
   float *d_sqnorm = nullptr;  // |row|^2 (batched L2 key)
   uint64_t *d_live = nullptr;
   IngestStats *d_stats = nullptr;
+  bool holds_streams = false;  // counted in its device's DeviceStreams::users
   uint32_t *d_tmp_u32 = nullptr;
   int64_t *d_del_ids = nullptr;  // tsh_index_set_deleted's id buffer, kept between calls
   int64_t del_ids_cap = 0;
@@ -384,27 +388,63 @@ struct Shard {
   }
 };
 
-// The stream sets live as long as the process -- except the CU-masked streams, which are destroyed by an
-// atexit handler: left to the runtime's own teardown they crash a python host at exit under rocprofv3
-// (tools/exitcheck.sh: SIGSEGV in __cxa_finalize after the tool wrote its output; plain streams are fine).  The
-// handler is registered after the first HIP call, so it runs before the runtime's exit handlers.
+// The stream sets live as long as the process -- except the CU-masked streams: left to the runtime's own teardown
+// they crash a python host at exit under rocprofv3 (tools/exitcheck.sh: SIGSEGV in __cxa_finalize after the tool
+// wrote its output; plain streams are fine).  They are destroyed when the LAST shard on their device is (and made
+// again for the next one), so a host that destroys its handles -- every host should -- has none left at exit.  The
+// atexit handler only covers leaked handles; it is registered after the first HIP call, so it runs before the
+// runtime's exit handlers.  (Round 3: with torch in the process rocprofv3 finalises its tool BEFORE that handler, and
+// a HIP call after that aborts -- tools/exitcheck_bench.sh; hence the reference count, which leaves the handler idle.)
 static std::mutex g_streams_mu;
 static std::map<int, DeviceStreams *> *g_stream_sets = nullptr;  // never freed
+static void destroy_masked_streams(DeviceStreams *ds) {  // g_streams_mu held, the device current
+  for (hipStream_t *st : {&ds->scan, &ds->scan2, &ds->tail, &ds->tail2})
+    if (*st) {
+      (void)hipStreamSynchronize(*st);
+      (void)hipStreamDestroy(*st);
+      *st = nullptr;
+    }
+  ds->cu_split = false;
+}
 static void destroy_masked_streams_at_exit() {
   std::lock_guard<std::mutex> lk(g_streams_mu);
   if (!g_stream_sets) return;
   for (auto &kv : *g_stream_sets) {
     DeviceStreams *ds = kv.second;
     if (!ds->cu_split || hipSetDevice(kv.first) != hipSuccess) continue;
-    for (hipStream_t *st : {&ds->scan, &ds->scan2, &ds->tail, &ds->tail2})
-      if (*st) {
-        (void)hipStreamSynchronize(*st);
-        (void)hipStreamDestroy(*st);
-        *st = nullptr;
-      }
+    destroy_masked_streams(ds);
   }
 }
 
+// the pipeline / tail streams: CU-masked where the device allows it, one plain stream otherwise
+static hipError_t make_scan_streams(DeviceStreams *ds) {
+  // CU mask bit i = CU slot i/8 of XCD i%8 on MI355X (measured, tools/cumask_probe.hip):
+  // bits 0..15 = two CUs of every XCD, reserved for the tails.
+  const char *env = getenv("TSH_NO_CU_SPLIT");
+  const int cus = ds->cus;
+  if (!(env && env[0] == '1') && cus >= 64 && cus % 32 == 0) {
+    std::vector<uint32_t> scan_mask((size_t)cus / 32, 0xFFFFFFFFu), tail_mask((size_t)cus / 32, 0u);
+    scan_mask[0] = 0xFFFF0000u;
+    tail_mask[0] = 0x0000FFFFu;
+    if (hipExtStreamCreateWithCUMask(&ds->scan, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
+        hipExtStreamCreateWithCUMask(&ds->scan2, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
+        hipExtStreamCreateWithCUMask(&ds->tail, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess &&
+        hipExtStreamCreateWithCUMask(&ds->tail2, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
+      ds->cu_split = true;
+      return hipSuccess;
+    }
+    if (ds->scan) (void)hipStreamDestroy(ds->scan);
+    if (ds->scan2) (void)hipStreamDestroy(ds->scan2);
+    if (ds->tail) (void)hipStreamDestroy(ds->tail);
+    if (ds->tail2) (void)hipStreamDestroy(ds->tail2);
+    ds->scan = ds->scan2 = ds->tail = ds->tail2 = nullptr;
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(&ds->scan, hipStreamNonBlocking);
+}
+
+// One more shard on `device`: its stream set (made on first use; the masked streams made again if the last shard
+// before this one took them along).  Pair with device_streams_release.
 DeviceStreams *device_streams(int device) {
   std::lock_guard<std::mutex> lk(g_streams_mu);
   if (!g_stream_sets) {
@@ -413,7 +453,19 @@ DeviceStreams *device_streams(int device) {
   }
   std::map<int, DeviceStreams *> &sets = *g_stream_sets;
   auto it = sets.find(device);
-  if (it != sets.end()) return it->second;
+  if (it != sets.end()) {
+    DeviceStreams *ds = it->second;
+    if (ds->rc == TSH_OK && !ds->scan) {
+      hipError_t e = hipSetDevice(device);
+      if (e == hipSuccess) e = make_scan_streams(ds);
+      if (e != hipSuccess) {
+        ds->rc = e == hipErrorOutOfMemory ? TSH_E_OOM : TSH_E_HIP;
+        ds->err = std::string("hipStreamCreate failed: ") + hipGetErrorString(e);
+      }
+    }
+    if (ds->rc == TSH_OK) ++ds->users;
+    return ds;
+  }
   DeviceStreams *ds = new DeviceStreams();
   sets[device] = ds;
   auto fail = [&](hipError_t e, const char *what) {
@@ -424,35 +476,23 @@ DeviceStreams *device_streams(int device) {
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return fail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&ds->ingest, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-  // CU mask bit i = CU slot i/8 of XCD i%8 on MI355X (measured, tools/cumask_probe.hip):
-  // bits 0..15 = two CUs of every XCD, reserved for the tails.
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
-  const char *env = getenv("TSH_NO_CU_SPLIT");
-  const int cus = prop.multiProcessorCount;
-  if (!(env && env[0] == '1') && cus >= 64 && cus % 32 == 0) {
-    std::vector<uint32_t> scan_mask((size_t)cus / 32, 0xFFFFFFFFu), tail_mask((size_t)cus / 32, 0u);
-    scan_mask[0] = 0xFFFF0000u;
-    tail_mask[0] = 0x0000FFFFu;
-    if (hipExtStreamCreateWithCUMask(&ds->scan, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
-        hipExtStreamCreateWithCUMask(&ds->scan2, (uint32_t)scan_mask.size(), scan_mask.data()) == hipSuccess &&
-        hipExtStreamCreateWithCUMask(&ds->tail, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess &&
-        hipExtStreamCreateWithCUMask(&ds->tail2, (uint32_t)tail_mask.size(), tail_mask.data()) == hipSuccess) {
-      ds->cu_split = true;
-    } else {
-      if (ds->scan) (void)hipStreamDestroy(ds->scan);
-      if (ds->scan2) (void)hipStreamDestroy(ds->scan2);
-      if (ds->tail) (void)hipStreamDestroy(ds->tail);
-      if (ds->tail2) (void)hipStreamDestroy(ds->tail2);
-      ds->scan = ds->scan2 = ds->tail = ds->tail2 = nullptr;
-      (void)hipGetLastError();
-    }
-  }
-  if (!ds->cu_split && (e = hipStreamCreateWithFlags(&ds->scan, hipStreamNonBlocking)) != hipSuccess)
-    return fail(e, "hipStreamCreate");
+  ds->cus = prop.multiProcessorCount;
+  if ((e = make_scan_streams(ds)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&ds->batch, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&ds->aux, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  ++ds->users;
   return ds;
+}
+
+void device_streams_release(int device) {
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  if (!g_stream_sets) return;
+  auto it = g_stream_sets->find(device);
+  if (it == g_stream_sets->end()) return;
+  DeviceStreams *ds = it->second;
+  if (ds->users > 0 && --ds->users == 0 && ds->cu_split && hipSetDevice(device) == hipSuccess) destroy_masked_streams(ds);
 }
 
 int shard_init(Shard *s) {
@@ -468,6 +508,7 @@ int shard_init(Shard *s) {
   s->aux_stream = ds->aux;
   s->cu_split = ds->cu_split;
   s->scan_mu = &ds->scan_mu;
+  s->holds_streams = true;
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
   HIPCHK(hipMalloc(&s->d_tmp_u32, 64));
@@ -1326,7 +1367,7 @@ void shard_destroy(Shard *s) {
     delete s->batch;
     s->batch = nullptr;
   }
-  // (streams are the device's, not the shard's: nothing to destroy)
+  // (streams are the device's, not the shard's; the last shard on a device takes the CU-masked ones along)
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
   hipFree(s->d_sqnorm);
@@ -1337,6 +1378,10 @@ void shard_destroy(Shard *s) {
   hipFree(s->d_del_ids);
   hipFree(s->d_quar);
   hipFree(s->d_irr);
+  if (s->holds_streams) {
+    s->holds_streams = false;
+    device_streams_release(s->device);
+  }
 }
 
 int check_create_args(int32_t dim, int32_t metric, int64_t cap, tsh_index **out) {
