@@ -47,4 +47,4 @@ for kk in (3,1,0):
     j=json.load(open('$O/bench_c3_k%d.json'%kk)); print('C3 kernel',kk, round(j['value']), j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernel_us'], j.get('ids_and_distances_bit_exact'))
 "
 # 4. ten minutes of the fuzz probe on the final build
-timeout -k 10 420 python tests/probes/long_fuzz.py 5 > $O/long_fuzz.txt 2>&1; tail -3 $O/long_fuzz.txt
+timeout -k 10 $((60*${FUZZ_MIN:-5}+120)) python tests/probes/long_fuzz.py ${FUZZ_MIN:-5} > $O/long_fuzz.txt 2>&1; tail -3 $O/long_fuzz.txt

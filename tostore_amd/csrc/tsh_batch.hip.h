@@ -1069,4 +1069,104 @@ static __global__ void __launch_bounds__(64 * RG_WAVES) rerank_batch_kernel(Rera
     if ((uint32_t)(lane + 64 * i) < nw) outw[lane + 64 * i] = stage[lane + 64 * i];
 }
 
+
+// K4 over a batch, second shape (round 3): every WAVE is on its own.  A wave owns up to 64 candidates of one query
+// (lane = candidate), brings their rows in pieces of 64 floats -- sixteen 1 KiB loads (four rows x 256 B each) in
+// flight while it walks the chains of the previous piece --, turns "lane = column" into "lane = candidate" through a
+// 17 KB LDS tile of its own, and takes the query from scalar registers.  No workgroup barrier anywhere: with eight
+// such waves per CU the load and chain phases of different waves interleave by themselves, where the four-wave shape
+// above had three of four waves idle through every chain phase and every workgroup of a launch in the same phase
+// at the same time.  Same arithmetic, bit for bit.
+constexpr int RW_WAVES = 2;          // waves per workgroup (they share nothing but the launch)
+constexpr int RW_P = 64;             // floats of a row per piece
+constexpr int RW_LD = RW_P + 4;      // LDS row stride in floats: rows 4 banks apart
+constexpr int RW_CAND = 64 * RW_WAVES;  // candidates per workgroup
+
+static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_wave_kernel(RerankBatchArgs a) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][64 * RW_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = a.q0 + (int)blockIdx.y;
+  const uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
+  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
+  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
+  const uint32_t c0 = (blockIdx.x * (uint32_t)RW_WAVES + (uint32_t)wave) * 64u;
+  if (c0 >= count) return;
+  const uint32_t left = count - c0;  // >= 1
+  const uint32_t slot = (uint32_t)lane < left ? (uint32_t)lane : left - 1u;  // idle lanes repeat the last candidate
+  const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
+  const int ld = (int)a.ld, dim = a.dim;
+  const int sub = lane >> 4, col4 = 4 * (lane & 15);
+  const float *rbase[16];  // load j of a piece covers candidates 4 j .. 4 j + 3, 256 B each
+#pragma unroll
+  for (int j = 0; j < 16; ++j) rbase[j] = a.rows + (int64_t)(uint32_t)__shfl((int)my_row, 4 * j + sub) * a.ld;
+  const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;  // wave-uniform: scalar loads
+  float *tile = tiles[wave];
+  const float *trow = tile + lane * RW_LD;
+  float *tput = tile + sub * RW_LD + col4;
+  const int npiece = (dim + RW_P - 1) / RW_P;
+  f32x4 in[16];
+  auto fetch = [&](int p) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
+    const int o = p * RW_P + col4 < ld - 4 ? p * RW_P + col4 : ld - 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase[j] + o));
+  };
+  double s0 = 0.0, s1 = 0.0;
+  auto chains = [&](auto METRIC) {
+    constexpr int M = decltype(METRIC)::value;
+    auto term = [&](float qf, float bf) {
+      const double qd = (double)qf, bd = (double)bf;
+      if (M == METRIC_L2) {
+        const double diff = qd - bd;
+        s0 = s0 + diff * diff;
+      } else {
+        s0 = __builtin_fma(qd, bd, s0);
+        if (M == METRIC_COS) s1 = __builtin_fma(bd, bd, s1);
+      }
+    };
+    fetch(0);
+    for (int p = 0; p < npiece; ++p) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) *reinterpret_cast<f32x4 *>(tput + 4 * j * RW_LD) = in[j];
+      fetch(p + 1);  // (past the last piece: clamped re-reads of cached lines)
+      __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
+      const float *qq = qp + p * RW_P;
+      const int m = dim - p * RW_P;  // wave-uniform; >= 1
+      if (m >= RW_P) {
+#pragma unroll
+        for (int g = 0; g < RW_P / 4; ++g) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) term(qq[4 * g + e], v[e]);
+        }
+      } else {
+        for (int i = 0; i < m; ++i) term(qq[i], trow[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (a.metric == METRIC_L2) chains(std::integral_constant<int, METRIC_L2>{});
+  else if (a.metric == METRIC_COS) chains(std::integral_constant<int, METRIC_COS>{});
+  else chains(std::integral_constant<int, METRIC_IP>{});
+  // entries: 24 bytes each, 64 of them contiguous -- staged in the wave's tile and stored as whole dwords side by side
+  uint32_t *stage = reinterpret_cast<uint32_t *>(tile);
+  {
+    const int64_t id = a.row_base + (int64_t)my_row;
+    const double e1 = a.metric == METRIC_COS ? s1 : 0.0;
+    stage[6 * lane + 0] = (uint32_t)id;
+    stage[6 * lane + 1] = (uint32_t)((uint64_t)id >> 32);
+    stage[6 * lane + 2] = (uint32_t)__double2loint(s0);
+    stage[6 * lane + 3] = (uint32_t)__double2hiint(s0);
+    stage[6 * lane + 4] = (uint32_t)__double2loint(e1);
+    stage[6 * lane + 5] = (uint32_t)__double2hiint(e1);
+  }
+  asm volatile("" ::: "memory");  // (one wave, LDS in program order: only the compiler must not reorder)
+  uint32_t *outw = reinterpret_cast<uint32_t *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader)) + 6 * (int64_t)c0;
+  const uint32_t nw = 6u * (left < 64u ? left : 64u);
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if ((uint32_t)(lane + 64 * i) < nw) outw[lane + 64 * i] = stage[lane + 64 * i];
+}
+
 }  // namespace tsh

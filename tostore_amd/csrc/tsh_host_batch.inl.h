@@ -515,7 +515,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = chunk_q(c), q1 = chunk_q(c + 1);
       rb.q0 = q0;
-      rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64 * RG_WAVES, 0, st>>>(rb);
+      static const bool old_rerank = getenv("TSH_RERANK_GEN") != nullptr && getenv("TSH_RERANK_GEN")[0] == '1';  // A/B
+      if (old_rerank)
+        rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64 * RG_WAVES, 0, st>>>(rb);
+      else
+        rerank_batch_wave_kernel<<<dim3((unsigned)((entries + RW_CAND - 1) / RW_CAND), (unsigned)(q1 - q0)), 64 * RW_WAVES, 0, st>>>(rb);
       if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
         QuarAppendArgs qa{};
         qa.rows = s->d_rows;
