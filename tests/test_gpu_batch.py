@@ -270,3 +270,67 @@ def test_default_switches_to_batched_by_estimated_cost(hip_lib, oracle_mod):
         assert np.array_equal(a[0], b[0][:2]) and np.array_equal(a[1], b[1][:2])
         eids, edist = oracle_mod.search_heap_mt(rows, qs[2], L2, k)
         assert np.array_equal(b[0][2], eids) and np.array_equal(b[1][2], edist)
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_device_finaliser_edges(hip_lib, oracle_mod, metric):
+    """The batched path's results are finalised on the device (distance from the exact sums, strict threshold, compareTo
+    order with the id as tie-break, cut to k): duplicate rows (equal distances, ids decide), a zero row (cosine: the
+    denominator rule), a threshold that EQUALS a returned distance (kept: the drop is strict), a threshold below
+    everything (empty lists), slots past the count, and k of 1 / of a whole list."""
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq = 96, 20000, 33
+    rows = _mk(n, d, 71, scale=None if metric == COS else (0.8, 1.2))
+    rows[100:140] = rows[7]          # forty copies of one row: ties inside every list that holds them
+    rows[5000] = 0.0                 # cosine: mag_b = 0 -> similarity 0 -> distance 1
+    qs = _queries(oracle_mod, nq, d, 72, metric)
+    qs[3] = rows[7] if metric != COS else oracle_mod.normalize_f32(rows[7])  # the copies are this query's top hits
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        for k in (1, 10, 50):
+            _check_batch(oracle_mod, idx, rows, qs, metric, k, tag=f"k{k}")
+        k = 50
+        _, ed = oracle_mod.search_exhaustive(rows, qs[3], metric, k)
+        for thr in (float(ed[20]), float(ed[0]), float(np.nextafter(ed[0], -np.inf))):
+            _check_batch(oracle_mod, idx, rows, qs, metric, k, thr=thr, tag=f"thr{thr}")
+        ids, dist, cnt = idx.search(qs, k, float(np.nextafter(ed[0], -np.inf)))
+        assert cnt[3] == 0 and np.all(ids[3] == -1) and np.all(np.isnan(dist[3]))
+        c = idx.counters()
+        assert c["batch_launches"] >= 7 and c["fallback_searches"] == 0
+
+
+def test_two_callers_overlap_bit_exact(hip_lib, oracle_mod):
+    """Two host threads with batched calls in flight on one handle (a shard keeps two scratch sets, the calls'
+    GPU work is one in-order sequence): every call's answers equal the oracle's."""
+    import threading
+    from tostore_amd import HipVectorIndex
+
+    d, n, nq, k, metric = 128, 60000, 96, 20, COS
+    rows = _mk(n, d, 81)
+    sets = [_queries(oracle_mod, nq, d, 82 + t, metric) for t in range(2)]
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows)
+        idx.search(sets[0][:8], k)  # planes built
+        got, err = [[], []], []
+
+        def caller(t):
+            try:
+                for _ in range(6):
+                    got[t].append(idx.search(sets[t], k))
+            except Exception as e:  # noqa: BLE001
+                err.append(repr(e))
+
+        th = [threading.Thread(target=caller, args=(t,)) for t in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not err, err
+        for t in range(2):
+            ref = [oracle_mod.search_heap(rows, sets[t][i], metric, k) for i in range(nq)]
+            for ids, dist, cnt in got[t]:
+                for i in range(nq):
+                    assert cnt[i] == len(ref[i][0])
+                    assert np.array_equal(ids[i, :cnt[i]], ref[i][0]) and np.array_equal(dist[i, :cnt[i]], ref[i][1])
+        assert idx.counters()["fallback_searches"] == 0

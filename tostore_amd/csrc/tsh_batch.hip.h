@@ -917,200 +917,59 @@ __device__ __forceinline__ void rerank_lane_sums(const float *__restrict__ rp, c
   *out_s1 = metric == METRIC_COS ? s1 : 0.0;
 }
 
-// K4 over a batch.  One workgroup (four waves) = RG candidates of ONE query.  The chains are serial per candidate,
-// so a candidate still belongs to one lane -- but a lane that streams its own row keeps only two 128-byte lines in
-// flight and waits out HBM latency a dozen times in a row.  Here the WAVES load: one instruction brings 1 KiB of
-// one candidate's row (64 lanes x 16 B, coalesced), each wave keeps 16 of them in flight, an LDS tile turns
-// "lane = column" into "lane = candidate", and while wave 0 walks the 64 chains over the tile (all 64 lanes busy)
-// the next 64 KiB are already on their way.
-// Measured per 256-query chunk of config C3 (32.5 k candidates, 100 MB of rows): a lane per row 57 us; this shape
-// 55 us, of which the loads alone take 22, the chains ~14 per workgroup (4.8 us per 256-float block: two LDS reads
-// of the tile and four of the query per eight terms keep the one chain wave waiting), the entries' stores to pinned
-// host memory ~13.  (f64 add / mul / fma / cvt issue at one per ~4.5 cycles whatever the number of active lanes --
-// tools/micro/f64_rate.hip -- so 16 candidates per chain wave cost four times the instructions: 60 us.  The query
-// as f64 scalar operands from global memory instead of LDS: 89 us, the scalar cache misses.)
+// K4 over a batch.  Every WAVE is on its own: it owns up to 64 candidates of one query (lane = candidate; the chains
+// are serial per candidate, so nothing crosses lanes), brings their rows in pieces of 64 floats -- sixteen 1 KiB loads
+// (four rows x 256 B each) in flight while it walks the chains of the previous piece --, turns "lane = column" into
+// "lane = candidate" through a 17 KB LDS tile of its own, and takes the query from scalar registers.  No workgroup
+// barrier anywhere: with eight such waves per CU the load and chain phases of different waves interleave by themselves.
+// (Round 2's shape -- a workgroup of four loading waves around one chain wave, 1 KiB row pieces, the query as f64
+// in LDS -- had three of four waves idle through every chain phase and all workgroups of a launch in the same phase at
+// the same time: 262 us for the 130 k candidates of a 1024-query C3 call against 215 us here in the same four
+// launches.  A wave here is latency-bound -- 12 pieces, one prefetched, ~4 us each -- so what matters is how many
+// waves are in flight: all queries of a call in ONE launch, rerank_final_kernel below.)
 //
 // Arithmetic, bit for bit that of rerank_kernel / the oracle (vs_exact_sums): every term is added in dimension
 // order with one rounding per addition.  For IP and cosine the product of two f32 values is exact in f64 (24 + 24
 // significand bits), so fma(q, b, s) rounds exactly what s + q * b rounds; L2's (q - b)^2 is not exact and keeps its
 // separate multiply.
-constexpr int RG = 64;              // candidates per workgroup
-constexpr int RG_WAVES = 4;         // loading waves (16 rows each); wave 0 also walks the chains
-constexpr int RG_ROWS = RG / RG_WAVES;
-constexpr int RG_BLK = 256;         // floats of a row per load instruction
-constexpr int RG_LD = RG_BLK + 4;   // LDS row stride in floats: rows 4 banks apart, 16 rows cover the 64 banks
+constexpr int RW_WAVES = 2;          // waves per workgroup
+constexpr int RW_CAND = 64 * RW_WAVES;  // candidates per workgroup and pass
+// Floats of a row per piece.  64 (256 B per row and load) measured against 128 on one box, all 130 k candidates of a
+// 1024-query C3 call in one launch: 126 us against 180 -- with 128 the registers and the 34 KB tile leave four waves
+// per CU instead of eight, and waves in flight are what this latency-bound walk lives on.
+constexpr int RW_P = 64;
+template <int P>
+struct RwTile {
+  static constexpr int LD = P + 4;       // LDS row stride in floats: rows 4 banks apart
+  static constexpr int FLOATS = 64 * LD; // a wave's tile
+  static constexpr int NLOAD = P / 4;    // 1 KiB load instructions per piece (64 rows x P floats)
+  static constexpr int RPL = 256 / P;    // rows per load instruction
+};
 
-static __global__ void __launch_bounds__(64 * RG_WAVES) rerank_batch_kernel(RerankBatchArgs a) {
+// One wave: the exact sums of candidates [c0, c0 + min(left, 64)) of query q's list, lane = candidate (lanes past the
+// list repeat the last candidate).  tile: this wave's RwTile<P>::FLOATS floats of LDS.
+template <int P>
+__device__ __forceinline__ void rerank_wave_sums(const RerankBatchArgs &a, int q, uint32_t c0, uint32_t left, float *tile,
+                                                 int lane, uint32_t *out_row, double *out_s0, double *out_s1) {
 #pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) float tile[RG * RG_LD];
-  __shared__ __attribute__((aligned(16))) double s_q[RG_BLK];  // the query's current block, as f64
-  __shared__ uint32_t stage[6 * RG];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = a.q0 + (int)blockIdx.y;
-  uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
-  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
-  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
-  const uint32_t c0 = blockIdx.x * (uint32_t)RG;
-  if (c0 >= count) return;
-  const uint32_t left = count - c0;  // >= 1
-  // lane c of a wave holds candidate c0 + c (slots past the list repeat the last candidate)
+  using T = RwTile<P>;
   const uint32_t slot = (uint32_t)lane < left ? (uint32_t)lane : left - 1u;
   const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
-  const float *rbase[RG_ROWS];  // this wave's rows (wave-uniform)
-#pragma unroll
-  for (int j = 0; j < RG_ROWS; ++j) {
-    const uint32_t r = (uint32_t)__shfl((int)my_row, wave * RG_ROWS + j);
-    rbase[j] = a.rows + (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)r) * a.ld;
-  }
-  const float *qp = a.Q + (int64_t)q * a.ld;
   const int ld = (int)a.ld, dim = a.dim;
-  const int nblk = (dim + RG_BLK - 1) / RG_BLK;
-
-  f32x4 in[RG_ROWS], qin;
-  auto fetch = [&](int b) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
-    const int o = b * RG_BLK + 4 * lane < ld - 4 ? b * RG_BLK + 4 * lane : ld - 4;
+  const int sub = lane / (P / 4), col4 = 4 * (lane % (P / 4));
+  uint32_t rrow[T::NLOAD];  // load j of a piece covers candidates RPL j .. RPL j + RPL - 1, P floats each
 #pragma unroll
-    for (int j = 0; j < RG_ROWS; ++j) in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase[j] + o));
-    qin = *reinterpret_cast<const f32x4 *>(qp + o);
-  };
-  double s0 = 0.0, s1 = 0.0;
-  const float *trow = tile + lane * RG_LD;
-  auto chain = [&](auto METRIC, int b) {
-    constexpr int M = decltype(METRIC)::value;
-    const int m = dim - b * RG_BLK < RG_BLK ? dim - b * RG_BLK : RG_BLK;  // wave-uniform
-    auto term = [&](double qd, float bf) {
-      const double bd = (double)bf;
-      if (M == METRIC_L2) {
-        const double diff = qd - bd;
-        s0 = s0 + diff * diff;
-      } else {
-        s0 = __builtin_fma(qd, bd, s0);
-        if (M == METRIC_COS) s1 = __builtin_fma(bd, bd, s1);
-      }
-    };
-    // groups of 8 terms, the next group's LDS reads issued before this group's arithmetic; two register sets
-    // take turns (copying one into the other doubled the chain's instruction count)
-    f32x4 va[2], vb[2];
-    double qa[8], qb[8];
-    auto read = [&](f32x4 (&dv)[2], double (&dq)[8], int g) {
-      const int o = 8 * g < RG_BLK - 8 ? 8 * g : RG_BLK - 8;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) dv[u] = *reinterpret_cast<const f32x4 *>(trow + o + 4 * u);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const __attribute__((ext_vector_type(2))) double t =
-            *reinterpret_cast<const __attribute__((ext_vector_type(2))) double *>(s_q + o + 2 * u);
-        dq[2 * u] = t[0];
-        dq[2 * u + 1] = t[1];
-      }
-    };
-    auto terms = [&](const f32x4 (&dv)[2], const double (&dq)[8]) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) term(dq[4 * u + e], dv[u][e]);
-    };
-    const int ng = m >> 3;
-    read(va, qa, 0);
-    int g = 0;
-    for (; g + 1 < ng; g += 2) {
-      read(vb, qb, g + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      terms(va, qa);
-      __builtin_amdgcn_sched_barrier(0);
-      read(va, qa, g + 2);  // (past the block: a clamped re-read, unused)
-      __builtin_amdgcn_sched_barrier(0);
-      terms(vb, qb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (g < ng) terms(va, qa);
-    for (int i = 8 * ng; i < m; ++i) term(s_q[i], trow[i]);
-  };
-  fetch(0);
-  for (int b = 0; b < nblk; ++b) {
-#pragma unroll
-    for (int j = 0; j < RG_ROWS; ++j)
-      *reinterpret_cast<f32x4 *>(tile + (wave * RG_ROWS + j) * RG_LD + 4 * lane) = in[j];
-    if (wave == 0) {
-      __attribute__((ext_vector_type(2))) double d01, d23;
-      d01[0] = (double)qin[0], d01[1] = (double)qin[1], d23[0] = (double)qin[2], d23[1] = (double)qin[3];
-      *reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(s_q + 4 * lane) = d01;
-      *reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(s_q + 4 * lane + 2) = d23;
-    }
-    fetch(b + 1);  // (past the last block: clamped re-reads of cached lines)
-    __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the barrier and the chains, not sunk below them
-    __syncthreads();
-    if (wave == 0) {
-      if (a.metric == METRIC_L2) chain(std::integral_constant<int, METRIC_L2>{}, b);
-      else if (a.metric == METRIC_COS) chain(std::integral_constant<int, METRIC_COS>{}, b);
-      else chain(std::integral_constant<int, METRIC_IP>{}, b);
-    }
-    __syncthreads();  // the tile is free again
-  }
-  if (wave != 0) return;
-  // entries: 24 bytes each, RG of them contiguous -- staged in LDS and stored as whole dwords side by side
-  {
-    const int64_t id = a.row_base + (int64_t)my_row;
-    const double e1 = a.metric == METRIC_COS ? s1 : 0.0;
-    stage[6 * lane + 0] = (uint32_t)id;
-    stage[6 * lane + 1] = (uint32_t)((uint64_t)id >> 32);
-    stage[6 * lane + 2] = (uint32_t)__double2loint(s0);
-    stage[6 * lane + 3] = (uint32_t)__double2hiint(s0);
-    stage[6 * lane + 4] = (uint32_t)__double2loint(e1);
-    stage[6 * lane + 5] = (uint32_t)__double2hiint(e1);
-  }
-  asm volatile("" ::: "memory");  // (one wave, LDS in program order: only the compiler must not reorder)
-  static_assert(sizeof(BlockEntry) == 24, "entry layout");
-  uint32_t *outw = reinterpret_cast<uint32_t *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader)) + 6 * (int64_t)c0;
-  const uint32_t nw = 6u * (left < (uint32_t)RG ? left : (uint32_t)RG);
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-    if ((uint32_t)(lane + 64 * i) < nw) outw[lane + 64 * i] = stage[lane + 64 * i];
-}
-
-
-// K4 over a batch, second shape (round 3): every WAVE is on its own.  A wave owns up to 64 candidates of one query
-// (lane = candidate), brings their rows in pieces of 64 floats -- sixteen 1 KiB loads (four rows x 256 B each) in
-// flight while it walks the chains of the previous piece --, turns "lane = column" into "lane = candidate" through a
-// 17 KB LDS tile of its own, and takes the query from scalar registers.  No workgroup barrier anywhere: with eight
-// such waves per CU the load and chain phases of different waves interleave by themselves, where the four-wave shape
-// above had three of four waves idle through every chain phase and every workgroup of a launch in the same phase
-// at the same time.  Same arithmetic, bit for bit.
-constexpr int RW_WAVES = 2;          // waves per workgroup (they share nothing but the launch)
-constexpr int RW_P = 64;             // floats of a row per piece
-constexpr int RW_LD = RW_P + 4;      // LDS row stride in floats: rows 4 banks apart
-constexpr int RW_CAND = 64 * RW_WAVES;  // candidates per workgroup
-
-static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_wave_kernel(RerankBatchArgs a) {
-#pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][64 * RW_LD];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = a.q0 + (int)blockIdx.y;
-  const uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
-  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
-  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
-  const uint32_t c0 = (blockIdx.x * (uint32_t)RW_WAVES + (uint32_t)wave) * 64u;
-  if (c0 >= count) return;
-  const uint32_t left = count - c0;  // >= 1
-  const uint32_t slot = (uint32_t)lane < left ? (uint32_t)lane : left - 1u;  // idle lanes repeat the last candidate
-  const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
-  const int ld = (int)a.ld, dim = a.dim;
-  const int sub = lane >> 4, col4 = 4 * (lane & 15);
-  const float *rbase[16];  // load j of a piece covers candidates 4 j .. 4 j + 3, 256 B each
-#pragma unroll
-  for (int j = 0; j < 16; ++j) rbase[j] = a.rows + (int64_t)(uint32_t)__shfl((int)my_row, 4 * j + sub) * a.ld;
+  for (int j = 0; j < T::NLOAD; ++j) rrow[j] = (uint32_t)__shfl((int)my_row, T::RPL * j + sub);
   const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;  // wave-uniform: scalar loads
-  float *tile = tiles[wave];
-  const float *trow = tile + lane * RW_LD;
-  float *tput = tile + sub * RW_LD + col4;
-  const int npiece = (dim + RW_P - 1) / RW_P;
-  f32x4 in[16];
+  const float *trow = tile + lane * T::LD;
+  float *tput = tile + sub * T::LD + col4;
+  const int npiece = (dim + P - 1) / P;
+  f32x4 in[T::NLOAD];
   auto fetch = [&](int p) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
-    const int o = p * RW_P + col4 < ld - 4 ? p * RW_P + col4 : ld - 4;
+    const int o = p * P + col4 < ld - 4 ? p * P + col4 : ld - 4;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rbase[j] + o));
+    for (int j = 0; j < T::NLOAD; ++j)
+      in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.rows + (int64_t)rrow[j] * a.ld + o));
   };
   double s0 = 0.0, s1 = 0.0;
   auto chains = [&](auto METRIC) {
@@ -1128,14 +987,14 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_wave_kernel
     fetch(0);
     for (int p = 0; p < npiece; ++p) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) *reinterpret_cast<f32x4 *>(tput + 4 * j * RW_LD) = in[j];
+      for (int j = 0; j < T::NLOAD; ++j) *reinterpret_cast<f32x4 *>(tput + T::RPL * j * T::LD) = in[j];
       fetch(p + 1);  // (past the last piece: clamped re-reads of cached lines)
       __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
-      const float *qq = qp + p * RW_P;
-      const int m = dim - p * RW_P;  // wave-uniform; >= 1
-      if (m >= RW_P) {
+      const float *qq = qp + p * P;
+      const int m = dim - p * P;  // wave-uniform; >= 1
+      if (m >= P) {
 #pragma unroll
-        for (int g = 0; g < RW_P / 4; ++g) {
+        for (int g = 0; g < P / 4; ++g) {
           const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + 4 * g);
 #pragma unroll
           for (int e = 0; e < 4; ++e) term(qq[4 * g + e], v[e]);
@@ -1149,24 +1008,163 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_wave_kernel
   if (a.metric == METRIC_L2) chains(std::integral_constant<int, METRIC_L2>{});
   else if (a.metric == METRIC_COS) chains(std::integral_constant<int, METRIC_COS>{});
   else chains(std::integral_constant<int, METRIC_IP>{});
+  *out_row = my_row;
+  *out_s0 = s0;
+  *out_s1 = a.metric == METRIC_COS ? s1 : 0.0;
+}
+
+// Entries out: blockIdx.y = query, blockIdx.x strides over its candidates.  (Shard mode, quarantined rows, wide
+// lists: whoever merges or finalises on the host wants the exact sums.)
+static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_kernel(RerankBatchArgs a) {
+  __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][RwTile<RW_P>::FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = a.q0 + (int)blockIdx.y;
+  const uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
+  uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
+  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
+  const uint32_t c0 = (blockIdx.x * (uint32_t)RW_WAVES + (uint32_t)wave) * 64u;
+  if (c0 >= count) return;
+  const uint32_t left = count - c0;  // >= 1
+  float *tile = tiles[wave];
+  uint32_t my_row;
+  double s0, s1;
+  rerank_wave_sums<RW_P>(a, q, c0, left, tile, lane, &my_row, &s0, &s1);
   // entries: 24 bytes each, 64 of them contiguous -- staged in the wave's tile and stored as whole dwords side by side
   uint32_t *stage = reinterpret_cast<uint32_t *>(tile);
   {
     const int64_t id = a.row_base + (int64_t)my_row;
-    const double e1 = a.metric == METRIC_COS ? s1 : 0.0;
     stage[6 * lane + 0] = (uint32_t)id;
     stage[6 * lane + 1] = (uint32_t)((uint64_t)id >> 32);
     stage[6 * lane + 2] = (uint32_t)__double2loint(s0);
     stage[6 * lane + 3] = (uint32_t)__double2hiint(s0);
-    stage[6 * lane + 4] = (uint32_t)__double2loint(e1);
-    stage[6 * lane + 5] = (uint32_t)__double2hiint(e1);
+    stage[6 * lane + 4] = (uint32_t)__double2loint(s1);
+    stage[6 * lane + 5] = (uint32_t)__double2hiint(s1);
   }
   asm volatile("" ::: "memory");  // (one wave, LDS in program order: only the compiler must not reorder)
+  static_assert(sizeof(BlockEntry) == 24, "entry layout");
   uint32_t *outw = reinterpret_cast<uint32_t *>(a.out_blocks + (int64_t)q * a.block_bytes + sizeof(BlockHeader)) + 6 * (int64_t)c0;
   const uint32_t nw = 6u * (left < 64u ? left : 64u);
 #pragma unroll
   for (int i = 0; i < 6; ++i)
     if ((uint32_t)(lane + 64 * i) < nw) outw[lane + 64 * i] = stage[lane + 64 * i];
+}
+
+// K4 + the finaliser in one launch: one workgroup per query re-ranks ALL its candidates and then does what the host
+// finaliser does (tsh_lib.hip finalize_query; ref ngh_graph_engine.dart:908-946,127,133-134): the distance from the
+// exact sums -- L2 sqrt(s0), IP -s0, cosine 1 - s0 / (sqrt(mag_a) * sqrt(s1)) with similarity 0 when the denominator
+// is not positive; f64 sqrt and divide are correctly rounded on the device like on the host, contraction off --,
+// the strict `> threshold` drop, double.compareTo order as integer keys with the id as tie-break, the cut to k.  The
+// k results per query (ids, distances, count) are stored straight into pinned host memory: 1.6 KB per query cross
+// PCIe instead of a 3 KB candidate list, and the host is left with a copy.
+// Order = rank by counting over the <= RF_MAX candidates in LDS (a list is k plus a band's worth of rows).
+constexpr int RF_MAXG = 4;                   // passes of 64 candidates per wave
+constexpr int RF_MAX = RW_CAND * RF_MAXG;    // candidates per query this kernel takes (wider lists: host finaliser)
+
+struct RerankFinalArgs {
+  RerankBatchArgs r;
+  const double *sqrt_mag_a;  // per query: sqrt of the query's sum of squares (cosine; element order, f64)
+  double thr;                // distance threshold (NaN: none)
+  int64_t *out_ids;          // nq x k
+  double *out_dist;          // nq x k
+  int32_t *out_count;        // nq
+  int32_t k;
+};
+
+__device__ __forceinline__ uint64_t order_key_of(double d) {  // tsh_lib.hip dart_order_key
+  if (d != d) return ~0ull;
+  const uint64_t b = (uint64_t)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double order_key_to_double(uint64_t key) {
+  if (key == ~0ull) return __builtin_nan("");
+  return __longlong_as_double((long long)((key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key));
+}
+
+static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(RerankFinalArgs fa) {
+  constexpr int P = RW_P;
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][RwTile<P>::FLOATS];
+  __shared__ uint32_t s_valid;
+  const RerankBatchArgs &a = fa.r;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = a.q0 + (int)blockIdx.x;
+  const BlockHeader *hd = reinterpret_cast<const BlockHeader *>(a.blocks + (int64_t)q * a.block_bytes);
+  uint32_t count = hd->count;  // 0 for a list that overflowed or failed its check: the host redoes that query
+  if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
+  if (count > (uint32_t)RF_MAX) count = 0;  // (the host does not launch this kernel for such lists)
+  const bool has_thr = fa.thr == fa.thr;
+  const double sqrt_mag_a = a.metric == METRIC_COS ? fa.sqrt_mag_a[q] : 0.0;
+  uint64_t key[RF_MAXG];
+  uint32_t row[RF_MAXG];
+#pragma unroll
+  for (int g = 0; g < RF_MAXG; ++g) {
+    key[g] = 0;
+    row[g] = 0xFFFFFFFFu;  // = no entry (past the list, or beyond the threshold)
+    const uint32_t c0 = (uint32_t)(g * RW_WAVES + wave) * 64u;
+    if (c0 < count) {  // wave-uniform
+      uint32_t r;
+      double s0, s1;
+      rerank_wave_sums<P>(a, q, c0, count - c0, tiles[wave], lane, &r, &s0, &s1);
+      double d;
+      if (a.metric == METRIC_L2) {
+        d = __builtin_sqrt(s0);
+      } else if (a.metric == METRIC_IP) {
+        d = -s0;
+      } else {
+        const double denom = sqrt_mag_a * __builtin_sqrt(s1);
+        const double sim = denom > 0 ? s0 / denom : 0;
+        d = 1.0 - sim;
+      }
+      if ((uint32_t)lane < count - c0 && !(has_thr && d > fa.thr)) {
+        key[g] = order_key_of(d);
+        row[g] = r;
+      }
+    }
+  }
+  if (tid == 0) s_valid = 0;
+  __syncthreads();  // every tile is free: the lists take their place
+  uint64_t *skey = reinterpret_cast<uint64_t *>(&tiles[0][0]);        // RF_MAX keys
+  uint32_t *srow = reinterpret_cast<uint32_t *>(skey + RF_MAX);       // RF_MAX local rows
+  static_assert(RF_MAX * 12 <= RW_WAVES * RwTile<P>::FLOATS * 4, "lists fit the tiles");
+  uint32_t mine = 0;
+#pragma unroll
+  for (int g = 0; g < RF_MAXG; ++g) {
+    const uint32_t c = (uint32_t)(g * RW_WAVES + wave) * 64u + (uint32_t)lane;
+    if (c < count) {
+      skey[c] = key[g];
+      srow[c] = row[g];
+      mine += row[g] != 0xFFFFFFFFu;
+    }
+  }
+  if (mine) atomicAdd(&s_valid, mine);
+  __syncthreads();
+  const uint32_t n_valid = s_valid;
+  const uint32_t kk = (uint32_t)fa.k, n_out = n_valid < kk ? n_valid : kk;
+  int64_t *oid = fa.out_ids + (int64_t)q * fa.k;
+  double *odist = fa.out_dist + (int64_t)q * fa.k;
+#pragma unroll
+  for (int g = 0; g < RF_MAXG; ++g) {
+    if (row[g] == 0xFFFFFFFFu) continue;
+    const uint64_t mk = key[g];
+    const uint32_t mr = row[g];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+      const uint64_t ok = skey[j];
+      const uint32_t orow = srow[j];
+      rank += (orow != 0xFFFFFFFFu) & ((ok < mk) | ((ok == mk) & (orow < mr)));
+    }
+    if (rank < kk) {
+      oid[rank] = a.row_base + (int64_t)mr;
+      odist[rank] = order_key_to_double(mk);
+    }
+  }
+  for (uint32_t i = n_out + (uint32_t)tid; i < kk; i += 64 * RW_WAVES) {  // unused slots read as "no row"
+    oid[i] = -1;
+    odist[i] = __builtin_nan("");
+  }
+  if (tid == 0) fa.out_count[q] = (int32_t)n_out;
 }
 
 }  // namespace tsh

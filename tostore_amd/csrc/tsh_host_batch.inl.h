@@ -6,7 +6,7 @@
 static uint64_t *g_f16_dbg_buf = nullptr;  // TSH_F16_DBG & 32 probe (probe builds only: -DTSH_PROBES)
 #endif
 struct BatchCtx {
-  std::mutex mu;  // one batch at a time per shard (a batch saturates the GPU)
+  std::mutex mu;  // one call at a time per scratch set (a shard has two: Shard::batch, batch2)
   float *d_Q = nullptr, *h_Q = nullptr;
   u32x4 *d_Qs = nullptr;  // bf16 planes of the padded queries
   int64_t qs_cap = 0;     // in u32x4 units
@@ -34,6 +34,13 @@ struct BatchCtx {
   int32_t last_sample_force = 0;  // tsh_probe_batch_keys: the next call's dense sample covers every row
   double last_wait_us = 0;  // how long the previous call waited for the GPU after enqueueing
   std::vector<double> mag_a;  // per query of the current call: sum of q[i]^2 in element order
+  // results finalised on the device (rerank_final_kernel): pinned host arrays the kernel stores into
+  int64_t *h_fin_ids = nullptr, *fin_ids_dev = nullptr;   // nq x k
+  double *h_fin_dist = nullptr, *fin_dist_dev = nullptr;  // nq x k
+  int32_t *h_fin_cnt = nullptr, *fin_cnt_dev = nullptr;   // nq
+  int64_t fin_cap = 0, fin_q_cap = 0;
+  double *d_sqrt_mag = nullptr, *h_sqrt_mag = nullptr;    // per query: sqrt(mag_a)
+  int64_t sqrt_mag_cap = 0;
 };
 
 void batch_free(BatchCtx *b) {
@@ -53,6 +60,11 @@ void batch_free(BatchCtx *b) {
   hipHostFree(b->h_mask);
   hipFree(b->d_quar_out);
   hipHostFree(b->h_quar_out);
+  hipHostFree(b->h_fin_ids);
+  hipHostFree(b->h_fin_dist);
+  hipHostFree(b->h_fin_cnt);
+  hipFree(b->d_sqrt_mag);
+  hipHostFree(b->h_sqrt_mag);
   for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done, b->e_chunk[0], b->e_chunk[1], b->e_chunk[2]})
     if (e) hipEventDestroy(e);
 }
@@ -68,6 +80,20 @@ int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
   }
   HIPCHK(hipMalloc(dev, (size_t)want * sizeof(T)));
   if (host) HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
+  *bytes += (want - *cap) * (int64_t)sizeof(T);
+  *cap = want;
+  return TSH_OK;
+}
+
+// pinned host memory the device stores into (zero-copy): host pointer + the address the device uses
+template <typename T>
+int regrow_pinned(T **host, T **dev_view, int64_t *cap, int64_t want, int64_t *bytes) {
+  if (want <= *cap) return TSH_OK;
+  hipHostFree(*host);
+  *host = nullptr;
+  *dev_view = nullptr;
+  HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
+  HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(dev_view), *host, 0));
   *bytes += (want - *cap) * (int64_t)sizeof(T);
   *cap = want;
   return TSH_OK;
@@ -164,7 +190,16 @@ inline bool trace_batch() {
 // *redo and answered by the single-query path.  Caller holds s->mu shared.
 int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
                        const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo) {
-  std::lock_guard<std::mutex> lk(b->mu);
+  // the shard's first scratch set stands for "either": a call that finds it taken by a concurrent call uses the second
+  std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
+  if (b == s->batch && s->batch2 && !lk.try_lock()) {
+    std::unique_lock<std::mutex> lk2(s->batch2->mu, std::try_to_lock);
+    if (lk2.owns_lock()) {
+      b = s->batch2;
+      lk = std::move(lk2);
+    }
+  }
+  if (!lk.owns_lock()) lk.lock();
   const double t_in = now_us();
   HIPCHK(hipSetDevice(s->device));
   const int64_t rows = s->rows, ld = s->ld;
@@ -228,27 +263,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t hchunks = use_f16 ? (int32_t)round_up((s->dim + 31) / 32, 4) : (int32_t)((s->dim + 31) / 32);
   // rows per workgroup tile: the f16 kernel's tile is 256 x 256 / 128 x 256 (tsh_batch_f16.hip.h), the others' square
   const int32_t tile_n = use_f16 ? 256 : tile;
-  if (use_planes) {
-    const int64_t row_bytes = (int64_t)hchunks * (use_f16 ? 64 : 128);  // fp16: 2 B per element, bf16 hi + lo: 4 B
-    if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
-    if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
-      if (s->d_split) hipFree(s->d_split);
-      s->d_split = nullptr;
-      s->bytes -= s->split_bytes;
-      s->split_bytes = 0;
-      s->split_cap = 0;
-      s->split_valid = 0;
-      const int64_t prow = round_up(s->cap, PLANE_GROUP);  // whole 256-row groups (plane_piece)
-      HIPCHK(hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes));
-      s->split_cap = s->cap;
-      s->split_bytes = prow * row_bytes;
-      s->bytes += s->split_bytes;
-    }
-    s->split_mode = kern;
-    s->split_exp = v_exp;
-    if ((rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, round_up(nq_pad, PLANE_GROUP) * hchunks * 8, &b->bytes)))
-      return rc;  // (sized for the bf16 hi + lo planes; the fp16 ones are half of it)
-  }
+  if (use_planes &&
+      (rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, round_up(nq_pad, PLANE_GROUP) * hchunks * 8, &b->bytes)))
+    return rc;  // (sized for the bf16 hi + lo planes; the fp16 ones are half of it)
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad, *h_kmax = b->h_qaux + 4 * (size_t)nq_pad;
@@ -321,6 +338,18 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     }
   }
 
+  // The finaliser runs on the device too (rerank_final_kernel) when the caller wants final results on the host and
+  // nothing but the device's own candidate lists goes into them
+  const bool gpu_final = out->on_final && !out->d_blocks && quar_sel.empty() && entries <= RF_MAX && k <= entries;
+  if (gpu_final) {
+    int64_t c1 = b->fin_cap, c2 = b->fin_cap;
+    if ((rc = regrow_pinned(&b->h_fin_ids, &b->fin_ids_dev, &c1, (int64_t)nq * k, &b->bytes))) return rc;
+    if ((rc = regrow_pinned(&b->h_fin_dist, &b->fin_dist_dev, &c2, (int64_t)nq * k, &b->bytes))) return rc;
+    b->fin_cap = std::min(c1, c2);
+    if ((rc = regrow_pinned(&b->h_fin_cnt, &b->fin_cnt_dev, &b->fin_q_cap, (int64_t)nq, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_sqrt_mag, &b->h_sqrt_mag, &b->sqrt_mag_cap, (int64_t)nq, &b->bytes))) return rc;
+    for (int32_t q = 0; q < nq; ++q) b->h_sqrt_mag[q] = std::sqrt(b->mag_a[(size_t)q]);
+  }
   const double t_prep = now_us();
   int n_chunks = 1;
   // chunk c of the tail = queries [chunk_q(c), chunk_q(c + 1)): the last chunk is the small one -- its finalisation
@@ -334,11 +363,32 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   };
   // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
   {
+    std::lock_guard<std::mutex> enq(s->batch_enq_mu);  // one call's sequence at a time on the one in-order stream
     hipStream_t st = s->batch_stream;
+    if (use_planes) {
+      const int64_t row_bytes = (int64_t)hchunks * (use_f16 ? 64 : 128);  // fp16: 2 B per element, bf16 hi + lo: 4 B
+      if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
+      if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
+        if (s->d_split) hipFree(s->d_split);
+        s->d_split = nullptr;
+        s->bytes -= s->split_bytes;
+        s->split_bytes = 0;
+        s->split_cap = 0;
+        s->split_valid = 0;
+        const int64_t prow = round_up(s->cap, PLANE_GROUP);  // whole 256-row groups (plane_piece)
+        HIPCHK(hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes));
+        s->split_cap = s->cap;
+        s->split_bytes = prow * row_bytes;
+        s->bytes += s->split_bytes;
+      }
+      s->split_mode = kern;
+      s->split_exp = v_exp;
+    }
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * sizeof(float), hipMemcpyHostToDevice, st));
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
+    if (gpu_final) HIPCHK(hipMemcpyAsync(b->d_sqrt_mag, b->h_sqrt_mag, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, st));
     if (!quar_sel.empty() && !out->d_blocks) {
       QuarArgs qa{};
       qa.rows = s->d_rows;
@@ -511,15 +561,26 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     // has stored its entries, was tried: 167 us against 4 x 48 -- no overlap to speak of -- and the waits for the
     // host-memory stores to land doubled it.  Consecutive chunks on two streams: no change, a chunk's 512 workgroups of
     // 70 KB LDS fill every CU and the next chunk's only start as they leave.)
-    n_chunks = !out->on_chunk ? 1 : (nq >= 512 ? 4 : (nq >= 256 ? 2 : 1));  // (256 queries: 1.00 -> 0.94 ms; 128: no gain)
+    n_chunks = gpu_final || !out->on_chunk ? 1 : (nq >= 512 ? 4 : (nq >= 256 ? 2 : 1));  // (256 queries: 1.00 -> 0.94 ms; 128: no gain)
+    if (gpu_final) {
+      // one launch for the whole call: a re-ranking wave is latency-bound, so the more of them are in flight the better,
+      // and with the finaliser on the device no host work is left to overlap chunk by chunk
+      RerankFinalArgs rf{};
+      rf.r = rb;
+      rf.r.q0 = 0;
+      rf.sqrt_mag_a = b->d_sqrt_mag;
+      rf.thr = out->fin_thr;
+      rf.out_ids = b->fin_ids_dev;
+      rf.out_dist = b->fin_dist_dev;
+      rf.out_count = b->fin_cnt_dev;
+      rf.k = k;
+      rerank_final_kernel<<<(unsigned)nq, 64 * RW_WAVES, 0, st>>>(rf);
+      HIPCHK(hipEventRecord(b->e_done, st));
+    } else
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = chunk_q(c), q1 = chunk_q(c + 1);
       rb.q0 = q0;
-      static const bool old_rerank = getenv("TSH_RERANK_GEN") != nullptr && getenv("TSH_RERANK_GEN")[0] == '1';  // A/B
-      if (old_rerank)
-        rerank_batch_kernel<<<dim3((unsigned)((entries + RG - 1) / RG), (unsigned)(q1 - q0)), 64 * RG_WAVES, 0, st>>>(rb);
-      else
-        rerank_batch_wave_kernel<<<dim3((unsigned)((entries + RW_CAND - 1) / RW_CAND), (unsigned)(q1 - q0)), 64 * RW_WAVES, 0, st>>>(rb);
+      rerank_batch_kernel<<<dim3((unsigned)((entries + RW_CAND - 1) / RW_CAND), (unsigned)(q1 - q0)), 64 * RW_WAVES, 0, st>>>(rb);
       if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
         QuarAppendArgs qa{};
         qa.rows = s->d_rows;
@@ -546,7 +607,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // the finalisation below starts the moment the GPU is done: if that is within a millisecond (going by the
   // previous call), the pool's workers keep polling through the wait instead of parking (waking them cost 50-70 us
   // of a 128-query call's 90 us of finalisation)
-  if (out->on_chunk && b->last_wait_us > 0 && b->last_wait_us < 900.0)
+  if ((out->on_chunk || gpu_final) && b->last_wait_us > 0 && b->last_wait_us < 900.0)
     HostPool::get().stay_awake_until(t_enq + b->last_wait_us * 1.1 + 50.0);
   std::vector<char> skip((size_t)nq, 0);
   int32_t n_unverified = 0;
@@ -554,7 +615,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // From the end of the key passes on the pool gets a job every few dozen microseconds (one per chunk of the tail):
   // the long wait blocks, then the workers are woken and poll until the call is over
   std::unique_ptr<HostPool::Hold> hold;
-  if (out->on_chunk && nq >= 24) {
+  if ((out->on_chunk || gpu_final) && nq >= 24) {
     HIPCHK(hipEventSynchronize(b->e3));
     hold.reset(new HostPool::Hold());
   }
@@ -582,7 +643,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       }
     }
     const double t_c0 = now_us();
-    if (out->on_chunk) {
+    if (gpu_final) {
+      out->on_final(q0, q1, skip.data(), b->h_fin_ids, b->h_fin_dist, b->h_fin_cnt);  // a copy is all that is left
+    } else if (out->on_chunk) {
       out->on_chunk(q0, q1, skip.data(), b->h_blocks, b->mag_a.data());  // finalised straight from the pinned buffer
       // (queries the single-query path will redo write their blocks to out->h_blocks themselves)
     } else if (out->h_blocks) {
@@ -678,6 +741,11 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
     part.user_stream = out->user_stream;
     part.extra = out->extra;
     part.q_base = out->q_base + q0;
+    part.fin_thr = out->fin_thr;
+    if (out->on_final)
+      part.on_final = [out, q0, k](int32_t a, int32_t b2, const char *skip, const int64_t *ids, const double *dist, const int32_t *cnt) {
+        out->on_final(q0 + a, q0 + b2, skip - q0, ids - (size_t)q0 * k, dist - (size_t)q0 * k, cnt - q0);
+      };
     if (out->on_chunk)  // indices of the callback are the caller's: shift this part's
       part.on_chunk = [out, q0, bb](int32_t a, int32_t b2, const char *skip, const uint8_t *base, const double *mag_a) {
         out->on_chunk(q0 + a, q0 + b2, skip - q0, base - (size_t)q0 * bb, mag_a - q0);

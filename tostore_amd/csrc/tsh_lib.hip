@@ -368,14 +368,20 @@ struct Shard {
   int64_t scan_us_samples = 0;
   int64_t bytes = 0;
   struct BatchCtx *batch = nullptr;  // matrix-core path scratch (created with the shard)
+  // A second scratch set: two batched calls (two host threads, or one call per isolate) overlap -- the later one's
+  // host preparation runs while the GPU works on the earlier one, whose finalisation runs while the GPU works on
+  // the later one.  The GPU side stays one in-order stream: batch_enq_mu covers a call's enqueue sequence and the
+  // upkeep of the converted planes.
+  struct BatchCtx *batch2 = nullptr;
+  std::mutex batch_enq_mu;
   // bf16 (hi, lo) planes of the rows for the bf16x3 batch kernel; built lazily by the first
-  // batch search, kept current from split_valid (guarded by batch->mu under a shared s->mu;
+  // batch search, kept current from split_valid (guarded by batch_enq_mu under a shared s->mu;
   // appends lower split_valid under the exclusive lock)
   u32x4 *d_split = nullptr;
   int64_t split_cap = 0;    // rows allocated
   int64_t split_valid = 0;  // rows [0, split_valid) are converted
   int batch_kernel = 3;     // TSH_OPT_BATCH_KERNEL: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (cosine: f16, else bf16x3)
-  int batch_kernel_last = -1;  // variant the last batched search ran
+  std::atomic<int> batch_kernel_last{-1};  // variant the last batched search ran
   int split_mode = 0;       // which kernel the planes were built for (1 / 2); 0 = none
   int64_t split_bytes = 0;
   int split_exp = 0;        // f16 planes: rows were scaled by 2^split_exp
@@ -1185,6 +1191,11 @@ struct SearchOut {
   // queries the single-query path will redo (those do land in h_blocks)
   // (mag_a[q]: query_mag_a of query q, computed while the queries were prepared)
   std::function<void(int32_t q0, int32_t q1, const char *skip, const uint8_t *base, const double *mag_a)> on_chunk;
+  // batched path, host mode: the caller takes FINAL results (threshold fin_thr applied, ordered, cut to k) -- the
+  // device finalises whatever it can (rerank_final_kernel) and hands over ids / distances (k per query) and counts of
+  // queries [q0, q1), indexed like the call's queries; what it cannot goes through on_chunk as before
+  double fin_thr = std::nan("");
+  std::function<void(int32_t q0, int32_t q1, const char *skip, const int64_t *ids, const double *dist, const int32_t *cnt)> on_final;
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1351,6 +1362,7 @@ int make_shard(int dim, int metric, int device, int64_t row_base, int64_t cap_ro
   int rc = shard_init(s.get());
   if (rc) return rc;
   s->batch = new BatchCtx();
+  s->batch2 = new BatchCtx();
   if (cap_rows > 0) {
     rc = shard_reserve(s.get(), cap_rows);
     if (rc) return rc;
@@ -1362,11 +1374,12 @@ int make_shard(int dim, int metric, int device, int64_t row_base, int64_t cap_ro
 void shard_destroy(Shard *s) {
   hipSetDevice(s->device);
   for (auto &c : s->ctx_all) ctx_free_all(c.get());
-  if (s->batch) {
-    batch_free(s->batch);
-    delete s->batch;
-    s->batch = nullptr;
-  }
+  for (BatchCtx **b : {&s->batch, &s->batch2})
+    if (*b) {
+      batch_free(*b);
+      delete *b;
+      *b = nullptr;
+    }
   // (streams are the device's, not the shard's; the last shard on a device takes the CU-masked ones along)
   hipFree(s->d_rows);
   hipFree(s->d_inv_norm);
@@ -1654,6 +1667,18 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
           finalized[(size_t)q] = 1;
         });
       };
+    if (ns == 1) {
+      so.fin_thr = thr;
+      so.on_final = [&](int32_t q0, int32_t q1, const char *skip, const int64_t *ids, const double *dist, const int32_t *cnt) {
+        parallel_for_range(q0, q1, [&](int32_t q) {
+          if (skip[q]) return;
+          memcpy(out_ids + (size_t)q * k, ids + (size_t)q * k, (size_t)k * sizeof(int64_t));
+          memcpy(out_dist + (size_t)q * k, dist + (size_t)q * k, (size_t)k * sizeof(double));
+          out_count[q] = cnt[q];
+          finalized[(size_t)q] = 1;
+        });
+      };
+    }
     rcs[g] = shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
     if (rcs[g]) errs[g] = g_err;
   };
