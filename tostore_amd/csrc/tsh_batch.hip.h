@@ -1082,8 +1082,8 @@ __device__ __forceinline__ double order_key_to_double(uint64_t key) {
 }
 
 static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(RerankFinalArgs fa) {
-  constexpr int P = RW_P;
 #pragma clang fp contract(off)
+  constexpr int P = RW_P;
   __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][RwTile<P>::FLOATS];
   __shared__ uint32_t s_valid;
   const RerankBatchArgs &a = fa.r;
