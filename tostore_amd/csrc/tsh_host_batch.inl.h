@@ -24,6 +24,7 @@ struct BatchCtx {
   int64_t mask_words = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
   hipEvent_t e_chunk[3] = {nullptr, nullptr, nullptr};  // tail chunks but the last
+  hipEvent_t e_up = nullptr;  // the call's inputs have arrived (upload stream -> batch stream)
   BlockEntry *d_quar_out = nullptr, *h_quar_out = nullptr;  // [query][quarantined row] exact sums
   int64_t quar_cap = 0;
   int64_t bytes = 0;
@@ -65,7 +66,7 @@ void batch_free(BatchCtx *b) {
   hipHostFree(b->h_fin_cnt);
   hipFree(b->d_sqrt_mag);
   hipHostFree(b->h_sqrt_mag);
-  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done, b->e_chunk[0], b->e_chunk[1], b->e_chunk[2]})
+  for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done, b->e_chunk[0], b->e_chunk[1], b->e_chunk[2], b->e_up})
     if (e) hipEventDestroy(e);
 }
 
@@ -223,6 +224,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0;
     HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming | wait_flag));
     for (hipEvent_t &e : b->e_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | wait_flag));
+    HIPCHK(hipEventCreateWithFlags(&b->e_up, hipEventDisableTiming));
   }
   int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
@@ -362,6 +364,18 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     return (int32_t)((int64_t)nq * pct / 100);
   };
   // ---- enqueue on the shard's batch stream (unmasked: the GEMM scales with CU count) ------
+  // the inputs travel on the device's upload stream: with two calls in flight they arrive while the call in front
+  // still computes (on the batch stream the 3 MB of a 1024 x 768 batch were 50-60 us of idle matrix cores per call:
+  // two callers 450-600 k queries/s against 608-638 k on one box, tools/ab_batch.sh; one caller: no difference)
+  {
+    hipStream_t up = s->upload_stream;
+    HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, up));
+    HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));
+    HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * sizeof(float), hipMemcpyHostToDevice, up));
+    if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, up));
+    if (gpu_final) HIPCHK(hipMemcpyAsync(b->d_sqrt_mag, b->h_sqrt_mag, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, up));
+    HIPCHK(hipEventRecord(b->e_up, up));
+  }
   {
     std::lock_guard<std::mutex> enq(s->batch_enq_mu);  // one call's sequence at a time on the one in-order stream
     hipStream_t st = s->batch_stream;
@@ -384,11 +398,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       s->split_mode = kern;
       s->split_exp = v_exp;
     }
-    HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * sizeof(float), hipMemcpyHostToDevice, st));
-    if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, st));
-    if (gpu_final) HIPCHK(hipMemcpyAsync(b->d_sqrt_mag, b->h_sqrt_mag, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamWaitEvent(st, b->e_up, 0));
     if (!quar_sel.empty() && !out->d_blocks) {
       QuarArgs qa{};
       qa.rows = s->d_rows;

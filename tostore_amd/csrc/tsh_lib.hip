@@ -295,6 +295,7 @@ struct DeviceStreams {
   hipStream_t tail = nullptr, tail2 = nullptr;  // the other 16 CUs (two queues: the tails of consecutive queries overlap)
   hipStream_t batch = nullptr;                  // unmasked: matrix-core batches
   hipStream_t aux = nullptr;                    // rare synchronous work (fallback filter, bench hooks)
+  hipStream_t upload = nullptr;                 // a batched call's queries on their way in, beside the call before it
   bool cu_split = false;
   std::mutex scan_mu;                           // one enqueue sequence (scan + hand-off + tail) at a time
   int rc = TSH_OK;
@@ -353,6 +354,7 @@ struct Shard {
   uint64_t tail_seq = 0;  // guarded by scan_mu
   bool cu_split = false;
   hipStream_t batch_stream = nullptr;  // matrix-core batches: compute-bound, so all CUs (no mask)
+  hipStream_t upload_stream = nullptr;  // H2D copies of a batched call's inputs (they overlap the call in front)
   std::mutex *scan_mu = nullptr;  // the device's (DeviceStreams): streams are shared by its shards
   std::atomic<int> inflight{0};
 
@@ -488,6 +490,7 @@ DeviceStreams *device_streams(int device) {
   if ((e = make_scan_streams(ds)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&ds->batch, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = hipStreamCreateWithFlags(&ds->aux, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = hipStreamCreateWithFlags(&ds->upload, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   ++ds->users;
   return ds;
 }
@@ -512,6 +515,7 @@ int shard_init(Shard *s) {
   s->tail_stream2 = ds->tail2;
   s->batch_stream = ds->batch;
   s->aux_stream = ds->aux;
+  s->upload_stream = ds->upload;
   s->cu_split = ds->cu_split;
   s->scan_mu = &ds->scan_mu;
   s->holds_streams = true;
