@@ -936,7 +936,9 @@ constexpr int RW_WAVES = 2;          // waves per workgroup
 constexpr int RW_CAND = 64 * RW_WAVES;  // candidates per workgroup and pass
 // Floats of a row per piece.  64 (256 B per row and load) measured against 128 on one box, all 130 k candidates of a
 // 1024-query C3 call in one launch: 126 us against 180 -- with 128 the registers and the 34 KB tile leave four waves
-// per CU instead of eight, and waves in flight are what this latency-bound walk lives on.
+// per CU instead of eight.  Two pieces in flight per wave (32 KB, 238 registers): 133 us; plain instead of nontemporal
+// loads: 136.  390 MB of rows in 125 us = 3.1 TB/s is what random 3 KB rows out of a 3 GB store deliver here, however
+// many bytes are in flight.
 constexpr int RW_P = 64;
 template <int P>
 struct RwTile {
