@@ -28,7 +28,10 @@ struct BatchCtx {
   BlockEntry *d_quar_out = nullptr, *h_quar_out = nullptr;  // [query][quarantined row] exact sums
   int64_t quar_cap = 0;
   int64_t bytes = 0;
-  double last_gemm_us = 0, last_flops = 0;
+  double last_gemm_us = 0, last_flops = 0;  // key passes of the last TIMED call
+  // timed: events around the key passes (tsh_bench_batch, TSH_TRACE_BATCH).  Off otherwise: every record between two
+  // kernels is a packet the queue works through while the GPU idles (~6 us each, three of them per call)
+  bool timed = false;
   int32_t est_backoff = 0;  // calls left during which the estimated threshold stays off (it failed too often)
   int64_t est_unverified = 0;  // queries whose estimated threshold turned out too tight (redone exactly)
   int64_t last_nq = 0, last_nq_pad = 0, last_sample = 0;  // shape of d_dense / h_qaux after the last call (tsh_probe_batch_keys)
@@ -135,19 +138,31 @@ int64_t batch_sample_rows(int64_t rows, int32_t k) {
   return std::min(n, rows);
 }
 
-// 2 * (error bound of the f32 MFMA key), absolute, per query
-bool batch_delta2(const Shard *s, const float *q, int kernel, float *out_delta2, float *out_qsq, float *out_qmax,
-                  double *out_qn2 = nullptr) {
-  double qn2 = 0;
-  float qmax = 0.f;
-  for (int i = 0; i < s->dim; ++i) {
-    float a = std::fabs(q[i]);
-    if (!(a <= BIG_ABS)) return false;
-    qmax = a > qmax ? a : qmax;
-    qn2 += (double)q[i] * (double)q[i];
+// Sum of squares (f64, element order, one rounding per addition: == query_mag_a) and largest magnitude of up to
+// QN_GROUP queries at once: a query's sum is one serial chain of additions, so a lone query waits out the add latency
+// dim times; eight chains side by side keep the adder busy (1024 x 768: 85 -> 45 us of a call's preparation).
+// ok[j] = every element of query j is within the error model (finite, |x| <= BIG_ABS).
+constexpr int QN_GROUP = 8;
+void query_norms(const float *q0, int64_t stride, int dim, int n, double *qn2, float *qmax, char *ok) {
+  double acc[QN_GROUP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float mx[QN_GROUP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float *p[QN_GROUP];
+  for (int j = 0; j < QN_GROUP; ++j) p[j] = q0 + (int64_t)(j < n ? j : 0) * stride;
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < QN_GROUP; ++j) {
+      const float v = p[j][i], a = std::fabs(v);
+      mx[j] = a > mx[j] ? a : mx[j];  // (a NaN never becomes the maximum: caught below through the sum)
+      acc[j] = acc[j] + (double)v * (double)v;
+    }
+  for (int j = 0; j < n; ++j) {
+    qn2[j] = acc[j];
+    qmax[j] = mx[j];
+    ok[j] = mx[j] <= BIG_ABS && acc[j] == acc[j] && acc[j] < INFINITY;  // NaN / inf elements poison the sum
   }
-  if (out_qmax) *out_qmax = qmax;
-  if (out_qn2) *out_qn2 = qn2;  // == query_mag_a(q): same terms, same order, one rounding per addition
+}
+
+// 2 * (error bound of the f32 MFMA key), absolute, per query.  qn2 / qmax: query_norms.
+bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, float *out_qsq) {
   const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
   const double u2 = 1.1920928955078125e-07;        // 2^-23
   double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
@@ -276,27 +291,27 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   std::vector<char> bad((size_t)nq, 0);
   std::vector<float> qmax((size_t)nq_pad, 0.f);
   b->mag_a.resize((size_t)nq);  // the finaliser's sum of q[i]^2 (cosine), a by-product of the band computation
-  parallel_for(nq_pad, [&](int32_t q) {
-    float *dst = b->h_Q + (size_t)q * ld;
-    if (q < nq) {
-      memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
-      for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
+  parallel_for((nq_pad + QN_GROUP - 1) / QN_GROUP, [&](int32_t g) {
+    const int32_t g0 = g * QN_GROUP, g1 = std::min(nq_pad, g0 + QN_GROUP), gn = std::max(0, std::min(nq, g1) - g0);
+    char ok[QN_GROUP];
+    if (gn > 0) query_norms(queries + (size_t)g0 * s->dim, s->dim, s->dim, gn, &b->mag_a[(size_t)g0], &qmax[(size_t)g0], ok);
+    for (int32_t q = g0; q < g1; ++q) {
+      float *dst = b->h_Q + (size_t)q * ld;
       h_kmax[q] = 0.f;
-      if (batch_delta2(s, dst, kern, &h_d2[q], &h_qsq[q], &qmax[(size_t)q], &b->mag_a[(size_t)q])) {
+      if (q < nq && ok[q - g0] && batch_delta2(s, kern, b->mag_a[(size_t)q], &h_d2[q], &h_qsq[q])) {
+        memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
+        for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
         const double km = std::sqrt(b->mag_a[(size_t)q]) * kmax_v * 1.001 + 1e-30;
         h_kmax[q] = km < 3e38 ? (float)km : 3e38f;
       } else {
-        qmax[(size_t)q] = 0.f;
-        bad[(size_t)q] = 1;  // outside the error model: zero it here, redo it alone
+        if (q < nq) {
+          qmax[(size_t)q] = 0.f;
+          bad[(size_t)q] = 1;  // outside the error model: a zero query here, redone alone
+        }
         memset(dst, 0, (size_t)ld * sizeof(float));
         h_d2[q] = 0.f;
         h_qsq[q] = 0.f;
       }
-    } else {
-      memset(dst, 0, (size_t)ld * sizeof(float));
-      h_d2[q] = 0.f;
-      h_qsq[q] = 0.f;
-      h_kmax[q] = 0.f;
     }
   });
   // f16: one power-of-two scale for the whole batch; queries much smaller than the largest one would sit
@@ -499,9 +514,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.row0 = 0;
     a.row1 = (int32_t)n_sample;
     a.n_tiles = (int32_t)((n_sample + tile_n - 1) / tile_n);
-    HIPCHK(hipEventRecord(b->e0, st));
+    const bool timed = b->timed || trace_batch();
+    if (timed) HIPCHK(hipEventRecord(b->e0, st));
     launch_batch_score_m(s->metric, a, true, st);
-    HIPCHK(hipEventRecord(b->e1, st));
+    if (timed) HIPCHK(hipEventRecord(b->e1, st));
     // B0s: per-query threshold + the sample's own candidates
     SampleSelArgs ss{};
     ss.dense = b->d_dense;
@@ -524,7 +540,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if (wide_select) batch_sample_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(ss);
     else batch_sample_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(ss);
     // B1: everything else, filtered
-    HIPCHK(hipEventRecord(b->e2, st));
+    if (timed) HIPCHK(hipEventRecord(b->e2, st));
     if (rows > n_sample) {
       a.row0 = (int32_t)n_sample;
       a.row1 = (int32_t)rows;
@@ -663,11 +679,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     }
     if (trace_batch()) fprintf(stderr, "[tsh batch]   chunk %d: event at %.0f us, finalised in %.0f us\n", c, t_c0 - t_enq, now_us() - t_c0);
   }
-  float ms0 = 0.f, ms1 = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
-  HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
-  b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
-  b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  if (b->timed || trace_batch()) {
+    float ms0 = 0.f, ms1 = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
+    HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
+    b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
+    b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  }
   b->est_unverified += n_unverified;
   if (b->est_backoff > 0) --b->est_backoff;
   else if (n_unverified > std::max(1, nq / 64)) b->est_backoff = 64;  // the sample does not represent these rows

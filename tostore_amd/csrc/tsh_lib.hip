@@ -2035,7 +2035,9 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
     SearchOut so;
     so.h_blocks = blocks.data();
     std::vector<int32_t> redo;
+    s->batch->timed = true;  // (read under its mutex by the call below; measurement hooks are not run concurrently)
     int rc = shard_search_batch(s, s->batch, queries, nq, k, nullptr, entries, &so, &redo);
+    s->batch->timed = false;
     if (rc) return rc;
     acc += s->batch->last_gemm_us;
   }
