@@ -932,46 +932,50 @@ __device__ __forceinline__ void rerank_lane_sums(const float *__restrict__ rp, c
 // order with one rounding per addition.  For IP and cosine the product of two f32 values is exact in f64 (24 + 24
 // significand bits), so fma(q, b, s) rounds exactly what s + q * b rounds; L2's (q - b)^2 is not exact and keeps its
 // separate multiply.
-constexpr int RW_WAVES = 2;          // waves per workgroup
-constexpr int RW_CAND = 64 * RW_WAVES;  // candidates per workgroup and pass
-// Floats of a row per piece.  64 (256 B per row and load) measured against 128 on one box, all 130 k candidates of a
-// 1024-query C3 call in one launch: 126 us against 180 -- with 128 the registers and the 34 KB tile leave four waves
-// per CU instead of eight.  Two pieces in flight per wave (32 KB, 238 registers): 133 us; plain instead of nontemporal
-// loads: 136.  390 MB of rows in 125 us = 3.1 TB/s is what random 3 KB rows out of a 3 GB store deliver here, however
-// many bytes are in flight.
-constexpr int RW_P = 64;
-template <int P>
-struct RwTile {
-  static constexpr int LD = P + 4;       // LDS row stride in floats: rows 4 banks apart
-  static constexpr int FLOATS = 64 * LD; // a wave's tile
-  static constexpr int NLOAD = P / 4;    // 1 KiB load instructions per piece (64 rows x P floats)
-  static constexpr int RPL = 256 / P;    // rows per load instruction
+// Shape: a wave owns CAND = 64 candidates and keeps DEPTH = 1 piece in flight beside the one it works on, two waves per
+// workgroup (a 1024-query C3 call: 2048 such waves, eight per CU).  Measured against it on one box: 16 candidates per
+// wave with six pieces in flight, eight waves per workgroup (64 queries, 8 k candidates: 73 us against 67; no difference
+// from 16 to 256 queries per call) -- the waves do not wait for their loads (s_memtime stamps: < 300 cycles per piece),
+// a piece costs ~4.5 k cycles of which the chains are 3.2 k.
+constexpr int RW_P = 64;               // floats of a row per piece
+constexpr int RW_LD = RW_P + 4;        // LDS row stride in floats: rows 4 banks apart
+constexpr int RW_CAND = 128;           // candidates per workgroup and pass, either shape
+// (128-float pieces measured with the BIG shape, 1024-query C3 call: 180 us against 126 -- four waves per CU instead of
+// eight; two pieces in flight per BIG wave: 133; plain instead of nontemporal loads: 136.)
+template <int CAND, int DEPTH>
+struct RwShape {
+  static constexpr int WAVES = RW_CAND / CAND;    // waves per workgroup
+  static constexpr int TILE = CAND * RW_LD;       // floats of a wave's LDS tile
+  static constexpr int NLOAD = CAND / 4;          // 1 KiB load instructions per piece (4 rows x 256 B each)
 };
+using RwBig = RwShape<64, 1>;
 
-// One wave: the exact sums of candidates [c0, c0 + min(left, 64)) of query q's list, lane = candidate (lanes past the
-// list repeat the last candidate).  tile: this wave's RwTile<P>::FLOATS floats of LDS.
-template <int P>
+// One wave: the exact sums of candidates [c0, c0 + min(left, CAND)) of query q's list, lane = candidate (lanes past
+// the list, or past CAND, repeat the last candidate).  tile: this wave's TILE floats of LDS.
+template <int CAND, int DEPTH>
 __device__ __forceinline__ void rerank_wave_sums(const RerankBatchArgs &a, int q, uint32_t c0, uint32_t left, float *tile,
                                                  int lane, uint32_t *out_row, double *out_s0, double *out_s1) {
 #pragma clang fp contract(off)
-  using T = RwTile<P>;
-  const uint32_t slot = (uint32_t)lane < left ? (uint32_t)lane : left - 1u;
+  using T = RwShape<CAND, DEPTH>;
+  constexpr int P = RW_P;
+  const uint32_t have = left < (uint32_t)CAND ? left : (uint32_t)CAND;
+  const uint32_t slot = (uint32_t)lane < have ? (uint32_t)lane : have - 1u;
   const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
   const int ld = (int)a.ld, dim = a.dim;
-  const int sub = lane / (P / 4), col4 = 4 * (lane % (P / 4));
-  uint32_t rrow[T::NLOAD];  // load j of a piece covers candidates RPL j .. RPL j + RPL - 1, P floats each
+  const int sub = lane >> 4, col4 = 4 * (lane & 15);
+  uint32_t rrow[T::NLOAD];  // load j of a piece covers candidates 4 j .. 4 j + 3, P floats each
 #pragma unroll
-  for (int j = 0; j < T::NLOAD; ++j) rrow[j] = (uint32_t)__shfl((int)my_row, T::RPL * j + sub);
+  for (int j = 0; j < T::NLOAD; ++j) rrow[j] = (uint32_t)__shfl((int)my_row, 4 * j + sub);
   const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;  // wave-uniform: scalar loads
-  const float *trow = tile + lane * T::LD;
-  float *tput = tile + sub * T::LD + col4;
+  const float *trow = tile + (lane < CAND ? lane : CAND - 1) * RW_LD;
+  float *tput = tile + sub * RW_LD + col4;
   const int npiece = (dim + P - 1) / P;
-  f32x4 in[T::NLOAD];
-  auto fetch = [&](int p) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
+  f32x4 in[DEPTH][T::NLOAD];
+  auto fetch = [&](f32x4 (&dst)[T::NLOAD], int p) {  // no branch around a load: offsets past the row clamp to its last 16 bytes (never used)
     const int o = p * P + col4 < ld - 4 ? p * P + col4 : ld - 4;
 #pragma unroll
     for (int j = 0; j < T::NLOAD; ++j)
-      in[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.rows + (int64_t)rrow[j] * a.ld + o));
+      dst[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.rows + (int64_t)rrow[j] * a.ld + o));
   };
   double s0 = 0.0, s1 = 0.0;
   auto chains = [&](auto METRIC) {
@@ -986,25 +990,32 @@ __device__ __forceinline__ void rerank_wave_sums(const RerankBatchArgs &a, int q
         if (M == METRIC_COS) s1 = __builtin_fma(bd, bd, s1);
       }
     };
-    fetch(0);
-    for (int p = 0; p < npiece; ++p) {
 #pragma unroll
-      for (int j = 0; j < T::NLOAD; ++j) *reinterpret_cast<f32x4 *>(tput + T::RPL * j * T::LD) = in[j];
-      fetch(p + 1);  // (past the last piece: clamped re-reads of cached lines)
-      __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
-      const float *qq = qp + p * P;
-      const int m = dim - p * P;  // wave-uniform; >= 1
-      if (m >= P) {
+    for (int d = 0; d < DEPTH; ++d) fetch(in[d], d);  // (past the last piece: clamped re-reads of cached lines)
+    for (int p0 = 0; p0 < npiece; p0 += DEPTH) {
 #pragma unroll
-        for (int g = 0; g < P / 4; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + 4 * g);
+      for (int d = 0; d < DEPTH; ++d) {
+        const int p = p0 + d;
+        if (p < npiece) {  // wave-uniform
 #pragma unroll
-          for (int e = 0; e < 4; ++e) term(qq[4 * g + e], v[e]);
+          for (int j = 0; j < T::NLOAD; ++j) *reinterpret_cast<f32x4 *>(tput + 4 * j * RW_LD) = in[d][j];
+          fetch(in[d], p + DEPTH);
+          __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
+          const float *qq = qp + p * P;
+          const int m = dim - p * P;  // wave-uniform; >= 1
+          if (m >= P) {
+#pragma unroll
+            for (int g = 0; g < P / 4; ++g) {
+              const f32x4 v = *reinterpret_cast<const f32x4 *>(trow + 4 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) term(qq[4 * g + e], v[e]);
+            }
+          } else {
+            for (int i = 0; i < m; ++i) term(qq[i], trow[i]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-      } else {
-        for (int i = 0; i < m; ++i) term(qq[i], trow[i]);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
   if (a.metric == METRIC_L2) chains(std::integral_constant<int, METRIC_L2>{});
@@ -1017,21 +1028,22 @@ __device__ __forceinline__ void rerank_wave_sums(const RerankBatchArgs &a, int q
 
 // Entries out: blockIdx.y = query, blockIdx.x strides over its candidates.  (Shard mode, quarantined rows, wide
 // lists: whoever merges or finalises on the host wants the exact sums.)
-static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_kernel(RerankBatchArgs a) {
-  __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][RwTile<RW_P>::FLOATS];
+static __global__ void __launch_bounds__(64 * RwBig::WAVES) rerank_batch_kernel(RerankBatchArgs a) {
+  using T = RwBig;
+  __shared__ __attribute__((aligned(16))) float tiles[T::WAVES][T::TILE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = a.q0 + (int)blockIdx.y;
   const uint8_t *blk = a.blocks + (int64_t)q * a.block_bytes;
   uint32_t count = reinterpret_cast<const BlockHeader *>(blk)->count;
   if (count > (uint32_t)a.entries) count = (uint32_t)a.entries;
-  const uint32_t c0 = (blockIdx.x * (uint32_t)RW_WAVES + (uint32_t)wave) * 64u;
+  const uint32_t c0 = (blockIdx.x * (uint32_t)T::WAVES + (uint32_t)wave) * 64u;
   if (c0 >= count) return;
   const uint32_t left = count - c0;  // >= 1
   float *tile = tiles[wave];
   uint32_t my_row;
   double s0, s1;
-  rerank_wave_sums<RW_P>(a, q, c0, left, tile, lane, &my_row, &s0, &s1);
+  rerank_wave_sums<64, 1>(a, q, c0, left, tile, lane, &my_row, &s0, &s1);
   // entries: 24 bytes each, 64 of them contiguous -- staged in the wave's tile and stored as whole dwords side by side
   uint32_t *stage = reinterpret_cast<uint32_t *>(tile);
   {
@@ -1060,7 +1072,7 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_batch_kernel(Rera
 // k results per query (ids, distances, count) are stored straight into pinned host memory: 1.6 KB per query cross
 // PCIe instead of a 3 KB candidate list, and the host is left with a copy.
 // Order = rank by counting over the <= RF_MAX candidates in LDS (a list is k plus a band's worth of rows).
-constexpr int RF_MAXG = 4;                   // passes of 64 candidates per wave
+constexpr int RF_MAXG = 4;                   // passes of RW_CAND candidates per workgroup
 constexpr int RF_MAX = RW_CAND * RF_MAXG;    // candidates per query this kernel takes (wider lists: host finaliser)
 
 struct RerankFinalArgs {
@@ -1083,10 +1095,11 @@ __device__ __forceinline__ double order_key_to_double(uint64_t key) {
   return __longlong_as_double((long long)((key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key));
 }
 
-static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(RerankFinalArgs fa) {
+template <int CAND, int DEPTH>
+static __global__ void __launch_bounds__(64 * (RW_CAND / CAND)) rerank_final_kernel(RerankFinalArgs fa) {
 #pragma clang fp contract(off)
-  constexpr int P = RW_P;
-  __shared__ __attribute__((aligned(16))) float tiles[RW_WAVES][RwTile<P>::FLOATS];
+  using T = RwShape<CAND, DEPTH>;
+  __shared__ __attribute__((aligned(16))) float tiles[T::WAVES][T::TILE];
   __shared__ uint32_t s_valid;
   const RerankBatchArgs &a = fa.r;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1103,12 +1116,12 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(Rera
 #pragma unroll
   for (int g = 0; g < RF_MAXG; ++g) {
     key[g] = 0;
-    row[g] = 0xFFFFFFFFu;  // = no entry (past the list, or beyond the threshold)
-    const uint32_t c0 = (uint32_t)(g * RW_WAVES + wave) * 64u;
+    row[g] = 0xFFFFFFFFu;  // = no entry (past the list, a lane past CAND, or beyond the threshold)
+    const uint32_t c0 = (uint32_t)(g * T::WAVES + wave) * (uint32_t)CAND;
     if (c0 < count) {  // wave-uniform
       uint32_t r;
       double s0, s1;
-      rerank_wave_sums<P>(a, q, c0, count - c0, tiles[wave], lane, &r, &s0, &s1);
+      rerank_wave_sums<CAND, DEPTH>(a, q, c0, count - c0, tiles[wave], lane, &r, &s0, &s1);
       double d;
       if (a.metric == METRIC_L2) {
         d = __builtin_sqrt(s0);
@@ -1119,7 +1132,7 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(Rera
         const double sim = denom > 0 ? s0 / denom : 0;
         d = 1.0 - sim;
       }
-      if ((uint32_t)lane < count - c0 && !(has_thr && d > fa.thr)) {
+      if (lane < CAND && (uint32_t)lane < count - c0 && !(has_thr && d > fa.thr)) {
         key[g] = order_key_of(d);
         row[g] = r;
       }
@@ -1129,12 +1142,12 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(Rera
   __syncthreads();  // every tile is free: the lists take their place
   uint64_t *skey = reinterpret_cast<uint64_t *>(&tiles[0][0]);        // RF_MAX keys
   uint32_t *srow = reinterpret_cast<uint32_t *>(skey + RF_MAX);       // RF_MAX local rows
-  static_assert(RF_MAX * 12 <= RW_WAVES * RwTile<P>::FLOATS * 4, "lists fit the tiles");
+  static_assert(RF_MAX * 12 <= T::WAVES * T::TILE * 4, "lists fit the tiles");
   uint32_t mine = 0;
 #pragma unroll
   for (int g = 0; g < RF_MAXG; ++g) {
-    const uint32_t c = (uint32_t)(g * RW_WAVES + wave) * 64u + (uint32_t)lane;
-    if (c < count) {
+    const uint32_t c = (uint32_t)(g * T::WAVES + wave) * (uint32_t)CAND + (uint32_t)lane;
+    if (lane < CAND && c < count) {
       skey[c] = key[g];
       srow[c] = row[g];
       mine += row[g] != 0xFFFFFFFFu;
@@ -1152,6 +1165,9 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(Rera
     const uint64_t mk = key[g];
     const uint32_t mr = row[g];
     uint32_t rank = 0;
+    // (eight entries per turn, their LDS reads issued together: one entry per turn waited out an LDS round trip per
+    // entry -- 12 us of a 64-query call's 67)
+#pragma unroll 8
     for (uint32_t j = 0; j < count; ++j) {
       const uint64_t ok = skey[j];
       const uint32_t orow = srow[j];
@@ -1162,7 +1178,7 @@ static __global__ void __launch_bounds__(64 * RW_WAVES) rerank_final_kernel(Rera
       odist[rank] = order_key_to_double(mk);
     }
   }
-  for (uint32_t i = n_out + (uint32_t)tid; i < kk; i += 64 * RW_WAVES) {  // unused slots read as "no row"
+  for (uint32_t i = n_out + (uint32_t)tid; i < kk; i += 64 * T::WAVES) {  // unused slots read as "no row"
     oid[i] = -1;
     odist[i] = __builtin_nan("");
   }

@@ -600,13 +600,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       rf.out_dist = b->fin_dist_dev;
       rf.out_count = b->fin_cnt_dev;
       rf.k = k;
-      rerank_final_kernel<<<(unsigned)nq, 64 * RW_WAVES, 0, st>>>(rf);
+      rerank_final_kernel<64, 1><<<(unsigned)nq, 64 * RwBig::WAVES, 0, st>>>(rf);
       HIPCHK(hipEventRecord(b->e_done, st));
     } else
     for (int c = 0; c < n_chunks; ++c) {
       const int32_t q0 = chunk_q(c), q1 = chunk_q(c + 1);
       rb.q0 = q0;
-      rerank_batch_kernel<<<dim3((unsigned)((entries + RW_CAND - 1) / RW_CAND), (unsigned)(q1 - q0)), 64 * RW_WAVES, 0, st>>>(rb);
+      rerank_batch_kernel<<<dim3((unsigned)((entries + RW_CAND - 1) / RW_CAND), (unsigned)(q1 - q0)), 64 * RwBig::WAVES, 0, st>>>(rb);
       if (!quar_sel.empty() && out->d_blocks) {  // shard mode: the quarantined rows go into the device blocks
         QuarAppendArgs qa{};
         qa.rows = s->d_rows;
