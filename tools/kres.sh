@@ -7,7 +7,7 @@ for l in sys.stdin:
     m=re.search(r"Function Name: (\S+)",l)
     if m: cur={"name":m.group(1)};rows.append(cur);continue
     if cur is None: continue
-    for k,pat in (("vgpr",r" VGPRs: (\d+)"),("agpr",r"AGPRs: (\d+)"),("sgpr",r"TotalSGPRs: (\d+)"),("spill",r"VGPR Spill: (\d+)"),("scratch",r"ScratchSize \[bytes/lane\]: (\d+)"),("occ",r"Occupancy \[waves/SIMD\]: (\d+)"),("lds",r"LDS Size \[bytes/block\]: (\d+)")):
+    for k,pat in (("vgpr",r" VGPRs: (\d+)"),("agpr",r"AGPRs: (\d+)"),("sgpr",r"TotalSGPRs: (\d+)"),("spill",r"VGPRs Spill: (\d+)"),("scratch",r"ScratchSize \[bytes/lane\]: (\d+)"),("occ",r"Occupancy \[waves/SIMD\]: (\d+)"),("lds",r"LDS Size \[bytes/block\]: (\d+)")):
         m=re.search(pat,l)
         if m: cur[k]=m.group(1)
 import subprocess

@@ -174,6 +174,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   // (row and query pointers already include + 4 * lane: lanes without data fall back to element 0 of the row --
   // 4 * lane floats further on may be past the end of the last row's allocation when rows are narrow)
   auto off = [&](int c) { return has(c) ? c * 256 : -4 * lane; };
+  uint32_t loff[NCH];  // !FULL: this lane's float offset into a row, per chunk
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) loff[c] = has(c) ? (uint32_t)(4 * lane + c * 256) : 0u;
 
   f32x4 q[NCH];
 #pragma unroll
@@ -225,10 +228,22 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
         } else {
           r = next_dense++;
         }
-        const float *rp = tbase + (int64_t)r * a.ld;
+        if (FULL) {
+          const float *rp = tbase + (int64_t)r * a.ld;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-          v[buf][j][c] = ld16<NT>(rp + off(c));
+          for (int c = 0; c < NCH; ++c) v[buf][j][c] = ld16<NT>(rp + off(c));
+        } else {
+          // a lane's offset differs from chunk to chunk here (lanes past the row's end fall back to its start), which as
+          // a 64-bit address per row and chunk cost R x NCH register pairs and spilled (d = 384: 30 registers, d = 1000:
+          // 164; 0.62 / 0.42 of the HBM peak where full widths reach 0.82): the row's start is wave-uniform -- a scalar
+          // base -- and the lane's part a 32-bit offset per chunk, computed once
+          // (through readfirstlane: otherwise the optimiser derives the next row's addresses from this row's, per lane)
+          const uint64_t rbi = (uint64_t)(a.rows + ((int64_t)t * 64 + r) * a.ld);
+          const float *rb = reinterpret_cast<const float *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(rbi >> 32)) << 32) |
+                                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)rbi));
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) v[buf][j][c] = ld16<NT>(rb + loff[c]);
+        }
       }
     };
 
@@ -250,11 +265,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
         for (int j = 0; j < R; ++j) {
           float s = 0.f;
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            f32x4 x = v[k & 1][j][c];
-            if (!has(c)) x = f32x4{0.f, 0.f, 0.f, 0.f};
-            s = accum4<METRIC>(s, q[c], x);
-          }
+          for (int c = 0; c < NCH; ++c)
+            if (has(c)) s = accum4<METRIC>(s, q[c], v[k & 1][j][c]);  // (!FULL: lanes past the row's end sit the chunk out)
           // tie the finished sum to the fence: pure math would otherwise be
           // sunk below the next group's loads, keeping every buffer live
           asm volatile("" : "+v"(s)::"memory");
