@@ -18,21 +18,39 @@ template <int NCH, bool MASKED> struct ScanTune {
   static constexpr int MINW =
       (NCH <= 2) ? 4 : (NCH == 3 ? (MASKED ? 4 : 3) : (NCH == 4 ? 4 : (NCH <= 6 ? 3 : (NCH <= 8 ? 2 : 1))));
 };
-#define TSH_LAUNCH(KERN, GRID, BLOCK, ST, EV, ARG)                                                       \
+#define TSH_LAUNCH(KERN, GRID, BLOCK, LDS, ST, EV, ARG)                                                  \
   do {                                                                                                  \
     if ((EV).start || (EV).stop)                                                                        \
-      hipExtLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), 0, ST, (EV).start,   \
-                            (EV).stop, 0, ARG);                                                         \
+      hipExtLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), (unsigned)(LDS), ST, \
+                            (EV).start, (EV).stop, 0, ARG);                                             \
     else                                                                                                \
-      KERN<<<(GRID), (BLOCK), 0, ST>>>(ARG);                                                            \
+      KERN<<<(GRID), (BLOCK), (unsigned)(LDS), ST>>>(ARG);                                              \
   } while (0)
+
+// How many waves of a dense scan share a CU.  The registers would allow 8 to 16, and that is slower: every wave
+// streams its own tile, and HBM serves fewer, longer streams better than many short ones -- measured per width with
+// the occupancy held down by an (unused) dynamic LDS allocation, two-wave workgroups (tools/dims_probe.sh; scan time
+// at the default occupancy -> at the one chosen here): d = 768 457 -> 439 us (0.840 -> 0.875 of the HBM peak), 1536
+// 562 -> 537, 2048 740 -> 705, 1000 367 -> 357, 512 191 -> 184, 384 147 -> 139.  Four waves per CU from three chunks
+// per row on, eight for two; one-chunk rows (d <= 256) keep the registers' occupancy (d = 200: 76 us against 79 / 113
+// at eight / four waves); two waves per CU are as good as four at d = 768 and one is far too few (657 us).  Masked
+// scans walk scattered rows and live on many waves: untouched.
+template <int NCH> struct ScanShape {
+  static constexpr int WPB = NCH == 1 ? 4 : 2;                          // waves per workgroup
+  static constexpr int LDS = NCH == 1 ? 0 : (NCH == 2 ? 32768 : 65536);  // 160 KB per CU: 4 resp. 2 workgroups
+};
 
 template <int NCH, int METRIC, bool FULL, bool MASKED>
 void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s, const LaunchEv &ev) {
   using T = ScanTune<NCH, MASKED>;
-  // grid > 0: 4-wave workgroups; grid < 0: -grid one-wave workgroups (small shards)
-  if (grid > 0) TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), grid, 256, s, ev, a);
-  else TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), -grid, 64, s, ev, a);
+  // grid > 0: a big shard -- dense scans in the shape of ScanShape, masked ones in 4-wave workgroups;
+  // grid < 0: -grid one-wave workgroups (small shards)
+  using S = ScanShape<NCH>;
+  if (grid > 0 && !MASKED)
+    TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), (a.a.n_tiles + S::WPB - 1) / S::WPB,
+               64 * S::WPB, S::LDS, s, ev, a);
+  else if (grid > 0) TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), grid, 256, 0, s, ev, a);
+  else TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), -grid, 64, 0, s, ev, a);
 }
 template <int NCH, int METRIC>
 void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
@@ -54,7 +72,7 @@ void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStr
 template <int SPLIT>
 void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s,
                    const LaunchEv &ev) {
-#define TSH_PK(M, MK) TSH_LAUNCH((scan_packed_kernel<SPLIT, M, MK, true>), grid, threads, s, ev, a)
+#define TSH_PK(M, MK) TSH_LAUNCH((scan_packed_kernel<SPLIT, M, MK, true>), grid, threads, 0, s, ev, a)
   if (metric == TSH_METRIC_L2) { if (masked) TSH_PK(METRIC_L2, true); else TSH_PK(METRIC_L2, false); }
   else if (metric == TSH_METRIC_IP) { if (masked) TSH_PK(METRIC_IP, true); else TSH_PK(METRIC_IP, false); }
   else { if (masked) TSH_PK(METRIC_COS, true); else TSH_PK(METRIC_COS, false); }
