@@ -245,8 +245,11 @@ int32_t tsh_index_metric(tsh_index *idx);
  *               i (WHERE pre-filter; new capability)
  *   out_ids     nq x k      out_dist nq x k      out_count nq
  * nq == 1 (or small) streams the corpus once per query (HBM-bound kernel);
- * larger nq uses the batched matrix-core path.  Empty index or k <= 0 returns
- * TSH_OK with counts 0 (the reference returns const []: :78). */
+ * larger nq uses the batched matrix-core path, whose last steps (exact f64
+ * re-rank, distance, threshold, order, cut) run on the device.  Thread-safe;
+ * two batched calls on one handle overlap (one prepares / copies out while the
+ * GPU works on the other), further concurrent ones queue.  Empty index or
+ * k <= 0 returns TSH_OK with counts 0 (the reference returns const []: :78). */
 int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                    double distance_threshold, const uint8_t *row_mask,
                    int64_t *out_ids, double *out_dist, int32_t *out_count);
