@@ -1082,6 +1082,7 @@ struct RerankFinalArgs {
   int64_t *out_ids;          // nq x k
   double *out_dist;          // nq x k
   int32_t *out_count;        // nq
+  uint32_t *out_info;        // nq: the list's header in one word, flags << 24 | count (the host needs nothing else of it)
   int32_t k;
 };
 
@@ -1182,7 +1183,10 @@ static __global__ void __launch_bounds__(64 * (RW_CAND / CAND)) rerank_final_ker
     oid[i] = -1;
     odist[i] = __builtin_nan("");
   }
-  if (tid == 0) fa.out_count[q] = (int32_t)n_out;
+  if (tid == 0) {
+    fa.out_count[q] = (int32_t)n_out;
+    fa.out_info[q] = (hd->flags << 24) | (hd->count & 0xFFFFFFu);
+  }
 }
 
 }  // namespace tsh

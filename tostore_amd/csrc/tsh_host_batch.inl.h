@@ -42,6 +42,8 @@ struct BatchCtx {
   int64_t *h_fin_ids = nullptr, *fin_ids_dev = nullptr;   // nq x k
   double *h_fin_dist = nullptr, *fin_dist_dev = nullptr;  // nq x k
   int32_t *h_fin_cnt = nullptr, *fin_cnt_dev = nullptr;   // nq
+  uint32_t *h_fin_info = nullptr, *fin_info_dev = nullptr;  // nq: flags << 24 | count of each list's header
+  int64_t fin_info_cap = 0;
   int64_t fin_cap = 0, fin_q_cap = 0;
   double *d_sqrt_mag = nullptr, *h_sqrt_mag = nullptr;    // per query: sqrt(mag_a)
   int64_t sqrt_mag_cap = 0;
@@ -67,6 +69,7 @@ void batch_free(BatchCtx *b) {
   hipHostFree(b->h_fin_ids);
   hipHostFree(b->h_fin_dist);
   hipHostFree(b->h_fin_cnt);
+  hipHostFree(b->h_fin_info);
   hipFree(b->d_sqrt_mag);
   hipHostFree(b->h_sqrt_mag);
   for (hipEvent_t e : {b->e0, b->e1, b->e2, b->e3, b->e_done, b->e_chunk[0], b->e_chunk[1], b->e_chunk[2], b->e_up})
@@ -364,6 +367,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     if ((rc = regrow_pinned(&b->h_fin_dist, &b->fin_dist_dev, &c2, (int64_t)nq * k, &b->bytes))) return rc;
     b->fin_cap = std::min(c1, c2);
     if ((rc = regrow_pinned(&b->h_fin_cnt, &b->fin_cnt_dev, &b->fin_q_cap, (int64_t)nq, &b->bytes))) return rc;
+    if ((rc = regrow_pinned(&b->h_fin_info, &b->fin_info_dev, &b->fin_info_cap, (int64_t)nq, &b->bytes))) return rc;
     if ((rc = regrow(&b->d_sqrt_mag, &b->h_sqrt_mag, &b->sqrt_mag_cap, (int64_t)nq, &b->bytes))) return rc;
     for (int32_t q = 0; q < nq; ++q) b->h_sqrt_mag[q] = std::sqrt(b->mag_a[(size_t)q]);
   }
@@ -559,7 +563,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     // valid entries cross PCIe, and no copy sits between the last kernel and the host)
     const bool zero_copy = out->d_blocks == nullptr;
     fs.blocks = b->d_blocks;
-    fs.blocks_host = zero_copy ? b->h_blocks_dev : nullptr;
+    // (device-finalised calls: the re-rank's launch reports each header in one word beside the results; the headers'
+    // own stores into host memory, 1024 small PCIe writes in front of that launch, are left out)
+    fs.blocks_host = zero_copy && !gpu_final ? b->h_blocks_dev : nullptr;
     fs.final_rows = b->d_final;
     fs.block_bytes = (int64_t)bb;
     fs.row_base = s->row_base;
@@ -599,6 +605,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       rf.out_ids = b->fin_ids_dev;
       rf.out_dist = b->fin_dist_dev;
       rf.out_count = b->fin_cnt_dev;
+      rf.out_info = b->fin_info_dev;
       rf.k = k;
       rerank_final_kernel<64, 1><<<(unsigned)nq, 64 * RwBig::WAVES, 0, st>>>(rf);
       HIPCHK(hipEventRecord(b->e_done, st));
@@ -655,12 +662,14 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     }
     for (int32_t q = q0; q < q1; ++q) {
       const BlockHeader *h = reinterpret_cast<const BlockHeader *>(b->h_blocks + (size_t)q * bb);
-      if (bad[(size_t)q] || (h->flags & FLAG_LIST_OVERFLOW)) {
-        if (h->flags & FLAG_TAU_UNVERIFIED) ++n_unverified;
+      const uint32_t h_flags = gpu_final ? b->h_fin_info[q] >> 24 : h->flags;
+      const uint32_t h_count = gpu_final ? b->h_fin_info[q] & 0xFFFFFFu : h->count;
+      if (bad[(size_t)q] || (h_flags & FLAG_LIST_OVERFLOW)) {
+        if (h_flags & FLAG_TAU_UNVERIFIED) ++n_unverified;
         redo->push_back(q);
         skip[(size_t)q] = 1;
       } else {
-        s->c_cands += h->count;
+        s->c_cands += h_count;
         if (!quar_sel.empty() && !out->d_blocks) {  // the quarantined rows join this query's candidates
           std::vector<BlockEntry> &ex = (*out->extra)[(size_t)(out->q_base + q)];
           ex.clear();
