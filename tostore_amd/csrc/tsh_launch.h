@@ -19,7 +19,12 @@ struct LaunchEv {
 
 // K1 for one query: picks the instantiation for the row width (nch), metric and mask, the grid shape for the
 // shard size.  tsh_scan_tu.hip
-void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev = LaunchEv());
+// mostly_live: a masked scan that keeps most rows (tombstones, a mild filter) streams like a dense one and is launched
+// in the dense scans' shape.
+void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev = LaunchEv(),
+                 bool mostly_live = false);
+// (live rows of a masked scan, as far as the host knows them) -> mostly_live
+inline bool scan_mostly_live(int64_t live_rows, int64_t rows) { return live_rows * 10 >= rows * 6; }
 
 // batched key pass (f32 MFMA / bf16x3 / f16 by a.Vs and a.dot_scale).  tsh_batch_tu.hip
 void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st);

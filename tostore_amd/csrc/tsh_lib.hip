@@ -983,7 +983,8 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     } else if (overlap) {
       ev.stop = c->ev_scanned;
     }
-    launch_scan(sa, s->nch, s->metric, j->masked, ps, ev);
+    launch_scan(sa, s->nch, s->metric, j->masked, ps, ev,
+                j->masked && scan_mostly_live(rows_est > 0 ? rows_est : s->rows - s->deleted, s->rows));
     hipStream_t ts = ps;
     if (overlap) {
       // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
@@ -1990,9 +1991,15 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, st));
   static thread_local ScanArgsQ sa;
   fill_scan_args(s, c, masked, row_mask != nullptr, &sa);
-  launch_scan(sa, s->nch, s->metric, masked, st);  // warm
+  int64_t live_rows = s->rows - s->deleted;
+  if (row_mask) {
+    live_rows = 0;
+    for (int32_t t = 0; t < n_tiles; ++t) live_rows += __builtin_popcountll(c->h_mask[t]);
+  }
+  const bool ml = masked && scan_mostly_live(live_rows, s->rows);
+  launch_scan(sa, s->nch, s->metric, masked, st, LaunchEv(), ml);  // warm
   HIPCHK(hipEventRecord(c->ev0, st));
-  for (int32_t i = 0; i < iters; ++i) launch_scan(sa, s->nch, s->metric, masked, st);
+  for (int32_t i = 0; i < iters; ++i) launch_scan(sa, s->nch, s->metric, masked, st, LaunchEv(), ml);
   HIPCHK(hipEventRecord(c->ev1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

@@ -34,7 +34,9 @@ template <int NCH, bool MASKED> struct ScanTune {
 // 562 -> 537, 2048 740 -> 705, 1000 367 -> 357, 512 191 -> 184, 384 147 -> 139.  Four waves per CU from three chunks
 // per row on, eight for two; one-chunk rows (d <= 256) keep the registers' occupancy (d = 200: 76 us against 79 / 113
 // at eight / four waves); two waves per CU are as good as four at d = 768 and one is far too few (657 us).  Masked
-// scans walk scattered rows and live on many waves: untouched (keep 50 %: +2 % at eight waves, keep 10 %: -8 %).  One
+// scans that keep most rows (tombstones, mild filters: scan_mostly_live) stream like dense ones and take the same shape
+// (keep 100 / 95 / 80 %: 481 / 460 / 385 -> 441-454 / 426-434 / 370 us); selective ones walk scattered rows and live on many
+// waves (keep 50 %: +2 % at eight waves, keep 10 %: -8 %): theirs stays.  One
 // tile per wave and a workgroup per two tiles stays: a grid of 480 / 960 / 1920 workgroups striding over the tiles
 // takes 560 / 500 / 457 us against 439-445.
 template <int NCH> struct ScanShape {
@@ -43,33 +45,33 @@ template <int NCH> struct ScanShape {
 };
 
 template <int NCH, int METRIC, bool FULL, bool MASKED>
-void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s, const LaunchEv &ev) {
+void launch_scan_t(const ScanArgsQ &a, int grid, hipStream_t s, const LaunchEv &ev, bool mostly_live) {
   using T = ScanTune<NCH, MASKED>;
   // grid > 0: a big shard -- dense scans in the shape of ScanShape, masked ones in 4-wave workgroups;
   // grid < 0: -grid one-wave workgroups (small shards)
   using S = ScanShape<NCH>;
-  if (grid > 0 && !MASKED)
+  if (grid > 0 && (!MASKED || mostly_live))
     TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), (a.a.n_tiles + S::WPB - 1) / S::WPB,
                64 * S::WPB, S::LDS, s, ev, a);
   else if (grid > 0) TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), grid, 256, 0, s, ev, a);
   else TSH_LAUNCH((scan_kernel<NCH, METRIC, FULL, MASKED, T::R, true, 4, T::MINW>), -grid, 64, 0, s, ev, a);
 }
 template <int NCH, int METRIC>
-void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
+void launch_scan_m(const ScanArgsQ &a, bool masked, int grid, hipStream_t s, const LaunchEv &ev, bool ml) {
   bool full = a.a.d4 == NCH * 64;
   if (full) {
-    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s, ev);
-    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s, ev);
+    if (masked) launch_scan_t<NCH, METRIC, true, true>(a, grid, s, ev, ml);
+    else launch_scan_t<NCH, METRIC, true, false>(a, grid, s, ev, ml);
   } else {
-    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s, ev);
-    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s, ev);
+    if (masked) launch_scan_t<NCH, METRIC, false, true>(a, grid, s, ev, ml);
+    else launch_scan_t<NCH, METRIC, false, false>(a, grid, s, ev, ml);
   }
 }
 template <int NCH>
-void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s, const LaunchEv &ev) {
-  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s, ev);
-  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s, ev);
-  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s, ev);
+void launch_scan_n(const ScanArgsQ &a, int metric, bool masked, int grid, hipStream_t s, const LaunchEv &ev, bool ml) {
+  if (metric == TSH_METRIC_L2) launch_scan_m<NCH, METRIC_L2>(a, masked, grid, s, ev, ml);
+  else if (metric == TSH_METRIC_IP) launch_scan_m<NCH, METRIC_IP>(a, masked, grid, s, ev, ml);
+  else launch_scan_m<NCH, METRIC_COS>(a, masked, grid, s, ev, ml);
 }
 template <int SPLIT>
 void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int threads, hipStream_t s,
@@ -83,7 +85,7 @@ void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int th
 
 }  // namespace
 
-void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev) {
+void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev, bool ml) {
   int grid = (a.a.n_tiles + 3) / 4;
   if (grid < 1) grid = 1;
   if (a.a.ld == 128 || a.a.ld == 64 || a.a.ld == 32) {
@@ -102,18 +104,18 @@ void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream
   // percent; one tile per workgroup lets the dispatcher even them out
   if (a.a.n_tiles < SMALL_SHARD_TILES) grid = -std::max(1, (int)a.a.n_tiles);
   switch (nch) {
-    case 1: launch_scan_n<1>(a, metric, masked, grid, s, ev); break;
-    case 2: launch_scan_n<2>(a, metric, masked, grid, s, ev); break;
-    case 3: launch_scan_n<3>(a, metric, masked, grid, s, ev); break;
-    case 4: launch_scan_n<4>(a, metric, masked, grid, s, ev); break;
-    case 5: launch_scan_n<5>(a, metric, masked, grid, s, ev); break;
-    case 6: launch_scan_n<6>(a, metric, masked, grid, s, ev); break;
-    case 7: launch_scan_n<7>(a, metric, masked, grid, s, ev); break;
-    case 8: launch_scan_n<8>(a, metric, masked, grid, s, ev); break;
-    case 10: launch_scan_n<10>(a, metric, masked, grid, s, ev); break;
-    case 12: launch_scan_n<12>(a, metric, masked, grid, s, ev); break;
-    case 14: launch_scan_n<14>(a, metric, masked, grid, s, ev); break;
-    default: launch_scan_n<16>(a, metric, masked, grid, s, ev); break;
+    case 1: launch_scan_n<1>(a, metric, masked, grid, s, ev, ml); break;
+    case 2: launch_scan_n<2>(a, metric, masked, grid, s, ev, ml); break;
+    case 3: launch_scan_n<3>(a, metric, masked, grid, s, ev, ml); break;
+    case 4: launch_scan_n<4>(a, metric, masked, grid, s, ev, ml); break;
+    case 5: launch_scan_n<5>(a, metric, masked, grid, s, ev, ml); break;
+    case 6: launch_scan_n<6>(a, metric, masked, grid, s, ev, ml); break;
+    case 7: launch_scan_n<7>(a, metric, masked, grid, s, ev, ml); break;
+    case 8: launch_scan_n<8>(a, metric, masked, grid, s, ev, ml); break;
+    case 10: launch_scan_n<10>(a, metric, masked, grid, s, ev, ml); break;
+    case 12: launch_scan_n<12>(a, metric, masked, grid, s, ev, ml); break;
+    case 14: launch_scan_n<14>(a, metric, masked, grid, s, ev, ml); break;
+    default: launch_scan_n<16>(a, metric, masked, grid, s, ev, ml); break;
   }
 }
 
