@@ -143,7 +143,7 @@ int64_t batch_sample_rows(int64_t rows, int32_t k) {
 
 // Sum of squares (f64, element order, one rounding per addition: == query_mag_a) and largest magnitude of up to
 // QN_GROUP queries at once: a query's sum is one serial chain of additions, so a lone query waits out the add latency
-// dim times; eight chains side by side keep the adder busy (1024 x 768: 85 -> 45 us of a call's preparation).
+// dim times; eight chains side by side keep the adder busy (1024 x 768: 85-100 -> 60-85 us of a call's preparation).
 // ok[j] = every element of query j is within the error model (finite, |x| <= BIG_ABS).
 constexpr int QN_GROUP = 8;
 void query_norms(const float *q0, int64_t stride, int dim, int n, double *qn2, float *qmax, char *ok) {
