@@ -36,7 +36,9 @@ extern "C" {
 /* 2: tsh_counters grew (fused_launches) and tsh_ngh_info grew (pages_absent, files_absent) after version 1 shipped; a
  * host built against the version-1 structs would be written past its buffers, so the number changed with them.
  * tsh_comm_create_host / tsh_comm_set_group and TSH_E_PEER came with version 2 as well. */
-#define TSH_ABI_VERSION 2
+#define TSH_ABI_VERSION 3
+/* 3: tsh_counters grew again (batch_plane_fallbacks, batch_scan_fallbacks); tsh_comm_get_timeline / tsh_comm_timeline
+ * came with it. */
 
 /* status codes */
 #define TSH_OK 0
@@ -83,6 +85,11 @@ typedef struct tsh_counters {
   int32_t quarantined_rows;  /* live rows outside the f32 error model (non-finite or > 1e15 elements; cosine: norm
                                 below 2^-50) that are kept out of the scan and re-ranked exactly on every search */
   int64_t fused_launches;    /* reserved (0): counted a single-dispatch experiment of round 2 that was removed */
+  /* A batched call whose device allocations fail degrades instead of failing (results are identical on every path): */
+  int64_t batch_plane_fallbacks; /* calls that could not allocate the fp16 / bf16x3 copy of the rows and scored
+                                    their queries with the f32 MFMA kernel on the rows as stored (no copy needed) */
+  int64_t batch_scan_fallbacks;  /* calls whose batch scratch could not be allocated either and that were answered by
+                                    pipelined single-query scans */
 } tsh_counters;
 
 int32_t tsh_abi_version(void);
@@ -341,6 +348,37 @@ int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
                            double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,
                            int32_t *out_count);
+
+/* Where the time of this rank's tsh_search_sharded calls went: sums over the calls since the communicator was made
+ * (or since the last reset).  On the calling thread a call is, group after group,
+ *   reserve | wait_scan | exchange_wait (= all-gather of the blocks + this rank's slice to the host) | merge |
+ *   result_gather | copy_out        (+ retry_scan for groups redone with larger blocks)
+ * so these seven add up to call_us but for loop overhead; scan_us runs beside them on the helper thread (group g + 1
+ * is scanned while group g is exchanged), and gather_us + slice_d2h_us are the device-side split of exchange_wait_us.
+ * A rank that waits for slower peers shows it in gather_us (the all-gather cannot finish before the last rank
+ * joins); a rank whose own scans are the bottleneck shows it in wait_scan_us.  No reference counterpart. */
+typedef struct tsh_comm_timeline {
+  int64_t calls;   /* tsh_search_sharded calls that reached their exchange */
+  int64_t queries; /* queries of those calls */
+  int64_t groups;  /* exchanges (retried ones count again) */
+  int64_t retries; /* groups redone with larger candidate blocks */
+  int32_t world;
+  int32_t rank;
+  int32_t transport; /* 0 RCCL, 1 host callback, 2 a library named by TSH_RCCL_LIB (tests) */
+  int32_t reserved;
+  double call_us;          /* wall time inside the calls */
+  double reserve_us;       /* buffers (+ the agreement all-gather when they grew) */
+  double wait_scan_us;     /* calling thread blocked until this rank's scans of the group were done */
+  double scan_us;          /* helper thread: tsh_search_shard of the groups (overlaps the previous group's exchange) */
+  double exchange_wait_us; /* from issuing the block all-gather until this rank's slice is on the host */
+  double gather_us;        /* of that: the all-gather (RCCL: device time on the communicator's stream) */
+  double slice_d2h_us;     /* of that: the slice's copy to the host */
+  double merge_us;         /* host merge of the slice (threshold, order, cut) */
+  double result_gather_us; /* every slice's results to every rank: H2D + all-gather + D2H */
+  double copy_out_us;      /* into the caller's arrays */
+  double retry_scan_us;    /* re-scans of overflowing groups, on the calling thread */
+} tsh_comm_timeline;
+int32_t tsh_comm_get_timeline(tsh_comm *comm, tsh_comm_timeline *out, int32_t reset);
 
 int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out);
 

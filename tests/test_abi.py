@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"{n} declared in tostore_hip.h but not exported"
     assert sorted(_ffi.SIGNATURES) == names, "ctypes SIGNATURES out of sync with the header"
-    assert _ffi.lib().tsh_abi_version() == _ffi.ABI_VERSION == 2
+    assert _ffi.lib().tsh_abi_version() == _ffi.ABI_VERSION == 3
 
 
 def test_no_device_is_an_error_not_a_fallback():
@@ -244,7 +244,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                     str(src), "-o", str(exe), "-L", libdir, "-ltostore_hip", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
-    assert out[0] == "2"
+    assert out[0] == str(_ffi.ABI_VERSION)
     if int(out[1]) == 0:
         assert int(out[2]) == _ffi.TSH_E_NO_DEVICE
     else:

@@ -20,6 +20,7 @@ C2DART = {
     "void*": "Pointer<Void>", "tsh_index*": "Pointer<Void>", "tsh_index**": "Pointer<Pointer<Void>>",
     "tsh_comm*": "Pointer<Void>", "tsh_comm**": "Pointer<Pointer<Void>>",
     "tsh_ngh_info*": "Pointer<TshNghInfo>", "tsh_counters*": "Pointer<TshCounters>",
+    "tsh_comm_timeline*": "Pointer<TshCommTimeline>",
     "tsh_allgather_fn": "Pointer<NativeFunction<TshAllgatherNative>>",
 }
 NATIVE2DART = {"Int32": "int", "Int64": "int", "Double": "double", "Float": "double", "Void": "void"}
@@ -151,6 +152,19 @@ def test_dart_counters_struct_matches_the_header():
         assert snake(dname) == cname, f"field order: Dart {dname} vs C {cname}"
 
 
+def test_dart_timeline_struct_matches_the_header():
+    text = _strip_comments(open(BRIDGE).read())
+    body = re.search(r"final\s+class\s+TshCommTimeline\s+extends\s+Struct\s*\{(.*?)\n\}", text, flags=re.S).group(1)
+    dart_fields = re.findall(r"@(\w+)\(\)\s*external\s+(\w+)\s+(\w+)\s*;", body)
+    c_fields = c_struct("tsh_comm_timeline")
+    assert len(dart_fields) == len(c_fields) == 19
+    snake = lambda s: re.sub(r"([A-Z])", lambda m: "_" + m.group(1).lower(), s)  # noqa: E731
+    for (ann, dtype, dname), (ctype, cname) in zip(dart_fields, c_fields):
+        assert ann == C2DART[ctype], f"{cname}: @{ann} vs {ctype}"
+        assert dtype == NATIVE2DART[ann]
+        assert snake(dname) == cname.replace("d2h", "d2h"), f"field order: Dart {dname} vs C {cname}"
+
+
 def test_bridge_checks_the_abi_version_of_the_header():
     hdr = int(re.search(r"#define\s+TSH_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
     dart = int(re.search(r"static\s+const\s+int\s+abiVersion\s*=\s*(\d+)", open(BRIDGE).read()).group(1))
@@ -182,7 +196,7 @@ def test_ctypes_table_matches_the_c_prototypes():
         assert res is C2CTYPES[ret], f"{name}: restype"
         assert len(args) == len(params), f"{name}: {len(args)} ctypes args, header has {len(params)}"
         for i, (a, p) in enumerate(zip(args, params)):
-            if p in ("tsh_ngh_info*", "tsh_counters*"):
+            if p in ("tsh_ngh_info*", "tsh_counters*", "tsh_comm_timeline*"):
                 assert issubclass(a, ctypes._Pointer) and issubclass(a._type_, ctypes.Structure), f"{name} arg {i}"
             else:
                 want = C2CTYPES[p]
@@ -190,7 +204,8 @@ def test_ctypes_table_matches_the_c_prototypes():
                 # POINTER(c_int32) objects are cached by ctypes, so identity holds for them too
                 assert same, f"{name} arg {i}: ctypes {a} vs header {p}"
     # struct mirrors: field order and widths
-    for cname, cls in (("tsh_counters", _ffi.TshCounters), ("tsh_ngh_info", _ffi.TshNghInfo)):
+    for cname, cls in (("tsh_counters", _ffi.TshCounters), ("tsh_ngh_info", _ffi.TshNghInfo),
+                       ("tsh_comm_timeline", _ffi.TshCommTimeline)):
         cf = c_struct(cname)
         assert [f for _, f in cf] == [f for f, _ in cls._fields_], cname
         for (ct, _), (_, pt) in zip(cf, cls._fields_):

@@ -27,7 +27,7 @@ TSH_E_FORMAT = -8
 TSH_E_BUSY = -9
 TSH_E_RCCL = -10
 TSH_E_PEER = -11
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 
@@ -48,6 +48,7 @@ class TshCounters(ctypes.Structure):
         ("bytes_resident", c_i64), ("safe_mode", c_i32), ("device_id", c_i32),
         ("scan_us_sum", c_f64), ("scan_us_samples", c_i64),
         ("batch_kernel_last", c_i32), ("quarantined_rows", c_i32), ("fused_launches", c_i64),
+        ("batch_plane_fallbacks", c_i64), ("batch_scan_fallbacks", c_i64),
     ]
 
 
@@ -57,6 +58,16 @@ class TshNghInfo(ctypes.Structure):
         ("max_degree", c_i32), ("reserved", c_i32), ("next_node_id", c_i64), ("total_vectors", c_i64),
         ("deleted_count", c_i64), ("max_partition_file_size", c_i64), ("rows_loaded", c_i64),
         ("tombstones", c_i64), ("files_read", c_i64), ("pages_absent", c_i64), ("files_absent", c_i64),
+    ]
+
+
+class TshCommTimeline(ctypes.Structure):
+    _fields_ = [
+        ("calls", c_i64), ("queries", c_i64), ("groups", c_i64), ("retries", c_i64),
+        ("world", c_i32), ("rank", c_i32), ("transport", c_i32), ("reserved", c_i32),
+        ("call_us", c_f64), ("reserve_us", c_f64), ("wait_scan_us", c_f64), ("scan_us", c_f64),
+        ("exchange_wait_us", c_f64), ("gather_us", c_f64), ("slice_d2h_us", c_f64), ("merge_us", c_f64),
+        ("result_gather_us", c_f64), ("copy_out_us", c_f64), ("retry_scan_us", c_f64),
     ]
 
 
@@ -95,6 +106,7 @@ SIGNATURES = {
     "tsh_comm_set_group": (c_i32, [p_void, c_i32]),
     "tsh_comm_world": (c_i32, [p_void]),
     "tsh_search_sharded": (c_i32, [p_void, p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
+    "tsh_comm_get_timeline": (c_i32, [p_void, ctypes.POINTER(TshCommTimeline), c_i32]),
     "tsh_get_counters": (c_i32, [p_void, ctypes.POINTER(TshCounters)]),
     "tsh_bench_scan": (c_i32, [p_void, p_f32, c_i32, p_u8, p_f64]),
     "tsh_bench_batch": (c_i32, [p_void, p_f32, c_i32, c_i32, c_i32, p_f64, p_f64]),

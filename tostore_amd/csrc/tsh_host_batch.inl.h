@@ -76,6 +76,14 @@ void batch_free(BatchCtx *b) {
     if (e) hipEventDestroy(e);
 }
 
+// TSH_TEST_FAIL_ALLOC_OVER=bytes (tests): device allocations of the batched path at or above this size fail as if the
+// device were full -- the degrade ladder of shard_search_any (planes -> f32 MFMA -> single-query scans) can then be
+// walked deterministically, beside the test that really fills the device
+inline bool alloc_fault(int64_t bytes) {
+  static const int64_t over = getenv("TSH_TEST_FAIL_ALLOC_OVER") ? atoll(getenv("TSH_TEST_FAIL_ALLOC_OVER")) : 0;
+  return over > 0 && bytes >= over;
+}
+
 template <typename T>
 int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
   if (want <= *cap) return TSH_OK;
@@ -85,9 +93,23 @@ int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
     hipHostFree(*host);
     *host = nullptr;
   }
-  HIPCHK(hipMalloc(dev, (size_t)want * sizeof(T)));
-  if (host) HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
-  *bytes += (want - *cap) * (int64_t)sizeof(T);
+  *bytes -= *cap * (int64_t)sizeof(T);  // (a failed allocation below leaves an empty buffer, not a dangling capacity)
+  *cap = 0;
+  if (alloc_fault(want * (int64_t)sizeof(T))) return set_err(TSH_E_OOM, "hipMalloc failed: out of memory (injected)");
+  hipError_t e = hipMalloc(dev, (size_t)want * sizeof(T));
+  if (e == hipSuccess && host) {
+    e = hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) {
+      hipFree(*dev);
+      *dev = nullptr;
+    }
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // the runtime's sticky copy: a later hipGetLastError() must not report this again
+    return set_err(e == hipErrorOutOfMemory ? TSH_E_OOM : TSH_E_HIP, "hipMalloc of %lld bytes failed: %s",
+                   (long long)(want * (int64_t)sizeof(T)), hipGetErrorString(e));
+  }
+  *bytes += want * (int64_t)sizeof(T);
   *cap = want;
   return TSH_OK;
 }
@@ -99,9 +121,11 @@ int regrow_pinned(T **host, T **dev_view, int64_t *cap, int64_t want, int64_t *b
   hipHostFree(*host);
   *host = nullptr;
   *dev_view = nullptr;
+  *bytes -= *cap * (int64_t)sizeof(T);
+  *cap = 0;
   HIPCHK(hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault));
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(dev_view), *host, 0));
-  *bytes += (want - *cap) * (int64_t)sizeof(T);
+  *bytes += want * (int64_t)sizeof(T);
   *cap = want;
   return TSH_OK;
 }
@@ -207,8 +231,12 @@ inline bool trace_batch() {
 // All nq queries in one pass over the rows on the matrix cores.  Queries the
 // error model cannot cover, or whose lists overflow (ties), are reported in
 // *redo and answered by the single-query path.  Caller holds s->mu shared.
+// force_kernel >= 0: that key kernel instead of the handle's choice (0 = f32 MFMA on the rows as stored, the one that
+// needs no converted copy: shard_search_any falls to it when the copy cannot be allocated).  An allocation failure
+// returns TSH_E_OOM before anything was enqueued or written: the caller may retry or answer another way.
 int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
-                       const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo) {
+                       const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo,
+                       int force_kernel = -1) {
   // the shard's first scratch set stands for "either": a call that finds it taken by a concurrent call uses the second
   std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
   if (b == s->batch && s->batch2 && !lk.try_lock()) {
@@ -227,9 +255,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // 128 x 128 otherwise.  f16: 256 x 256 resp. 128 x 256.  Which key kernel runs is decided below (it needs the
   // scale of the rows); the padding of the batch only depends on the query side of the tile.
   static const int forced_tile = getenv("TSH_BATCH_TILE") ? atoi(getenv("TSH_BATCH_TILE")) : 0;  // experiments
-  const int32_t tile = (forced_tile == 128 || forced_tile == 256) && s->batch_kernel != 0
+  const int want_kernel = force_kernel >= 0 ? force_kernel : s->batch_kernel;
+  const int32_t tile = (forced_tile == 128 || forced_tile == 256) && want_kernel != 0
                            ? forced_tile
-                           : ((s->batch_kernel != 0 && nq > 128) ? 256 : 128);  // (the f32 kernel has the 128 tile only)
+                           : ((want_kernel != 0 && nq > 128) ? 256 : 128);  // (the f32 kernel has the 128 tile only)
   const int32_t nq_pad = (int32_t)round_up(nq, tile);
   // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
@@ -267,7 +296,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // 25x tighter error keeps the candidate lists short when norms vary widely
   // -- unless the rows are nearly equal in norm (the usual normalised embeddings), when f16 serves them too
   const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm;
-  int kern = s->batch_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : s->batch_kernel;
+  int kern = want_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : want_kernel;
   int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
   if (kern == 2) {
     const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
@@ -409,7 +438,16 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         s->split_cap = 0;
         s->split_valid = 0;
         const int64_t prow = round_up(s->cap, PLANE_GROUP);  // whole 256-row groups (plane_piece)
-        HIPCHK(hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes));
+        // (nothing of this call has been launched yet: a device too full for the copy is the caller's cue to score
+        // with the f32 kernel instead, shard_search_any)
+        const hipError_t pe = alloc_fault(prow * row_bytes) ? hipErrorOutOfMemory
+                                                            : hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes);
+        if (pe != hipSuccess) {
+          s->d_split = nullptr;
+          (void)hipGetLastError();
+          return set_err(pe == hipErrorOutOfMemory ? TSH_E_OOM : TSH_E_HIP, "hipMalloc of the %s copy of the rows (%lld bytes) failed: %s",
+                         use_f16 ? "fp16" : "bf16x3", (long long)(prow * row_bytes), hipGetErrorString(pe));
+        }
         s->split_cap = s->cap;
         s->split_bytes = prow * row_bytes;
         s->bytes += s->split_bytes;
@@ -788,7 +826,41 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
         out->on_chunk(q0 + a, q0 + b2, skip - q0, base - (size_t)q0 * bb, mag_a - q0);
       };
     std::vector<int32_t> r;
-    int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r);
+    const int force = s->planes_denied.load() > 0 && s->batch_kernel != 0 ? 0 : -1;
+    int rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r, force);
+    // A device too full for this call's allocations is no reason to fail a search the rows themselves can answer:
+    // first without the converted copy of the rows (f32 MFMA kernel on the rows as stored, smaller scratch), then
+    // without the batched path at all (pipelined single-query scans need nothing beyond their contexts).  Same
+    // results on every path; tsh_counters says which ran.
+    if (rc == TSH_E_OOM && force != 0 && s->batch_kernel != 0) {
+      r.clear();
+      rc = shard_search_batch(s, b, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &part, &r, 0);
+      if (rc == TSH_OK) {
+        s->c_plane_fallbacks++;
+        s->planes_denied.store(64);  // the copy is tried again after that many calls, not on every one
+      }
+    } else if (rc == TSH_OK && force == 0) {
+      s->c_plane_fallbacks++;
+      s->planes_denied.fetch_sub(1);
+    }
+    if (rc == TSH_E_OOM) {
+      s->c_scan_fallbacks++;
+      r.clear();
+      // (no callbacks: the blocks land in the caller's buffers and the caller finalises them, as it does for
+      // queries the batch hands back)
+      std::vector<std::vector<BlockEntry>> sp((size_t)(out->spill ? nc : 0)), ex((size_t)(out->extra ? nc : 0));
+      SearchOut scans;
+      scans.h_blocks = part.h_blocks;
+      scans.d_blocks = part.d_blocks;
+      scans.user_stream = part.user_stream;
+      scans.spill = out->spill ? &sp : nullptr;
+      scans.extra = out->extra ? &ex : nullptr;
+      rc = shard_search_blocks(s, queries + (size_t)q0 * s->dim, nc, k, mask, entries, &scans, PIPE_DEPTH);
+      for (int32_t q = 0; q < nc && rc == TSH_OK; ++q) {
+        if (out->spill) (*out->spill)[(size_t)(q0 + q)] = std::move(sp[(size_t)q]);
+        if (out->extra) (*out->extra)[(size_t)(out->q_base + q0 + q)] = std::move(ex[(size_t)q]);
+      }
+    }
     if (rc) return rc;
     for (int32_t q : r) redo.push_back(q0 + q);
   }

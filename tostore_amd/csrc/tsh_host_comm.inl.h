@@ -37,18 +37,32 @@ struct RcclApi {
   const char *(*GetErrorString)(int) = nullptr;
   std::string err;
   bool ok = false;
+  bool overridden = false;  // TSH_RCCL_LIB named the library
 };
 
 RcclApi *rccl() {
   static RcclApi *api = [] {
     RcclApi *a = new RcclApi();
     void *h = nullptr;
+    // TSH_RCCL_LIB: another library with the same five entry points.  tests/fake_rccl (several ranks on ONE GPU,
+    // which the real library refuses) is the one user; a path that does not load is an error, not a reason to
+    // fall back to the system's librccl behind the host's back
+    if (const char *over = getenv("TSH_RCCL_LIB"); over && *over) {
+      h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!h) {
+        const char *why = dlerror();
+        a->err = std::string("TSH_RCCL_LIB=") + over + " does not load: " + (why ? why : "");
+        return a;
+      }
+      a->overridden = true;
+    }
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (h) break;
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!h) {
-      a->err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      const char *why = dlerror();
+      a->err = std::string("librccl not found: ") + (why ? why : "");
       return a;
     }
     auto sym = [&](const char *n) -> void * {
@@ -106,7 +120,9 @@ struct tsh_comm {
   int32_t *d_agree = nullptr, *h_agree = nullptr;  // 1 + world words (allocated with the communicator)
   int32_t group = 0;  // queries per exchange; 0 = by the size of the call
   std::unique_ptr<OneWorker> helper;
-  int64_t c_groups = 0, c_retries = 0;
+  hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};  // RCCL: before / after the block all-gather, after the slice's D2H
+  tsh_comm_timeline tl = {};  // guarded by mu (scan_us: written by the helper thread, read after helper->wait())
+  std::atomic<int64_t> scan_ns{0};
 };
 
 namespace {
@@ -267,6 +283,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   const int32_t a = std::min<int32_t>(gq, c->rank * slice_q), b = std::min<int32_t>(gq, a + slice_q);
   const size_t rec = res_rec_bytes(k), res = sizeof(ResHeader) + (size_t)slice_q * rec;
   int rc;
+  tsh_comm_timeline &tl = c->tl;
   if (local_rc != TSH_OK) {
     rc = comm_error_blocks(c, slot, gq, entries, local_rc);
     if (rc) return rc;
@@ -274,25 +291,38 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   // ---- 1. every rank's blocks of the group; this rank's query slice of them to the host -------------------
   const uint8_t *slice_base;  // block (rank w, query a + i) at slice_base + w * slice_pitch + i * bb
   size_t slice_pitch;
+  const double t1 = now_us();
   if (c->host_fn) {
     HIPCHK(hipMemcpyAsync(c->h_mine, c->d_mine[slot], mine, hipMemcpyDeviceToHost, c->stream));
     rc = comm_sync(c);
     if (rc) return rc;
+    const double t1b = now_us();
     rc = comm_allgather_host(c, c->h_mine, c->h_slice, mine);
     if (rc) return rc;
+    tl.slice_d2h_us += t1b - t1;  // (host transport: the rank's whole group goes to the host, not a slice)
+    tl.gather_us += now_us() - t1b;
     slice_base = c->h_slice + (size_t)a * bb;
     slice_pitch = mine;
   } else {
+    HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
     rc = comm_allgather_dev(c, c->d_mine[slot], c->d_all, mine);  // k' x 24 B per rank and query: latency-bound
     if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
     if (b > a)
       HIPCHK(hipMemcpy2DAsync(c->h_slice, (size_t)(b - a) * bb, c->d_all + (size_t)a * bb, mine, (size_t)(b - a) * bb, W,
                               hipMemcpyDeviceToHost, c->stream));
-    rc = comm_sync(c);
-    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_t[2]));
+    float ms_g = 0.f, ms_d = 0.f;  // device time on the communicator's stream; the all-gather's includes the wait
+    HIPCHK(hipEventElapsedTime(&ms_g, c->ev_t[0], c->ev_t[1]));  // for the slowest rank to arrive
+    HIPCHK(hipEventElapsedTime(&ms_d, c->ev_t[1], c->ev_t[2]));
+    tl.gather_us += 1e3 * ms_g;
+    tl.slice_d2h_us += 1e3 * ms_d;
     slice_base = c->h_slice;
     slice_pitch = (size_t)(b - a) * bb;
   }
+  const double t2 = now_us();
+  tl.exchange_wait_us += t2 - t1;
   // ---- 2. merge the slice ---------------------------------------------------------------------------------
   ResHeader *rh = reinterpret_cast<ResHeader *>(c->h_res_mine);
   memset(rh, 0, sizeof *rh);
@@ -341,6 +371,8 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
     }
   }
   // ---- 3. every slice's results + status to every rank ----------------------------------------------------
+  const double t3 = now_us();
+  tl.merge_us += t3 - t2;
   const uint8_t *all_res = c->h_res_mine;
   if (W > 1) {
     if (c->host_fn) {
@@ -356,6 +388,8 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
     }
     all_res = c->h_res_all;
   }
+  const double t4 = now_us();
+  tl.result_gather_us += t4 - t3;
   int32_t need = 0;
   for (size_t w = 0; w < W; ++w) {
     const ResHeader *h = reinterpret_cast<const ResHeader *>(all_res + w * res);
@@ -379,6 +413,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
       out_count[q] = *reinterpret_cast<const int32_t *>(r + (size_t)k * 16);
     }
   }
+  tl.copy_out_us += now_us() - t4;
   return TSH_OK;
 }
 
@@ -388,6 +423,7 @@ int comm_common_create(tsh_comm *c, int32_t world, int32_t rank, int32_t device)
   c->device = device;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming | hipEventBlockingSync));
+  for (auto &e : c->ev_t) HIPCHK(hipEventCreateWithFlags(&e, hipEventBlockingSync));  // timed: the exchange's phases
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_agree), 4 * (size_t)(world + 1)));
   HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_agree), 4 * (size_t)(world + 1), hipHostMallocDefault));
   c->helper.reset(new OneWorker());
@@ -410,6 +446,8 @@ void comm_free(tsh_comm *c) {
   hipFree(c->d_agree);
   hipHostFree(c->h_agree);
   if (c->ev) hipEventDestroy(c->ev);
+  for (auto e : c->ev_t)
+    if (e) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -495,6 +533,21 @@ int32_t tsh_comm_set_group(tsh_comm *c, int32_t queries_per_exchange) {
   return TSH_OK;
 }
 
+int32_t tsh_comm_get_timeline(tsh_comm *c, tsh_comm_timeline *out, int32_t reset) {
+  if (!c || !out) return set_err(TSH_E_BAD_ARG, "comm / out is NULL");
+  std::lock_guard<std::mutex> lk(c->mu);  // never in the middle of a call
+  *out = c->tl;
+  out->scan_us = 1e-3 * (double)c->scan_ns.load(std::memory_order_relaxed);
+  out->world = c->world;
+  out->rank = c->rank;
+  out->transport = c->host_fn ? 1 : (rccl()->overridden ? 2 : 0);
+  if (reset) {
+    c->tl = tsh_comm_timeline{};
+    c->scan_ns.store(0, std::memory_order_relaxed);
+  }
+  return TSH_OK;
+}
+
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, int32_t nq, int32_t k, double thr,
                            const uint8_t *row_mask, int64_t *out_ids, double *out_dist, int32_t *out_count) {
   // arguments that are the same on every rank by contract are answered locally ...
@@ -522,7 +575,20 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
   G = std::min(G, nq);
   int32_t entries = tsh_default_block_entries(k);
   bool grew = false;
+  const double t_in = now_us();
+  tsh_comm_timeline &tl = c->tl;
+  struct CallClock {  // every way out of the call books its wall time
+    tsh_comm_timeline &tl;
+    double t0;
+    int32_t nq;
+    ~CallClock() {
+      tl.calls++;
+      tl.queries += nq;
+      tl.call_us += now_us() - t0;
+    }
+  } call_clock{tl, t_in, nq};
   int rc = comm_reserve_agreed(c, G, entries, k, &grew);
+  tl.reserve_us += now_us() - t_in;
   if (rc) return rc;
   const int32_t dim = local_rc == TSH_OK ? shard->dim : 0;
   const int dev = c->device;
@@ -537,20 +603,23 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
     }
     (void)hipSetDevice(dev);
     const int32_t q0 = g * G, gq = std::min(G, nq - q0);
+    const double t0 = now_us();
     scan_rc[(size_t)g] = tsh_search_shard(shard, queries + (size_t)q0 * dim, gq, k, row_mask, ent, c->d_mine[slot], nullptr);
+    c->scan_ns.fetch_add((int64_t)((now_us() - t0) * 1e3), std::memory_order_relaxed);
     if (scan_rc[(size_t)g]) scan_err[(size_t)g] = g_err;
   };
-  const double t_in = now_us();
   c->helper->post([&] { scan(0, 0, entries); });
   for (int32_t g = 0; g < n_groups; ++g) {
     const int32_t q0 = g * G, gq = std::min(G, nq - q0);
+    const double t_w = now_us();
     c->helper->wait();  // group g's blocks are in d_mine[g & 1]
+    tl.wait_scan_us += now_us() - t_w;
     if (g + 1 < n_groups) c->helper->post([&, g] { scan(g + 1, (g + 1) & 1, entries); });
     if (scan_rc[(size_t)g]) g_err = scan_err[(size_t)g];
     GroupOut go;
     rc = comm_exchange_group(c, shard, g & 1, scan_rc[(size_t)g], queries + (size_t)q0 * dim, gq, k, thr, entries,
                              out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0, &go);
-    c->c_groups++;
+    tl.groups++;
     int32_t ent = entries;
     bool lookahead_lost = false;
     for (int attempt = 0; rc == TSH_OK && go.need > 0; ++attempt) {
@@ -558,17 +627,20 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
       // The look-ahead scan must be done first; if the buffers have to grow its blocks go with them and it is redone
       if (attempt == 3) rc = set_err(TSH_E_OVERFLOW, "candidate blocks kept overflowing");
       if (rc) break;
+      const double t_r = now_us();
       c->helper->wait();
       ent = go.need;
-      c->c_retries++;
+      tl.retries++;
       rc = comm_reserve_agreed(c, G, ent, k, &grew);
       lookahead_lost |= grew;
       if (rc) break;
-      scan(g, g & 1, ent);
+      scan(g, g & 1, ent);  // on the calling thread: nothing overlaps a retry
+      tl.retry_scan_us += now_us() - t_r;
       if (scan_rc[(size_t)g]) g_err = scan_err[(size_t)g];
       go = GroupOut();
       rc = comm_exchange_group(c, shard, g & 1, scan_rc[(size_t)g], queries + (size_t)q0 * dim, gq, k, thr, ent,
                                out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0, &go);
+      tl.groups++;
     }
     if (rc == TSH_OK && lookahead_lost && g + 1 < n_groups) c->helper->post([&, g] { scan(g + 1, (g + 1) & 1, entries); });
     if (rc) {

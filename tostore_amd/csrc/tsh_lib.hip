@@ -366,6 +366,8 @@ struct Shard {
   std::atomic<uint64_t> mask_epoch_src{1};
 
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
+  std::atomic<int64_t> c_plane_fallbacks{0}, c_scan_fallbacks{0};  // batched calls degraded by a full device
+  std::atomic<int> planes_denied{0};  // batched calls left that go straight to the f32 kernel (the copy did not fit)
   double scan_us_sum = 0;  // guarded by ctx_mu
   int64_t scan_us_samples = 0;
   int64_t bytes = 0;
@@ -1946,6 +1948,8 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     out->scan_launches += s->c_scans.load();
     out->batch_launches += s->c_batches.load();
     out->fallback_searches += s->c_fallbacks.load();
+    out->batch_plane_fallbacks += s->c_plane_fallbacks.load();
+    out->batch_scan_fallbacks += s->c_scan_fallbacks.load();
     out->candidates_total += s->c_cands.load();
     int64_t b = s->bytes;
     {

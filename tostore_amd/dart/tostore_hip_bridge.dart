@@ -114,6 +114,8 @@ typedef _CommWorldC = Int32 Function(Pointer<Void>);
 typedef _CommWorldD = int Function(Pointer<Void>);
 typedef _CommSetGroupC = Int32 Function(Pointer<Void>, Int32);
 typedef _CommSetGroupD = int Function(Pointer<Void>, int);
+typedef _CommTimelineC = Int32 Function(Pointer<Void>, Pointer<TshCommTimeline>, Int32);
+typedef _CommTimelineD = int Function(Pointer<Void>, Pointer<TshCommTimeline>, int);
 typedef _SearchShardedC = Int32 Function(Pointer<Void>, Pointer<Void>, Pointer<Float>, Int32, Int32,
     Double, Pointer<Uint8>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
 typedef _SearchShardedD = int Function(Pointer<Void>, Pointer<Void>, Pointer<Float>, int, int,
@@ -152,6 +154,53 @@ final class TshCounters extends Struct {
   external int quarantinedRows;
   @Int64()
   external int fusedLaunches;
+  @Int64()
+  external int batchPlaneFallbacks;
+  @Int64()
+  external int batchScanFallbacks;
+}
+
+/// `tsh_comm_timeline` (include/tostore_hip.h): where this rank's tsh_search_sharded time went.  Field order and
+/// widths are checked against the header by tests/test_dart_bridge.py.
+final class TshCommTimeline extends Struct {
+  @Int64()
+  external int calls;
+  @Int64()
+  external int queries;
+  @Int64()
+  external int groups;
+  @Int64()
+  external int retries;
+  @Int32()
+  external int world;
+  @Int32()
+  external int rank;
+  @Int32()
+  external int transport;
+  @Int32()
+  external int reserved;
+  @Double()
+  external double callUs;
+  @Double()
+  external double reserveUs;
+  @Double()
+  external double waitScanUs;
+  @Double()
+  external double scanUs;
+  @Double()
+  external double exchangeWaitUs;
+  @Double()
+  external double gatherUs;
+  @Double()
+  external double sliceD2hUs;
+  @Double()
+  external double mergeUs;
+  @Double()
+  external double resultGatherUs;
+  @Double()
+  external double copyOutUs;
+  @Double()
+  external double retryScanUs;
 }
 
 /// `tsh_ngh_info` (include/tostore_hip.h): what tsh_index_open_ngh found.  Field order and
@@ -232,9 +281,10 @@ final class HipVectorBackend {
   static late final _CommWorldD _commWorld;
   static late final _CommSetGroupD _commSetGroup;
   static late final _SearchShardedD _searchSharded;
+  static late final _CommTimelineD _commTimeline;
 
   /// include/tostore_hip.h TSH_ABI_VERSION this file was written against.
-  static const int abiVersion = 2;
+  static const int abiVersion = 3;
 
   /// True when libtostore_hip.so is loadable, ABI-compatible and sees a GPU.
   static bool get available {
@@ -278,7 +328,9 @@ final class HipVectorBackend {
       _commSetGroup = lib.lookupFunction<_CommSetGroupC, _CommSetGroupD>('tsh_comm_set_group');
       _searchSharded =
           lib.lookupFunction<_SearchShardedC, _SearchShardedD>('tsh_search_sharded');
-      // the structs of this file are the version-2 layouts: any other library is not used
+      _commTimeline =
+          lib.lookupFunction<_CommTimelineC, _CommTimelineD>('tsh_comm_get_timeline');
+      // the structs of this file are the version-3 layouts: any other library is not used
       if (_abiVersion() != abiVersion || _deviceCount() < 1) return false;
       _lib = lib;
       return true;
@@ -552,9 +604,22 @@ final class HipVectorBackend {
       calloc.free(ticket);
       if (mask != nullptr) calloc.free(mask);
     }
-    // every ticket must be waited exactly once: from here on nothing may return before _wait ran
-    while (_ready(_handle, t) == 0) {
-      await Future<void>.delayed(Duration.zero); // yield to the event loop, as YieldController does
+    // every ticket must be waited exactly once: from here on nothing may return before _wait ran.
+    // The first polls yield with a zero delay (a short scan is over by then); after that the isolate sleeps
+    // between polls -- a zero-delay timer loop would keep its event loop at 100 % CPU for the whole scan, and
+    // several isolates or ranks per container share one CPU quota.
+    var polls = 0;
+    while (true) {
+      final ready = _ready(_handle, t);
+      if (ready > 0) break;
+      if (ready < 0) {
+        // the ticket is not pollable (it still must be waited: _wait reports the error and releases it)
+        Logger.warn('tsh_search_ready failed ($ready): ${_errorText()}', label: 'HipVectorBackend');
+        break;
+      }
+      polls++;
+      await Future<void>.delayed(
+          polls <= 4 ? Duration.zero : Duration(microseconds: polls <= 12 ? 50 : 200));
     }
     final ids = calloc<Int64>(topK);
     final dist = calloc<Double>(topK);
@@ -595,6 +660,9 @@ final class HipVectorBackend {
         'safeMode': r.safeMode,
         'deviceId': r.deviceId,
         'quarantinedRows': r.quarantinedRows,
+        'batchKernelLast': r.batchKernelLast,
+        'batchPlaneFallbacks': r.batchPlaneFallbacks,
+        'batchScanFallbacks': r.batchScanFallbacks,
       };
     } finally {
       calloc.free(c);
@@ -741,6 +809,38 @@ final class HipShardComm {
       calloc.free(dist);
       calloc.free(cnt);
       if (mask != nullptr) calloc.free(mask);
+    }
+  }
+
+  /// Where this rank's [search] time went, summed over the calls so far (tsh_comm_timeline): microseconds per
+  /// phase, for Logger diagnostics of a slow multi-GPU deployment.  `reset` starts a new period.
+  Map<String, num>? timeline({bool reset = false}) {
+    final t = calloc<TshCommTimeline>();
+    try {
+      if (HipVectorBackend._commTimeline(_comm, t, reset ? 1 : 0) != 0) return null;
+      final r = t.ref;
+      return {
+        'calls': r.calls,
+        'queries': r.queries,
+        'groups': r.groups,
+        'retries': r.retries,
+        'world': r.world,
+        'rank': r.rank,
+        'transport': r.transport,
+        'callUs': r.callUs,
+        'reserveUs': r.reserveUs,
+        'waitScanUs': r.waitScanUs,
+        'scanUs': r.scanUs,
+        'exchangeWaitUs': r.exchangeWaitUs,
+        'gatherUs': r.gatherUs,
+        'sliceD2hUs': r.sliceD2hUs,
+        'mergeUs': r.mergeUs,
+        'resultGatherUs': r.resultGatherUs,
+        'copyOutUs': r.copyOutUs,
+        'retryScanUs': r.retryScanUs,
+      };
+    } finally {
+      calloc.free(t);
     }
   }
 

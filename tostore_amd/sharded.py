@@ -237,6 +237,15 @@ class CommSearcher:
         """Queries per exchange (0 = by the size of the call).  Same value on every rank."""
         _ffi.check(_ffi.lib().tsh_comm_set_group(self._c, int(queries_per_exchange)))
 
+    def timeline(self, reset: bool = False) -> dict:
+        """Where this rank's tsh_search_sharded time went (tsh_comm_timeline, include/tostore_hip.h): sums of
+        microseconds per phase since the communicator was made or last reset."""
+        t = _ffi.TshCommTimeline()
+        _ffi.check(_ffi.lib().tsh_comm_get_timeline(self._c, ctypes.byref(t), 1 if reset else 0))
+        d = {k: getattr(t, k) for k, _ in t._fields_ if k != "reserved"}
+        d["transport"] = {0: "rccl", 1: "host callback", 2: "TSH_RCCL_LIB"}.get(d["transport"], d["transport"])
+        return d
+
     def close(self) -> None:
         if self._c:
             _ffi.lib().tsh_comm_destroy(self._c)
