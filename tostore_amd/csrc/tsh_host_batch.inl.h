@@ -15,7 +15,7 @@ struct BatchCtx {
   float *d_dense = nullptr;
   int64_t dense_cap = 0;  // floats
   uint32_t *d_ck = nullptr, *d_cr = nullptr, *d_cc = nullptr;
-  int64_t cand_total = 0;  // nq * cand_cap capacity
+  int64_t ck_cap = 0, cr_cap = 0;  // elements (nq * cand_cap wanted)
   uint8_t *d_blocks = nullptr, *h_blocks = nullptr;
   uint8_t *h_blocks_dev = nullptr;  // h_blocks as the device sees it (results are stored straight into it)
   uint32_t *d_final = nullptr;
@@ -44,7 +44,7 @@ struct BatchCtx {
   int32_t *h_fin_cnt = nullptr, *fin_cnt_dev = nullptr;   // nq
   uint32_t *h_fin_info = nullptr, *fin_info_dev = nullptr;  // nq: flags << 24 | count of each list's header
   int64_t fin_info_cap = 0;
-  int64_t fin_cap = 0, fin_q_cap = 0;
+  int64_t fin_ids_cap = 0, fin_dist_cap = 0, fin_q_cap = 0;
   double *d_sqrt_mag = nullptr, *h_sqrt_mag = nullptr;    // per query: sqrt(mag_a)
   int64_t sqrt_mag_cap = 0;
 };
@@ -278,10 +278,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 5, &b->bytes))) return rc;  // + thr, tau_est, kmax
   if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
   {
-    int64_t want = (int64_t)nq * cand_cap, c1 = b->cand_total, c2 = b->cand_total;
-    if ((rc = regrow(&b->d_ck, (uint32_t **)nullptr, &c1, want, &b->bytes))) return rc;
-    if ((rc = regrow(&b->d_cr, (uint32_t **)nullptr, &c2, want, &b->bytes))) return rc;
-    b->cand_total = std::max(b->cand_total, want);
+    // (each buffer keeps its own capacity: one that failed to grow must read as empty on the next call)
+    const int64_t want = (int64_t)nq * cand_cap;
+    if ((rc = regrow(&b->d_ck, (uint32_t **)nullptr, &b->ck_cap, want, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_cr, (uint32_t **)nullptr, &b->cr_cap, want, &b->bytes))) return rc;
     if ((rc = regrow(&b->d_cc, (uint32_t **)nullptr, &b->cc_cap, (int64_t)nq_pad * CC_STRIDE, &b->bytes))) return rc;
   }
   if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
@@ -391,10 +391,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // nothing but the device's own candidate lists goes into them
   const bool gpu_final = out->on_final && !out->d_blocks && quar_sel.empty() && entries <= RF_MAX && k <= entries;
   if (gpu_final) {
-    int64_t c1 = b->fin_cap, c2 = b->fin_cap;
-    if ((rc = regrow_pinned(&b->h_fin_ids, &b->fin_ids_dev, &c1, (int64_t)nq * k, &b->bytes))) return rc;
-    if ((rc = regrow_pinned(&b->h_fin_dist, &b->fin_dist_dev, &c2, (int64_t)nq * k, &b->bytes))) return rc;
-    b->fin_cap = std::min(c1, c2);
+    if ((rc = regrow_pinned(&b->h_fin_ids, &b->fin_ids_dev, &b->fin_ids_cap, (int64_t)nq * k, &b->bytes))) return rc;
+    if ((rc = regrow_pinned(&b->h_fin_dist, &b->fin_dist_dev, &b->fin_dist_cap, (int64_t)nq * k, &b->bytes))) return rc;
     if ((rc = regrow_pinned(&b->h_fin_cnt, &b->fin_cnt_dev, &b->fin_q_cap, (int64_t)nq, &b->bytes))) return rc;
     if ((rc = regrow_pinned(&b->h_fin_info, &b->fin_info_dev, &b->fin_info_cap, (int64_t)nq, &b->bytes))) return rc;
     if ((rc = regrow(&b->d_sqrt_mag, &b->h_sqrt_mag, &b->sqrt_mag_cap, (int64_t)nq, &b->bytes))) return rc;
