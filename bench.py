@@ -29,6 +29,14 @@ configurations measured in the same process (C1 latency, C3 1024-query
 batches, C5 masked scans); a side leg that fails reports its error text and
 never takes the headline down.
 
+N > 1 lines carry `exchange_timeline` (where every rank's tsh_search_sharded time
+went, phase by phase, against ms_per_step), `host_cpu` per rank, and a `side.C4_per_rank`
+leg at BASELINE.json's C4 per-rank shape (1.25 M x 1536 per rank, inner product): the strong
+(C2) and the weak (C4) point of the scaling curve from one command.
+
+The CPU oracle is reached through bench_check.py only, and only outside timed regions
+(`timed_region` below; bench_check refuses to load or run inside one).
+
 The device side sits behind `Env` so that tests/test_bench_logic.py can drive
 every line of the arithmetic below on a machine without a GPU.
 """
@@ -44,6 +52,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+import contextlib
+
+
+@contextlib.contextmanager
+def timed_region():
+    """Everything measured runs inside one of these: bench_check.py (the oracle) refuses to load or run meanwhile."""
+    prev = os.environ.get("TSH_BENCH_TIMED")
+    os.environ["TSH_BENCH_TIMED"] = "1"
+    try:
+        yield
+    finally:
+        if prev is None:
+            del os.environ["TSH_BENCH_TIMED"]
+        else:
+            os.environ["TSH_BENCH_TIMED"] = prev
+
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3  # same guide: dense f32 MFMA
@@ -101,6 +126,13 @@ def parse(argv=None):
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="N > 1 started without WORLD_SIZE: seconds before the ranks this process started are given up")
     ap.add_argument("--ranks-share-gpu", action="store_true", help="testing: every rank uses cuda:0")
+    ap.add_argument("--fake-rccl", action="store_true",
+                    help="testing (implies --ranks-share-gpu): the library's RCCL branch over tests/fake_rccl, the "
+                         "stand-in that lets several ranks share one GPU (TSH_RCCL_LIB); torch's own collectives run over gloo")
+    ap.add_argument("--c4-rows-per-rank", type=int, default=1_250_000,
+                    help="N > 1: rows per rank of the side.C4_per_rank leg (BASELINE.json C4: 10 M x 1536 over 8 GPUs); 0 = skip")
+    ap.add_argument("--c3-check", type=int, default=1024, help="side.C3: queries of one batch checked against the oracle")
+    ap.add_argument("--c5-check", type=int, default=100, help="side.C5: queries checked per selectivity")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the N>1 code path (process group, all-gather, merge) even with one rank")
     a = ap.parse_args(argv)
@@ -109,6 +141,8 @@ def parse(argv=None):
     a.dim = preset[1] if a.dim is None else a.dim
     a.k = preset[2] if a.k is None else a.k
     a.metric = preset[3] if a.metric is None else a.metric
+    if a.fake_rccl:
+        a.ranks_share_gpu = True
     if a.ranks_share_gpu and a.backend == "nccl":
         a.backend = "gloo"  # RCCL refuses two ranks on one device
     return a
@@ -137,11 +171,6 @@ def sharded_group(group, count):
     """N > 1: up to --group queries per all-gather / merge; short runs use smaller groups so that
     at least four of them pipeline (scan of group g+1 behind the exchange of group g)."""
     return int(max(1, max(16, min(group or 64, count // 4))))
-
-
-def cpu_sample_size(per_query_s, budget_s, pool):
-    """Queries of the single-thread cpu_baseline leg: what fits the budget, 2..32, never more than the pool."""
-    return int(max(1, min(pool, max(2, min(32, budget_s / max(per_query_s, 1e-3))))))
 
 
 def clean_json(o):
@@ -189,39 +218,6 @@ def make_mask(n, keep, kind, seed=20260614):
 # ------------------------------------------------------------------ device side
 CORPUS_SEED = 20260612
 CORPUS_CHUNK = 131072  # rows per generator chunk: chunk c depends on (seed, c) only, so a rank generates just its own
-
-
-def order_keys(d):
-    """double.compareTo as integers (NaN greatest, -0 < +0), for merging oracle answers of row chunks."""
-    b = np.ascontiguousarray(d, np.float64).view(np.int64)
-    key = np.where(b < 0, ~b, b | np.int64(-2 ** 63)).view(np.uint64)
-    return np.where(np.isnan(d), np.uint64(2 ** 64 - 1), key)
-
-
-def oracle_topk_stream(chunks, queries, metric, k, row_mask=None):
-    """The exhaustive CPU oracle over a corpus that arrives as (first row id, rows) chunks (a sharded corpus is
-    never whole in one place): the oracle's own top k of every chunk, merged by (compareTo order, row id).
-    -> (ids[nq,k], dist[nq,k], cnt[nq]) like oracle.search_heap_many_mt."""
-    import oracle
-
-    nq = len(queries)
-    acc = [([], []) for _ in range(nq)]
-    bits = None if row_mask is None else np.unpackbits(np.asarray(row_mask, np.uint8), bitorder="little")
-    for r0, rows in chunks:
-        keep = None if bits is None else np.packbits(bits[r0:r0 + len(rows)], bitorder="little")
-        ids, dist, cnt = oracle.search_heap_many_mt(rows, queries, metric, k, None, keep)
-        for q in range(nq):
-            acc[q][0].append(ids[q, :cnt[q]] + r0)
-            acc[q][1].append(dist[q, :cnt[q]])
-    out_ids = np.full((nq, k), -1, np.int64)
-    out_dist = np.full((nq, k), np.nan, np.float64)
-    out_cnt = np.zeros(nq, np.int32)
-    for q in range(nq):
-        i, d = np.concatenate(acc[q][0]), np.concatenate(acc[q][1])
-        order = np.lexsort((i, order_keys(d)))[:k]
-        out_cnt[q] = len(order)
-        out_ids[q, :len(order)], out_dist[q, :len(order)] = i[order], d[order]
-    return out_ids, out_dist, out_cnt
 
 
 class Env:
@@ -315,34 +311,61 @@ class Env:
         from tostore_amd.sharded import CommSearcher, ShardedSearcher
 
         want = self.a.exchange
+        fake = bool(os.environ.get("TSH_RCCL_LIB"))  # tests/fake_rccl: the RCCL branch with ranks sharing a GPU
         if want == "torch":
             self.exchange = "torch.distributed all_gather_into_tensor (%s) + tsh_merge_candidates" % self.a.backend
             return ShardedSearcher(idx)
-        if self.a.backend == "gloo":  # several ranks on one GPU: the library's protocol over a host transport
+        if self.a.backend == "gloo" and not fake:  # several ranks on one GPU: the library's protocol over a host transport
             self.exchange = "tsh_search_sharded over a host transport (gloo)"
             return CommSearcher.over_torch(idx, device=self.local_rank)
+        # Every step that can fail on one rank alone is followed by an agreement, so that the ranks take the same
+        # branch: a rank that skipped a collective the others entered would hang the job until --launch-timeout
         cs, err = None, None
         try:
             box = [CommSearcher.unique_id() if self.rank == 0 else None]
-            self.dist.broadcast_object_list(box, src=0)
-            cs = CommSearcher(idx, self.world, self.rank, box[0], self.local_rank)
-            if want == "auto":  # the library's exchange against torch's on a few queries, before anything is timed
-                ref = ShardedSearcher(idx)
-                qs = make_queries(6, idx.dim, idx.metric, seed=20260617)
-                got, exp = cs.search(qs, 10), ref.search(qs, 10)
-                if not (np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])):
-                    raise RuntimeError("tsh_search_sharded and the torch exchange disagree")
         except Exception as e:  # noqa: BLE001
-            if want == "capi":
-                raise
-            err = repr(e)
+            box, err = [None], repr(e)
+        self.dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            err = err or "rank 0 could not make a communicator id"
+        else:
+            try:
+                cs = CommSearcher(idx, self.world, self.rank, box[0], self.local_rank)  # collective inside the library
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
         bad = self.reduce_max(1.0 if err else 0.0)
+        if bad == 0.0 and want == "auto":
+            # the library's exchange against torch's on a few queries, before anything is timed
+            qs = make_queries(6, idx.dim, idx.metric, seed=20260617)
+            got = None
+            try:
+                got = cs.search(qs, 10)
+            except Exception as e:  # noqa: BLE001 -- (a rank failing locally stays in the library's collective)
+                err = repr(e)
+            bad = self.reduce_max(1.0 if err else 0.0)
+            if bad == 0.0:
+                exp = ShardedSearcher(idx).search(qs, 10)  # collective: entered by all ranks or (above) by none
+                if not (np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])):
+                    err = "tsh_search_sharded and the torch exchange disagree"
+                bad = self.reduce_max(1.0 if err else 0.0)
         if bad == 0.0:
-            self.exchange = "tsh_search_sharded (RCCL inside the library)"
+            self.exchange = "tsh_search_sharded (%s inside the library)" % ("tests/fake_rccl stand-in" if fake else "RCCL")
             return cs
-        self.exchange = "torch.distributed all_gather_into_tensor (nccl) + tsh_merge_candidates"
+        if want == "capi":
+            raise RuntimeError("tsh_search_sharded is not usable: %s" % (err or "another rank failed"))
+        if cs is not None:
+            cs.close()
+        self.exchange = "torch.distributed all_gather_into_tensor (%s) + tsh_merge_candidates" % self.a.backend
         self.exchange_note = "tsh_search_sharded failed its check on some rank (%s): fell back" % (err or "another rank")
         return ShardedSearcher(idx)
+
+    def gather_objects(self, obj):
+        """Every rank's object, on rank 0 (None elsewhere)."""
+        if self.dist is None:
+            return [obj]
+        box = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, box, dst=0)
+        return box
 
     def max_inflight(self):
         return int(self._ffi.lib().tsh_max_inflight())
@@ -373,17 +396,6 @@ class Env:
 
 
 # ------------------------------------------------------------------ helpers shared by the legs
-def compare_with_oracle(got, ref):
-    """got / ref: (ids[nq,k], dist[nq,k], cnt[nq]).  -> (recall, bit_exact)."""
-    g_ids, g_dist, g_cnt = got
-    r_ids, r_dist, r_cnt = ref
-    nq = len(r_cnt)
-    hits = sum(len(set(g_ids[i, :g_cnt[i]].tolist()) & set(r_ids[i, :r_cnt[i]].tolist())) for i in range(nq))
-    same = all(g_cnt[i] == r_cnt[i] and np.array_equal(g_ids[i, :g_cnt[i]], r_ids[i, :r_cnt[i]])
-               and np.array_equal(g_dist[i, :g_cnt[i]], r_dist[i, :r_cnt[i]]) for i in range(nq))
-    return hits / max(int(np.sum(r_cnt[:nq])), 1), bool(same)
-
-
 def pmc_traffic(rows, d):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (not measured in this run:
     counters need their own rocprofv3 passes) -> (bytes or None, source or None)."""
@@ -464,33 +476,36 @@ def measure_batch(env, idx, host_rows, metric, n, d, k, nq, steps, warm, kernel,
         idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)
     env.fence()
     per_step = []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        t1 = time.perf_counter()
-        ids, dist, cnt = idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)  # synchronous: results are on the host
-        per_step.append(time.perf_counter() - t1)
-    env.fence()
-    mean_step = (time.perf_counter() - t0) / steps
+    with timed_region():
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t1 = time.perf_counter()
+            ids, dist, cnt = idx.search(qs[(i % 2) * nq:(i % 2 + 1) * nq], k)  # synchronous: results are on the host
+            per_step.append(time.perf_counter() - t1)
+        env.fence()
+        mean_step = (time.perf_counter() - t0) / steps
+        gemm_us, flops = idx.bench_batch(qs[:nq], k, iters=3)
+        two = two_callers_batch(env, idx, qs, nq, k, steps)
     # the container's CPU quota freezes the process for milliseconds now and then (tools/throttle_probe.py): the
-    # MEDIAN step is the measurement, the mean is reported beside it
+    # MEDIAN step is the measurement; mean, p99 and the slowest step are reported beside it
+    srt = np.sort(np.asarray(per_step))
     elapsed = float(np.median(per_step)) * steps
-    gemm_us, flops = idx.bench_batch(qs[:nq], k, iters=3)
     ran = idx.counters()["batch_kernel_last"]  # what auto resolved to
     out = {"value": nq * steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warm,
-           "ms_per_step": elapsed / steps * 1e3, "ms_per_step_mean": mean_step * 1e3, "timing": "median step",
+           "ms_per_step": elapsed / steps * 1e3, "ms_per_step_mean": mean_step * 1e3,
+           "ms_per_step_p99": float(srt[min(len(srt) - 1, int(math.ceil(len(srt) * 0.99)) - 1)]) * 1e3,
+           "ms_per_step_max": float(srt[-1]) * 1e3, "timing": "median step",
            "queries_per_step": nq, "callers": 1,
-           "two_callers": two_callers_batch(env, idx, qs, nq, k, steps),
+           "two_callers": two,
            "dtype": BATCH_DTYPE.get(ran, str(ran)), "batch_kernel": BATCH_KERNEL_NAME.get(ran, str(ran)),
            "roofline": batch_roofline(ran, gemm_us, flops),
            "key_passes_share_of_step": gemm_us * 1e-3 / (elapsed / steps * 1e3)}
     if host_rows is not None and check_queries > 0:
-        import oracle
+        import bench_check
 
         m = min(check_queries, nq)
         base = ((steps - 1) % 2) * nq
-        ref = oracle.search_heap_many_mt(host_rows, qs[base:base + m], metric, k)
-        rec, same = compare_with_oracle((ids[:m], dist[:m], cnt[:m]), ref)
-        out["recall_at_k"], out["ids_and_distances_bit_exact"], out["checked_queries"] = rec, same, m
+        out.update(bench_check.check_answers(host_rows, qs[base:base + m], metric, k, (ids, dist, cnt)))
     c = idx.counters()
     out["counters"] = {k2: c[k2] for k2 in ("batch_launches", "scan_launches", "fallback_searches")}
     out["counters"]["candidates_per_query"] = c["candidates_total"] / max(c["searches"], 1)
@@ -509,7 +524,8 @@ def bench_batch(a, env, idx, host_rows, metric):
            "config": {"workload": "C3: %dx%d f32, %s, k=%d, %d-query batch" % (n, d, a.metric, k, nq),
                       "batch_kernel": r["batch_kernel"]}}
     for key in ("roofline", "recall_at_k", "ids_and_distances_bit_exact", "checked_queries", "counters",
-                "key_passes_share_of_step", "callers", "two_callers", "ms_per_step_mean"):
+                "key_passes_share_of_step", "callers", "two_callers", "ms_per_step_mean", "ms_per_step_p99",
+                "ms_per_step_max"):
         if key in r:
             out[key] = r[key]
     idx.close()
@@ -517,65 +533,70 @@ def bench_batch(a, env, idx, host_rows, metric):
 
 
 # ------------------------------------------------------------------ side legs (N = 1, after the headline)
-def side_c5(env, idx, host_rows, queries, metric, n, d, k):
-    """C5: the headline corpus behind a WHERE pre-filter bitmask, Bernoulli keep 1 / 10 / 50 %."""
-    out = {"workload": "C5: %dx%d f32, L2, k=%d, device-side row bitmask (Bernoulli)" % (n, d, k),
+def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
+    """C5: the headline corpus behind a WHERE pre-filter bitmask -- Bernoulli keep
+    1 / 10 / 50 / 100 % and one contiguous id range of 10 %."""
+    out = {"workload": "C5: %dx%d f32, L2, k=%d, device-side row bitmask" % (n, d, k),
            "note": "value = every query scans its kept rows on its own (masked HBM scan, pipelined, 64 queries per "
                    "call); library_default_path = the same calls with the library free to choose"}
     idx.set_batch_min_nq(0)
-    for keep in (0.01, 0.10, 0.50):
-        mask, kept = make_mask(n, keep, "bernoulli")
-        cnt = 1024
-        sel = [i % len(queries) for i in range(cnt)]
+    cnt = 1024
+    sel = [i % len(queries) for i in range(cnt)]
+    m = max(0, min(check, cnt))
+    for keep, kind in ((0.01, "bernoulli"), (0.10, "bernoulli"), (0.50, "bernoulli"), (1.00, "bernoulli"), (0.10, "range")):
+        mask, kept = make_mask(n, keep, kind)
         idx.search(queries[sel[:32]], k, None, mask)
         env.fence()
         c0 = idx.counters()
-        t0 = time.perf_counter()
-        for g0 in range(0, cnt, 64):
-            got = idx.search(queries[sel[g0:g0 + 64]], k, None, mask)
-        env.fence()
-        el = time.perf_counter() - t0
-        c1 = idx.counters()
-        scan_us = idx.bench_scan(queries[0], iters=20, row_mask=mask)
+        got = [None] * (cnt // 64)
+        with timed_region():
+            t0 = time.perf_counter()
+            for g in range(cnt // 64):
+                got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mask)
+            env.fence()
+            el = time.perf_counter() - t0
+            c1 = idx.counters()
+            scan_us = idx.bench_scan(queries[0], iters=20, row_mask=mask)
         useful = float(kept) * d * 4 + n / 8
-        ent = {"value": cnt / el, "unit": "queries/s", "ms_per_step": el / cnt * 1e3, "kept_rows": kept,
+        ent = {"value": cnt / el, "unit": "queries/s", "ms_per_step": el / cnt * 1e3, "kept_rows": kept, "mask": kind,
                "roofline": {"bound": "hbm", "achieved": useful / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": useful / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "kernel": "tsh::scan_kernel<MASKED>", "kernel_us": scan_us,
                             "algorithmic_bytes_per_launch": useful},
                "fallback_searches": c1["fallback_searches"] - c0["fallback_searches"]}
-        if host_rows is not None:
-            import oracle
-
-            m = 8
-            ref = oracle.search_heap_many_mt(host_rows, queries[sel[cnt - 64:cnt - 64 + m]], metric, k, None, mask)
-            ent["recall_at_k"], ent["ids_and_distances_bit_exact"] = compare_with_oracle(
-                tuple(x[:m] for x in got), ref)
-            ent["checked_queries"] = m
+        tail = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None
         # the same 64-query calls with the library's own choice of path (cost model: for a call of this size it
         # scores all queries in one matrix-core pass and applies the mask in the epilogue)
+        tail2 = None
         try:
             idx.set_batch_min_nq(1)
             idx.search(queries[sel[:64]], k, None, mask)
             env.fence()
             c0 = idx.counters()
-            t0 = time.perf_counter()
-            for g0 in range(0, cnt, 64):
-                got2 = idx.search(queries[sel[g0:g0 + 64]], k, None, mask)
-            env.fence()
-            el2 = time.perf_counter() - t0
+            with timed_region():
+                t0 = time.perf_counter()
+                for g in range(cnt // 64):
+                    got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mask)
+                env.fence()
+                el2 = time.perf_counter() - t0
             c1 = idx.counters()
             ent["library_default_path"] = {"value": cnt / el2, "unit": "queries/s", "ms_per_step": el2 / cnt * 1e3,
                                            "batch_launches": c1["batch_launches"] - c0["batch_launches"],
                                            "scan_launches": c1["scan_launches"] - c0["scan_launches"]}
-            if host_rows is not None:
-                ent["library_default_path"]["ids_and_distances_bit_exact"] = compare_with_oracle(
-                    tuple(x[:m] for x in got2), ref)[1]
+            tail2 = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None
         except Exception as e:  # noqa: BLE001
             ent["library_default_path"] = {"error": repr(e)}
         finally:
             idx.set_batch_min_nq(0)
-        out["keep_%d%%" % round(keep * 100)] = ent
+        if host_rows is not None and m:
+            import bench_check
+
+            ref = bench_check.oracle_answers(host_rows, queries[sel[cnt - m:]], metric, k, mask)
+            ent["recall_at_k"], ent["ids_and_distances_bit_exact"] = bench_check.compare(tail, ref)
+            ent["checked_queries"] = m
+            if tail2 is not None:
+                ent["library_default_path"]["ids_and_distances_bit_exact"] = bench_check.compare(tail2, ref)[1]
+        out["keep_%d%%%s" % (round(keep * 100), "" if kind == "bernoulli" else "_" + kind)] = ent
     return out
 
 
@@ -589,62 +610,31 @@ def side_c1(env, with_oracle):
         for i in range(50):
             idx.search(qs[i], k)
         lat = []
-        for i in range(1000):
-            t1 = time.perf_counter()
-            idx.search(qs[i], k)
-            lat.append(time.perf_counter() - t1)
-        lat = np.sort(np.asarray(lat)) * 1e6
-        env.fence()
-        t0 = time.perf_counter()
-        for g0 in range(0, 1000, 64):
-            idx.search(qs[g0:g0 + 64], k)
-        env.fence()
-        el = time.perf_counter() - t0
-        scan_us = idx.bench_scan(qs[0], iters=50)
+        with timed_region():
+            for i in range(1000):
+                t1 = time.perf_counter()
+                idx.search(qs[i], k)
+                lat.append(time.perf_counter() - t1)
+            lat = np.sort(np.asarray(lat)) * 1e6
+            env.fence()
+            t0 = time.perf_counter()
+            for g0 in range(0, 1000, 64):
+                idx.search(qs[g0:g0 + 64], k)
+            env.fence()
+            el = time.perf_counter() - t0
+            scan_us = idx.bench_scan(qs[0], iters=50)
         out = {"workload": "C1: %dx%d f32, L2, k=%d, single query" % (n, d, k),
                "latency_us": {"p50": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)]),
                               "mean": float(lat.mean()), "queries": len(lat)},
                "value": 1000 / el, "unit": "queries/s (pipelined, 64 per call)", "scan_kernel_us": scan_us}
         if host_rows is not None:
-            import oracle
+            import bench_check
 
             got = idx.search(qs, k)
-            t1 = time.perf_counter()
-            ref = oracle.search_heap_many_mt(host_rows, qs, metric, k)
-            out["recall_at_k"], out["ids_and_distances_bit_exact"] = compare_with_oracle(got, ref)
+            ref = bench_check.oracle_answers(host_rows, qs, metric, k)
+            out["recall_at_k"], out["ids_and_distances_bit_exact"] = bench_check.compare(got, ref)
             out["checked_queries"] = len(qs)
-            t1 = time.perf_counter()
-            for i in range(20):
-                oracle.search_heap(host_rows, qs[i], metric, k)
-            out["cpu_baseline"] = {"value": 20 / (time.perf_counter() - t1), "unit": "queries/s", "cores": 1,
-                                   "kind": "port", "sample": "20 queries, oracle/vs_oracle.c single thread"}
-            # context: what the reference's OWN search -- the approximate NGH graph walk this
-            # build replaces -- returns on the same rows and queries.  A restatement (oracle/ngh_ann.c), not the
-            # reference: its PQ training draws come from NumPy instead of Dart's Random(42), nothing here was produced
-            # by a Dart VM, so the numbers are properties of the restatement and must not be quoted as ToStore's.
-            try:
-                t1 = time.perf_counter()
-                ann = oracle.NghAnnIndex(d, metric, host_rows[:2500])
-                for b0 in range(2500, n, 2500):
-                    ann.insert_batch(host_rows[b0:b0 + 2500])
-                t_build = time.perf_counter() - t1
-                nqa = 200
-                ann.counters()
-                t1 = time.perf_counter()
-                found = [ann.search(qs[i], k)[0] for i in range(nqa)]
-                t_search = time.perf_counter() - t1
-                ctr = ann.counters()
-                hit = sum(len(np.intersect1d(found[i], ref[0][i][:k])) for i in range(nqa))
-                out["reference_ann_restated"] = {
-                    "label": "restatement of the reference's NGH graph search (PQ/ADC beam search + exact re-rank), CPU, "
-                             "1 thread, in memory; unverifiable here: Dart's PRNG differs, no Dart VM in the image",
-                    "recall_at_k": hit / float(nqa * k), "ms_per_query": 1e3 * t_search / nqa, "queries": nqa,
-                    "build_seconds": t_build, "adc_evaluations_per_query": ctr["adc_evaluations"] / nqa,
-                    "hops_per_query": ctr["hops"] / nqa,
-                    "defaults": "M=%d K=%d R=64 efSearch=64 efConstruction=128 alpha=1.2" % (ann.subspaces, ann.centroids)}
-                ann.close()
-            except Exception as e:  # context only: never fails the line
-                out["reference_ann_restated"] = {"error": repr(e)}
+            out.update(bench_check.c1_cpu_context(host_rows, qs, metric, k, ref[0]))
         return out
     finally:
         idx.close()
@@ -657,7 +647,7 @@ def side_c3(env, a, with_oracle):
     idx, host_rows = env.build_index(d, metric, n, 0, n, keep_host=with_oracle)
     try:
         out = {"workload": "C3: %dx%d f32, cosine, k=%d, %d-query batch (matrix-core path)" % (n, d, k, nq)}
-        r = measure_batch(env, idx, host_rows, metric, n, d, k, nq, 10, 2, 3, 128)
+        r = measure_batch(env, idx, host_rows, metric, n, d, k, nq, 10, 2, 3, a.c3_check)
         out.update(r)
         try:
             out["f32_mfma_variant"] = measure_batch(env, idx, host_rows, metric, n, d, k, nq, 3, 1, 0, 16)
@@ -690,34 +680,48 @@ def make_env(a):
     return getattr(importlib.import_module(mod), cls)(a)
 
 
-def run_bench(a, env=None):
-    env = env or make_env(a)
-    metric = METRICS[a.metric]
-    world, rank = env.world, env.rank
-    n, d, k = a.rows, a.dim, a.k
+TIMELINE_MAIN = ("reserve_us", "wait_scan_us", "exchange_wait_us", "merge_us", "result_gather_us", "copy_out_us",
+                 "retry_scan_us")  # the calling thread's phases of tsh_search_sharded: they add up to call_us
 
-    # ---- resident corpus: this rank generates and holds its own row range only -------
-    per = (n + world - 1) // world
-    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
-    # a host copy for the CPU baseline / recall check, unless the corpus is too big for one (C4: 61 GB): then the
-    # oracle sees it chunk by chunk, as in a sharded run
-    big = float(n) * d * 4 > 16e9
-    want_host = rank == 0 and world == 1 and not a.no_cpu_baseline and not big
-    idx, host_rows = env.build_index(d, metric, n, lo, hi, keep_host=want_host)
 
-    if a.batch > 0:
-        return bench_batch(a, env, idx, host_rows, metric)
+def exchange_timeline(per_rank, steps_total, ms_per_step):
+    """The N > 1 line's account of where the time went: every rank's tsh_comm_timeline over the timed regions
+    (sums of microseconds -> ms per step), the calling thread's phases summed and set against ms_per_step, and the
+    slowest rank of every phase (a slow first 8-GPU run must say where it was slow)."""
+    ranks = []
+    for r in per_rank:
+        t = r.get("timeline")
+        if not t:
+            ranks.append({"rank": r["rank"], "timeline": None, "host_cpu": r.get("host_cpu")})
+            continue
+        ent = {"rank": r["rank"], "calls": t["calls"], "groups": t["groups"], "retries": t["retries"],
+               "host_cpu": r.get("host_cpu")}
+        for key in ("call_us",) + TIMELINE_MAIN + ("scan_us", "gather_us", "slice_d2h_us"):
+            ent[key.replace("_us", "_ms_per_step")] = t[key] * 1e-3 / max(steps_total, 1)
+        ent["phases_sum_ms_per_step"] = sum(t[key] for key in TIMELINE_MAIN) * 1e-3 / max(steps_total, 1)
+        ranks.append(ent)
+    have = [e for e in ranks if e.get("calls") is not None]
+    out = {"unit": "ms per step (sums over the timed regions / timed steps), per rank",
+           "phases": "calling thread: reserve | wait_scan | exchange_wait (= block all-gather + this rank's slice to the "
+                     "host) | merge | result_gather | copy_out (+ retry_scan); scan runs beside them on a helper "
+                     "thread; gather + slice_d2h are the device-side split of exchange_wait",
+           "ms_per_step": ms_per_step, "ranks": ranks}
+    if have:
+        worst = max(have, key=lambda e: e["call_ms_per_step"])
+        out["slowest_rank"] = worst["rank"]
+        out["phases_sum_ms_per_step"] = worst["phases_sum_ms_per_step"]
+        out["call_ms_per_step"] = worst["call_ms_per_step"]
+        out["phases_sum_over_ms_per_step"] = worst["phases_sum_ms_per_step"] / ms_per_step if ms_per_step > 0 else None
+        out["max_over_ranks"] = {key: max(e[key] for e in have) for key in have[0] if key.endswith("_ms_per_step")}
+    return out
 
-    pool = query_pool_size(a.steps, a.warmup, a.recall_queries if world == 1 else 0)
-    queries = make_queries(pool, d, metric)
+
+def measure_single(env, a, idx, searcher, queries, k, row_mask, steps, warmup, repeats):
+    """The headline measurement: W warm-up steps, then `repeats` timed regions of exactly `steps` single-query
+    searches each, every region between a barrier + device synchronise on both sides, MAX over ranks.
+    -> dict(regions, scan_us, scan samples, per-rank records on rank 0, cgroup stats)."""
     nqp = len(queries)
-    searcher = env.searcher(idx)
     py_groups = getattr(searcher, "python_groups", True)  # False: the library forms the groups (tsh_search_sharded)
-    idx.set_batch_min_nq(0)  # headline workload: every query scans the corpus on its own (no MFMA batching)
-
-    row_mask = None
-    if a.mask_keep > 0:  # C5 as the main line
-        row_mask, _ = make_mask(n, a.mask_keep, a.mask_kind)
 
     def one(i):
         q = queries[i % nqp]
@@ -754,6 +758,147 @@ def run_bench(a, env=None):
             while pend:
                 idx.wait(pend.popleft())
 
+    run(0, warmup)
+    regions = []
+    env.fence()
+    has_tl = hasattr(searcher, "timeline")
+    if has_tl:
+        searcher.timeline(reset=True)
+    cg0, t_cg0 = cgroup_cpu_stat(), time.perf_counter()
+    cpu0 = time.process_time()
+    c0 = idx.counters()
+    with timed_region():
+        for r in range(repeats):
+            env.fence()
+            t0 = time.perf_counter()
+            run(warmup + r * steps, steps)
+            env.fence()
+            regions.append(env.reduce_max(time.perf_counter() - t0))
+    c1 = idx.counters()
+    cpu1 = time.process_time()
+    cg1, t_cg1 = cgroup_cpu_stat(), time.perf_counter()
+    ns = c1["scan_us_samples"] - c0["scan_us_samples"]
+    scan_us = (c1["scan_us_sum"] - c0["scan_us_sum"]) / ns if ns > 0 else float("nan")
+    mine = {"rank": env.rank, "timeline": searcher.timeline() if has_tl else None,
+            "host_cpu": {"cpus_busy": (cpu1 - cpu0) / max(t_cg1 - t_cg0, 1e-9), "cpu_s": cpu1 - cpu0,
+                         "wall_s": t_cg1 - t_cg0, "note": "this rank's process, all threads, over its timed regions"},
+            "scan_us": scan_us}
+    per_rank = env.gather_objects(mine) if env.world > 1 else [mine]
+    host_cpu = None
+    if cg0 and cg1:  # host side of the timed regions, all ranks together: CPUs busy, and whether the quota throttled
+        host_cpu = {"cpus_busy": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 / max(t_cg1 - t_cg0, 1e-9),
+                    "throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                    "throttled_ms": (cg1.get("throttled_usec", cg1.get("throttled_time", 0)) -
+                                     cg0.get("throttled_usec", cg0.get("throttled_time", 0))) / 1e3,
+                    "wall_s": t_cg1 - t_cg0}
+    return {"regions": regions, "scan_us": scan_us, "scan_samples": int(ns), "per_rank": per_rank, "host_cpu": host_cpu,
+            "one": one, "py_groups": py_groups}
+
+
+def side_c4_per_rank(env, a):
+    """N > 1: BASELINE.json's C4 at its per-rank shape -- every rank holds --c4-rows-per-rank (1.25 M) x 1536 rows,
+    inner product, k = 100, so 8 ranks are the whole 10 M x 1536 configuration and fewer ranks the same per-GPU load
+    (the WEAK-scaling point beside the headline's strong one).  Single queries through the exchange like the headline,
+    then 1024-query calls (every shard on its matrix cores).  Collective: every rank runs it."""
+    d, k, metric = 1536, 100, METRICS["ip"]
+    per = int(a.c4_rows_per_rank)
+    n = per * env.world
+    lo, hi = env.rank * per, (env.rank + 1) * per
+    idx, _ = env.build_index(d, metric, n, lo, hi, keep_host=False)
+    searcher = None
+    try:
+        steps, warmup = max(a.steps, 20), min(max(a.warmup, 2), 10)
+        queries = make_queries(max(1024, steps + warmup), d, metric, seed=20260618)
+        searcher = env.searcher(idx)
+        idx.set_batch_min_nq(0)
+        repeats = max(3, min(10, auto_repeats(steps, a.repeats)))
+        m = measure_single(env, a, idx, searcher, queries, k, None, steps, warmup, repeats)
+        elapsed = float(np.median(m["regions"]))
+        scan_us = env.reduce_max(m["scan_us"] if math.isfinite(m["scan_us"]) else idx.bench_scan(queries[0], iters=10))
+        shard_bytes = float(hi - lo) * d * 4
+        out = None
+        # 1024 queries per call: the library hands each shard's share to its matrix cores
+        idx.set_batch_min_nq(1)
+        bt = []
+        searcher.search(queries[:1024], k)
+        if hasattr(searcher, "timeline"):
+            searcher.timeline(reset=True)
+        with timed_region():
+            for i in range(3):
+                env.fence()
+                t0 = time.perf_counter()
+                got_b = searcher.search(queries[:1024], k)
+                env.fence()
+                bt.append(env.reduce_max(time.perf_counter() - t0))
+        mine_b = {"rank": env.rank, "timeline": searcher.timeline() if hasattr(searcher, "timeline") else None}
+        per_rank_b = env.gather_objects(mine_b)
+        idx.set_batch_min_nq(0)
+        got_s = searcher.search(queries[:2], k)
+        if env.rank == 0:
+            ms = elapsed / steps * 1e3
+            out = {"workload": "C4 per-rank shape: %d ranks x %d x %d f32, ip, k=%d (= %dx%d in all), single query per step"
+                               % (env.world, per, d, k, n, d),
+                   "value": steps / elapsed, "unit": "queries/s", "scaling": "weak", "n_gpus": env.world, "steps": steps,
+                   "warmup": warmup, "ms_per_step": ms,
+                   "timed_regions": {"count": repeats, "seconds": [float(x) for x in m["regions"]]},
+                   "roofline": {"bound": "hbm", "achieved": shard_bytes / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": shard_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                "kernel": "tsh::scan_kernel", "kernel_us": scan_us, "algorithmic_bytes_per_launch": shard_bytes,
+                                "note": "per rank: its shard's bytes over its scan's duration"},
+                   "exchange_timeline": exchange_timeline(m["per_rank"], steps * repeats, ms),
+                   "batch_1024": {"value": 1024 / float(np.median(bt)), "unit": "queries/s",
+                                  "ms_per_call": float(np.median(bt)) * 1e3, "calls": len(bt),
+                                  "exchange_timeline": exchange_timeline(per_rank_b, len(bt), float(np.median(bt)) * 1e3)},
+                   "single_and_batched_agree": bool(np.array_equal(got_s[0], got_b[0][:2]) and
+                                                    np.array_equal(got_s[1], got_b[1][:2]))}
+        # parity on sampled queries: rank 0 regenerates the corpus chunk by chunk for the oracle, all ranks search
+        n_chk = 0
+        if env.rank == 0 and not a.no_cpu_baseline:
+            n_chk = max(1, min(2, int(a.cpu_seconds * 6e9 / (float(n) * d * 4))))
+        n_chk = env.bcast_int(n_chk)
+        if n_chk:
+            got = searcher.search(queries[:n_chk], k)
+            if env.rank == 0:
+                import bench_check
+
+                ref = bench_check.oracle_topk_stream(env.oracle_chunks(n, d, metric), queries[:n_chk], metric, k)
+                out["recall_at_k"], out["ids_and_distances_bit_exact"] = bench_check.compare(got, ref)
+                out["recall_queries"] = n_chk
+        return out
+    finally:
+        if searcher is not None and hasattr(searcher, "close"):
+            searcher.close()
+        idx.close()
+
+
+def run_bench(a, env=None):
+    env = env or make_env(a)
+    metric = METRICS[a.metric]
+    world, rank = env.world, env.rank
+    n, d, k = a.rows, a.dim, a.k
+
+    # ---- resident corpus: this rank generates and holds its own row range only -------
+    per = (n + world - 1) // world
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    # a host copy for the CPU baseline / recall check, unless the corpus is too big for one (C4: 61 GB): then the
+    # oracle sees it chunk by chunk, as in a sharded run
+    big = float(n) * d * 4 > 16e9
+    want_host = rank == 0 and world == 1 and not a.no_cpu_baseline and not big
+    idx, host_rows = env.build_index(d, metric, n, lo, hi, keep_host=want_host)
+
+    if a.batch > 0:
+        return bench_batch(a, env, idx, host_rows, metric)
+
+    pool = query_pool_size(a.steps, a.warmup, a.recall_queries if world == 1 else 0)
+    queries = make_queries(pool, d, metric)
+    nqp = len(queries)
+    searcher = env.searcher(idx)
+    idx.set_batch_min_nq(0)  # headline workload: every query scans the corpus on its own (no MFMA batching)
+
+    row_mask = None
+    if a.mask_keep > 0:  # C5 as the main line
+        row_mask, _ = make_mask(n, a.mask_keep, a.mask_kind)
+
     # the harness's own garbage collector stays out of everything that is timed (a full collection of a Python
     # heap with torch imported takes 37 ms: four timed regions' worth)
     import gc
@@ -761,20 +906,9 @@ def run_bench(a, env=None):
     gc.collect()
     gc_was = gc.isenabled()
     gc.disable()
-    run(0, a.warmup)
     repeats = auto_repeats(a.steps, a.repeats)
-    regions = []
-    env.fence()
-    cg0, t_cg0 = cgroup_cpu_stat(), time.perf_counter()
-    c0 = idx.counters()
-    for r in range(repeats):
-        env.fence()
-        t0 = time.perf_counter()
-        run(a.warmup + r * a.steps, a.steps)
-        env.fence()
-        regions.append(env.reduce_max(time.perf_counter() - t0))
-    c1 = idx.counters()
-    cg1, t_cg1 = cgroup_cpu_stat(), time.perf_counter()
+    m = measure_single(env, a, idx, searcher, queries, k, row_mask, a.steps, a.warmup, repeats)
+    regions, one, py_groups = m["regions"], m["one"], m["py_groups"]
     elapsed = float(np.median(regions))
 
     # single-query latency, one at a time (not the headline value).  Round 2's line carried p99 = 42.8 ms: one
@@ -790,10 +924,11 @@ def run_bench(a, env=None):
             gc_ms.append((time.perf_counter() - _t[0]) * 1e3)
     gc.callbacks.append(_gc_cb)
     try:
-        for i in range(a.lat_queries if world == 1 else min(a.lat_queries, 200)):
-            t1 = time.perf_counter()
-            one(i)
-            lat.append(time.perf_counter() - t1)
+        with timed_region():
+            for i in range(a.lat_queries if world == 1 else min(a.lat_queries, 200)):
+                t1 = time.perf_counter()
+                one(i)
+                lat.append(time.perf_counter() - t1)
     finally:
         if gc_was:
             gc.enable()
@@ -803,9 +938,9 @@ def run_bench(a, env=None):
 
     # ---- roofline of the dominant kernel (K1 scan): HIP events recorded by the library
     # around real scan launches on its pipeline stream, during the timed regions above
-    ns = c1["scan_us_samples"] - c0["scan_us_samples"]
-    scan_us = (c1["scan_us_sum"] - c0["scan_us_sum"]) / ns if ns > 0 else float("nan")
-    scan_alone_us = idx.bench_scan(queries[0], iters=50, row_mask=row_mask) if hi > lo else float("nan")
+    ns, scan_us = m["scan_samples"], m["scan_us"]
+    with timed_region():
+        scan_alone_us = idx.bench_scan(queries[0], iters=50, row_mask=row_mask) if hi > lo else float("nan")
     if not math.isfinite(scan_us):
         scan_us = scan_alone_us
     shard_bytes = float(hi - lo) * d * 4  # algorithmic: every stored f32 read once
@@ -814,37 +949,28 @@ def run_bench(a, env=None):
         shard_bytes = float(kept) * d * 4 + (hi - lo) / 8
     scan_us = env.reduce_max(scan_us)
 
-    # ---- recall + CPU baseline: oracle on rank 0, every rank joins the GPU searches ----
-    n_cpu, ref, cpu_elapsed = 0, None, 0.0
+    # ---- recall + CPU baseline: oracle on rank 0 (bench_check.py), every rank joins the GPU searches ----
+    n_cpu, ref, cpu_elapsed, big_cpu = 0, None, 0.0, None
     if rank == 0 and host_rows is not None:
-        import oracle
+        import bench_check
 
-        t1 = time.perf_counter()
-        oracle.search_heap(host_rows, queries[0], metric, k, None, row_mask)
-        per_q = time.perf_counter() - t1
-        n_cpu = cpu_sample_size(per_q, a.cpu_seconds, nqp)
-        t1 = time.perf_counter()
-        ref = [oracle.search_heap(host_rows, queries[i % nqp], metric, k, None, row_mask) for i in range(n_cpu)]
-        cpu_elapsed = time.perf_counter() - t1
+        ref, cpu_elapsed = bench_check.cpu_baseline_single(host_rows, queries, metric, k, row_mask, a.cpu_seconds)
+        n_cpu = len(ref)
     elif rank == 0 and not a.no_cpu_baseline:
         # sharded run (or a corpus too big for a host copy): no process holds the corpus.  Rank 0 regenerates it
         # chunk by chunk (counter-based generator) and runs the exhaustive oracle on a few sampled queries -- a
         # parity check; cpu_baseline is reported at N = 1 only
+        import bench_check
+
         n_cpu = max(2, min(8, int(a.cpu_seconds * 6e9 / (float(n) * d * 4))))
-        r_ids, r_dist, r_cnt = oracle_topk_stream(env.oracle_chunks(n, d, metric), queries[:n_cpu], metric, k, row_mask)
+        if world == 1:
+            n_cpu = max(n_cpu, 8)  # (--config c4 --gpus 1: at least eight queries against the whole 10 M rows)
+        r_ids, r_dist, r_cnt = bench_check.oracle_topk_stream(env.oracle_chunks(n, d, metric), queries[:n_cpu], metric, k,
+                                                              row_mask)
         ref = [(r_ids[i, :r_cnt[i]], r_dist[i, :r_cnt[i]]) for i in range(n_cpu)]
         if world == 1:  # big corpus on one GPU: the single-thread baseline on a bounded sample of its rows
-            import oracle
-
-            sample = np.concatenate([rows for _, rows in
-                                     (c for i, c in zip(range(8), env.oracle_chunks(n, d, metric)))])
-            smask = None if row_mask is None else row_mask[:(len(sample) + 7) // 8]
-            t1 = time.perf_counter()
-            m_cpu = 0
-            while m_cpu < 2 or (time.perf_counter() - t1 < a.cpu_seconds and m_cpu < 32):
-                oracle.search_heap(sample, queries[m_cpu % nqp], metric, k, None, smask)
-                m_cpu += 1
-            big_cpu = (m_cpu / (time.perf_counter() - t1) * len(sample) / n, m_cpu, len(sample))
+            big_cpu = bench_check.cpu_baseline_sample_of_rows(env.oracle_chunks(n, d, metric), n, queries, metric, k,
+                                                              row_mask, a.cpu_seconds)
     n_cpu = env.bcast_int(n_cpu)
     got = [one(i) for i in range(n_cpu)]
 
@@ -900,42 +1026,25 @@ def run_bench(a, env=None):
             # run side by side, so one launch's own duration is about twice its share of the HBM time
             out["roofline"]["scans_side_by_side"] = 2
             out["roofline"]["achieved_alone"] = shard_bytes / (scan_alone_us * 1e-6) / 1e9
+        if searcher is not None:  # N > 1: where every rank's time went, against the step
+            out["exchange_timeline"] = exchange_timeline(m["per_rank"], a.steps * repeats, elapsed / a.steps * 1e3)
         if ref is not None:
-            import oracle
+            import bench_check
 
-            hits, tot, exact = 0, 0, True
-            for i in range(n_cpu):
-                ids, dd, cnt = got[i]
-                g = ids[0, :cnt[0]]
-                hits += len(set(g.tolist()) & set(ref[i][0].tolist()))
-                tot += len(ref[i][0])
-                exact &= bool(np.array_equal(g, ref[i][0]) and np.array_equal(dd[0, :cnt[0]], ref[i][1]))
+            hits, tot, exact = bench_check.compare_refs(got, ref)
             out["recall_at_k"] = hits / max(tot, 1)
             out["recall_queries"] = n_cpu
             out["ids_and_distances_bit_exact"] = exact
             if world == 1 and a.recall_queries > n_cpu and host_rows is not None:
                 # recall@k over >= 1000 queries: the oracle's OpenMP form, same
-                # per-(query,row) arithmetic, against the GPU answers of the same queries; 100-query chunks
-                # until the time budget is used
-                nr, t_or, rec_hits, rec_tot, same = 0, 0.0, 0, 0, True
-                want = min(a.recall_queries, nqp)
-                while nr < want and t_or < a.recall_seconds:
-                    m = min(100, want - nr)
-                    t1 = time.perf_counter()
-                    rr = oracle.search_heap_many_mt(host_rows, queries[nr:nr + m], metric, k, None, row_mask)
-                    t_or += time.perf_counter() - t1
-                    gg = idx.search(queries[nr:nr + m], k, None, row_mask)
-                    rec, ok = compare_with_oracle(gg, rr)
-                    rec_hits += rec * int(np.sum(rr[2]))
-                    rec_tot += int(np.sum(rr[2]))
-                    same &= ok
-                    nr += m
-                out["recall_at_k"] = rec_hits / max(rec_tot, 1)
-                out["recall_queries"] = nr
-                out["ids_and_distances_bit_exact"] = bool(same and exact)
-                out["cpu_baseline_mt_batched"] = {"value": nr / t_or, "unit": "queries/s",
-                                                  "cores": oracle.mt_max_threads(), "kind": "port",
-                                                  "sample": "%d queries, OpenMP over query groups" % nr}
+                # per-(query,row) arithmetic, against the GPU answers of the same queries
+                rl = bench_check.recall_leg(host_rows, queries, metric, k, row_mask,
+                                            lambda qq: idx.search(qq, k, None, row_mask), min(a.recall_queries, nqp),
+                                            a.recall_seconds)
+                out["recall_at_k"] = rl["recall_at_k"]
+                out["recall_queries"] = rl["recall_queries"]
+                out["ids_and_distances_bit_exact"] = bool(rl["bit_exact"] and exact)
+                out["cpu_baseline_mt_batched"] = rl["cpu_baseline_mt_batched"]
             if world == 1 and host_rows is None:
                 out["cpu_baseline"] = {
                     "value": big_cpu[0], "unit": "queries/s", "cores": 1, "kind": "port",
@@ -947,13 +1056,8 @@ def run_bench(a, env=None):
                     "sample": "%d of the same queries over the full %dx%d corpus, oracle/vs_oracle.c "
                               "single thread (the reference searches on one isolate)" % (n_cpu, n, d)}
                 try:
-                    thr = oracle.mt_max_threads()
-                    t1 = time.perf_counter()
-                    m = max(2, min(n_cpu, 8))
-                    for i in range(m):
-                        oracle.search_heap_mt(host_rows, queries[i % nqp], metric, k, None, row_mask)
-                    out["cpu_baseline_mt"] = {"value": m / (time.perf_counter() - t1), "unit": "queries/s",
-                                              "cores": thr, "kind": "port", "sample": "%d queries, OpenMP" % m}
+                    out["cpu_baseline_mt"] = bench_check.cpu_baseline_mt(host_rows, queries, metric, k, row_mask,
+                                                                         max(2, min(n_cpu, 8)))
                 except Exception:  # noqa: BLE001
                     pass
         out["latency_ms_one_at_a_time"] = {"p50": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)]),
@@ -961,23 +1065,39 @@ def run_bench(a, env=None):
                                            "mean": float(lat.mean()), "queries": int(len(lat)),
                                            "harness_gc_collections_inside": len(gc_ms)}
         c = idx.counters()
-        if cg0 and cg1:  # host side of the timed regions, all ranks together: CPUs busy, and whether the quota throttled
-            out["host_cpu"] = {"cpus_busy": (cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 / max(t_cg1 - t_cg0, 1e-9),
-                               "throttled_periods": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
-                               "throttled_ms": (cg1.get("throttled_usec", cg1.get("throttled_time", 0)) -
-                                                cg0.get("throttled_usec", cg0.get("throttled_time", 0))) / 1e3,
-                               "wall_s": t_cg1 - t_cg0}
+        if m["host_cpu"]:
+            out["host_cpu"] = m["host_cpu"]
+            if world > 1:
+                out["host_cpu"]["per_rank"] = [r.get("host_cpu") for r in m["per_rank"]]
         out["counters"] = {"fallback_searches": c["fallback_searches"],
                            "candidates_per_query": c["candidates_total"] / max(c["searches"], 1)}
 
+    # ---- C4 on ONE GPU (--config c4 --gpus 1): the 1024-query batched figure of SURVEY section 8d beside the headline
+    if world == 1 and rank == 0 and a.config == "c4" and a.mask_keep == 0 and not a.no_side:
+        try:
+            r = measure_batch(env, idx, None, metric, n, d, k, 1024, 3, 1, 3, 0)
+            out["batch_1024"] = {key: r[key] for key in ("value", "unit", "ms_per_step", "ms_per_step_max", "batch_kernel",
+                                                           "roofline", "key_passes_share_of_step")}
+            if n_cpu and ref is not None:  # the oracle's sampled queries once more, through the batched path
+                import bench_check
+
+                idx.set_batch_min_nq(1)
+                got_b = idx.search(queries[:n_cpu], k)
+                idx.set_batch_min_nq(0)
+                _, _, eb = bench_check.compare_refs([tuple(x[i:i + 1] for x in got_b) for i in range(n_cpu)], ref)
+                out["batch_1024"]["checked_queries"] = n_cpu
+                out["batch_1024"]["ids_and_distances_bit_exact"] = eb
+        except Exception as e:  # noqa: BLE001
+            out["batch_1024"] = {"error": repr(e)}
+
     # ---- side legs: the other BASELINE.json configurations, same process, after the headline ----
-    if world == 1 and rank == 0 and not a.no_side and a.mask_keep == 0 and searcher is None:
+    if world == 1 and rank == 0 and not a.no_side and a.mask_keep == 0 and searcher is None and a.config == "c2":
         side = {}
         legs = [s.strip() for s in a.side.split(",") if s.strip()]
         t_side = time.perf_counter()
         if "c5" in legs:
             try:
-                side["C5"] = side_c5(env, idx, host_rows, queries, metric, n, d, k)
+                side["C5"] = side_c5(env, idx, host_rows, queries, metric, n, d, k, a.c5_check)
             except Exception as e:  # noqa: BLE001
                 side["C5"] = {"error": repr(e)}
         idx.close()
@@ -995,6 +1115,22 @@ def run_bench(a, env=None):
                 side["C3"] = {"error": repr(e)}
         side["seconds"] = time.perf_counter() - t_side
         out["side"] = side
+    # ---- N > 1: the weak-scaling point (C4's per-rank shape), every rank takes part ----
+    if world > 1 and searcher is not None and not a.no_side and a.c4_rows_per_rank > 0 and a.mask_keep == 0 \
+            and a.config == "c2":
+        if hasattr(searcher, "close"):
+            searcher.close()
+        idx.close()
+        idx = None
+        t_side = time.perf_counter()
+        try:
+            leg = side_c4_per_rank(env, a)
+        except Exception as e:  # noqa: BLE001 -- (a rank failing alone here leaves the others in a collective: the
+            leg = {"error": repr(e)}  # launcher's timeout ends the job; the headline is then lost with it)
+            raise
+        if rank == 0:
+            leg["seconds"] = time.perf_counter() - t_side
+            out["side"] = {"C4_per_rank": leg}
     env.finish()
     if idx is not None:
         idx.close()
@@ -1089,6 +1225,11 @@ def launch_ranks(a, argv, timeout):
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
+    if a.fake_rccl and not os.environ.get("TSH_RCCL_LIB"):  # before any rank is started / the library is loaded
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fake_rccl
+
+        os.environ["TSH_RCCL_LIB"] = fake_rccl.build()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.force_sharded:
         # started plainly: be the launcher.  Rank 0's line is handed through only when the whole job succeeded.
         rc, line = launch_ranks(a, argv, a.launch_timeout)

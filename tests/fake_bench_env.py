@@ -79,14 +79,46 @@ class FakeSearcher:
     def __init__(self, whole):
         self.whole = whole
         self.groups = []
+        self.tl = dict.fromkeys(("calls", "queries", "groups", "retries", "call_us", "reserve_us", "wait_scan_us", "scan_us",
+                                 "exchange_wait_us", "gather_us", "slice_d2h_us", "merge_us", "result_gather_us",
+                                 "copy_out_us", "retry_scan_us"), 0)
+
+    def _book(self, nq, dt):
+        t = self.tl
+        t["calls"] += 1
+        t["queries"] += nq
+        t["groups"] += 1
+        t["call_us"] += dt * 1e6
+        for key, share in (("wait_scan_us", 0.6), ("exchange_wait_us", 0.2), ("merge_us", 0.1), ("result_gather_us", 0.05),
+                           ("copy_out_us", 0.04)):
+            t[key] += dt * 1e6 * share
+        t["gather_us"] += dt * 1e6 * 0.15
+        t["slice_d2h_us"] += dt * 1e6 * 0.05
+        t["scan_us"] += dt * 1e6 * 0.9
+
+    def timeline(self, reset=False):
+        out = dict(self.tl)
+        if reset:
+            self.tl = dict.fromkeys(self.tl, 0)
+        return out
 
     def search(self, q, k, thr=None, row_mask=None):
-        return self.whole.search(q, k, thr, row_mask)
+        import time
+
+        t0 = time.perf_counter()
+        r = self.whole.search(q, k, thr, row_mask)
+        self._book(len(np.atleast_2d(q)), time.perf_counter() - t0)
+        return r
 
     def search_many(self, qs, k, thr=None, row_mask=None, group=8):
+        import time
+
         assert group >= 1 and len(qs) >= 1
         self.groups.append((len(qs), group))
-        return self.whole.search(qs, k, thr, row_mask)
+        t0 = time.perf_counter()
+        r = self.whole.search(qs, k, thr, row_mask)
+        self._book(len(qs), time.perf_counter() - t0)
+        return r
 
 
 class FakeEnv:
@@ -118,6 +150,7 @@ class FakeEnv:
         self.fences = 0
         self.made = []
         self.last_searcher = None
+        self.searchers = []  # the headline's first, then the side legs'
         self.exchange, self.exchange_note = "stand-in", None
 
     def corpus(self, n, d, metric):
@@ -144,6 +177,7 @@ class FakeEnv:
         if self.world == 1:
             return None
         self.last_searcher = FakeSearcher(self._whole)
+        self.searchers.append(self.last_searcher)
         return self.last_searcher
 
     def max_inflight(self):
@@ -171,6 +205,13 @@ class FakeEnv:
         t = torch.tensor([int(x)], dtype=torch.int64)
         self.dist.broadcast(t, src=0)
         return int(t.item())
+
+    def gather_objects(self, obj):
+        if self.dist is None:
+            return [obj]
+        box = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, box, dst=0)
+        return box
 
     def finish(self):
         if self.dist is not None:

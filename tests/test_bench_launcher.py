@@ -9,7 +9,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--rows", "3000", "--dim", "32", "--k", "10", "--cpu-seconds", "0.2", "--steps", "20", "--warmup", "5"]
+SMALL = ["--rows", "3000", "--dim", "32", "--k", "10", "--cpu-seconds", "0.2", "--steps", "20", "--warmup", "5",
+         "--c4-rows-per-rank", "200"]
 
 
 def _run(extra_env, *args, timeout=300):
@@ -30,7 +31,12 @@ def test_plain_command_starts_its_own_ranks():
     assert out["scaling"] == "strong" and out["config"]["workload"].startswith("C2")
     assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True
     assert out["roofline"]["algorithmic_bytes_per_launch"] == 1500 * 32 * 4  # rank 0's shard
-    assert "side" not in out and "cpu_baseline" not in out  # N = 1 only
+    assert "cpu_baseline" not in out  # N = 1 only
+    # both ranks' accounts reach rank 0's line; the weak-scaling leg (C4's per-rank shape) ran on both
+    assert [r["rank"] for r in out["exchange_timeline"]["ranks"]] == [0, 1]
+    assert len(out["host_cpu"]["per_rank"]) == 2
+    c4 = out["side"]["C4_per_rank"]
+    assert c4["n_gpus"] == 2 and "400x1536" in c4["workload"] and c4["ids_and_distances_bit_exact"] is True
 
 
 def test_a_failing_rank_fails_the_command():

@@ -24,7 +24,8 @@ from fake_bench_env import FakeEnv  # noqa: E402
 
 def _args(*extra):
     return bench.parse(["--rows", "3000", "--dim", "32", "--k", "10", "--cpu-seconds", "0.2",
-                        "--recall-queries", "150", "--recall-seconds", "5"] + list(extra))
+                        "--recall-queries", "150", "--recall-seconds", "5", "--c4-rows-per-rank", "300",
+                        "--c3-check", "200", "--c5-check", "40"] + list(extra))
 
 
 DRIVER_ARGS = [(1, 0), (5, 0), (20, 5), (1000, 50)]
@@ -50,15 +51,19 @@ def test_single_gpu_line(oracle_mod, steps, warmup):
     assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True
     assert out["recall_queries"] == 150
     side = out["side"]
-    for keep in ("keep_1%", "keep_10%", "keep_50%"):
+    for keep in ("keep_1%", "keep_10%", "keep_50%", "keep_100%", "keep_10%_range"):  # SURVEY section 8d's list
         assert side["C5"][keep]["ids_and_distances_bit_exact"] is True, side["C5"]
+        assert side["C5"][keep]["checked_queries"] == 40
+        assert side["C5"][keep]["library_default_path"]["ids_and_distances_bit_exact"] is True
+    assert side["C5"]["keep_10%_range"]["mask"] == "range" and side["C5"]["keep_100%"]["kept_rows"] == 3000
     assert side["C1"]["ids_and_distances_bit_exact"] is True and side["C1"]["latency_us"]["p50"] > 0
     ann = side["C1"]["reference_ann_restated"]  # context only, labelled as a restatement
     assert "error" not in ann and 0.0 <= ann["recall_at_k"] <= 1.0 and ann["ms_per_query"] > 0
     assert "restatement" in ann["label"] and "unverifiable" in ann["label"]
     if steps == 20:
         c3 = side["C3"]
-        assert c3["ids_and_distances_bit_exact"] is True and c3["checked_queries"] == 128
+        assert c3["ids_and_distances_bit_exact"] is True and c3["checked_queries"] == 200
+        assert c3["ms_per_step"] <= c3["ms_per_step_p99"] <= c3["ms_per_step_max"]
         assert c3["roofline"]["bound"] == "mfma" and c3["f32_mfma_variant"]["roofline"]["peak"] == 157.3
         assert set(c3["smaller_calls"]) == {"16_queries", "128_queries"}
     assert all(i.closed for i in env.made)
@@ -70,12 +75,24 @@ def test_sharded_branch_arithmetic(oracle_mod, steps, warmup):
     a = _args("--steps", str(steps), "--warmup", str(warmup), "--gpus", "2")
     env = FakeEnv(oracle_mod, world=2)
     out = json.loads(bench.run_bench(a, env))
-    assert out["n_gpus"] == 2 and "side" not in out and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    # the N > 1 line says where the time went, phase by phase, against the step
+    tl = out["exchange_timeline"]
+    assert len(tl["ranks"]) == 1 and tl["ranks"][0]["calls"] == bench.auto_repeats(steps)
+    assert abs(tl["phases_sum_ms_per_step"] - 0.99 * tl["call_ms_per_step"]) < 1e-6 * max(1.0, tl["call_ms_per_step"])
+    assert 0.0 < tl["phases_sum_over_ms_per_step"] <= 1.0 + 1e-9
+    assert tl["ranks"][0]["host_cpu"]["cpus_busy"] > 0
+    # and carries the weak-scaling point: BASELINE.json C4's per-rank shape (here 300 rows per rank)
+    c4 = out["side"]["C4_per_rank"]
+    assert c4["scaling"] == "weak" and c4["n_gpus"] == 2 and "600x1536" in c4["workload"] and c4["value"] > 0
+    assert c4["ids_and_distances_bit_exact"] is True and c4["single_and_batched_agree"] is True
+    assert c4["batch_1024"]["value"] > 0 and c4["exchange_timeline"]["ranks"][0]["calls"] >= 3
+    assert c4["roofline"]["algorithmic_bytes_per_launch"] == 300 * 1536 * 4
     assert out["roofline"]["algorithmic_bytes_per_launch"] == 1500 * 32 * 4
     assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True
     g = bench.sharded_group(64, steps)
     assert out["config"]["queries_per_call"] == g >= 1
-    timed = [x for x in env.last_searcher.groups if x[0] == steps]
+    timed = [x for x in env.searchers[0].groups if x[0] == steps]
     assert len(timed) == bench.auto_repeats(steps) and all(x[1] == g for x in timed)
 
 
@@ -111,9 +128,38 @@ def test_sizing_helpers():
         assert bench.sharded_group(64, steps) >= 1
     assert bench.auto_repeats(20) == 25 and bench.auto_repeats(1000) == 3 and bench.auto_repeats(5, 4) == 4
     # the round-1 crash: a fast host wants 32 baseline queries, the pool had 25
-    assert bench.cpu_sample_size(0.1, 15.0, 25) == 25
-    assert bench.cpu_sample_size(0.47, 15.0, 1000) == 31
-    assert bench.cpu_sample_size(100.0, 15.0, 1000) == 2
-    assert bench.cpu_sample_size(100.0, 15.0, 1) == 1
+    import bench_check
+
+    assert bench_check.cpu_sample_size(0.1, 15.0, 25) == 25
+    assert bench_check.cpu_sample_size(0.47, 15.0, 1000) == 31
+    assert bench_check.cpu_sample_size(100.0, 15.0, 1000) == 2
+    assert bench_check.cpu_sample_size(100.0, 15.0, 1) == 1
     line = bench.dumps({"a": float("nan"), "b": [np.float32(1.5), float("inf")], "c": np.int64(3), "d": np.bool_(True)})
     assert json.loads(line) == {"a": None, "b": [1.5, None], "c": 3, "d": True}
+
+
+def test_the_oracle_is_out_of_reach_of_timed_code(oracle_mod):
+    """bench.py reaches oracle/ through bench_check.py only, and bench_check refuses to run (or load) while a
+    timed region is open."""
+    import ast
+    import importlib
+
+    import bench_check
+
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            assert all(al.name.split(".")[0] != "oracle" for al in node.names), "bench.py imports oracle"
+        if isinstance(node, ast.ImportFrom):
+            assert (node.module or "").split(".")[0] != "oracle", "bench.py imports from oracle"
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name):
+            assert node.value.id != "oracle", "bench.py calls into oracle directly (line %d)" % node.lineno
+    rows = np.zeros((8, 4), np.float32)
+    with bench.timed_region():
+        with pytest.raises(RuntimeError, match="timed region"):
+            bench_check.oracle_answers(rows, rows[:1], 0, 2)
+        with pytest.raises(RuntimeError, match="timed region"):
+            importlib.reload(bench_check)
+    assert os.environ.get("TSH_BENCH_TIMED") is None
+    importlib.reload(bench_check)
+    assert bench_check.oracle_answers(rows, rows[:1], 0, 2)[2][0] == 2
