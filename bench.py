@@ -699,6 +699,11 @@ def exchange_timeline(per_rank, steps_total, ms_per_step):
         for key in ("call_us",) + TIMELINE_MAIN + ("scan_us", "gather_us", "slice_d2h_us"):
             ent[key.replace("_us", "_ms_per_step")] = t[key] * 1e-3 / max(steps_total, 1)
         ent["phases_sum_ms_per_step"] = sum(t[key] for key in TIMELINE_MAIN) * 1e-3 / max(steps_total, 1)
+        if "closing_fence_ms_per_step" in r:
+            ent["closing_fence_ms_per_step"] = r["closing_fence_ms_per_step"]
+            ent["harness_ms_per_step"] = r["run_ms_per_step"] - ent["call_ms_per_step"]  # Python around the library call
+            # what this rank can account for of a step: its phases inside the library + the region's closing fence
+            ent["accounted_ms_per_step"] = ent["phases_sum_ms_per_step"] + r["closing_fence_ms_per_step"]
         ranks.append(ent)
     have = [e for e in ranks if e.get("calls") is not None]
     out = {"unit": "ms per step (sums over the timed regions / timed steps), per rank",
@@ -712,6 +717,10 @@ def exchange_timeline(per_rank, steps_total, ms_per_step):
         out["phases_sum_ms_per_step"] = worst["phases_sum_ms_per_step"]
         out["call_ms_per_step"] = worst["call_ms_per_step"]
         out["phases_sum_over_ms_per_step"] = worst["phases_sum_ms_per_step"] / ms_per_step if ms_per_step > 0 else None
+        if "accounted_ms_per_step" in worst and ms_per_step > 0:
+            # (ms_per_step is the MEDIAN region, the accounts are means over all regions)
+            acc = [e["accounted_ms_per_step"] / ms_per_step for e in have if "accounted_ms_per_step" in e]
+            out["accounted_over_ms_per_step"] = {"rank0": acc[0], "min": min(acc), "max": max(acc)}
         out["max_over_ranks"] = {key: max(e[key] for e in have) for key in have[0] if key.endswith("_ms_per_step")}
     return out
 
@@ -767,13 +776,18 @@ def measure_single(env, a, idx, searcher, queries, k, row_mask, steps, warmup, r
     cg0, t_cg0 = cgroup_cpu_stat(), time.perf_counter()
     cpu0 = time.process_time()
     c0 = idx.counters()
+    run_s = fence_s = 0.0
     with timed_region():
         for r in range(repeats):
             env.fence()
             t0 = time.perf_counter()
             run(warmup + r * steps, steps)
-            env.fence()
-            regions.append(env.reduce_max(time.perf_counter() - t0))
+            t_run = time.perf_counter()
+            env.fence()  # (inside the region, as the contract asks: barrier + device synchronise)
+            t_end = time.perf_counter()
+            run_s += t_run - t0
+            fence_s += t_end - t_run
+            regions.append(env.reduce_max(t_end - t0))
     c1 = idx.counters()
     cpu1 = time.process_time()
     cg1, t_cg1 = cgroup_cpu_stat(), time.perf_counter()
@@ -782,7 +796,11 @@ def measure_single(env, a, idx, searcher, queries, k, row_mask, steps, warmup, r
     mine = {"rank": env.rank, "timeline": searcher.timeline() if has_tl else None,
             "host_cpu": {"cpus_busy": (cpu1 - cpu0) / max(t_cg1 - t_cg0, 1e-9), "cpu_s": cpu1 - cpu0,
                          "wall_s": t_cg1 - t_cg0, "note": "this rank's process, all threads, over its timed regions"},
-            "scan_us": scan_us}
+            "scan_us": scan_us,
+            # this rank's timed regions, split at the end of its last search: the closing fence (waiting for the other
+            # ranks + the device) is part of every region
+            "run_ms_per_step": run_s * 1e3 / max(steps * repeats, 1),
+            "closing_fence_ms_per_step": fence_s * 1e3 / max(steps * repeats, 1)}
     per_rank = env.gather_objects(mine) if env.world > 1 else [mine]
     host_cpu = None
     if cg0 and cg1:  # host side of the timed regions, all ranks together: CPUs busy, and whether the quota throttled
@@ -823,14 +841,19 @@ def side_c4_per_rank(env, a):
         searcher.search(queries[:1024], k)
         if hasattr(searcher, "timeline"):
             searcher.timeline(reset=True)
+        run_s = fence_s = 0.0
         with timed_region():
             for i in range(3):
                 env.fence()
                 t0 = time.perf_counter()
                 got_b = searcher.search(queries[:1024], k)
+                t_run = time.perf_counter()
                 env.fence()
+                run_s += t_run - t0
+                fence_s += time.perf_counter() - t_run
                 bt.append(env.reduce_max(time.perf_counter() - t0))
-        mine_b = {"rank": env.rank, "timeline": searcher.timeline() if hasattr(searcher, "timeline") else None}
+        mine_b = {"rank": env.rank, "timeline": searcher.timeline() if hasattr(searcher, "timeline") else None,
+                  "run_ms_per_step": run_s * 1e3 / 3, "closing_fence_ms_per_step": fence_s * 1e3 / 3}
         per_rank_b = env.gather_objects(mine_b)
         idx.set_batch_min_nq(0)
         got_s = searcher.search(queries[:2], k)

@@ -12,7 +12,7 @@ import json
 try:
     d=json.load(open("$O/fake_rccl_n$N.json"))
     print({k:d.get(k) for k in ("value","ms_per_step","recall_at_k","ids_and_distances_bit_exact")}, d["config"]["sharding"])
-    t=d["exchange_timeline"]; print("timeline: call %.3f phases %.3f of step %.3f ms (ratio %.2f)" % (t["call_ms_per_step"], t["phases_sum_ms_per_step"], t["ms_per_step"], t["phases_sum_over_ms_per_step"]))
+    t=d["exchange_timeline"]; print("timeline: call %.3f phases %.3f of step %.3f ms (ratio %.2f), accounted incl. closing fence:" % (t["call_ms_per_step"], t["phases_sum_ms_per_step"], t["ms_per_step"], t["phases_sum_over_ms_per_step"]), t.get("accounted_over_ms_per_step"))
     print("  max over ranks:", {k: round(v,4) for k,v in t["max_over_ranks"].items()})
     print("  host_cpu:", d.get("host_cpu",{}).get("cpus_busy"), [round(r["cpus_busy"],2) for r in d["host_cpu"]["per_rank"]])
     c=d["side"]["C4_per_rank"]; print("C4 per rank:", {k:c.get(k) for k in ("value","ms_per_step","recall_at_k","ids_and_distances_bit_exact","seconds","error")})
