@@ -210,3 +210,97 @@ def test_ctypes_table_matches_the_c_prototypes():
         assert [f for _, f in cf] == [f for f, _ in cls._fields_], cname
         for (ct, _), (_, pt) in zip(cf, cls._fields_):
             assert ctypes.sizeof(pt) == {"int32_t": 4, "int64_t": 8, "double": 8, "float": 4}[ct]
+
+
+# ---- the VectorIndexManager hook (tostore_amd/dart/hip_vector_hook.dart) --------------------
+HOOK = os.path.join(ROOT, "tostore_amd", "dart", "hip_vector_hook.dart")
+REF_VIM = "/root/reference/lib/src/core/vector_index_manager.dart"
+
+
+def _call_args(text, start):
+    """Arguments of the call whose '(' is at text[start]: (positional count, set of named arguments)."""
+    depth, i, cur, args = 0, start, "", []
+    while True:
+        ch = text[i]
+        if ch in "([{<" and not (ch == "<" and text[i - 1] == " "):
+            depth += 1
+        elif ch in ")]}>" and not (ch == ">" and text[i - 1] in " ="):
+            depth -= 1
+            if depth == 0:
+                break
+        if ch == "," and depth == 1:
+            args.append(cur.strip())
+            cur = ""
+        elif depth >= 1 and not (depth == 1 and ch == "("):
+            cur += ch
+        i += 1
+    if cur.strip():
+        args.append(cur.strip())
+    named = {a.split(":")[0].strip() for a in args if re.match(r"^\w+\s*:", a)}
+    return len(args) - len(named), named
+
+
+def _bridge_members():
+    """name -> (positional parameter count, named parameter names) of HipVectorBackend's methods, plus its getters."""
+    text = _strip_comments(open(BRIDGE).read())
+    cls = text[text.index("final class HipVectorBackend"):text.index("final class HipShardComm")]
+    members = {}
+    for m in re.finditer(r"\n  (?:static\s+)?[\w<>?, ]+?\s+(\w+)\(([^)]*)\)\s*(?:async\s*)?(?:\{|=>)", cls):
+        name, params = m.group(1), m.group(2)
+        pos, _, named = params.partition("{")
+        npos = len([p for p in pos.split(",") if p.strip()])
+        nnames = {p.strip().split("=")[0].split()[-1] for p in named.rstrip("} ").split(",") if p.strip()}
+        members[name] = (npos, nnames)
+    getters = set(re.findall(r"\n  (?:static\s+)?[\w<>?]+\s+get\s+(\w+)", cls))
+    return members, getters
+
+
+def test_hook_calls_only_what_the_bridge_has():
+    """Every HipVectorBackend member the hook uses exists in the bridge with the arity / named parameters used."""
+    hook = _strip_comments(open(HOOK).read())
+    members, getters = _bridge_members()
+    assert {"tryOpen", "search", "searchAsync", "append", "setDeleted", "dispose", "counters"} <= set(members)
+    used = 0
+    for m in re.finditer(r"\b(?:hip|b|HipVectorBackend|e\.value)\.(\w+)(\()?", hook):
+        name, is_call = m.group(1), m.group(2) is not None
+        if not is_call:
+            assert name in getters or name in members, "the hook reads HipVectorBackend.%s, which the bridge lacks" % name
+            continue
+        assert name in members, "the hook calls HipVectorBackend.%s(), which the bridge lacks" % name
+        npos, named = _call_args(hook, m.end() - 1)
+        want_pos, want_named = members[name]
+        assert npos == want_pos, "%s: the hook passes %d positional arguments, the bridge takes %d" % (name, npos, want_pos)
+        assert named <= want_named, "%s: named arguments %s not in the bridge's %s" % (name, sorted(named), sorted(want_named))
+        used += 1
+    assert used >= 8
+    # the mixin's own surface: the four call sites the maintainer wires up
+    for fn in ("hipSearch", "hipAfterInsert", "hipAfterDelete", "hipDrop", "hipDropTable", "hipDisposeAll", "hipFor"):
+        assert re.search(r"\b%s\(" % fn, hook), fn
+    assert "mixin HipVectorHook implements HipVectorHookHost" in hook
+
+
+def test_hook_call_sites_name_real_reference_lines():
+    """The line numbers the hook cites hold what it says (checked where the reference tree exists: this container)."""
+    import pytest
+
+    if not os.path.exists(REF_VIM):
+        pytest.skip("no reference tree on this machine")
+    ref = open(REF_VIM).read().split("\n")
+
+    def span(a, b):
+        return "\n".join(ref[a - 1:b])
+
+    assert "class VectorIndexManager" in span(28, 28)
+    assert "_metaLoadingFutures" in span(35, 37)
+    assert "_prepareInsertVectorsBatch" in span(349, 356) and "startNodeId = meta.nextNodeId" in span(359, 359)
+    assert "_graphEngine.insertBatch" in span(368, 377) and "dirtyRawVectorPages" in span(378, 388)
+    assert "_persistMeta" in span(401, 401) and "_graphEngine.deleteBatch" in span(429, 434)
+    assert "_toFloat32" in span(514, 520) and "_normalizeFloat32" in span(514, 520)
+    assert "_graphEngine.search(" in span(536, 551) and "lease?.release()" in span(536, 551)
+    assert "return true;" in span(1154, 1158)
+    # ... and the hook file cites exactly these
+    hook = open(HOOK).read()
+    for cite in (":349-356", ":359,", ":368-388", ":378-388", ":401)", ":429-434", ":514-520", ":536-551", ":1154-1158", ":1192", ":1198", ":1205"):
+        assert cite in hook, cite
+    assert "void clearCacheForTable" in span(1192, 1192) and "void clearCacheForIndex" in span(1198, 1198)
+    assert "Future<void> dispose()" in span(1205, 1205)

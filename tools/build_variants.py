@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Links probe variants of libtostore_hip.so side by side: the key-kernel translation unit is recompiled with the
-given -D flags, the other objects are reused (build the library with -DTSH_PROBES first).  Usage:
+"""Links probe variants of libtostore_hip.so side by side: the key-kernel translation unit is recompiled with
+-DTSH_PROBES and the given -D flags, the shipped library's other objects are reused (enough for switches the key
+kernels' own translation unit reads: TSH_F16_GEN, PP_ISSUE, PP_K; probes that need the host side's hooks -- TSH_F16_DBG --
+want the whole library as a variant: `python -m tostore_amd.build -DTSH_PROBES`, which never touches the shipped
+library either).  Usage:
   python tools/build_variants.py name1:-DPP_ISSUE=1 name2:-DPP_ISSUE=2,-DFOO ...
 -> tostore_amd/csrc/_build/var_<name>.so, selected at run time with TSH_LIB_PATH."""
 import os, subprocess, sys

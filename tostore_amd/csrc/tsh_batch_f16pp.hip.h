@@ -16,14 +16,20 @@
 //   * every wave issues its share of the stream (4 pieces per chunk at MI = 4), three chunks ahead, and waits for
 //     its own pieces of chunk c + 1 with a counted vmcnt at the END of LOAD(c) -- two whole iterations after their
 //     issue.
-//   * IP and cosine only (L2's key has a per-row term, |v|^2, that a per-query start value cannot absorb: L2 keeps the
-//     second generation).  In the filtered pass the accumulators START at -theta_q (theta_q = the query's threshold
-//     in accumulator units), so "this row passes" is the accumulator's sign: a 32 x 32 block is tested with eight
-//     v_max3_i32 and one compare, and only blocks with a survivor (3.7 of a wave's eight per tile at k = 100) are
-//     looked at register by register (epilogue, below).  The key stored for a survivor is (seed - acc) * scale; the
-//     error model's accumulation term doubles (the chain now carries |theta| <= |q| max|v| as well:
-//     tsh_host_batch.inl.h, batch_delta2).  Thresholds are capped at the largest key a row can have
-//     (BatchArgs::kmax), so an "everything passes" threshold stays finite.  The dense (sample) pass starts at zero.
+//   * In the filtered pass the accumulators START at -theta_q (theta_q = the query's threshold in accumulator units),
+//     so "this row passes" is the accumulator's sign: a 32 x 32 block is tested with eight v_max3_i32 and one
+//     compare, and only blocks with a survivor (3.7 of a wave's eight per tile at k = 100) are looked at register by
+//     register (epilogue, below).  The key stored for a survivor is (seed - acc) * scale; the error model's
+//     accumulation term doubles (the chain now carries |theta| <= |q| max|v| as well: tsh_host_batch.inl.h,
+//     batch_delta2).  Thresholds are capped at the largest key a row can have (BatchArgs::kmax), so an "everything
+//     passes" threshold stays finite.  The dense (sample) pass starts at zero.
+//   * L2 (round 4): key = |q|^2 + |v|^2 - 2 q.v <= thr  <=>  dot_acc - |v|^2 / (2 s) - (|q|^2 - thr) / (2 s) >= 0
+//     (s = the power-of-two dot scale).  The per-query term is the seed as before; the per-ROW term is one value per
+//     lane and column block in the 32 x 32 MFMA's C layout (column = lane & 31 = corpus row), so the accumulators
+//     start at seed_q - c_v with c_v = |v|^2 / (2 s): a v_sub where IP / cosine have a v_mov, and everything after
+//     it -- sign test, notes, appends -- is the same code.  A survivor's key is thr'_q - 2 s acc (thr' = the capped
+//     threshold).  c_v of the NEXT tile's rows is loaded in the epilogue, beside the liveness words (a compiler-
+//     tracked global load in the K loop would drain the DMA ring with its vmcnt wait).
 //   * thresholds live in per-wave LDS tables (a wave only needs its own 32 MI query rows): nothing in the kernel
 //     needs a workgroup-wide barrier besides the phase barriers, whose count is the same for every wave.  After a
 //     tile's last chunk group 0 passes the phase barrier before its epilogue, group 1 after its own: the two
@@ -85,10 +91,11 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
 #endif
   auto piece_off = [](int u) -> int { return u * 1024; };
   constexpr int QROWS = 32 * MI;                   // query rows of a wave's patch
-  static_assert(METRIC != METRIC_L2, "IP / cosine only (cosine planes hold unit rows: its key is -dot, as for IP)");
+  constexpr bool L2 = METRIC == METRIC_L2;  // (cosine planes hold unit rows: its key is -dot, as for IP)
   constexpr bool SEEDED = !DENSE;
   __shared__ __attribute__((aligned(1024))) unsigned char ring[NST * STAGE];
   __shared__ __attribute__((aligned(16))) float s_seed[8][QROWS];  // per wave: -theta of its query rows
+  __shared__ __attribute__((aligned(16))) float s_aux[8][L2 ? QROWS : 4];  // L2: thr' (filtered) resp. |q|^2 (dense)
   __shared__ uint2 s_hits[8][F16_HITS + 64];  // + one spare slot per lane
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -261,7 +268,23 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
   };
 
   float *my_seed = s_seed[wave];
+  float *my_aux = s_aux[wave];
   uint2 *my_hits = s_hits[wave];
+  // L2: c_v = |v|^2 / (2 s) of this lane's two corpus rows (column blocks j = 0, 1) of a tile; +inf past the last row
+  // (nothing passes, and no read past the norms' end)
+  float cv[2] = {0.f, 0.f};
+  const float half_over_s = 0.5f / a.dot_scale;  // a power of two: exact
+  auto load_cv = [&](int tile) {
+    int qt, nt;
+    batch_tile_of(a, tile, &qt, &nt);
+    const int nb = a.row0 + nt * TN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = nb + wn * 64 + j * 32 + l31;
+      cv[j] = col < a.row1 ? a.sqnorm[col] * half_over_s : __builtin_inff();
+    }
+  };
+  if (L2) load_cv((int)blockIdx.x);
 
   // ---- prologue: three chunks in flight, chunk 0 landed; group 1 starts one phase late ---------------------------
   set_src(i_tile);
@@ -287,7 +310,18 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
         // (power-of-two scale: exact).  Capped at the largest key any row can have: every row still passes, and
         // the chain's start stays within the error model.  Padding rows: -inf, nothing passes.
         float th = -__builtin_inff();
-        if (SEEDED && q < a.nq) th = __builtin_fminf(a.thr[q], a.kmax[q]) / a.dot_scale;
+        if (L2) {
+          // seed = -(|q|^2 - thr') / (2 s): one rounding (the subtraction); thr' kept for the survivors' keys
+          float ax = 0.f;
+          if (q < a.nq) {
+            const float tc = SEEDED ? __builtin_fminf(a.thr[q], a.kmax[q]) : 0.f;
+            if (SEEDED) th = -((a.qsq[q] - tc) * half_over_s);
+            ax = SEEDED ? tc : a.qsq[q];
+          }
+          my_aux[t] = ax;
+        } else if (SEEDED && q < a.nq) {
+          th = __builtin_fminf(a.thr[q], a.kmax[q]) / a.dot_scale;
+        }
         my_seed[t] = th;
       }
       cur_q_tile = q_tile;
@@ -302,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = sd[r >> 2][r & 3];
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = L2 ? sd[r >> 2][r & 3] - cv[j] : sd[r >> 2][r & 3];
       }
     } else {
 #pragma unroll
@@ -380,6 +414,10 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
     };
     float scale_w = a.dot_scale;
     asm volatile("" : "+s"(scale_w));
+    // a survivor's key from its accumulator: IP / cosine -(dot * scale) = (seed - acc) * scale; L2 thr' - 2 s acc
+    auto key_of = [&](int ql, float av) -> float {
+      return L2 ? __builtin_fmaf(-2.f * scale_w, av, my_aux[ql]) : (my_seed[ql] - av) * scale_w;
+    };
     // CODE SIZE matters here: the epilogue runs once per tile, and whatever of it is not in the instruction cache
     // comes from L2 a line at a time (a first version with the 2 MI blocks' register walks unrolled -- 70 KB of
     // code for the kernel -- spent 5-8 k cycles per wave and tile in here for ~500 executed instructions).
@@ -405,9 +443,14 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
         const int cj = j ? cl[1] : cl[0];
         const bool okj = j ? col_ok[1] : col_ok[0], alj = j ? alive_l[1] : alive_l[0];
         float *dst = a.dense + (int64_t)(qbase + wm * QROWS + i * 32 + 4 * half_t) * a.dense_ld + (nbase + cj - a.row0);
+        const float sq = L2 ? (j ? cv[1] : cv[0]) * (2.f * scale_w) : 0.f;  // |v|^2 back from c_v (exact scaling)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (okj) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * a.dense_ld] = alj ? -(t[r] * scale_w) : __builtin_nanf("");
+          if (okj) {
+            float key = -(t[r] * scale_w);
+            if (L2) key = __builtin_fmaf(-2.f * scale_w, t[r], my_aux[i * 32 + 4 * half_t + (r & 3) + 8 * (r >> 2)] + sq);
+            dst[(int64_t)((r & 3) + 8 * (r >> 2)) * a.dense_ld] = alj ? key : __builtin_nanf("");
+          }
       }
     } else {
       // Three steps, the first two straight-line vector code (a ballot -> branch hop costs ~100 cycles; a loop over
@@ -483,7 +526,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
             const float av = t[r];  // (r is wave-uniform: an indexed register read)
             const bool mine = (int)__float_as_uint(av) >= 0 && alj;
             const uint64_t mm = __ballot(mine);
-            if (mm) append(mm, mine, (my_seed[ql] - av) * scale_w, wm * QROWS + ql, cj);
+            if (mm) append(mm, mine, key_of(ql, av), wm * QROWS + ql, cj);
           }
         }
       } else {
@@ -496,7 +539,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
             if (mm) {
               const int w = rr[j][sl];
               const int ql = (w >> 4) * 32 + 4 * half_t + (w & 3) + 8 * ((w & 15) >> 2);
-              append(mm, mine, (my_seed[ql] - val[j][sl]) * scale_w, wm * QROWS + ql, cl[j]);  // key = -(dot * scale)
+              append(mm, mine, key_of(ql, val[j][sl]), wm * QROWS + ql, cl[j]);
             }
           }
         }
@@ -515,6 +558,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
       pend_qbase = qbase;
       pend_nbase = nbase;
     }
+    if (L2 && tile + G < total_tiles) load_cv(tile + G);  // (waited for where the next tile's accumulators start)
     stamp(9);
     __builtin_amdgcn_sched_barrier(0);
     if (wm) __builtin_amdgcn_s_barrier();  // (group 1's barrier of the tile's last COMPUTE phase: see compute_phase)

@@ -22,42 +22,17 @@ void launch_batch_score(const BatchArgs &a, bool dense, hipStream_t st) {
   else batch_score_kernel<METRIC, false><<<grid, BT_THREADS, 0, st>>>(a);
 }
 template <int METRIC>
-void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
+void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st, int cus) {
   int grid = a.q_tiles * a.n_tiles;
   if (grid <= 0) return;
   if (a.dot_scale != 0.f) {  // f16 variant: tsh_batch_f16.hip.h (persistent: one 8-wave workgroup per CU)
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (cus <= 0) cus = 256;
-    }
-    const int pgrid = std::min(grid, cus);
-    // IP / cosine: third generation (ping-pong phases, tsh_batch_f16pp.hip.h); L2 (a per-row term in the key: no sign
-    // test) stays on the second.  Probe builds (-DTSH_PROBES) keep the second generation for IP / cosine as well,
-    // TSH_F16_GEN=2 selects it there (tools/r3_ab.sh)
-    if constexpr (METRIC != METRIC_L2) {
+    const int pgrid = std::min(grid, cus > 0 ? cus : 256);  // (cus: the launching shard's device, DeviceStreams::cus)
+    // Third generation (ping-pong phases, tsh_batch_f16pp.hip.h) for every metric; L2's per-row term rides in the
+    // accumulators' start values since round 4.  Probe builds (-DTSH_PROBES) carry the second generation beside it,
+    // TSH_F16_GEN=2 selects it there (tools/r4_ab_l2.sh)
 #ifdef TSH_PROBES
-      static const bool gen2 = getenv("TSH_F16_GEN") != nullptr && getenv("TSH_F16_GEN")[0] == '2';
-#else
-      constexpr bool gen2 = false;
-#endif
-      if (!gen2) {
-        if (a.tile_m == 256) {
-          if (dense) batch_score_f16pp_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
-          else batch_score_f16pp_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
-        } else {
-          if (dense) batch_score_f16pp_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
-          else batch_score_f16pp_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
-        }
-        return;
-      }
-    }
-#ifndef TSH_PROBES
-    if constexpr (METRIC == METRIC_L2)
-#endif
-    {
+    static const bool gen2 = getenv("TSH_F16_GEN") != nullptr && getenv("TSH_F16_GEN")[0] == '2';
+    if (gen2) {
       if (a.tile_m == 256) {
         if (dense) batch_score_f16_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
         else batch_score_f16_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
@@ -65,6 +40,15 @@ void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
         if (dense) batch_score_f16_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
         else batch_score_f16_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
       }
+      return;
+    }
+#endif
+    if (a.tile_m == 256) {
+      if (dense) batch_score_f16pp_kernel<METRIC, true, 4><<<pgrid, 512, 0, st>>>(a);
+      else batch_score_f16pp_kernel<METRIC, false, 4><<<pgrid, 512, 0, st>>>(a);
+    } else {
+      if (dense) batch_score_f16pp_kernel<METRIC, true, 2><<<pgrid, 512, 0, st>>>(a);
+      else batch_score_f16pp_kernel<METRIC, false, 2><<<pgrid, 512, 0, st>>>(a);
     }
     return;
   }
@@ -78,11 +62,11 @@ void launch_batch_score_bf16(const BatchArgs &a, bool dense, hipStream_t st) {
 }
 }  // namespace
 
-void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st) {
+void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st, int cus) {
   if (a.Vs) {
-    if (metric == TSH_METRIC_L2) launch_batch_score_bf16<METRIC_L2>(a, dense, st);
-    else if (metric == TSH_METRIC_IP) launch_batch_score_bf16<METRIC_IP>(a, dense, st);
-    else launch_batch_score_bf16<METRIC_COS>(a, dense, st);
+    if (metric == TSH_METRIC_L2) launch_batch_score_bf16<METRIC_L2>(a, dense, st, cus);
+    else if (metric == TSH_METRIC_IP) launch_batch_score_bf16<METRIC_IP>(a, dense, st, cus);
+    else launch_batch_score_bf16<METRIC_COS>(a, dense, st, cus);
     return;
   }
   if (metric == TSH_METRIC_L2) launch_batch_score<METRIC_L2>(a, dense, st);

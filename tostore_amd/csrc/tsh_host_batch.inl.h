@@ -188,6 +188,8 @@ void query_norms(const float *q0, int64_t stride, int dim, int n, double *qn2, f
   }
 }
 
+inline double hld_f16(const Shard *s) { return (double)round_up(s->dim, 64); }  // padded reduction length of the fp16 planes
+
 // 2 * (error bound of the f32 MFMA key), absolute, per query.  qn2 / qmax: query_norms.
 bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, float *out_qsq) {
   const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
@@ -204,16 +206,27 @@ bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, flo
     // sit >= 27 binades under the largest operand value after the power-of-two scaling
     const double hld = (double)round_up(s->dim, 64);
     // (a query is only batched when its largest element is within 2^8 of the batch's, see top_q)
-    // The filtered IP / cosine pass starts its accumulators at -theta (|theta| <= |q| max|v| (1 + 1e-3), capped by
+    // The filtered IP / cosine pass starts its accumulators at -theta (|theta| <= |q| max|v| (1 + 1e-2), capped by
     // BatchArgs::kmax) instead of zero: the chain carries twice the magnitude, and the key is formed from the
     // accumulator by one more subtraction and one multiplication by a power of two (tsh_batch_f16pp.hip.h)
-    gam = 2.0 * (hld + 10.0) * u2 * (1.0 + 0.002) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
+    gam = 2.0 * (hld + 10.0) * u2 * (1.0 + 0.01) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
           std::sqrt(hld) * 9.3e-10;
   }
   double delta;
   if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
   else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07) * (kernel == 2 ? 1.0 + 1e-6 : 1.0);
-  else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
+  else if (kernel == 2) {
+    // L2 on the fp16 kernel (round 4): key = |q|^2 + |v|^2 - 2 q.v with the accumulators of the
+    // filtered pass starting at seed_q - c_v = -(|q|^2 - thr') / (2 s) - |v|^2 / (2 s), thr' <= kmax = 1.01 (|q| +
+    // max|v|)^2.  In key units (x 2 s) the f32 chain's partial sums stay below
+    //   M = (|q|^2 + kmax + max|v|^2) / 2 + |q| max|v| (1 + 2^-10) <= 2.03 A,   A = |q|^2 + max|v|^2,
+    // so its hld + 10 roundings cost 2 (hld + 10) u M <= 4.06 (hld + 10) u A (the dense pass, which starts at zero,
+    // carries less).  The operand roundings act on the products only: 2 e_op |q| max|v| as before.  Roundings of
+    // |q|^2, |v|^2 (f32 from f64 sums), of the seed's subtraction, the start value and the key's fma: 14 u2 A.
+    const double A = qn * qn + vmax * vmax;
+    const double e_op = 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 + std::sqrt(hld_f16(s)) * 9.3e-10;
+    delta = 2.0 * e_op * qn * vmax + 4.06 * (hld_f16(s) + 10.0) * u2 * A + 14.0 * u2 * A;
+  } else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
   delta += (double)s->dim * 7.5e-37;
   double d2 = 2.0 * delta * 1.0001;
   if (!(d2 < 1e30)) return false;
@@ -318,7 +331,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad, *h_kmax = b->h_qaux + 4 * (size_t)nq_pad;
-  // the largest key a row can have (IP: -dot <= |q| max|v|; cosine planes hold unit rows): caps the thresholds
+  // the largest key a row can have (IP: -dot <= |q| max|v|; cosine planes hold unit rows; L2: (|q| + max|v|)^2): caps
+  // the thresholds of the fp16 kernel's filtered pass.  1 % above it: a row AT the largest key still passes an
+  // "everything passes" threshold with its key's error (<= 0.13 % of that scale) on top
   const double kmax_v = s->metric == TSH_METRIC_COSINE ? 1.0 : (double)s->max_norm;
   std::vector<char> bad((size_t)nq, 0);
   std::vector<float> qmax((size_t)nq_pad, 0.f);
@@ -333,7 +348,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       if (q < nq && ok[q - g0] && batch_delta2(s, kern, b->mag_a[(size_t)q], &h_d2[q], &h_qsq[q])) {
         memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
         for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
-        const double km = std::sqrt(b->mag_a[(size_t)q]) * kmax_v * 1.001 + 1e-30;
+        const double qn_q = std::sqrt(b->mag_a[(size_t)q]);
+        const double km = (s->metric == TSH_METRIC_L2 ? (qn_q + kmax_v) * (qn_q + kmax_v) : qn_q * kmax_v) * 1.01 + 1e-30;
         h_kmax[q] = km < 3e38 ? (float)km : 3e38f;
       } else {
         if (q < nq) {
@@ -556,7 +572,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.n_tiles = (int32_t)((n_sample + tile_n - 1) / tile_n);
     const bool timed = b->timed || trace_batch();
     if (timed) HIPCHK(hipEventRecord(b->e0, st));
-    launch_batch_score_m(s->metric, a, true, st);
+    launch_batch_score_m(s->metric, a, true, st, s->cus);
     if (timed) HIPCHK(hipEventRecord(b->e1, st));
     // B0s: per-query threshold + the sample's own candidates
     SampleSelArgs ss{};
@@ -585,7 +601,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.row0 = (int32_t)n_sample;
       a.row1 = (int32_t)rows;
       a.n_tiles = (int32_t)((rows - n_sample + tile_n - 1) / tile_n);
-      launch_batch_score_m(s->metric, a, false, st);
+      launch_batch_score_m(s->metric, a, false, st, s->cus);
     }
     HIPCHK(hipEventRecord(b->e3, st));
     // B2 + rerank

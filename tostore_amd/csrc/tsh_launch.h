@@ -26,7 +26,8 @@ void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream
 // (live rows of a masked scan, as far as the host knows them) -> mostly_live
 inline bool scan_mostly_live(int64_t live_rows, int64_t rows) { return live_rows * 10 >= rows * 6; }
 
-// batched key pass (f32 MFMA / bf16x3 / f16 by a.Vs and a.dot_scale).  tsh_batch_tu.hip
-void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st);
+// batched key pass (f32 MFMA / bf16x3 / f16 by a.Vs and a.dot_scale).  cus: compute units of the device the stream
+// belongs to (the persistent f16 kernels run one workgroup per CU).  tsh_batch_tu.hip
+void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st, int cus);
 
 }  // namespace tsh

@@ -367,6 +367,7 @@ struct Shard {
 
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   std::atomic<int64_t> c_plane_fallbacks{0}, c_scan_fallbacks{0};  // batched calls degraded by a full device
+  int cus = 0;  // compute units of the shard's device (grid of the persistent key kernels)
   std::atomic<int> planes_denied{0};  // batched calls left that go straight to the f32 kernel (the copy did not fit)
   double scan_us_sum = 0;  // guarded by ctx_mu
   int64_t scan_us_samples = 0;
@@ -519,6 +520,7 @@ int shard_init(Shard *s) {
   s->aux_stream = ds->aux;
   s->upload_stream = ds->upload;
   s->cu_split = ds->cu_split;
+  s->cus = ds->cus;
   s->scan_mu = &ds->scan_mu;
   s->holds_streams = true;
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
