@@ -121,7 +121,9 @@ struct ScanArgs {
   int64_t ld;             // floats per row, multiple of 4
   int64_t n;              // rows
   int32_t d4;             // float4 per row (= ld/4)
-  int32_t n_tiles;        // ceil(n/64)
+  int32_t n_tiles;        // ceil(n/64); list scans: ceil(list entries / 64) -- keys / gmin are in LIST order then
+  const uint32_t *list;   // list scans (scan_list_kernel): local row ids of the rows to scan, ascending, padded with
+                          // 0xFFFFFFFF to a multiple of 64; NULL otherwise
 };
 
 // Kernel parameter block: the scan arguments plus up to 960 query floats inline,
@@ -311,6 +313,113 @@ __global__ void __launch_bounds__(WAVES * 64, MINW) scan_kernel(ScanArgsQ aq) {
   }
 }
 
+// K1 for SELECTIVE row masks (a WHERE clause that keeps a few percent of the rows; config C5): the host compacts the
+// kept row ids into a list once per mask, and the scan is a gather over that list instead of a walk over tiles that
+// are mostly dead.  Why: a masked scan_kernel wave meets 0.6 live rows per tile at keep 1 %, reads the tile's mask
+// words, then the row, then moves on -- three dependent round trips for 3 KB, every row in another 2 MB page (a TLB
+// miss each: profiles/r03_rerank_tlb_counters.txt).  Here ONE wave owns eight consecutive list entries and has all
+// eight rows in flight at once; consecutive list entries are neighbours in the row store (the list is ascending),
+// so a wave's rows share one or two pages, and all of a mask's waves are resident together.
+// A workgroup = 8 waves = 64 list entries = one "tile" of the downstream select kernel, which runs unchanged on the
+// compact keys (n_tiles = entries / 64: a 1 % mask of 1 M rows selects among 157 tiles instead of 15 625) and maps
+// list positions back to row ids when it emits candidates (SelectArgs::list).
+template <int NCH, int METRIC, int R, bool NT>
+__global__ void __launch_bounds__(512, 2) scan_list_kernel(ScanArgsQ aq) {
+  static_assert(R == 2 || R == 4, "R must give an even number of groups per 8-row batch");
+  static_assert(2 * R * NCH * 4 + NCH * 4 <= 200, "two register buffers + the query within 256 VGPRs");
+  const ScanArgs &a = aq.a;
+  const float *qsrc = a.query;
+  if (!qsrc) {
+    typedef const char __attribute__((address_space(4))) * karg_ptr;
+    qsrc = (const float *)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ScanArgsQ, q));
+  }
+  constexpr int G = 8 / R;
+  __shared__ uint32_t s_min[8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = (int)blockIdx.x;  // one workgroup per 64 list entries
+  // this lane's 16 bytes of chunk c exist (the row may end inside a chunk, and NCH comes from a short list of widths)
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) vmask |= (c * 64 + lane < a.d4) ? (1u << c) : 0u;
+  auto has = [&](int c) { return ((vmask >> c) & 1u) != 0u; };
+  uint32_t loff[NCH];  // lanes past the row's end reload its first 16 bytes (valid memory) and sit the chunk out
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) loff[c] = has(c) ? (uint32_t)(4 * lane + c * 256) : 0u;
+  f32x4 q[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    q[c] = *reinterpret_cast<const f32x4 *>(qsrc + loff[c]);
+    if (!has(c)) q[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (a.query_out && blockIdx.x == 0 && wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (has(c)) *reinterpret_cast<f32x4 *>(a.query_out + 4 * lane + c * 256) = q[c];
+  }
+  // my wave's eight list entries: lanes wave * 8 .. wave * 8 + 7 of the tile (the lanes that end up with their keys)
+  const int e0 = wave * 8;
+  uint32_t my_id = 0xFFFFFFFFu;
+  if ((lane >> 3) == wave) my_id = a.list[(int64_t)t * 64 + lane];
+  bool alive = my_id != 0xFFFFFFFFu;
+  if (alive) alive = (a.live[my_id >> 6] >> (my_id & 63)) & 1ull;  // (tombstoned since the mask was made: still a dead row)
+  const uint64_t valid = __ballot(my_id != 0xFFFFFFFFu) >> e0;  // bit j = entry e0 + j exists (a prefix: padding is last)
+  const int cnt = __popcll(valid & 0xFFull);
+  float val = 0.f;
+  if (cnt > 0) {
+    f32x4 v[2][R][NCH];
+    auto load_group = [&](int buf, int g) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        int e = g * R + j;
+        e = e < cnt ? e : cnt - 1;  // a short batch repeats its last row
+        const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, e0 + e);
+        const float *rb = a.rows + (int64_t)id * a.ld;  // wave-uniform: a scalar base + one 32-bit lane offset per chunk
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[buf][j][c] = ld16<NT>(rb + loff[c]);
+      }
+    };
+    float acc[8];
+    load_group(0, 0);
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      if (k + 1 < G) load_group((k + 1) & 1, k + 1);
+      TSH_FENCE();
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (has(c)) sum = accum4<METRIC>(sum, q[c], v[k & 1][j][c]);
+        asm volatile("" : "+v"(sum)::"memory");
+        acc[k * R + j] = sum;
+      }
+      TSH_FENCE();
+    }
+    float o = treduce8<0>(acc, lane);  // octet partial of row (lane & 7), then across the 8 octets
+    o += __shfl_xor(o, 8);
+    o += __shfl_xor(o, 16);
+    o += __shfl_xor(o, 32);
+    val = o;  // every lane with (lane & 7) == j holds row j's sum: the wave's own lanes e0 + j take theirs
+  }
+  if (METRIC == METRIC_IP) {
+    val = -val;
+  } else if (METRIC == METRIC_COS) {
+    const float inv = alive ? a.inv_norm[my_id] : 0.f;
+    val = -(val * inv);
+  }
+  const uint32_t key = alive ? f2key(val) : KEY_DEAD;  // (lanes outside the wave's eight: my_id invalid -> KEY_DEAD)
+  if ((lane >> 3) == wave) a.keys[(int64_t)t * 64 + lane] = key;
+  const uint32_t m = wave_min_u32(key);
+  if (lane == 0) s_min[wave] = m;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t x = lane < 8 ? s_min[lane] : KEY_DEAD;
+    x = wave_min_u32(x);
+    if (lane == 0) a.gmin[t] = x;
+  }
+}
+
 // K1 for narrow rows (ld = 128 / 64 / 32 floats): one 1 KiB wave load covers
 // 2 / 4 / 8 whole rows, so every lane stays busy.  A "virtual row" is the 256
 // floats of one wave load; the butterfly is the same as above but stops before
@@ -438,6 +547,7 @@ struct SelectArgs {
   int32_t metric;
   int64_t row_base;
   int64_t shard_rows;
+  const uint32_t *list;  // list scans: keys / gmin are in list order; candidate rows = list[position]
 };
 
 constexpr int SEL_THREADS = 1024;   // one whole CU; tile minima stay in registers
@@ -750,7 +860,7 @@ __device__ __forceinline__ void select_body(const SelectArgs &a) {
           base = (uint32_t)__shfl((int)base, 0);
           if (pass) {
             uint32_t p = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-            if (p < (uint32_t)a.cand_cap) a.cand_rows[p] = tile[u] * 64 + lane;
+            if (p < (uint32_t)a.cand_cap) a.cand_rows[p] = a.list ? a.list[tile[u] * 64 + lane] : tile[u] * 64 + lane;
           }
         }
       }
@@ -872,7 +982,7 @@ static __global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *
 // K3: whole-grid filter (fallback).  count accumulates in *out_count.
 static __global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys, const uint32_t *gmin, int64_t n_keys,
                                                      uint32_t band, uint32_t *out_rows,
-                                                     uint32_t *out_count, uint32_t cap) {
+                                                     uint32_t *out_count, uint32_t cap, const uint32_t *list = nullptr) {
   const int lane = threadIdx.x & 63;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t n_round = (n_keys + 63) & ~(int64_t)63;
@@ -885,7 +995,7 @@ static __global__ void __launch_bounds__(256) filter_kernel(const uint32_t *keys
       base = __shfl((int)base, 0);
       if (pass) {
         uint32_t p = base + __popcll(bm & ((1ull << lane) - 1ull));
-        if (p < cap) out_rows[p] = (uint32_t)i;
+        if (p < cap) out_rows[p] = list ? list[i] : (uint32_t)i;  // (list scans: keys are in list order)
       }
     }
   }

@@ -26,6 +26,11 @@ void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream
 // (live rows of a masked scan, as far as the host knows them) -> mostly_live
 inline bool scan_mostly_live(int64_t live_rows, int64_t rows) { return live_rows * 10 >= rows * 6; }
 
+// K1 over a compacted list of row ids (selective masks: a.a.list, a.a.n_tiles = list tiles).  Row widths up to eight
+// 1 KiB chunks (d <= 2048) that are not served by the packed kernels; tsh_scan_tu.hip
+bool scan_list_supported(int nch, int64_t ld);
+void launch_scan_list(const ScanArgsQ &a, int nch, int metric, hipStream_t s, const LaunchEv &ev = LaunchEv());
+
 // batched key pass (f32 MFMA / bf16x3 / f16 by a.Vs and a.dot_scale).  cus: compute units of the device the stream
 // belongs to (the persistent f16 kernels run one workgroup per CU).  tsh_batch_tu.hip
 void launch_batch_score_m(int metric, const BatchArgs &a, bool dense, hipStream_t st, int cus);

@@ -269,6 +269,9 @@ struct Ctx {
   uint64_t *h_mask = nullptr;  // pinned
   int64_t mask_words = 0;
   uint64_t mask_epoch = 0;  // which caller mask the device copy holds
+  uint32_t *d_list = nullptr, *h_list = nullptr;  // selective masks: the kept rows' ids (scan_list_kernel), h_ pinned
+  int64_t list_cap = 0;
+  uint64_t list_epoch = 0;
   uint32_t *d_keys = nullptr;
   uint32_t *d_gmin = nullptr;
   uint32_t *d_hist = nullptr;  // radix select of the fallback path (256 bins)
@@ -677,6 +680,8 @@ void ctx_free_all(Ctx *c) {
   hipHostFree(c->h_query);
   hipFree(c->d_mask);
   hipHostFree(c->h_mask);
+  hipFree(c->d_list);
+  hipHostFree(c->h_list);
   hipFree(c->d_keys);
   hipFree(c->d_gmin);
   hipFree(c->d_hist);
@@ -818,6 +823,7 @@ void fill_scan_args(const Shard *s, const Ctx *c, bool masked, bool user_mask, S
   a->n = s->rows;
   a->d4 = (int32_t)(s->ld / 4);
   a->n_tiles = (int32_t)((s->rows + 63) / 64);
+  a->list = nullptr;
 }
 
 // slice the caller's GLOBAL keep mask into this shard's tile words
@@ -854,7 +860,15 @@ struct Job {
   bool counted = false;           // contributes to Shard::inflight
   float eps_rel = 0.f, delta_abs = 0.f;  // this query's error band (for the fallback's own threshold)
   bool force_all = false;
+  int32_t list_tiles = 0;  // > 0: a list scan -- the context's keys / gmin are in list order, that many tiles of them
   std::vector<uint32_t> quar_sel;  // entries of c->h_quar that belong to this query's candidates
+};
+
+// A selective caller mask as a list: local ids of the kept rows, ascending, padded with 0xFFFFFFFF to whole tiles of
+// 64.  Made once per call (shard_search_blocks) and shared by the call's queries; nullptr = scan by tiles.
+struct RowList {
+  const uint32_t *ids = nullptr;
+  int32_t padded = 0;  // entries incl. padding (multiple of 64)
 };
 
 void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
@@ -886,11 +900,48 @@ void launch_quarantine_append(Shard *s, Ctx *c, Job *j, hipStream_t st) {
 // mask_words: this shard's slice of the caller mask (host), or NULL; epoch
 // identifies it so a context uploads it once per call
 // rows_est: rows the scan will actually read (popcount of the caller's mask; <= 0: all of them)
+int ctx_reserve_list(Ctx *c, int64_t padded) {
+  if (padded <= c->list_cap) return TSH_OK;
+  hipFree(c->d_list);
+  hipHostFree(c->h_list);
+  c->d_list = c->h_list = nullptr;
+  c->bytes -= c->list_cap * 4;
+  c->list_cap = 0;
+  c->list_epoch = 0;
+  const int64_t want = round_up(padded + padded / 2, 4096);
+  HIPCHK(hipMalloc(&c->d_list, (size_t)want * sizeof(uint32_t)));
+  HIPCHK(hipHostMalloc(&c->h_list, (size_t)want * sizeof(uint32_t), hipHostMallocDefault));
+  c->list_cap = want;
+  c->bytes += want * 4;
+  return TSH_OK;
+}
+
+// A selective mask (a WHERE clause that keeps a few percent of the rows) is scanned as a LIST of row ids: scan_list_kernel
+// gathers the kept rows, eight per wave, instead of walking tiles that are mostly dead (tsh_kernels.hip.h).  The list
+// pays below one kept row in list_div (tools/r4_list_probe.sh); TSH_LIST_DIV=0 switches it off.  -> ids filled (padded
+// with 0xFFFFFFFF to whole tiles) and true when the scan should use them.
+bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles, int64_t rows_kept, std::vector<uint32_t> *ids) {
+  static const int64_t list_div = getenv("TSH_LIST_DIV") ? atoll(getenv("TSH_LIST_DIV")) : 24;
+  if (!mask_words || list_div <= 0 || rows_kept * list_div > s->rows || s->rows < 4096 || !scan_list_supported(s->nch, s->ld))
+    return false;
+  ids->clear();
+  ids->reserve((size_t)round_up(rows_kept, 64));
+  for (int32_t t = 0; t < n_tiles; ++t)  // (bits past the shard's last row cannot be set: slice_mask clears them)
+    for (uint64_t w = mask_words[(size_t)t]; w; w &= w - 1) ids->push_back((uint32_t)t * 64u + (uint32_t)__builtin_ctzll(w));
+  if (ids->empty()) return false;
+  ids->resize((size_t)round_up((int64_t)ids->size(), 64), 0xFFFFFFFFu);
+  return true;
+}
+
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
-                const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target, int64_t rows_est = 0) {
+                const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target, int64_t rows_est = 0,
+                const RowList *list = nullptr) {
   Ctx *c = j->c;
   int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
   if (rc) return rc;
+  const bool use_list = list && list->ids && mask_words;
+  if (use_list && (rc = ctx_reserve_list(c, list->padded))) return rc;
+  j->list_tiles = use_list ? list->padded / 64 : 0;
   const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
   j->k = k;
   j->entries = entries;
@@ -906,13 +957,23 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     }
   }
   uint8_t *dev_block = dev_target ? dev_target : c->d_block;  // where the device header lives
-  const bool upload_mask = mask_words && c->mask_epoch != epoch;
+  // (a list scan needs the mask words on the device only where quarantined rows are matched against them)
+  const bool upload_mask = mask_words && c->mask_epoch != epoch && (!use_list || (!j->quar_sel.empty() && dev_target));
   if (upload_mask) {
     memcpy(c->h_mask, mask_words, (size_t)n_tiles * 8);
     c->mask_epoch = epoch;
   }
+  const bool upload_list = use_list && c->list_epoch != epoch;
+  if (upload_list) {
+    memcpy(c->h_list, list->ids, (size_t)list->padded * sizeof(uint32_t));
+    c->list_epoch = epoch;
+  }
   static thread_local ScanArgsQ sa;  // 4 KiB: keep it off the stack of deep callers
   fill_scan_args(s, c, j->masked, j->user_mask, &sa);
+  if (use_list) {
+    sa.a.list = c->d_list;
+    sa.a.n_tiles = j->list_tiles;
+  }
   const bool inline_q = s->ld <= SCAN_Q_INLINE;
   float *qdst = inline_q ? sa.q : c->h_query;
   memcpy(qdst, query, (size_t)s->dim * sizeof(float));
@@ -931,7 +992,8 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   se.hdr = reinterpret_cast<BlockHeader *>(dev_block);
   se.hdr_host = reinterpret_cast<BlockHeader *>(c->h_block_dev);
   se.cand_rows = c->d_cand;
-  se.n_tiles = n_tiles;
+  se.n_tiles = use_list ? j->list_tiles : n_tiles;
+  se.list = use_list ? c->d_list : nullptr;
   se.k = k;
   se.cand_cap = entries;
   se.eps_rel = band.eps_rel;
@@ -974,6 +1036,8 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     }
     if (upload_mask)
       HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
+    if (upload_list)
+      HIPCHK(hipMemcpyAsync(c->d_list, c->h_list, (size_t)list->padded * sizeof(uint32_t), hipMemcpyHostToDevice, ps));
     if (!inline_q)
       HIPCHK(hipMemcpyAsync(c->d_query, c->h_query, (size_t)s->ld * sizeof(float), hipMemcpyHostToDevice, ps));
     // (short scans as ONE dispatch -- every workgroup scans its tiles, the one drawing the last ticket selects and
@@ -987,8 +1051,10 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     } else if (overlap) {
       ev.stop = c->ev_scanned;
     }
-    launch_scan(sa, s->nch, s->metric, j->masked, ps, ev,
-                j->masked && scan_mostly_live(rows_est > 0 ? rows_est : s->rows - s->deleted, s->rows));
+    if (use_list) launch_scan_list(sa, s->nch, s->metric, ps, ev);
+    else
+      launch_scan(sa, s->nch, s->metric, j->masked, ps, ev,
+                  j->masked && scan_mostly_live(rows_est > 0 ? rows_est : s->rows - s->deleted, s->rows));
     hipStream_t ts = ps;
     if (overlap) {
       // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
@@ -1000,7 +1066,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     // (short rows and lists, config C1: K2 + K4 as ONE dispatch, the selecting workgroup re-ranking its dozen
     // candidates a lane each, was tried -- 17 us against 9 + 4.4 for the two launches: the lone workgroup waits out
     // count -> candidate ids -> rows one after the other, which the second launch's ramp-up hides)
-    launch_select(se, n_tiles, ts);
+    launch_select(se, se.n_tiles, ts);
     // the completion event rides on the re-rank's own dispatch packet unless more kernels follow (a separate
     // hipEventRecord is one more runtime call and one more barrier packet per query)
     bool done_recorded = false;
@@ -1061,7 +1127,9 @@ inline uint32_t h_band_of(uint32_t tau_key, float eps_rel, float delta_abs) {
 int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *spill) {
   Ctx *c = j->c;
   hipStream_t st = s->aux_stream;
-  int64_t n_keys = ((s->rows + 63) / 64) * 64;
+  // (a list scan left its keys in list order: fewer keys, and the filter maps positions back to row ids)
+  const int64_t n_keys = j->list_tiles > 0 ? (int64_t)j->list_tiles * 64 : ((s->rows + 63) / 64) * 64;
+  const uint32_t *list = j->list_tiles > 0 ? c->d_list : nullptr;
   if (s->cap > c->big_cap) {
     hipFree(c->d_big_rows);
     hipFree(c->d_big_entries);
@@ -1073,7 +1141,7 @@ int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *s
     c->big_cap = s->cap;
   }
   int fgrid = (int)std::min<int64_t>((n_keys + 255) / 256, 4096);
-  if (band_key >= KEY_NAN && !j->force_all && j->k < s->rows) {
+  if (band_key >= KEY_NAN && !j->force_all && j->k < n_keys) {
     // K2 could not bound the k-th key (k beyond its tile-minimum scheme, or fewer than k live tiles and a full
     // list): find the exact k-th smallest key with a 4-pass radix select over all keys -- 4 small kernels and
     // host round trips instead of an f64 rerank of every row (k = 2000 on 1 M rows: 0.9 ms instead of 9)
@@ -1103,7 +1171,7 @@ int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *s
   }
   HIPCHK(hipMemsetAsync(c->d_big_count, 0, 4, st));
   filter_kernel<<<fgrid, 256, 0, st>>>(c->d_keys, c->d_gmin, n_keys, band_key, c->d_big_rows, c->d_big_count,
-                                      (uint32_t)c->big_cap);
+                                      (uint32_t)c->big_cap, list);
   uint32_t count = 0;
   HIPCHK(hipMemcpyAsync(&count, c->d_big_count, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -1211,7 +1279,8 @@ struct SearchOut {
 // `depth` of them in flight on separate contexts so one query's select / rerank / copies hide
 // behind the next query's scan.
 int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, int32_t k, const uint64_t *mask_words,
-                       uint64_t epoch, int32_t entries, SearchOut *out, int depth, int64_t rows_est) {
+                       uint64_t epoch, int32_t entries, SearchOut *out, int depth, int64_t rows_est,
+                       const RowList *list = nullptr) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   depth = std::max(1, std::min(depth, std::min(q1 - q0, MAX_CTX)));
   std::vector<Job> jobs((size_t)depth);
@@ -1236,7 +1305,7 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
       Job &j = jobs[(size_t)((submitted - q0) % depth)];
       j.c = c;
       rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries, mask_words, epoch,
-                       out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr, rows_est);
+                       out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr, rows_est, list);
       if (rc) {
         release_all();
         return rc;
@@ -1277,19 +1346,27 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
     for (uint64_t w : mask_words) rows_est += __builtin_popcountll(w);
     if (rows_est == 0) rows_est = 1;
   }
+  // (made here once for all queries of the call)
+  std::vector<uint32_t> list_ids;
+  RowList list;
+  if (mask && build_row_list(s, mask_words.data(), n_tiles, rows_est, &list_ids)) {
+    list.ids = list_ids.data();
+    list.padded = (int32_t)list_ids.size();
+  }
+  const RowList *lp = list.ids ? &list : nullptr;
   const uint64_t *mw = mask ? mask_words.data() : nullptr;
   // short scans (small shards, selective masks) are bound by the submitting thread's ~25 us per query: two threads
   const int64_t scan_bytes = (rows_est > 0 ? rows_est : s->rows) * s->ld * 4;
   static const int forced_threads = getenv("TSH_SUBMIT_THREADS") ? atoi(getenv("TSH_SUBMIT_THREADS")) : 0;
   const int want = forced_threads > 0 ? forced_threads : (scan_bytes <= (160ll << 20) ? 2 : SUBMIT_THREADS);
   const int T = std::min(want, nq / 8);
-  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est);
+  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est, lp);
   std::vector<int> rcs((size_t)T, TSH_OK);
   std::vector<std::string> errs((size_t)T);
   const int per_depth = std::max(2, depth / T);
   auto run = [&](int t) {
     const int32_t q0 = (int32_t)((int64_t)nq * t / T), q1 = (int32_t)((int64_t)nq * (t + 1) / T);
-    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth, rows_est);
+    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth, rows_est, lp);
     if (rcs[(size_t)t]) errs[(size_t)t] = g_err;
   };
   std::vector<std::thread> th;
@@ -2003,9 +2080,23 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
     for (int32_t t = 0; t < n_tiles; ++t) live_rows += __builtin_popcountll(c->h_mask[t]);
   }
   const bool ml = masked && scan_mostly_live(live_rows, s->rows);
-  launch_scan(sa, s->nch, s->metric, masked, st, LaunchEv(), ml);  // warm
+  std::vector<uint32_t> list_ids;  // the kernel a search with this mask would run: the list scan for selective ones
+  const bool use_list = row_mask && build_row_list(s, c->h_mask, n_tiles, live_rows, &list_ids);
+  if (use_list) {
+    if ((rc = ctx_reserve_list(c, (int64_t)list_ids.size()))) return rc;
+    memcpy(c->h_list, list_ids.data(), list_ids.size() * sizeof(uint32_t));
+    c->list_epoch = 0;
+    HIPCHK(hipMemcpyAsync(c->d_list, c->h_list, list_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    sa.a.list = c->d_list;
+    sa.a.n_tiles = (int32_t)(list_ids.size() / 64);
+  }
+  auto launch = [&]() {
+    if (use_list) launch_scan_list(sa, s->nch, s->metric, st);
+    else launch_scan(sa, s->nch, s->metric, masked, st, LaunchEv(), ml);
+  };
+  launch();  // warm
   HIPCHK(hipEventRecord(c->ev0, st));
-  for (int32_t i = 0; i < iters; ++i) launch_scan(sa, s->nch, s->metric, masked, st, LaunchEv(), ml);
+  for (int32_t i = 0; i < iters; ++i) launch();
   HIPCHK(hipEventRecord(c->ev1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

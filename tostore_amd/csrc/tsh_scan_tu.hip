@@ -83,7 +83,32 @@ void launch_packed(const ScanArgsQ &a, int metric, bool masked, int grid, int th
 #undef TSH_PK
 }
 
+template <int NCH>
+void launch_scan_list_n(const ScanArgsQ &a, int metric, hipStream_t s, const LaunchEv &ev) {
+  constexpr int R = NCH <= 5 ? 4 : 2;  // two register buffers of R rows: all eight rows of a wave in flight up to d = 1280
+  const int grid = a.a.n_tiles;
+  if (metric == TSH_METRIC_L2) TSH_LAUNCH((scan_list_kernel<NCH, METRIC_L2, R, true>), grid, 512, 0, s, ev, a);
+  else if (metric == TSH_METRIC_IP) TSH_LAUNCH((scan_list_kernel<NCH, METRIC_IP, R, true>), grid, 512, 0, s, ev, a);
+  else TSH_LAUNCH((scan_list_kernel<NCH, METRIC_COS, R, true>), grid, 512, 0, s, ev, a);
+}
+
 }  // namespace
+
+bool scan_list_supported(int nch, int64_t ld) { return nch >= 1 && nch <= 8 && ld != 128 && ld != 64 && ld != 32; }
+
+void launch_scan_list(const ScanArgsQ &a, int nch, int metric, hipStream_t s, const LaunchEv &ev) {
+  if (a.a.n_tiles <= 0) return;
+  switch (nch) {
+    case 1: launch_scan_list_n<1>(a, metric, s, ev); break;
+    case 2: launch_scan_list_n<2>(a, metric, s, ev); break;
+    case 3: launch_scan_list_n<3>(a, metric, s, ev); break;
+    case 4: launch_scan_list_n<4>(a, metric, s, ev); break;
+    case 5: launch_scan_list_n<5>(a, metric, s, ev); break;
+    case 6: launch_scan_list_n<6>(a, metric, s, ev); break;
+    case 7: launch_scan_list_n<7>(a, metric, s, ev); break;
+    default: launch_scan_list_n<8>(a, metric, s, ev); break;
+  }
+}
 
 void launch_scan(const ScanArgsQ &a, int nch, int metric, bool masked, hipStream_t s, const LaunchEv &ev, bool ml) {
   int grid = (a.a.n_tiles + 3) / 4;
