@@ -263,6 +263,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const double t_in = now_us();
   HIPCHK(hipSetDevice(s->device));
   const int64_t rows = s->rows, ld = s->ld;
+  // A call the device finalises (below: gpu_final) never shows its candidate blocks to anybody, so their size is this
+  // function's own business: as wide as the finalising kernel takes.  The caller's default (k + 156) is the
+  // single-query path's, whose f32 keys have a band 100 x narrower than fp16 ones: an L2 / IP corpus whose norms
+  // vary (band ~ max|v|, interesting rows ~ min|v|) overflowed 256-entry lists for a third of its queries, and every
+  // overflow is a query redone by a whole scan (1 M x 768 L2, 1024 queries: 97 ms per call instead of 2.4).
+  if (out->on_final && !out->d_blocks && s->quar_ids.empty() && entries <= RF_MAX && k <= entries) entries = RF_MAX;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   // Workgroup tile (queries x rows).  f32 MFMA: 128 x 128.  bf16x3: 256 x 256 for batches of more than 128 queries,
   // 128 x 128 otherwise.  f16: 256 x 256 resp. 128 x 256.  Which key kernel runs is decided below (it needs the
@@ -308,7 +314,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // band that is narrow against ANY data; IP / L2 bands scale with the largest row norm, where bf16x3's
   // 25x tighter error keeps the candidate lists short when norms vary widely
   // -- unless the rows are nearly equal in norm (the usual normalised embeddings), when f16 serves them too
-  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm;
+  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm && !s->f16_denied.load();
   int kern = want_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : want_kernel;
   int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
   if (kern == 2) {
@@ -746,6 +752,16 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
     b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
     b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+  }
+  // auto mode: fp16 keys whose band keeps overflowing the lists of this corpus (every overflow is a whole scan) give
+  // way to bf16x3 ones, 25 x narrower, after two such calls (cosine keys are scale-free: never)
+  if (kern == 2 && want_kernel == 3 && s->metric != TSH_METRIC_COSINE) {
+    const int32_t n_over = (int32_t)redo->size() - n_unverified;
+    if (n_over > std::max(2, nq / 16)) {
+      if (s->f16_strikes.fetch_add(1) + 1 >= 2) s->f16_denied.store(true);
+    } else if (n_over == 0) {
+      s->f16_strikes.store(0);
+    }
   }
   b->est_unverified += n_unverified;
   if (b->est_backoff > 0) --b->est_backoff;

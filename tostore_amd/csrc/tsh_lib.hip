@@ -371,6 +371,8 @@ struct Shard {
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   std::atomic<int64_t> c_plane_fallbacks{0}, c_scan_fallbacks{0};  // batched calls degraded by a full device
   int cus = 0;  // compute units of the shard's device (grid of the persistent key kernels)
+  std::atomic<int> f16_strikes{0};      // batched calls in a row whose fp16 bands overflowed many candidate lists
+  std::atomic<bool> f16_denied{false};  // auto key-kernel choice: bf16x3 instead of fp16 for this shard from now on
   std::atomic<int> planes_denied{0};  // batched calls left that go straight to the f32 kernel (the copy did not fit)
   double scan_us_sum = 0;  // guarded by ctx_mu
   int64_t scan_us_samples = 0;
