@@ -113,6 +113,9 @@ def parse(argv=None):
     ap.add_argument("--lat-queries", type=int, default=1000,
                     help="queries of the one-at-a-time latency leg (p50 / p99 / max in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unit-rows", action="store_true",
+                    help="corpus rows stay L2-normalised for every metric (the demo's own recipe; default: L2 / IP rows are "
+                         "also scaled by U(0.5, 2) so that the three metrics rank differently, SURVEY.md section 8d)")
     ap.add_argument("--no-side", action="store_true", help="skip the side legs (C1 / C3 / C5)")
     ap.add_argument("--side", default="c5,c1,c3", help="side legs to run, comma separated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -277,7 +280,7 @@ class Env:
             g.manual_seed(CORPUS_SEED + c)
             x = torch.randn((e - s, d), generator=g, device=self.dev, dtype=torch.float32)
             x /= x.norm(dim=1, keepdim=True)
-            if metric != 2:
+            if metric != 2 and not self.a.unit_rows:
                 x *= torch.rand((e - s, 1), generator=g, device=self.dev) * 1.5 + 0.5
             a0, a1 = max(s, lo), min(e, hi)
             yield a0, x[a0 - s:a1 - s].contiguous()

@@ -202,9 +202,17 @@ def test_bf16_planes_follow_appends_overwrites_and_growth(hip_lib, oracle_mod, m
         _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="f32 kernel")
         idx.set_batch_kernel(2)                               # planes rebuilt in the other format
         _check_batch(oracle_mod, idx, rows, qs, metric, k, tag="f16 kernel")
+        c_before = idx.counters()
+        assert c_before["scan_launches"] == 0
         idx.append(30_000, rows[:500] * np.float32(40.0))     # larger magnitudes: the f16 scale must follow
         _check_batch(oracle_mod, idx, np.concatenate([rows, rows[:500] * np.float32(40.0)]), qs, metric, k, tag="f16 rescale")
-        assert idx.counters()["scan_launches"] == 0
+        c = idx.counters()
+        assert c["batch_launches"] > c_before["batch_launches"]
+        # IP / cosine: still answered by the batched path alone.  L2 keys carry |v|^2: with fp16 FORCED onto rows
+        # whose norms now span a factor 40, the band (it scales with the largest row) holds more
+        # rows than a candidate list does, and the queries are handed to the scans -- exact, and what the automatic
+        # choice avoids by taking bf16x3 for such a corpus (test_auto_kernel_choice)
+        assert metric == L2 or c["scan_launches"] == 0
 
 
 def test_bf16x3_wide_dynamic_range(hip_lib, oracle_mod):
@@ -334,3 +342,37 @@ def test_two_callers_overlap_bit_exact(hip_lib, oracle_mod):
                     assert cnt[i] == len(ref[i][0])
                     assert np.array_equal(ids[i, :cnt[i]], ref[i][0]) and np.array_equal(dist[i, :cnt[i]], ref[i][1])
         assert idx.counters()["fallback_searches"] == 0
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_batched_range_mask_takes_its_sample_inside_the_range(hip_lib, oracle_mod, metric, kernel):
+    """A WHERE clause that keeps ONE id range leaves the first rows -- the default sample -- without a kept row: the
+    batched path then moves its sample window to where the kept rows are (round 4; before, every query of such a call
+    overflowed and was redone by a scan of its own).  Ranges at the start, in the middle and at the end of the rows;
+    a mask kept in two clusters; the filtered pass runs on both sides of the window."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(17 + metric)
+    n, d, k, nq = 150_000, 128, 20, 48
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    if metric == 2:
+        qs = np.stack([oracle_mod.normalize_f32(q) for q in qs])
+    with HipVectorIndex(d, metric, capacity_rows=n) as idx:
+        idx.append(0, rows)
+        idx.set_batch_min_nq(2)
+        idx.set_batch_kernel(kernel)
+        for spans in ([(0, 15_000)], [(70_001, 90_003)], [(n - 12_345, n)], [(30_000, 33_000), (120_000, 140_000)]):
+            keep = np.zeros(n, bool)
+            for a, b in spans:
+                keep[a:b] = True
+            mask = np.packbits(keep, bitorder="little")
+            c0 = idx.counters()
+            ids, dist, cnt = idx.search(qs, k, None, mask)
+            c1 = idx.counters()
+            ref = oracle_mod.search_heap_many_mt(rows, qs, metric, k, None, mask)
+            assert np.array_equal(cnt, ref[2]) and np.array_equal(ids, ref[0])
+            assert np.array_equal(dist.view(np.uint64), ref[1].view(np.uint64))
+            assert c1["batch_launches"] > c0["batch_launches"]
+            assert c1["scan_launches"] == c0["scan_launches"], (spans, c1["scan_launches"] - c0["scan_launches"])

@@ -7,7 +7,7 @@ python tools/build_variants.py gen2: > $O/build.log 2>&1 || { tail -5 $O/build.l
 VAR=$(tail -1 $O/build.log)
 one() {  # name metric env...
   local name=$1 metric=$2; shift 2
-  env "$@" timeout 400 python bench.py --batch 1024 --metric $metric --batch-kernel 2 --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline > $O/$name.json 2> $O/$name.err
+  env "$@" timeout 400 python bench.py --batch 1024 --metric $metric --batch-kernel 2 --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline $EXTRA > $O/$name.json 2> $O/$name.err
   python - <<PY
 import json
 try:
@@ -17,9 +17,13 @@ except Exception as e: print("$name: no line", e)
 PY
 }
 for rep in 1 2; do
+  # the verdict's comparison: the same unit-norm rows under L2 (gen 3 / gen 2) and under cosine
+  EXTRA=--unit-rows one l2unit_gen3_$rep l2 TSH_NOP=1
+  EXTRA=--unit-rows one l2unit_gen2_$rep l2 TSH_LIB_PATH=$VAR TSH_F16_GEN=2
+  one cos_gen3_$rep cosine TSH_NOP=1
+  # the bench's default L2 corpus (row norms U(0.5, 2): a wider band, more survivors per tile)
   one l2_gen3_$rep l2 TSH_NOP=1
   one l2_gen2_$rep l2 TSH_LIB_PATH=$VAR TSH_F16_GEN=2
-  one cos_gen3_$rep cosine TSH_NOP=1
 done
 python - <<PY
 import json,glob

@@ -286,8 +286,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t k_est = batch_k_est(b, k, rows, n_sample);
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
-    for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2, &b->e3}) HIPCHK(hipEventCreate(e));
     const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0;
+    for (hipEvent_t *e : {&b->e0, &b->e1, &b->e2}) HIPCHK(hipEventCreate(e));
+    HIPCHK(hipEventCreateWithFlags(&b->e3, wait_flag));  // timed, and the call's longest wait (the end of the key passes)
     HIPCHK(hipEventCreateWithFlags(&b->e_done, hipEventDisableTiming | wait_flag));
     for (hipEvent_t &e : b->e_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | wait_flag));
     HIPCHK(hipEventCreateWithFlags(&b->e_up, hipEventDisableTiming));
@@ -398,6 +399,26 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     }
   }
   if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
+  // Where the sample sits.  The first n_sample rows serve any mask that keeps rows everywhere; a WHERE clause that
+  // keeps one id RANGE leaves them without a single kept row -- no threshold, every kept row a survivor, every list
+  // overflowing, every query redone by a scan of its own (1 M x 768, a 10 % range, 64-query calls: 5.5 k queries/s where
+  // Bernoulli masks reach 120 k).  With a mask the window of n_sample consecutive rows (whole 256-row tiles) that keeps
+  // the most rows is taken instead -- candidates every half window -- and the first one on a tie.  The bound needs
+  // nothing of the sample but k kept rows inside it; an estimate it makes unrepresentative is caught by B2 as ever.
+  int64_t s0 = 0;
+  if (mask && n_sample < rows) {
+    const int64_t wt = n_sample / 64, step = std::max<int64_t>(4, wt / 2 / 4 * 4);  // in 64-row mask words; 256-row aligned
+    std::vector<int32_t> pre((size_t)n_tiles_all + 1, 0);
+    for (int32_t t = 0; t < n_tiles_all; ++t) pre[(size_t)t + 1] = pre[(size_t)t] + __builtin_popcountll(b->h_mask[t]);
+    int64_t best = -1;
+    for (int64_t w0 = 0; w0 * 64 + n_sample <= rows; w0 += step) {
+      const int64_t kept = pre[(size_t)std::min<int64_t>(w0 + wt, n_tiles_all)] - pre[(size_t)w0];
+      if (kept > best) {
+        best = kept;
+        s0 = w0 * 64;
+      }
+    }
+  }
   // quarantined rows (not live on the device): their exact sums for every query, added to the blocks below
   std::vector<uint32_t> quar_sel;
   const int32_t n_quar = (int32_t)s->quar_ids.size();
@@ -573,8 +594,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.tile_m = tile;
     a.q_tiles = nq_pad / tile;
     // B0: dense keys of the sample rows
-    a.row0 = 0;
-    a.row1 = (int32_t)n_sample;
+    a.row0 = (int32_t)s0;
+    a.row1 = (int32_t)(s0 + n_sample);
     a.n_tiles = (int32_t)((n_sample + tile_n - 1) / tile_n);
     const bool timed = b->timed || trace_batch();
     if (timed) HIPCHK(hipEventRecord(b->e0, st));
@@ -594,7 +615,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     ss.k_est = k_est;
     ss.tau_est = d_tau_est;
     ss.cand_cap = cand_cap;
-    ss.row0 = 0;
+    ss.row0 = (int32_t)s0;
     // one workgroup per query: a small batch leaves most CUs empty, so its workgroups get sixteen waves instead of
     // four (128 queries: 76 -> 54 and 58 -> 50 us); with a thousand workgroups the wide shape loses (the one-wave
     // bisect phases idle fifteen waves: 103 -> 235 us)
@@ -603,10 +624,16 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     else batch_sample_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(ss);
     // B1: everything else, filtered
     if (timed) HIPCHK(hipEventRecord(b->e2, st));
-    if (rows > n_sample) {
-      a.row0 = (int32_t)n_sample;
+    if (s0 > 0) {  // (a sample window inside the rows: the filtered pass runs on either side of it)
+      a.row0 = 0;
+      a.row1 = (int32_t)s0;
+      a.n_tiles = (int32_t)((s0 + tile_n - 1) / tile_n);
+      launch_batch_score_m(s->metric, a, false, st, s->cus);
+    }
+    if (rows > s0 + n_sample) {
+      a.row0 = (int32_t)(s0 + n_sample);
       a.row1 = (int32_t)rows;
-      a.n_tiles = (int32_t)((rows - n_sample + tile_n - 1) / tile_n);
+      a.n_tiles = (int32_t)((rows - s0 - n_sample + tile_n - 1) / tile_n);
       launch_batch_score_m(s->metric, a, false, st, s->cus);
     }
     HIPCHK(hipEventRecord(b->e3, st));
@@ -705,8 +732,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   double t_gpu = 0;
   // From the end of the key passes on the pool gets a job every few dozen microseconds (one per chunk of the tail):
   // the long wait blocks, then the workers are woken and poll until the call is over
+  // (ranks that outnumber the CPU quota: a device-finalised call has one copy left for the pool -- not worth workers
+  // polling through the select and re-rank kernels)
   std::unique_ptr<HostPool::Hold> hold;
-  if ((out->on_chunk || gpu_final) && nq >= 24) {
+  if ((out->on_chunk || gpu_final) && nq >= 24 && !(gpu_final && blocking_wait())) {
     HIPCHK(hipEventSynchronize(b->e3));
     hold.reset(new HostPool::Hold());
   }
@@ -774,7 +803,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if (out->d_blocks) {
     hipStream_t us = out->user_stream ? out->user_stream : s->batch_stream;
     HIPCHK(hipMemcpyAsync(out->d_blocks, b->d_blocks, (size_t)nq * bb, hipMemcpyDeviceToDevice, us));
-    HIPCHK(hipStreamSynchronize(us));
+    if (blocking_wait()) {  // (hipStreamSynchronize spins)
+      HIPCHK(hipEventRecord(b->e_done, us));
+      HIPCHK(hipEventSynchronize(b->e_done));
+    } else {
+      HIPCHK(hipStreamSynchronize(us));
+    }
   }
 #ifdef TSH_PROBES
   if (g_f16_dbg_buf && nq >= 1024) {  // probe: step timeline of two waves of workgroup 0 (main pass: the last launch)
