@@ -398,6 +398,9 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
       }
       alive_l[j] = alive;
     }
+    // L2, filtered pass: the NEXT tile's c_v, issued beside the liveness words above so that one wait covers both and
+    // the rest of the epilogue hides it (this tile's went into the accumulators' start values and is not needed again)
+    if (L2 && !DENSE && tile + G < total_tiles) load_cv(tile + G);
     // one survivor: into the wave's LDS list while it has room (slot = running count + rank among the passing
     // lanes; no atomics), straight into the query's global list otherwise (ties, duplicated rows: rare)
     auto append = [&](uint64_t m, bool mine, float key, int qrow, int cj) {
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
       pend_qbase = qbase;
       pend_nbase = nbase;
     }
-    if (L2 && tile + G < total_tiles) load_cv(tile + G);  // (waited for where the next tile's accumulators start)
+    if (L2 && DENSE && tile + G < total_tiles) load_cv(tile + G);  // (the dense keys above still needed this tile's)
     stamp(9);
     __builtin_amdgcn_sched_barrier(0);
     if (wm) __builtin_amdgcn_s_barrier();  // (group 1's barrier of the tile's last COMPUTE phase: see compute_phase)

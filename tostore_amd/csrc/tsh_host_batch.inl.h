@@ -140,8 +140,9 @@ int regrow_pinned(T **host, T **dev_view, int64_t *cap, int64_t want, int64_t *b
 // correctness -- and a call that sees more than a few failures switches the estimate off for the next calls.
 int32_t batch_k_est(BatchCtx *b, int32_t k, int64_t rows, int64_t n_sample) {
   static const bool off = getenv("TSH_BATCH_PROVEN_TAU") != nullptr && getenv("TSH_BATCH_PROVEN_TAU")[0] == '1';
-  if (off || n_sample >= rows || k <= 8 || b->est_backoff > 0) return k;
+  if (off || n_sample >= rows || n_sample <= 0 || k <= 8 || b->est_backoff > 0) return k;
   const double pr = (double)n_sample / (double)rows;
+  if (pr > 0.5) return k;  // (most of the rows are in the sample: its k-th key is as good as proven)
   // tail P(Binomial(k, pr) >= p) from p = k downwards
   std::vector<double> pmf((size_t)k + 1);
   const double lq = std::log1p(-pr), lp = std::log(pr);
@@ -283,7 +284,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
   const int64_t n_sample = b->last_sample_force ? rows : batch_sample_rows(rows, k);
   const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
-  const int32_t k_est = batch_k_est(b, k, rows, n_sample);
+  int32_t k_est = batch_k_est(b, k, rows, n_sample);  // (with a mask: recomputed below from the KEPT rows)
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
     const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0;
@@ -418,6 +419,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         s0 = w0 * 64;
       }
     }
+    // the estimate's order statistic counts KEPT rows: a range mask may have half of them inside the window, where
+    // n_sample / rows would say a thirtieth -- and a threshold taken that much too low fails its check for every query
+    k_est = batch_k_est(b, k, std::max<int64_t>(pre[(size_t)n_tiles_all], 1), std::max<int64_t>(best, 0));
   }
   // quarantined rows (not live on the device): their exact sums for every query, added to the blocks below
   std::vector<uint32_t> quar_sel;
