@@ -84,6 +84,22 @@ inline bool alloc_fault(int64_t bytes) {
   return over > 0 && bytes >= over;
 }
 
+// Is there room on the current device for an allocation of `bytes`?  Asked BEFORE hipMalloc for the batched path's big
+// buffers: the runtime's own out-of-memory path is best not entered -- it walks its queues to release memory, and in
+// a process that had created and destroyed CU-masked streams before (the test-suite; a host that opens and closes
+// indexes) a failing 200 MB hipMalloc ended in a segmentation fault inside libhsa-runtime64 instead of
+// hipErrorOutOfMemory (native backtrace: tools/abort_trace.sh).  Not a reservation -- another thread may take the room
+// in between, and then hipMalloc's own verdict stands.
+inline bool device_has_room(int64_t bytes) {
+  if (bytes < (4ll << 20)) return true;  // (small buffers: not worth the query)
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;
+  }
+  return (int64_t)free_b >= bytes + (16ll << 20);
+}
+
 template <typename T>
 int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
   if (want <= *cap) return TSH_OK;
@@ -96,6 +112,8 @@ int regrow(T **dev, T **host, int64_t *cap, int64_t want, int64_t *bytes) {
   *bytes -= *cap * (int64_t)sizeof(T);  // (a failed allocation below leaves an empty buffer, not a dangling capacity)
   *cap = 0;
   if (alloc_fault(want * (int64_t)sizeof(T))) return set_err(TSH_E_OOM, "hipMalloc failed: out of memory (injected)");
+  if (!device_has_room(want * (int64_t)sizeof(T)))
+    return set_err(TSH_E_OOM, "no room on the device for %lld bytes of batch scratch", (long long)(want * (int64_t)sizeof(T)));
   hipError_t e = hipMalloc(dev, (size_t)want * sizeof(T));
   if (e == hipSuccess && host) {
     e = hipHostMalloc(host, (size_t)want * sizeof(T), hipHostMallocDefault);
@@ -485,8 +503,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         const int64_t prow = round_up(s->cap, PLANE_GROUP);  // whole 256-row groups (plane_piece)
         // (nothing of this call has been launched yet: a device too full for the copy is the caller's cue to score
         // with the f32 kernel instead, shard_search_any)
-        const hipError_t pe = alloc_fault(prow * row_bytes) ? hipErrorOutOfMemory
-                                                            : hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes);
+        const hipError_t pe = alloc_fault(prow * row_bytes) || !device_has_room(prow * row_bytes)
+                                  ? hipErrorOutOfMemory
+                                  : hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes);
         if (pe != hipSuccess) {
           s->d_split = nullptr;
           (void)hipGetLastError();
