@@ -876,7 +876,11 @@ struct RowList {
 void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
   // a few hundred tiles (an index of some ten thousand rows): four waves instead of sixteen synchronise
   // faster (10 k x 128: p50 42.8 -> 39.8 us); from a few thousand tiles on the wide workgroup wins
-  if (n_tiles <= 512 && se.k <= 256) select_kernel<256, true><<<1, 256, 0, st>>>(se);
+  // (fewer tiles than k: the tile-minimum bound says nothing, every tile is a hit and step (f) bisects over all of
+  // them -- from registers only while they fit a workgroup's: 64 tiles for four waves, 256 for sixteen.  A list scan
+  // of a few thousand kept rows lands exactly there: 79 tiles, k = 100 took 85 us per query instead of 30)
+  const bool all_hit = n_tiles < se.k && n_tiles > 64;
+  if (n_tiles <= 512 && se.k <= 256 && !all_hit) select_kernel<256, true><<<1, 256, 0, st>>>(se);
   else if (n_tiles <= SEL_VPT * SEL_THREADS) select_kernel<SEL_THREADS, true><<<1, SEL_THREADS, 0, st>>>(se);
   else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
 }
