@@ -36,9 +36,11 @@ for keep, kind in ((0.002, "b"), (0.005, "b"), (0.01, "b"), (0.02, "b"), (0.03, 
     kept = int(bits.sum())
     us = idx.bench_scan(qs[0], 50, mask)
     idx.search(qs[:64], k, None, mask)
-    t0 = time.perf_counter()
-    for i in range(0, 256, 64):
-        idx.search(qs[i:i + 64], k, None, mask)
-    el = time.perf_counter() - t0
+    el = 1e9
+    for rep in range(3):  # (the best of three: the first pass after a new mask may still grow the contexts' buffers)
+        t0 = time.perf_counter()
+        for i in range(0, 256, 64):
+            idx.search(qs[i:i + 64], k, None, mask)
+        el = min(el, time.perf_counter() - t0)
     useful = kept * d * 4 + n / 8
     print("keep %.3f %s: kept %7d  scan %7.1f us  useful %.3f of HBM peak  %7.0f queries/s" % (keep, kind, kept, us, useful / (us * 1e-6) / 8e12, 256 / el))
