@@ -807,7 +807,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   // auto mode: fp16 keys whose band keeps overflowing the lists of this corpus (every overflow is a whole scan) give
   // way to bf16x3 ones, 25 x narrower, after two such calls (cosine keys are scale-free: never)
-  if (kern == 2 && want_kernel == 3 && s->metric != TSH_METRIC_COSINE) {
+  if (kern == 2 && want_kernel == 3 && s->metric != TSH_METRIC_COSINE && entries >= RF_MAX) {  // (at the widest lists only)
     const int32_t n_over = (int32_t)redo->size() - n_unverified;
     if (n_over > std::max(2, nq / 16)) {
       if (s->f16_strikes.fetch_add(1) + 1 >= 2) s->f16_denied.store(true);
