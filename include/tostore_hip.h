@@ -322,7 +322,8 @@ int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries,
  * Inside one call the queries travel in groups: while a group's candidate blocks are all-gathered (device to
  * device) and merged, a helper thread already scans the next group on this rank's shard.  Of every group each
  * rank copies back and merges only its own slice of the queries (world blocks per query); a second, small
- * all-gather hands every slice's final ids / distances to every rank.
+ * all-gather hands every slice's final ids / distances to every rank.  (Groups of at most 128 blocks in all -- world x
+ * queries -- are merged whole on every rank instead, and the second all-gather does not happen.)
  * Failures: a rank whose own part fails (bad handle, TSH_E_BUSY, a HIP error in its shard search, an allocation)
  * STAYS in the collective, contributes blocks that say so, and returns its error; the other ranks return
  * TSH_E_PEER; the communicator remains usable.  Only a failing all-gather / stream operation (TSH_E_RCCL,

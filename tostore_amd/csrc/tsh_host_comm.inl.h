@@ -97,6 +97,20 @@ constexpr uint32_t FLAG_RANK_ERROR = 0x80000000u;  // BlockHeader.flags: this ra
 
 inline size_t res_rec_bytes(int32_t k) { return (size_t)k * 16 + 8; }  // k ids, k distances, count + pad
 
+// Small groups are merged WHOLE on every rank: each rank copies back all W x gq gathered blocks and finalises all gq
+// queries itself, and the second all-gather (every slice's results to every rank: an H2D, a collective, a D2H and a
+// wait -- the larger half of a small group's exchange) does not happen.  W times the merge work, which for a few
+// queries is microseconds; every rank reads the same gathered bytes, so every rank reaches the same verdict without
+// being told.  Matters where the exchange is exposed: the last group of a call, i.e. short calls on many GPUs (the
+// driver's 20-query regions at N = 8 are three groups).  Larger groups keep the per-rank slices.
+constexpr size_t WHOLE_MERGE_MAX_BLOCKS = 128;  // W x gq
+inline bool merge_whole(size_t W, size_t gq) { return W > 1 && W * gq <= WHOLE_MERGE_MAX_BLOCKS; }
+// queries a rank may have to merge in a group of up to gq: its slice, or a whole small group
+inline size_t merge_queries_max(size_t W, size_t gq) {
+  const size_t slice = (gq + W - 1) / W, whole = W > 1 ? std::min(gq, WHOLE_MERGE_MAX_BLOCKS / W) : 0;
+  return std::max(slice, whole);
+}
+
 }  // namespace
 
 struct tsh_comm {
@@ -194,7 +208,7 @@ int grow_host(T **p, size_t *cap, size_t want) {
 // identical on every rank, since capacities only depend on the calls made so far
 int comm_reserve(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, bool *grew) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world;
-  const size_t slice_q = ((size_t)gq + W - 1) / W;
+  const size_t slice_q = merge_queries_max(W, (size_t)gq);
   const size_t mine = bb * (size_t)gq, res = sizeof(ResHeader) + slice_q * res_rec_bytes(k);
   const size_t slice = c->host_fn ? W * mine : W * slice_q * bb;
   *grew = mine > c->mine_cap[0] || mine > c->mine_cap[1] || res > c->res_cap || slice > c->slice_cap ||
@@ -279,8 +293,9 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
                         int32_t k, double thr, int32_t entries, int64_t *out_ids, double *out_dist, int32_t *out_count,
                         GroupOut *go) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world, mine = bb * (size_t)gq;
-  const int32_t slice_q = (int32_t)(((size_t)gq + W - 1) / W);
-  const int32_t a = std::min<int32_t>(gq, c->rank * slice_q), b = std::min<int32_t>(gq, a + slice_q);
+  const bool whole = merge_whole(W, (size_t)gq);  // (same on every rank: W and gq are)
+  const int32_t slice_q = whole ? gq : (int32_t)(((size_t)gq + W - 1) / W);
+  const int32_t a = whole ? 0 : std::min<int32_t>(gq, c->rank * slice_q), b = std::min<int32_t>(gq, a + slice_q);
   const size_t rec = res_rec_bytes(k), res = sizeof(ResHeader) + (size_t)slice_q * rec;
   int rc;
   tsh_comm_timeline &tl = c->tl;
@@ -374,7 +389,8 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   const double t3 = now_us();
   tl.merge_us += t3 - t2;
   const uint8_t *all_res = c->h_res_mine;
-  if (W > 1) {
+  const size_t RW = whole ? 1 : W;  // result slices to read below: one (this rank's own, the whole group) or every rank's
+  if (W > 1 && !whole) {
     if (c->host_fn) {
       rc = comm_allgather_host(c, c->h_res_mine, c->h_res_all, res);
       if (rc) return rc;
@@ -391,7 +407,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   const double t4 = now_us();
   tl.result_gather_us += t4 - t3;
   int32_t need = 0;
-  for (size_t w = 0; w < W; ++w) {
+  for (size_t w = 0; w < RW; ++w) {
     const ResHeader *h = reinterpret_cast<const ResHeader *>(all_res + w * res);
     if (h->status != TSH_OK) {
       if (local_rc != TSH_OK) return local_rc;  // (this rank's own error text is still in place)
@@ -404,7 +420,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   }
   go->need = need;
   if (need) return TSH_OK;
-  for (size_t w = 0; w < W; ++w) {
+  for (size_t w = 0; w < RW; ++w) {
     const int32_t wa = std::min<int32_t>(gq, (int32_t)w * slice_q), wb = std::min<int32_t>(gq, wa + slice_q);
     const uint8_t *r = all_res + w * res + sizeof(ResHeader);
     for (int32_t q = wa; q < wb; ++q, r += rec) {
