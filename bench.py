@@ -167,7 +167,13 @@ def query_pool_size(steps, warmup, recall_queries, batch=0):
 
 def library_group(nq):
     """tsh_search_sharded's own choice of queries per exchange (tsh_host_comm.inl.h), for the report."""
-    return int(min(nq, 256 if nq >= 512 else max(8, min(64, (nq + 3) // 4))))
+    if nq >= 512:
+        return int(min(nq, 256))
+    if nq > 128:
+        return 64
+    if nq > 16:
+        return (nq + 1) // 2
+    return max(int(nq), 1)
 
 
 def sharded_group(group, count):

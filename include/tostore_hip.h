@@ -343,8 +343,8 @@ int32_t tsh_comm_create_host(int32_t world, int32_t rank, int32_t device, tsh_al
                              tsh_comm **out);
 int32_t tsh_comm_destroy(tsh_comm *comm);
 int32_t tsh_comm_world(tsh_comm *comm);
-/* queries per exchange of tsh_search_sharded; 0 (default) = by the size of the call (a quarter of it, 8..64; 256 for
- * calls of 512 queries and more).  Same value on every rank. */
+/* queries per exchange of tsh_search_sharded; 0 (default) = by the size of the call: the whole call up to 16 queries,
+ * half of it up to 128, 64 up to 512, 256 beyond.  Same value on every rank. */
 int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
                            double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,

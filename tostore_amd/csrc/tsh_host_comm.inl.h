@@ -86,6 +86,13 @@ int rccl_fail(const char *what, int rc) {
   return set_err(TSH_E_RCCL, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "?");
 }
 
+inline int32_t sharded_group_auto(int32_t nq) {
+  if (nq >= 512) return 256;
+  if (nq > 128) return 64;
+  if (nq > 16) return (nq + 1) / 2;
+  return std::max(nq, 1);
+}
+
 // header of one rank's result slice in the second all-gather
 struct ResHeader {
   int32_t status;  // TSH_OK, or why this rank could not merge its slice (its own error, or TSH_E_PEER)
@@ -584,10 +591,14 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
   std::string local_err = g_err;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  // queries per exchange: enough groups for the look-ahead to matter, not so many that the two all-gathers of a
-  // group (some tens of microseconds each) show; big calls go to the matrix cores, which want big groups
+  // Queries per exchange.  A call costs nq scans + per group the fill and drain of the shard's scan pipeline (~45 us:
+  // the first scan runs alone, the last query's select / re-rank is waited for) + the LAST group's exchange (the
+  // others hide behind the next group's scans).  So: as few groups as keep that last exchange small -- one group up to
+  // 16 queries, two up to 128 (each at most 64: merged whole or in small slices), 64 per group up to 512; big calls go
+  // to the matrix cores, which want big groups.  (Round 3 took a quarter of the call, 8..64: a 20-query call on a
+  // 125 k-row shard -- one of eight GPUs -- was three groups, 82.7 us per query against 70 with two.)
   int32_t G = c->group;
-  if (G <= 0) G = nq >= 512 ? 256 : std::max(8, std::min(64, (nq + 3) / 4));
+  if (G <= 0) G = sharded_group_auto(nq);
   G = std::min(G, nq);
   int32_t entries = tsh_default_block_entries(k);
   bool grew = false;
