@@ -831,7 +831,19 @@ def side_c4_per_rank(env, a):
     per = int(a.c4_rows_per_rank)
     n = per * env.world
     lo, hi = env.rank * per, (env.rank + 1) * per
-    idx, _ = env.build_index(d, metric, n, lo, hi, keep_host=False)
+    # this rank's shard is the one step of the leg that can fail on one rank alone (7.7 GB of rows): agree on it before
+    # any rank enters the leg's collectives -- a rank waiting in one for a rank that gave up would hang the whole job
+    # (and the headline with it) until the launcher's timeout
+    idx, err = None, 0.0
+    try:
+        idx, _ = env.build_index(d, metric, n, lo, hi, keep_host=False)
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("[bench] rank %d: C4 per-rank shard not built: %r\n" % (env.rank, e))
+        err = 1.0
+    if env.reduce_max(err) > 0.0:
+        if idx is not None:
+            idx.close()
+        return {"error": "a rank could not build its %d x %d shard: leg skipped on every rank" % (per, d)} if env.rank == 0 else None
     searcher = None
     try:
         steps, warmup = max(a.steps, 20), min(max(a.warmup, 2), 10)
