@@ -942,30 +942,43 @@ constexpr int RW_LD = RW_P + 4;        // LDS row stride in floats: rows 4 banks
 constexpr int RW_CAND = 128;           // candidates per workgroup and pass, either shape
 // (128-float pieces measured with the BIG shape, 1024-query C3 call: 180 us against 126 -- four waves per CU instead of
 // eight; two pieces in flight per BIG wave: 133; plain instead of nontemporal loads: 136.)
-template <int CAND, int DEPTH>
+template <int CAND, int DEPTH, int P = RW_P, int NWAVES = RW_CAND / CAND>
 struct RwShape {
-  static constexpr int WAVES = RW_CAND / CAND;    // waves per workgroup
-  static constexpr int TILE = CAND * RW_LD;       // floats of a wave's LDS tile
-  static constexpr int NLOAD = CAND / 4;          // 1 KiB load instructions per piece (4 rows x 256 B each)
+  static constexpr int WAVES = NWAVES;            // waves per workgroup
+  static constexpr int NDEPTH = DEPTH;            // pieces in flight beside the one being worked on
+  static constexpr int LD = P + 4;                // LDS row stride in floats: rows 4 banks apart
+  static constexpr int TILE = CAND * LD;          // floats of a wave's LDS tile
+  static constexpr int LPR = P / 4;               // lanes per row of a 1 KiB load (16 B each)
+  static constexpr int RPL = 64 / LPR;            // rows a load covers: 4 x 256 B at P = 64, 8 x 128 B at P = 32
+  static constexpr int NLOAD = CAND / RPL;        // 1 KiB load instructions per piece
 };
 using RwBig = RwShape<64, 1>;
+// The finalising kernel's shape (round 4): FOUR waves of 64 candidates per query and 32-float pieces.  Lists are ~130
+// entries (k = 100): on two waves that is three wave passes, two of them in sequence, the last for a handful of
+// candidates at the price of a full one (a pass is latency: twelve pieces of dependent f64 chains).  Four waves take a
+// list of up to 256 in ONE round; with 32-float pieces a wave's tile is 9.2 KB instead of 17.4, so four such
+// workgroups still share a CU and all 1024 queries of a call are resident at once.  Measured on the 1024-query C3
+// call, same box, alternating (tools/r4_rf_ab.sh): 133 -> 106-107 us; two pieces in flight (DEPTH 2): 110; 16-float pieces:
+// 154.  Lists of ~240 (the bench's L2 corpus) take 189 us either way: four wave passes are two rounds on two waves and
+// still one round of longer pieces here.
+using RwFin = RwShape<64, 1, 32, 4>;
 
 // One wave: the exact sums of candidates [c0, c0 + min(left, CAND)) of query q's list, lane = candidate (lanes past
 // the list, or past CAND, repeat the last candidate).  tile: this wave's TILE floats of LDS.
-template <int CAND, int DEPTH>
+template <int CAND, int DEPTH, int P = RW_P, int NWAVES = RW_CAND / CAND>
 __device__ __forceinline__ void rerank_wave_sums(const RerankBatchArgs &a, int q, uint32_t c0, uint32_t left, float *tile,
                                                  int lane, uint32_t *out_row, double *out_s0, double *out_s1) {
 #pragma clang fp contract(off)
-  using T = RwShape<CAND, DEPTH>;
-  constexpr int P = RW_P;
+  using T = RwShape<CAND, DEPTH, P, NWAVES>;
+  constexpr int RW_LD = T::LD;  // (shadows the namespace constant: this shape's own stride)
   const uint32_t have = left < (uint32_t)CAND ? left : (uint32_t)CAND;
   const uint32_t slot = (uint32_t)lane < have ? (uint32_t)lane : have - 1u;
   const uint32_t my_row = a.final_rows[(int64_t)q * a.entries + c0 + slot];
   const int ld = (int)a.ld, dim = a.dim;
-  const int sub = lane >> 4, col4 = 4 * (lane & 15);
-  uint32_t rrow[T::NLOAD];  // load j of a piece covers candidates 4 j .. 4 j + 3, P floats each
+  const int sub = lane / T::LPR, col4 = 4 * (lane % T::LPR);
+  uint32_t rrow[T::NLOAD];  // load j of a piece covers candidates RPL j .. RPL j + RPL - 1, P floats each
 #pragma unroll
-  for (int j = 0; j < T::NLOAD; ++j) rrow[j] = (uint32_t)__shfl((int)my_row, 4 * j + sub);
+  for (int j = 0; j < T::NLOAD; ++j) rrow[j] = (uint32_t)__shfl((int)my_row, T::RPL * j + sub);
   const float *__restrict__ qp = a.Q + (int64_t)q * a.ld;  // wave-uniform: scalar loads
   const float *trow = tile + (lane < CAND ? lane : CAND - 1) * RW_LD;
   float *tput = tile + sub * RW_LD + col4;
@@ -998,7 +1011,7 @@ __device__ __forceinline__ void rerank_wave_sums(const RerankBatchArgs &a, int q
         const int p = p0 + d;
         if (p < npiece) {  // wave-uniform
 #pragma unroll
-          for (int j = 0; j < T::NLOAD; ++j) *reinterpret_cast<f32x4 *>(tput + 4 * j * RW_LD) = in[d][j];
+          for (int j = 0; j < T::NLOAD; ++j) *reinterpret_cast<f32x4 *>(tput + T::RPL * j * RW_LD) = in[d][j];
           fetch(in[d], p + DEPTH);
           __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued BEFORE the chains, not sunk below them
           const float *qq = qp + p * P;
@@ -1072,8 +1085,7 @@ static __global__ void __launch_bounds__(64 * RwBig::WAVES) rerank_batch_kernel(
 // k results per query (ids, distances, count) are stored straight into pinned host memory: 1.6 KB per query cross
 // PCIe instead of a 3 KB candidate list, and the host is left with a copy.
 // Order = rank by counting over the <= RF_MAX candidates in LDS (a list is k plus a band's worth of rows).
-constexpr int RF_MAXG = 4;                   // passes of RW_CAND candidates per workgroup
-constexpr int RF_MAX = RW_CAND * RF_MAXG;    // candidates per query this kernel takes (wider lists: host finaliser)
+constexpr int RF_MAX = 512;                  // candidates per query this kernel takes (wider lists: host finaliser)
 
 struct RerankFinalArgs {
   RerankBatchArgs r;
@@ -1096,10 +1108,12 @@ __device__ __forceinline__ double order_key_to_double(uint64_t key) {
   return __longlong_as_double((long long)((key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key));
 }
 
-template <int CAND, int DEPTH>
-static __global__ void __launch_bounds__(64 * (RW_CAND / CAND)) rerank_final_kernel(RerankFinalArgs fa) {
+template <typename T>
+static __global__ void __launch_bounds__(64 * T::WAVES) rerank_final_kernel(RerankFinalArgs fa) {
 #pragma clang fp contract(off)
-  using T = RwShape<CAND, DEPTH>;
+  constexpr int CAND = 64;
+  constexpr int RF_MAXG = RF_MAX / (T::WAVES * CAND);  // rounds of WAVES x 64 candidates per workgroup
+  static_assert(RF_MAXG * T::WAVES * CAND == RF_MAX, "whole rounds");
   __shared__ __attribute__((aligned(16))) float tiles[T::WAVES][T::TILE];
   __shared__ uint32_t s_valid;
   const RerankBatchArgs &a = fa.r;
@@ -1122,7 +1136,7 @@ static __global__ void __launch_bounds__(64 * (RW_CAND / CAND)) rerank_final_ker
     if (c0 < count) {  // wave-uniform
       uint32_t r;
       double s0, s1;
-      rerank_wave_sums<CAND, DEPTH>(a, q, c0, count - c0, tiles[wave], lane, &r, &s0, &s1);
+      rerank_wave_sums<CAND, T::NDEPTH, T::LD - 4, T::WAVES>(a, q, c0, count - c0, tiles[wave], lane, &r, &s0, &s1);
       double d;
       if (a.metric == METRIC_L2) {
         d = __builtin_sqrt(s0);

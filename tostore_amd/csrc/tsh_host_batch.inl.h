@@ -715,7 +715,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       rf.out_count = b->fin_cnt_dev;
       rf.out_info = b->fin_info_dev;
       rf.k = k;
-      rerank_final_kernel<64, 1><<<(unsigned)nq, 64 * RwBig::WAVES, 0, st>>>(rf);
+      static const bool old_shape = getenv("TSH_RF_SHAPE") != nullptr && getenv("TSH_RF_SHAPE")[0] == '2';  // A/B: two waves, 64-float pieces
+      if (old_shape) rerank_final_kernel<RwBig><<<(unsigned)nq, 64 * RwBig::WAVES, 0, st>>>(rf);
+      else rerank_final_kernel<RwFin><<<(unsigned)nq, 64 * RwFin::WAVES, 0, st>>>(rf);
       HIPCHK(hipEventRecord(b->e_done, st));
     } else
     for (int c = 0; c < n_chunks; ++c) {
