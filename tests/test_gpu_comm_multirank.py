@@ -49,3 +49,26 @@ def test_bench_gpus_2_plain_command(hip_lib):
     assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True and out["recall_queries"] >= 2
     assert "tsh_search_sharded" in out["config"]["sharding"]
     assert out["roofline"]["algorithmic_bytes_per_launch"] == 100000 * 768 * 4
+
+
+def test_bench_under_torch_distributed_run(hip_lib):
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks sharing this box's
+    GPU over the RCCL branch of the library (--fake-rccl): one JSON line from rank 0, with the exchange's account and the
+    C4-per-rank leg in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--fake-rccl", "--rows", "200000", "--c4-rows-per-rank", "50000", "--cpu-seconds", "3"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True
+    assert "fake_rccl" in out["config"]["sharding"]
+    tl = out["exchange_timeline"]
+    assert [r["rank"] for r in tl["ranks"]] == [0, 1] and tl["ranks"][0]["calls"] > 0
+    assert 0.8 <= tl["accounted_over_ms_per_step"]["rank0"] <= 1.2, tl["accounted_over_ms_per_step"]
+    c4 = out["side"]["C4_per_rank"]
+    assert c4["ids_and_distances_bit_exact"] is True and c4["batch_1024"]["value"] > 0 and c4["single_and_batched_agree"] is True
