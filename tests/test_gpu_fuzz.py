@@ -120,7 +120,13 @@ def _batch_case(oracle, rng, case):
         qs = np.stack([oracle.normalize_f32(q) for q in qs])
     keep = None
     if rng.random() < 0.4:
-        keep = np.packbits(rng.random(n) < rng.choice([0.1, 0.6]), bitorder="little")
+        if rng.random() < 0.35:  # WHERE id BETWEEN ...: one contiguous run (the batched path moves its sample window there)
+            kb = np.zeros(n, bool)
+            a0 = int(rng.integers(0, n))
+            kb[a0:a0 + int(rng.integers(1, max(2, n // 3)))] = True
+            keep = np.packbits(kb, bitorder="little")
+        else:
+            keep = np.packbits(rng.random(n) < rng.choice([0.1, 0.6]), bitorder="little")
     alive = np.ones(n, bool)
     with HipVectorIndex(d, metric) as idx:
         idx.set_batch_kernel(kernel)
