@@ -428,7 +428,7 @@ def batch_roofline(kind, gemm_us, flops):
     if kind == 2:
         return {"bound": "mfma", "achieved": tf, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf / F16_MFMA_PEAK_TF, "traffic": None,
-                "kernel": "tsh::batch_score_f16pp_kernel (IP / cosine) or batch_score_f16_kernel (L2): sample + filtered passes",
+                "kernel": "tsh::batch_score_f16pp_kernel: sample + filtered passes",
                 "kernel_us": gemm_us, "algorithmic_flops_per_launch": flops, "vs_f32_mfma_peak": tf / F32_MFMA_PEAK_TF}
     # three bf16 MFMAs per algorithmic multiply-add: the ceiling for ALGORITHMIC flops is 2500 / 3
     return {"bound": "mfma", "achieved": tf, "peak": F16_MFMA_PEAK_TF / 3, "unit": "TFLOP/s",
