@@ -284,3 +284,19 @@ def test_open_ngh_reads_meta_before_it_needs_a_device(tmp_path):
     else:
         assert rc == 0
         L.tsh_index_destroy(out)
+
+
+def test_rccl_override_that_does_not_load_is_an_error():
+    """TSH_RCCL_LIB names the library tsh_comm_* loads instead of librccl (tests/fake_rccl is the one user): a path that
+    does not load is TSH_E_RCCL with the reason -- never a silent fall-back to the system's librccl.  (Read once per
+    process: a process of its own.)"""
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from tostore_amd import _ffi; L = _ffi.lib(); "
+            "b = ctypes.create_string_buffer(128); rc = L.tsh_comm_unique_id(b); print(rc, _ffi.last_error())" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TSH_RCCL_LIB="/nonexistent/librccl_stand_in.so"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rc, _, msg = p.stdout.strip().partition(" ")
+    assert int(rc) == -10 and "TSH_RCCL_LIB" in msg and "does not load" in msg, p.stdout
