@@ -1,6 +1,7 @@
 """CPU: the host-side mirror of VectorIndexManager's arithmetic around the seam
 (product code in tostore_amd/vector_index_manager.py) against the oracle."""
 import math
+import os
 
 import numpy as np
 
@@ -42,3 +43,25 @@ def test_distance_to_score(oracle_mod):
             a, b = distance_to_score(x, metric), oracle_mod.distance_to_score(x, metric)
             assert (math.isnan(a) and math.isnan(b)) or (a == b and math.copysign(1, a) == math.copysign(1, b)), \
                 (metric, x, a, b)
+
+
+def test_flagged_builds_never_touch_the_shipped_library(tmp_path, monkeypatch):
+    """tostore_amd/build.py: a build with extra flags gets an object directory and an output of its
+    own, and objects compiled with other flags are stale whatever their age."""
+    from tostore_amd import build as B
+
+    tag = B.variant_tag(["-DTSH_PROBES"])
+    objdir, out = B.variant_paths(tag)
+    assert out != B.OUT and os.path.dirname(out) == objdir and objdir.startswith(B.OBJ + os.sep)
+    assert B.variant_tag(["-DTSH_PROBES", "-DPP_ISSUE=1"]) != tag
+    # the staleness rule, on a scratch object directory
+    d = tmp_path / "objs"
+    d.mkdir()
+    flags = B.CFLAGS + ["-DTSH_PROBES"]
+    for u in B.UNITS:
+        (d / u.replace(".hip", ".o")).write_bytes(b"x")
+        os.utime(d / u.replace(".hip", ".o"), (4e9, 4e9))  # newer than every source
+    assert all(B._unit_stale(u, str(d), flags) for u in B.UNITS)      # no flags recorded: stale
+    (d / "flags.txt").write_text(" ".join(flags))
+    assert not any(B._unit_stale(u, str(d), flags) for u in B.UNITS)  # same flags, newer than the sources: current
+    assert all(B._unit_stale(u, str(d), B.CFLAGS) for u in B.UNITS)   # other flags: stale whatever the age
