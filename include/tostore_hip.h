@@ -249,11 +249,18 @@ int32_t tsh_index_metric(tsh_index *idx);
  *               vector_index_manager.dart:514-520 does (_toFloat32, and
  *               _normalizeFloat32 for cosine)
  *   row_mask    nullable; ceil(size/8) bytes, bit i (LSB first) = 1 keeps row
- *               i (WHERE pre-filter; new capability)
+ *               i (WHERE pre-filter; new capability).  Bytes read
+ *               scale with the rows kept: a mask that keeps fewer than one row
+ *               in 24 is compacted into a list of row ids once per call and
+ *               scanned as a gather; a one-range mask (WHERE id BETWEEN ...)
+ *               costs a batched call no more than a scattered one
  *   out_ids     nq x k      out_dist nq x k      out_count nq
  * nq == 1 (or small) streams the corpus once per query (HBM-bound kernel);
  * larger nq uses the batched matrix-core path, whose last steps (exact f64
- * re-rank, distance, threshold, order, cut) run on the device.  Thread-safe;
+ * re-rank, distance, threshold, order, cut) run on the device.  A device too
+ * full for that path's buffers degrades the call (f32 matrix-core kernel on the
+ * rows as stored, then pipelined scans: tsh_counters.batch_*_fallbacks) instead
+ * of failing it.  Thread-safe;
  * two batched calls on one handle overlap (one prepares / copies out while the
  * GPU works on the other), further concurrent ones queue.  Empty index or
  * k <= 0 returns TSH_OK with counts 0 (the reference returns const []: :78). */
