@@ -117,7 +117,9 @@ def parse(argv=None):
                     help="corpus rows stay L2-normalised for every metric (the demo's own recipe; default: L2 / IP rows are "
                          "also scaled by U(0.5, 2) so that the three metrics rank differently, SURVEY.md section 8d)")
     ap.add_argument("--no-side", action="store_true", help="skip the side legs (C1 / C3 / C5)")
-    ap.add_argument("--side", default="c5,c1,c3", help="side legs to run, comma separated")
+    ap.add_argument("--side", default="c5,s8,c1,c3",
+                    help="side legs to run, comma separated (s8 = side.shard_of_8: one rank's share of the headline at N = 8 "
+                         "through tsh_search_sharded)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--exchange", choices=["auto", "torch", "capi"], default="auto",
@@ -165,15 +167,25 @@ def query_pool_size(steps, warmup, recall_queries, batch=0):
     return int(max(warmup + steps, 64, recall_queries, 2 * batch, 1))
 
 
-def library_group(nq):
-    """tsh_search_sharded's own choice of queries per exchange (tsh_host_comm.inl.h), for the report."""
-    if nq >= 512:
-        return int(min(nq, 256))
+def library_schedule(nq, rows_per_shard, dim):
+    """tsh_search_sharded's own schedule of queries per exchange (sharded_schedule, tsh_host_comm.inl.h), for the
+    report: shrinking groups up to 128 queries, uniform ones beyond."""
     if nq > 128:
-        return 64
-    if nq > 16:
-        return (nq + 1) // 2
-    return max(int(nq), 1)
+        g = 256 if nq >= 512 else 64
+        return [min(g, nq - q) for q in range(0, nq, g)]
+    scan_us = float(rows_per_shard) * ((dim + 3) // 4 * 4) * 4.0 / 6.5e6
+    g_min = int(min(128.0, max(4.0, math.ceil(150.0 / max(scan_us, 1.0)))))
+    out, rem = [], int(nq)
+    while rem > 0:
+        g = rem if rem < 2 * g_min else max(g_min, (rem + 1) // 2)
+        out.append(g)
+        rem -= g
+    return out
+
+
+def library_group(nq, rows_per_shard=125_000, dim=768):
+    """The largest group of that schedule."""
+    return max(library_schedule(max(int(nq), 1), rows_per_shard, dim))
 
 
 def sharded_group(group, count):
@@ -367,6 +379,13 @@ class Env:
         self.exchange = "torch.distributed all_gather_into_tensor (%s) + tsh_merge_candidates" % self.a.backend
         self.exchange_note = "tsh_search_sharded failed its check on some rank (%s): fell back" % (err or "another rank")
         return ShardedSearcher(idx)
+
+    def shard_comm(self, idx):
+        """A communicator of ONE rank over real RCCL around `idx` (side.shard_of_8): tsh_comm_create + tsh_search_sharded
+        exactly as a rank of an N-GPU job runs them, the collective included (an all-gather in a world of one)."""
+        from tostore_amd.sharded import CommSearcher
+
+        return CommSearcher(idx, 1, 0, CommSearcher.unique_id(), self.local_rank)
 
     def gather_objects(self, obj):
         """Every rank's object, on rank 0 (None elsewhere)."""
@@ -740,6 +759,7 @@ def measure_single(env, a, idx, searcher, queries, k, row_mask, steps, warmup, r
     -> dict(regions, scan_us, scan samples, per-rank records on rank 0, cgroup stats)."""
     nqp = len(queries)
     py_groups = getattr(searcher, "python_groups", True)  # False: the library forms the groups (tsh_search_sharded)
+    batches = {}
 
     def one(i):
         q = queries[i % nqp]
@@ -759,9 +779,10 @@ def measure_single(env, a, idx, searcher, queries, k, row_mask, steps, warmup, r
         elif searcher is not None:
             # N > 1: groups of queries share one all-gather + one merge call, and the next group's
             # shard scans run while this group is exchanged and merged
-            sel = [(first + j) % nqp for j in range(count)]
-            searcher.search_many(queries[sel], k, None, row_mask,
-                                 group=sharded_group(a.group, count) if py_groups else 0)
+            qb = batches.get((first, count))
+            if qb is None:
+                qb = queries[[(first + j) % nqp for j in range(count)]]
+            searcher.search_many(qb, k, None, row_mask, group=sharded_group(a.group, count) if py_groups else 0)
         elif a.group > 0:
             for g0 in range(0, count, a.group):
                 sel = [(first + g0 + j) % nqp for j in range(min(a.group, count - g0))]
@@ -778,6 +799,10 @@ def measure_single(env, a, idx, searcher, queries, k, row_mask, steps, warmup, r
 
     run(0, warmup)
     regions = []
+    if searcher is not None and a.inflight > 1:  # the regions' query batches exist before their clocks start
+        for r in range(repeats):
+            first = warmup + r * steps
+            batches[(first, steps)] = np.ascontiguousarray(queries[[(first + j) % nqp for j in range(steps)]])
     env.fence()
     has_tl = hasattr(searcher, "timeline")
     if has_tl:
@@ -915,6 +940,96 @@ def side_c4_per_rank(env, a):
         idx.close()
 
 
+def side_shard_of_8(env, a, c2_ms_per_step):
+    """N = 1 line: the headline's PER-RANK load of an 8-GPU run -- rows [0, rows / 8) of the same corpus, same metric
+    and k -- through tsh_search_sharded over real RCCL in a world of one, in the driver's own shape (timed regions of
+    --steps single-query steps per call, fenced on both sides).  What one GPU of eight has to do per step, collective
+    launch included; what it cannot show is the wait for seven peers.  upper_bound_speedup = the headline's
+    ms_per_step / this leg's: the 8-GPU speed-up if the real collective cost no more than the one-rank one."""
+    d, k, metric = a.dim, a.k, METRICS[a.metric]
+    n = a.rows
+    per = (n + 7) // 8
+    idx, host = env.build_index(d, metric, n, 0, per, keep_host=not a.no_cpu_baseline)
+    cs = None
+    try:
+        idx.set_batch_min_nq(0)  # every query scans the shard on its own, as in the headline
+        cs = env.shard_comm(idx)
+        steps, warmup = a.steps, min(max(a.warmup, 2), 50)
+        repeats = auto_repeats(steps, a.repeats)
+        queries = make_queries(max(64, steps * min(repeats, 8) + warmup), d, metric, seed=20260619)
+        nqp = len(queries)
+
+        def batch_of(first, count):
+            return np.ascontiguousarray(queries[[(first + j) % nqp for j in range(count)]])
+
+        def call(first, count, group=0):
+            return cs.search_many(batch_of(first, count), k, None, None, group=group)
+
+        def regions_of(group, reps):
+            call(0, max(warmup, 1), group)
+            call(0, steps, group)
+            cs.timeline(reset=True)
+            c0 = idx.counters()
+            out = []
+            batches = [batch_of(warmup + r * steps, steps) for r in range(reps)]  # (the inputs exist before the clock starts)
+            with timed_region():
+                for r in range(reps):
+                    env.fence()
+                    t0 = time.perf_counter()
+                    cs.search_many(batches[r], k, None, None, group=group)
+                    env.fence()
+                    out.append(time.perf_counter() - t0)
+            c1 = idx.counters()
+            ns = c1["scan_us_samples"] - c0["scan_us_samples"]
+            scan_us = (c1["scan_us_sum"] - c0["scan_us_sum"]) / ns if ns > 0 else float("nan")
+            return out, cs.timeline(), scan_us
+
+        regions, tl, scan_us = regions_of(0, repeats)
+        med = float(np.median(regions))
+        ms = med / steps * 1e3
+        mine = {"rank": 0, "timeline": tl}
+        shard_bytes = float(per) * d * 4
+        out = {"workload": "one rank's share of %s at N = 8: %dx%d f32, %s, k=%d, %d single-query steps per "
+                           "tsh_search_sharded call, RCCL in a world of one" % (a.config.upper(), per, d, a.metric, k, steps),
+               "steps": steps, "warmup": warmup, "us_per_query": ms * 1e3, "ms_per_step": ms,
+               "timed_regions": {"count": repeats, "steps_each": steps, "reported": "median",
+                                 "seconds": [float(x) for x in regions]},
+               "upper_bound_speedup": c2_ms_per_step / ms if ms > 0 else None,
+               "upper_bound_note": "headline ms_per_step / this leg's: what 8 GPUs reach if the 8-rank collective costs "
+                                   "no more than the 1-rank one and no rank waits for another",
+               "queries_per_exchange": library_schedule(steps, per, d),
+               "exchange_timeline": exchange_timeline([mine], steps * repeats, ms),
+               "roofline": {"bound": "hbm", "kernel": "tsh::scan_kernel", "kernel_us": scan_us,
+                            "algorithmic_bytes_per_launch": shard_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "achieved": shard_bytes / (scan_us * 1e-6) / 1e9 if scan_us == scan_us else None,
+                            "frac": shard_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS if scan_us == scan_us else None,
+                            "scans_side_by_side": 2,
+                            "note": "shards below 6144 tiles alternate their scans between two streams: a launch's own "
+                                    "duration is about twice its share of the HBM time"},
+               "floor_us_per_query": shard_bytes / (HBM_PEAK_GBS * 1e9) * 1e6}
+        # the library's group choice against its neighbours (same queries, fewer regions)
+        sweep = {}
+        for g in sorted({1, 2, 4, 5, 10, steps} - {0}):
+            if g > steps:
+                continue
+            rg, _, _ = regions_of(g, max(3, min(repeats, 7)))
+            sweep[str(g)] = float(np.median(rg)) / steps * 1e6
+        out["group_sweep_us_per_query"] = sweep
+        got = call(0, min(steps, 16))
+        if host is not None:
+            import bench_check
+
+            sel = [j % nqp for j in range(min(steps, 16))]
+            ref = bench_check.oracle_topk_stream([(0, host)], queries[sel], metric, k)
+            out["recall_at_k"], out["ids_and_distances_bit_exact"] = bench_check.compare(got, ref)
+            out["checked_queries"] = len(sel)
+        return out
+    finally:
+        if cs is not None and hasattr(cs, "close"):
+            cs.close()
+        idx.close()
+
+
 def run_bench(a, env=None):
     env = env or make_env(a)
     metric = METRICS[a.metric]
@@ -1029,7 +1144,7 @@ def run_bench(a, env=None):
         elif searcher is None:
             in_flight = a.inflight
         else:
-            in_flight = min(env.max_inflight(), sharded_group(a.group, a.steps) if py_groups else library_group(a.steps))
+            in_flight = min(env.max_inflight(), sharded_group(a.group, a.steps) if py_groups else library_group(a.steps, hi - lo, d))
         out = {
             "metric": "kNN queries/sec + recall@k, 1Mx768 f32 brute-force" if a.config == "c2" else
                       "kNN queries/sec + recall@k, %dx%d f32 brute-force (%s)" % (n, d, a.config.upper()),
@@ -1052,7 +1167,7 @@ def run_bench(a, env=None):
                        "mask_kind": a.mask_kind if a.mask_keep else None,
                        "queries_in_flight": in_flight,
                        "queries_per_call": (min(a.group, a.steps) if a.group else 1) if searcher is None
-                       else (sharded_group(a.group, a.steps) if py_groups else library_group(a.steps)),
+                       else (sharded_group(a.group, a.steps) if py_groups else library_schedule(a.steps, hi - lo, d)),
                        "note": "every query scans the whole corpus on its own (HBM-bound kernel, no matrix-core "
                                "batching); independent queries are handed over in groups and pipelined",
                        "sharding": "row-range x%d, all-gather of top-k candidate blocks: %s" % (world, env.exchange)
@@ -1147,6 +1262,11 @@ def run_bench(a, env=None):
         idx.close()
         idx = None
         host_rows = None
+        if "s8" in legs:
+            try:
+                side["shard_of_8"] = side_shard_of_8(env, a, elapsed / a.steps * 1e3)
+            except Exception as e:  # noqa: BLE001
+                side["shard_of_8"] = {"error": repr(e)}
         if "c1" in legs:
             try:
                 side["C1"] = side_c1(env, not a.no_cpu_baseline)

@@ -36,9 +36,10 @@ extern "C" {
 /* 2: tsh_counters grew (fused_launches) and tsh_ngh_info grew (pages_absent, files_absent) after version 1 shipped; a
  * host built against the version-1 structs would be written past its buffers, so the number changed with them.
  * tsh_comm_create_host / tsh_comm_set_group and TSH_E_PEER came with version 2 as well. */
-#define TSH_ABI_VERSION 3
+#define TSH_ABI_VERSION 4
 /* 3: tsh_counters grew again (batch_plane_fallbacks, batch_scan_fallbacks); tsh_comm_get_timeline / tsh_comm_timeline
- * came with it. */
+ * came with it.
+ * 4: tsh_search_shard_begin / _progress / _end (the progressive shard search tsh_search_sharded is now built on). */
 
 /* status codes */
 #define TSH_OK 0
@@ -299,13 +300,43 @@ int32_t tsh_default_block_entries(int32_t k);
 /* d_out_blocks: device buffer of nq * tsh_candidate_block_bytes(entries) on the
  * handle's device; the kernels store the blocks into it directly and the call
  * returns after they completed (host-synchronised), so any stream may read it
- * next.  stream: reserved (pass NULL or the consumer's hipStream_t).
+ * next.  stream: reserved (pass NULL or the consumer's hipStream_t) -- a block is
+ * final only once the HOST has seen its header (ties that overflow a block's
+ * candidate list are redone by a wider pass the host starts), so completion
+ * cannot be handed to a stream; a caller that wants to work on the first blocks
+ * while the later ones are still being scanned uses the progressive form below.
  * row_mask is GLOBAL (bit = global row id).  Rows kept out of the scan (tsh_counters.quarantined_rows) are
  * appended to every block the mask lets them into; a block they do not fit in reports count > entries like any
  * other overflow, and tsh_merge_candidates answers TSH_E_OVERFLOW with the entry count to retry with. */
 int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                          const uint8_t *row_mask, int32_t entries, void *d_out_blocks,
                          void *stream);
+/* Progressive form of tsh_search_shard, for callers that exchange the blocks in
+ * groups (tsh_search_sharded is built on it; tostore_amd/sharded.py can be): the
+ * scans of ALL nq queries run as one pipeline on a library thread -- the GPU sees
+ * no group boundaries, where group-by-group tsh_search_shard calls pay the fill and
+ * drain of the scan pipeline per call (~45 us on a 125 k x 768 shard) -- and the
+ * blocks become final in query order.
+ *   _begin     starts the search and returns at once; queries / row_mask are copied
+ *              (no pointer is retained), d_out_blocks must stay valid until _end.
+ *              step: the caller's group size (queries it will ask for at a time);
+ *              where a call of `step` queries would go to the matrix cores the
+ *              search proceeds in calls of `step` queries, otherwise every query is
+ *              its own scan.  0 = nq.
+ *   _progress  blocks until the first min(want, nq) queries' blocks are final in
+ *              d_out_blocks (host-synchronised: any stream may read them next) and
+ *              returns TSH_OK, or until the search failed before it got there and
+ *              returns its error; *out_done (nullable) = leading queries final.
+ *   _end       waits for whatever still runs, frees the handle, returns the
+ *              search's status.  Must be called exactly once per _begin.
+ * Blocks, masks, overflow protocol: exactly tsh_search_shard's.  No reference
+ * counterpart (the reference has no distributed compute). */
+typedef struct tsh_shard_stream tsh_shard_stream;
+int32_t tsh_search_shard_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
+                               const uint8_t *row_mask, int32_t entries, void *d_out_blocks,
+                               int32_t step, tsh_shard_stream **out);
+int32_t tsh_search_shard_progress(tsh_shard_stream *stream, int32_t want, int32_t *out_done);
+int32_t tsh_search_shard_end(tsh_shard_stream *stream);
 /* Host-side merge of n_blocks x nq candidate blocks (layout [block][query]),
  * applying the final sqrt / negate / 1-cos, threshold, ordering and top-k cut.
  * Pure host code (no device needed).  Returns TSH_E_OVERFLOW if any block was
@@ -326,8 +357,9 @@ int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries,
  *               on every rank; identical answer on every rank -- the one tsh_search gives on one un-sharded
  *               index over the same rows)
  *   every rank: tsh_comm_destroy(comm)
- * Inside one call the queries travel in groups: while a group's candidate blocks are all-gathered (device to
- * device) and merged, a helper thread already scans the next group on this rank's shard.  Of every group each
+ * Inside one call the queries travel in groups: this rank's scans of ALL the call's queries run as one pipeline
+ * (tsh_search_shard_begin), and every group is all-gathered (device to device) and merged as soon as its blocks
+ * are final, while the scans of the later groups go on.  Of every group each
  * rank copies back and merges only its own slice of the queries (world blocks per query); a second, small
  * all-gather hands every slice's final ids / distances to every rank.  (Groups of at most 128 blocks in all -- world x
  * queries -- are merged whole on every rank instead, and the second all-gather does not happen.)
@@ -350,8 +382,11 @@ int32_t tsh_comm_create_host(int32_t world, int32_t rank, int32_t device, tsh_al
                              tsh_comm **out);
 int32_t tsh_comm_destroy(tsh_comm *comm);
 int32_t tsh_comm_world(tsh_comm *comm);
-/* queries per exchange of tsh_search_sharded; 0 (default) = by the size of the call: the whole call up to 16 queries,
- * half of it up to 128, 64 up to 512, 256 beyond.  Same value on every rank. */
+/* queries per exchange of tsh_search_sharded; 0 (default) = the library's own schedule: calls of up to 128 queries go
+ * in SHRINKING groups (half of what is left each time, never below what hides an exchange behind the scans that
+ * follow -- sized by the largest shard's rows, which the ranks tell each other whenever their buffers grow -- nor below
+ * four: 20 queries on 125 k x 768 shards as 10 + 5 + 5), because only the LAST group's exchange is exposed; 64 per
+ * group up to 512 queries, 256 beyond.  n > 0: uniform groups of n.  Same value on every rank. */
 int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
                            double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,

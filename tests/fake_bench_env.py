@@ -110,10 +110,13 @@ class FakeSearcher:
         self._book(len(np.atleast_2d(q)), time.perf_counter() - t0)
         return r
 
+    def close(self):
+        pass
+
     def search_many(self, qs, k, thr=None, row_mask=None, group=8):
         import time
 
-        assert group >= 1 and len(qs) >= 1
+        assert group >= 0 and len(qs) >= 1
         self.groups.append((len(qs), group))
         t0 = time.perf_counter()
         r = self.whole.search(qs, k, thr, row_mask)
@@ -179,6 +182,10 @@ class FakeEnv:
         self.last_searcher = FakeSearcher(self._whole)
         self.searchers.append(self.last_searcher)
         return self.last_searcher
+
+    def shard_comm(self, idx):
+        self.searchers.append(FakeSearcher(idx))
+        return self.searchers[-1]
 
     def max_inflight(self):
         return 8

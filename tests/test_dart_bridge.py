@@ -19,6 +19,7 @@ C2DART = {
     "int32_t*": "Pointer<Int32>", "int64_t*": "Pointer<Int64>", "uint8_t*": "Pointer<Uint8>",
     "void*": "Pointer<Void>", "tsh_index*": "Pointer<Void>", "tsh_index**": "Pointer<Pointer<Void>>",
     "tsh_comm*": "Pointer<Void>", "tsh_comm**": "Pointer<Pointer<Void>>",
+    "tsh_shard_stream*": "Pointer<Void>", "tsh_shard_stream**": "Pointer<Pointer<Void>>",
     "tsh_ngh_info*": "Pointer<TshNghInfo>", "tsh_counters*": "Pointer<TshCounters>",
     "tsh_comm_timeline*": "Pointer<TshCommTimeline>",
     "tsh_allgather_fn": "Pointer<NativeFunction<TshAllgatherNative>>",
@@ -31,6 +32,7 @@ C2CTYPES = {
     "uint8_t*": ctypes.POINTER(ctypes.c_uint8), "void*": ctypes.c_void_p, "tsh_index*": ctypes.c_void_p,
     "tsh_index**": ctypes.POINTER(ctypes.c_void_p), "tsh_comm*": ctypes.c_void_p,
     "tsh_comm**": ctypes.POINTER(ctypes.c_void_p), "tsh_allgather_fn": ctypes.c_void_p,
+    "tsh_shard_stream*": ctypes.c_void_p, "tsh_shard_stream**": ctypes.POINTER(ctypes.c_void_p),
 }
 
 

@@ -27,7 +27,7 @@ TSH_E_FORMAT = -8
 TSH_E_BUSY = -9
 TSH_E_RCCL = -10
 TSH_E_PEER = -11
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 
@@ -97,6 +97,9 @@ SIGNATURES = {
     "tsh_candidate_block_bytes": (c_i64, [c_i32]),
     "tsh_default_block_entries": (c_i32, [c_i32]),
     "tsh_search_shard": (c_i32, [p_void, p_f32, c_i32, c_i32, p_u8, c_i32, p_void, p_void]),
+    "tsh_search_shard_begin": (c_i32, [p_void, p_f32, c_i32, c_i32, p_u8, c_i32, p_void, c_i32, ctypes.POINTER(p_void)]),
+    "tsh_search_shard_progress": (c_i32, [p_void, c_i32, p_i32]),
+    "tsh_search_shard_end": (c_i32, [p_void]),
     "tsh_merge_candidates": (c_i32, [c_i32, c_i32, p_f32, c_i32, c_i32, c_f64, p_void, c_i32, c_i32,
                                      p_i64, p_f64, p_i32, p_i32]),
     "tsh_comm_unique_id": (c_i32, [p_void]),

@@ -874,10 +874,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   return TSH_OK;
 }
 
-// nq queries on one shard: matrix-core batch when it pays, single-query pipeline
-// otherwise and for whatever the batch hands back.
-int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
-                     const uint8_t *mask, int32_t entries, SearchOut *out) {
+// does a call of nq queries on this shard go to the matrix cores?
+bool shard_takes_batch(const Shard *s, int32_t batch_min_nq, int32_t nq, int32_t k) {
   // batch_min_nq == 1: decide by cost.  Measured: a batched call costs about 0.30 ms plus one
   // pass over the converted rows at ~4 TB/s, whatever nq <= 128 is; pipelined single-query scans cost one
   // pass over the f32 rows at ~6.6 TB/s plus ~25 us each.  At 1 M x 768 that is 0.67 vs 1.04 ms for TWO queries.
@@ -889,8 +887,14 @@ int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *q
     const double t_single = (double)nq * ((double)s->rows * (double)s->ld * 4.0 / 6.6e6 + 25.0);
     enough = t_single > t_batch;
   }
-  const bool use_batch = enough && !s->safe_mode() && s->rows >= 4096 &&
-                         k <= 1024 && s->rows < 0x7FFFFF00ll;
+  return enough && !s->safe_mode() && s->rows >= 4096 && k <= 1024 && s->rows < 0x7FFFFF00ll;
+}
+
+// nq queries on one shard: matrix-core batch when it pays, single-query pipeline
+// otherwise and for whatever the batch hands back.
+int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
+                     const uint8_t *mask, int32_t entries, SearchOut *out) {
+  const bool use_batch = shard_takes_batch(s, batch_min_nq, nq, k);
   if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
   std::vector<int32_t> redo;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);

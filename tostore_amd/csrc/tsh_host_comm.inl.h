@@ -9,8 +9,11 @@
 // gets that one.
 //
 // One tsh_search_sharded call, nq queries, W ranks:
-//   * the queries go in GROUPS; a helper thread scans group g + 1 on this rank's shard (tsh_search_shard into
-//     device blocks) while the calling thread exchanges and merges group g;
+//   * the queries are exchanged in GROUPS, but scanned as ONE pipeline: a progressive shard search
+//     (tsh_search_shard_begin: a library thread keeps this rank's scans back to back over all queries of the call)
+//     fills this rank's device blocks while the calling thread exchanges and merges every group whose blocks are
+//     final -- group boundaries do not exist for the GPU (round 4 scanned group by group and paid the pipeline's
+//     fill and drain, ~45 us, per group);
 //   * exchange of a group: all-gather of every rank's candidate blocks (RCCL: device to device over xGMI);
 //     rank r then copies back and merges only ITS SLICE of the group's queries (W blocks per query), so the host
 //     work of a group is done once, spread over the ranks, not W times;
@@ -86,11 +89,36 @@ int rccl_fail(const char *what, int rc) {
   return set_err(TSH_E_RCCL, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "?");
 }
 
-inline int32_t sharded_group_auto(int32_t nq) {
+constexpr int32_t SHARDED_WINDOW = 4096;  // queries of a call whose blocks this rank keeps at once
+// largest group any schedule of an nq-query call can contain (what the buffers are sized for: capacities must not
+// depend on anything a rank knows alone)
+inline int32_t sharded_group_max(int32_t nq) {
   if (nq >= 512) return 256;
   if (nq > 128) return 64;
-  if (nq > 16) return (nq + 1) / 2;
   return std::max(nq, 1);
+}
+// Queries per exchange, group after group.  The scans of a call run as ONE pipeline whatever the groups are, so a
+// group costs its exchange only (collective latency + copy + merge: ~0.1 ms): hidden behind the scans of the groups
+// after it, exposed for the LAST group.  Up to 128 queries the groups therefore shrink -- half of what is left each
+// time, never below what it takes to hide an exchange (scan_us: one query's scan on the largest shard, from the
+// rows the ranks told each other at their last agreement) nor below four, the rest in one piece once it is that
+// small: 20 queries on 125 k x 768 shards go as 10 + 5 + 5, on 10 k-row shards (a scan is shorter than any exchange)
+// as one group.  Bigger calls go to the matrix cores, which want big uniform groups.
+inline void sharded_schedule(int32_t nq, double scan_us, std::vector<int32_t> *sizes) {
+  sizes->clear();
+  if (nq > 128) {
+    const int32_t G = sharded_group_max(nq);
+    for (int32_t q = 0; q < nq; q += G) sizes->push_back(std::min(G, nq - q));
+    return;
+  }
+  const double exchange_us = 150.0;
+  const int32_t g_min = (int32_t)std::min(128.0, std::max(4.0, std::ceil(exchange_us / std::max(scan_us, 1.0))));
+  int32_t rem = nq;
+  while (rem > 0) {
+    const int32_t g = rem < 2 * g_min ? rem : std::max(g_min, (rem + 1) / 2);
+    sizes->push_back(g);
+    rem -= g;
+  }
 }
 
 // header of one rank's result slice in the second all-gather
@@ -128,8 +156,10 @@ struct tsh_comm {
   hipStream_t stream = nullptr;
   hipEvent_t ev = nullptr;
   std::mutex mu;  // collectives of one communicator are issued one call at a time
-  uint8_t *d_mine[2] = {nullptr, nullptr};  // this rank's blocks of the group being scanned / exchanged
-  size_t mine_cap[2] = {0, 0};
+  uint8_t *d_mine = nullptr;  // this rank's blocks of a whole call (or of a window of SHARDED_WINDOW queries of it)
+  size_t mine_cap = 0;
+  uint8_t *d_retry = nullptr;  // this rank's blocks of a group redone with larger blocks (ties)
+  size_t retry_cap = 0;
   uint8_t *h_mine = nullptr;  // host transport: pinned copy of d_mine
   size_t h_mine_cap = 0;
   uint8_t *d_all = nullptr;  // RCCL: every rank's blocks of the group
@@ -138,17 +168,17 @@ struct tsh_comm {
   size_t slice_cap = 0;
   uint8_t *h_res_mine = nullptr, *h_res_all = nullptr, *d_res_mine = nullptr, *d_res_all = nullptr;
   size_t res_cap = 0;  // bytes of one rank's result slice
-  int32_t *d_agree = nullptr, *h_agree = nullptr;  // 1 + world words (allocated with the communicator)
+  int64_t *d_agree = nullptr, *h_agree = nullptr;  // (1 + world) x {status, rows of the rank's shard} (allocated with the communicator)
+  int64_t rows_hint = 0;  // largest shard of any rank as of the last agreement: the same number on every rank
   int32_t group = 0;  // queries per exchange; 0 = by the size of the call
-  std::unique_ptr<OneWorker> helper;
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};  // RCCL: before / after the block all-gather, after the slice's D2H
-  tsh_comm_timeline tl = {};  // guarded by mu (scan_us: written by the helper thread, read after helper->wait())
-  std::atomic<int64_t> scan_ns{0};
+  tsh_comm_timeline tl = {};  // guarded by mu
+  std::atomic<int64_t> scan_ns{0};  // the scanning thread's busy time (+ retries' scans)
 };
 
 namespace {
 
-int comm_sync(tsh_comm *c) {  // the communicator's stream, without burning a core (event with blocking sync)
+int comm_sync(tsh_comm *c) {  // the communicator's stream (an event: blocking where CPUs are scarce, see comm_common_create)
   HIPCHK(hipEventRecord(c->ev, c->stream));
   HIPCHK(hipEventSynchronize(c->ev));
   return TSH_OK;
@@ -168,25 +198,34 @@ int comm_allgather_host(tsh_comm *c, const void *h_send, void *h_recv, size_t by
 }
 
 // every rank says whether its part of a step that may fail locally (allocations) worked; all ranks get the
-// same answer.  Collective.
-int comm_agree(tsh_comm *c, int local_rc) {
-  if (c->world == 1) return local_rc;
+// same answer.  Collective.  The same exchange tells every rank how many rows the largest shard holds (rows_hint:
+// what the group schedule of later calls is sized by -- identical on every rank, because it only changes here).
+int comm_agree(tsh_comm *c, int local_rc, int64_t local_rows) {
+  if (c->world == 1) {
+    c->rows_hint = local_rows;
+    return local_rc;
+  }
   c->h_agree[0] = local_rc;
-  int32_t *all = c->h_agree + 1;
+  c->h_agree[1] = local_rows;
+  int64_t *all = c->h_agree + 2;
   if (c->host_fn) {
-    int rc = comm_allgather_host(c, c->h_agree, all, 4);
+    int rc = comm_allgather_host(c, c->h_agree, all, 16);
     if (rc) return rc;
   } else {
-    HIPCHK(hipMemcpyAsync(c->d_agree, c->h_agree, 4, hipMemcpyHostToDevice, c->stream));
-    int rc = comm_allgather_dev(c, c->d_agree, c->d_agree + 1, 4);
+    HIPCHK(hipMemcpyAsync(c->d_agree, c->h_agree, 16, hipMemcpyHostToDevice, c->stream));
+    int rc = comm_allgather_dev(c, c->d_agree, c->d_agree + 2, 16);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(all, c->d_agree + 1, 4 * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(all, c->d_agree + 2, 16 * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
     rc = comm_sync(c);
     if (rc) return rc;
   }
+  int64_t rows = 0;
+  for (int r = 0; r < c->world; ++r) rows = std::max(rows, all[2 * r + 1]);
+  c->rows_hint = rows;
   if (local_rc != TSH_OK) return local_rc;
   for (int r = 0; r < c->world; ++r)
-    if (all[r] != TSH_OK) return set_err(TSH_E_PEER, "rank %d could not allocate its exchange buffers (%d)", r, all[r]);
+    if (all[2 * r] != TSH_OK)
+      return set_err(TSH_E_PEER, "rank %d could not allocate its exchange buffers (%d)", r, (int)all[2 * r]);
   return TSH_OK;
 }
 
@@ -211,18 +250,20 @@ int grow_host(T **p, size_t *cap, size_t want) {
   return TSH_OK;
 }
 
-// buffers for groups of up to gq queries with `entries` entries per block.  *grew: anything was (re)allocated --
-// identical on every rank, since capacities only depend on the calls made so far
-int comm_reserve(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, bool *grew) {
+// buffers for groups of up to gq queries with `entries` entries per block; this rank's own blocks: call_q queries'
+// worth (the window of the call the scans run ahead in), or -- retry -- one group's in d_retry.  *grew: anything was
+// (re)allocated -- identical on every rank, since capacities only depend on the calls made so far
+int comm_reserve(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, int32_t call_q, bool retry, bool *grew) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world;
   const size_t slice_q = merge_queries_max(W, (size_t)gq);
   const size_t mine = bb * (size_t)gq, res = sizeof(ResHeader) + slice_q * res_rec_bytes(k);
   const size_t slice = c->host_fn ? W * mine : W * slice_q * bb;
-  *grew = mine > c->mine_cap[0] || mine > c->mine_cap[1] || res > c->res_cap || slice > c->slice_cap ||
+  const size_t own = retry ? 0 : bb * (size_t)call_q, again = retry ? mine : 0;
+  *grew = own > c->mine_cap || again > c->retry_cap || res > c->res_cap || slice > c->slice_cap ||
           (c->host_fn ? mine > c->h_mine_cap : W * mine > c->all_cap);
   if (!*grew) return TSH_OK;
-  int rc = TSH_OK;
-  for (int s = 0; s < 2 && !rc; ++s) rc = grow_dev(&c->d_mine[s], &c->mine_cap[s], mine);
+  int rc = grow_dev(&c->d_mine, &c->mine_cap, own);
+  if (!rc) rc = grow_dev(&c->d_retry, &c->retry_cap, again);
   if (!rc) rc = grow_host(&c->h_slice, &c->slice_cap, slice);
   if (!rc && c->host_fn) rc = grow_host(&c->h_mine, &c->h_mine_cap, mine);
   if (!rc && !c->host_fn) rc = grow_dev(&c->d_all, &c->all_cap, W * mine);
@@ -251,11 +292,10 @@ int comm_reserve(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, bool *grew
 // after a growth some rank could not follow, every rank drops its buffers: capacities must stay identical on all
 // ranks, or the next call's "did anything grow" would differ from rank to rank
 void comm_drop_buffers(tsh_comm *c) {
-  for (int s = 0; s < 2; ++s) {
-    hipFree(c->d_mine[s]);
-    c->d_mine[s] = nullptr;
-    c->mine_cap[s] = 0;
-  }
+  hipFree(c->d_mine);
+  hipFree(c->d_retry);
+  c->d_mine = c->d_retry = nullptr;
+  c->mine_cap = c->retry_cap = 0;
   hipHostFree(c->h_mine);
   hipFree(c->d_all);
   hipHostFree(c->h_slice);
@@ -266,17 +306,18 @@ void comm_drop_buffers(tsh_comm *c) {
   c->h_mine = c->d_all = c->h_slice = c->h_res_mine = c->h_res_all = c->d_res_mine = c->d_res_all = nullptr;
   c->h_mine_cap = c->all_cap = c->slice_cap = c->res_cap = 0;
 }
-int comm_reserve_agreed(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, bool *grew) {
-  int rc = comm_reserve(c, gq, entries, k, grew);
+int comm_reserve_agreed(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, int32_t call_q, bool retry, int64_t rows,
+                        bool *grew) {
+  int rc = comm_reserve(c, gq, entries, k, call_q, retry, grew);
   if (*grew) {
-    rc = comm_agree(c, rc);
+    rc = comm_agree(c, rc, rows);
     if (rc) comm_drop_buffers(c);
   }
   return rc;
 }
 
 // this rank's blocks of a group, as error markers (its shard search failed with `rc`): the rank stays in the collective
-int comm_error_blocks(tsh_comm *c, int slot, int32_t gq, int32_t entries, int rc_local) {
+int comm_error_blocks(uint8_t *d_blocks, int32_t gq, int32_t entries, int rc_local) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   std::vector<BlockHeader> h((size_t)gq);
   memset(h.data(), 0, h.size() * sizeof(BlockHeader));
@@ -285,7 +326,7 @@ int comm_error_blocks(tsh_comm *c, int slot, int32_t gq, int32_t entries, int rc
     x.flags = FLAG_RANK_ERROR;
     x.pad[0] = (uint32_t)rc_local;
   }
-  HIPCHK(hipMemcpy2D(c->d_mine[slot], bb, h.data(), sizeof(BlockHeader), sizeof(BlockHeader), (size_t)gq,
+  HIPCHK(hipMemcpy2D(d_blocks, bb, h.data(), sizeof(BlockHeader), sizeof(BlockHeader), (size_t)gq,
                      hipMemcpyHostToDevice));
   return TSH_OK;
 }
@@ -294,9 +335,9 @@ struct GroupOut {
   int32_t need = 0;  // > 0: every rank retries the group with this many entries
 };
 
-// Exchange + merge of one group whose blocks sit in d_mine[slot].  local_rc: what this rank's shard search said.
+// Exchange + merge of one group whose blocks sit at d_blocks (device).  local_rc: what this rank's shard search said.
 // Collective; returns the same verdict class on every rank (own error / TSH_E_PEER / TSH_OK + need).
-int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, const float *queries, int32_t gq,
+int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int local_rc, const float *queries, int32_t gq,
                         int32_t k, double thr, int32_t entries, int64_t *out_ids, double *out_dist, int32_t *out_count,
                         GroupOut *go) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world, mine = bb * (size_t)gq;
@@ -307,7 +348,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   int rc;
   tsh_comm_timeline &tl = c->tl;
   if (local_rc != TSH_OK) {
-    rc = comm_error_blocks(c, slot, gq, entries, local_rc);
+    rc = comm_error_blocks(d_blocks, gq, entries, local_rc);
     if (rc) return rc;
   }
   // ---- 1. every rank's blocks of the group; this rank's query slice of them to the host -------------------
@@ -315,7 +356,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
   size_t slice_pitch;
   const double t1 = now_us();
   if (c->host_fn) {
-    HIPCHK(hipMemcpyAsync(c->h_mine, c->d_mine[slot], mine, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_mine, d_blocks, mine, hipMemcpyDeviceToHost, c->stream));
     rc = comm_sync(c);
     if (rc) return rc;
     const double t1b = now_us();
@@ -327,10 +368,14 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, int slot, int local_rc, c
     slice_pitch = mine;
   } else {
     HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
-    rc = comm_allgather_dev(c, c->d_mine[slot], c->d_all, mine);  // k' x 24 B per rank and query: latency-bound
+    rc = comm_allgather_dev(c, d_blocks, c->d_all, mine);  // k' x 24 B per rank and query: latency-bound
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
-    if (b > a)
+    // every query of the group (a world of one, or a small group merged whole) is one contiguous copy; the pitched
+    // form took ~30 us of device time for 60 KB
+    if (b - a == gq)
+      HIPCHK(hipMemcpyAsync(c->h_slice, c->d_all, W * mine, hipMemcpyDeviceToHost, c->stream));
+    else if (b > a)
       HIPCHK(hipMemcpy2DAsync(c->h_slice, (size_t)(b - a) * bb, c->d_all + (size_t)a * bb, mine, (size_t)(b - a) * bb, W,
                               hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
@@ -445,20 +490,21 @@ int comm_common_create(tsh_comm *c, int32_t world, int32_t rank, int32_t device)
   c->rank = rank;
   c->device = device;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming | hipEventBlockingSync));
-  for (auto &e : c->ev_t) HIPCHK(hipEventCreateWithFlags(&e, hipEventBlockingSync));  // timed: the exchange's phases
-  HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_agree), 4 * (size_t)(world + 1)));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_agree), 4 * (size_t)(world + 1), hipHostMallocDefault));
-  c->helper.reset(new OneWorker());
+  // (waits spin unless the ranks outnumber the CPUs, blocking_wait(): an interrupt-driven wake-up costs tens of
+  // microseconds, and the last exchange of every call is waited for in full view)
+  const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0u;
+  HIPCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming | wait_flag));
+  for (auto &e : c->ev_t) HIPCHK(hipEventCreateWithFlags(&e, wait_flag));  // timed: the exchange's phases
+  HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_agree), 16 * (size_t)(world + 1)));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_agree), 16 * (size_t)(world + 1), hipHostMallocDefault));
   return TSH_OK;
 }
 
 void comm_free(tsh_comm *c) {
-  c->helper.reset();
   hipSetDevice(c->device);
   if (c->comm) rccl()->CommDestroy(c->comm);
-  hipFree(c->d_mine[0]);
-  hipFree(c->d_mine[1]);
+  hipFree(c->d_mine);
+  hipFree(c->d_retry);
   hipHostFree(c->h_mine);
   hipFree(c->d_all);
   hipHostFree(c->h_slice);
@@ -591,16 +637,17 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
   std::string local_err = g_err;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  // Queries per exchange.  A call costs nq scans + per group the fill and drain of the shard's scan pipeline (~45 us:
-  // the first scan runs alone, the last query's select / re-rank is waited for) + the LAST group's exchange (the
-  // others hide behind the next group's scans).  So: as few groups as keep that last exchange small -- one group up to
-  // 16 queries, two up to 128 (each at most 64: merged whole or in small slices), 64 per group up to 512; big calls go
-  // to the matrix cores, which want big groups.  (Round 3 took a quarter of the call, 8..64: a 20-query call on a
-  // 125 k-row shard -- one of eight GPUs -- was three groups, 82.7 us per query against 70 with two.)
-  int32_t G = c->group;
-  if (G <= 0) G = sharded_group_auto(nq);
-  G = std::min(G, nq);
-  int32_t entries = tsh_default_block_entries(k);
+  const int32_t entries = tsh_default_block_entries(k);
+  // buffers: for the largest group any schedule of this call may hold, and this rank's own blocks for a window of the
+  // call (whole groups; 4096 queries = 25 MB at k = 100)
+  const int32_t Gmax = c->group > 0 ? std::min(c->group, nq) : sharded_group_max(nq);
+  const int32_t win_cap = std::min(nq, std::max(Gmax, SHARDED_WINDOW));
+  int64_t my_rows = 0;
+  if (local_rc == TSH_OK) {
+    Shard *s0 = shard->shards[0].get();
+    std::shared_lock<RwLock> sl = share(shard, s0);
+    my_rows = s0->rows;
+  }
   bool grew = false;
   const double t_in = now_us();
   tsh_comm_timeline &tl = c->tl;
@@ -614,69 +661,99 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
       tl.call_us += now_us() - t0;
     }
   } call_clock{tl, t_in, nq};
-  int rc = comm_reserve_agreed(c, G, entries, k, &grew);
+  int rc = comm_reserve_agreed(c, Gmax, entries, k, win_cap, false, my_rows, &grew);
   tl.reserve_us += now_us() - t_in;
   if (rc) return rc;
   const int32_t dim = local_rc == TSH_OK ? shard->dim : 0;
-  const int dev = c->device;
-  const int32_t n_groups = (nq + G - 1) / G;
-  std::vector<int> scan_rc((size_t)n_groups, TSH_OK);
-  std::vector<std::string> scan_err((size_t)n_groups);
-  auto scan = [&](int32_t g, int slot, int32_t ent) {
-    if (local_rc != TSH_OK) {
-      scan_rc[(size_t)g] = local_rc;
-      scan_err[(size_t)g] = local_err;
-      return;
+  // queries per exchange, group after group (the same list on every rank: nq, the communicator's setting and the
+  // rows the ranks told each other are all it depends on)
+  std::vector<int32_t> sizes;
+  if (c->group > 0) {
+    for (int32_t q = 0; q < nq; q += Gmax) sizes.push_back(std::min(Gmax, nq - q));
+  } else {
+    const double scan_us = (double)c->rows_hint * (double)round_up(std::max(dim, 1), 4) * 4.0 / 6.5e6;  // (dim: same on every rank by contract)
+    sharded_schedule(nq, scan_us, &sizes);
+  }
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+  size_t gi = 0;  // next group
+  for (int32_t w0 = 0; w0 < nq;) {
+    // a window: as many whole groups as fit this rank's block buffer (at least one)
+    size_t ge = gi;
+    int32_t wn = 0;
+    while (ge < sizes.size() && (ge == gi || wn + sizes[ge] <= win_cap)) wn += sizes[ge++];
+    // this rank's scans of the window: one pipeline on a library thread, blocks final in query order
+    tsh_shard_stream *ss = nullptr;
+    int scan_rc = local_rc;
+    std::string scan_err = local_err;
+    if (scan_rc == TSH_OK) {
+      scan_rc = shard_stream_begin(shard, queries + (size_t)w0 * dim, wn, k, row_mask, entries, c->d_mine, sizes[gi],
+                                   /*copy_inputs=*/false, &ss);
+      if (scan_rc) scan_err = g_err;
     }
-    (void)hipSetDevice(dev);
-    const int32_t q0 = g * G, gq = std::min(G, nq - q0);
-    const double t0 = now_us();
-    scan_rc[(size_t)g] = tsh_search_shard(shard, queries + (size_t)q0 * dim, gq, k, row_mask, ent, c->d_mine[slot], nullptr);
-    c->scan_ns.fetch_add((int64_t)((now_us() - t0) * 1e3), std::memory_order_relaxed);
-    if (scan_rc[(size_t)g]) scan_err[(size_t)g] = g_err;
-  };
-  c->helper->post([&] { scan(0, 0, entries); });
-  for (int32_t g = 0; g < n_groups; ++g) {
-    const int32_t q0 = g * G, gq = std::min(G, nq - q0);
-    const double t_w = now_us();
-    c->helper->wait();  // group g's blocks are in d_mine[g & 1]
-    tl.wait_scan_us += now_us() - t_w;
-    if (g + 1 < n_groups) c->helper->post([&, g] { scan(g + 1, (g + 1) & 1, entries); });
-    if (scan_rc[(size_t)g]) g_err = scan_err[(size_t)g];
-    GroupOut go;
-    rc = comm_exchange_group(c, shard, g & 1, scan_rc[(size_t)g], queries + (size_t)q0 * dim, gq, k, thr, entries,
-                             out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0, &go);
-    tl.groups++;
-    int32_t ent = entries;
-    bool lookahead_lost = false;
-    for (int attempt = 0; rc == TSH_OK && go.need > 0; ++attempt) {
-      // ties made a block overflow: every rank saw the same verdict and redoes this group with larger blocks.
-      // The look-ahead scan must be done first; if the buffers have to grow its blocks go with them and it is redone
-      if (attempt == 3) rc = set_err(TSH_E_OVERFLOW, "candidate blocks kept overflowing");
-      if (rc) break;
-      const double t_r = now_us();
-      c->helper->wait();
-      ent = go.need;
-      tl.retries++;
-      rc = comm_reserve_agreed(c, G, ent, k, &grew);
-      lookahead_lost |= grew;
-      if (rc) break;
-      scan(g, g & 1, ent);  // on the calling thread: nothing overlaps a retry
-      tl.retry_scan_us += now_us() - t_r;
-      if (scan_rc[(size_t)g]) g_err = scan_err[(size_t)g];
-      go = GroupOut();
-      rc = comm_exchange_group(c, shard, g & 1, scan_rc[(size_t)g], queries + (size_t)q0 * dim, gq, k, thr, ent,
-                               out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0, &go);
+    auto end_stream = [&] {  // nothing of this call may still run when it returns
+      if (!ss) return;
+      double busy = 0;
+      (void)shard_stream_end(ss, &busy);
+      c->scan_ns.fetch_add((int64_t)(busy * 1e3), std::memory_order_relaxed);
+      ss = nullptr;
+    };
+    for (int32_t q0 = 0; gi < ge; q0 += sizes[gi], ++gi) {
+      const int32_t gq = sizes[gi], qa = w0 + q0;  // qa: the group's first query in the call
+      if (ss && scan_rc == TSH_OK) {
+        const double t_w = now_us();
+        int32_t done = 0;
+        scan_rc = shard_stream_progress(ss, q0 + gq, &done);  // the group's blocks are final in d_mine
+        tl.wait_scan_us += now_us() - t_w;
+        if (scan_rc) scan_err = g_err;  // (the pipeline has ended: this group and the ones after it carry the error)
+      }
+      if (scan_rc) g_err = scan_err;
+      GroupOut go;
+      rc = comm_exchange_group(c, shard, c->d_mine + (size_t)q0 * bb, scan_rc, queries + (size_t)qa * dim, gq, k, thr,
+                               entries, out_ids + (size_t)qa * k, out_dist + (size_t)qa * k, out_count + qa, &go);
       tl.groups++;
+      for (int attempt = 0; rc == TSH_OK && go.need > 0; ++attempt) {
+        // ties made a block overflow: every rank saw the same verdict and redoes this group with larger blocks, in a
+        // buffer of their own (the pipeline keeps its block size), after the pipeline has run out: nothing overlaps a
+        // retry
+        if (attempt == 3) rc = set_err(TSH_E_OVERFLOW, "candidate blocks kept overflowing");
+        if (rc) break;
+        const double t_r = now_us();
+        if (ss) {
+          int32_t done = 0;
+          (void)shard_stream_progress(ss, wn, &done);  // (a failure there belongs to a later group)
+        }
+        const int32_t ent = go.need;
+        tl.retries++;
+        rc = comm_reserve_agreed(c, Gmax, ent, k, 0, true, my_rows, &grew);
+        if (rc) break;
+        int again_rc = local_rc;
+        std::string again_err = local_err;
+        if (again_rc == TSH_OK) {
+          const double t0 = now_us();
+          again_rc = tsh_search_shard(shard, queries + (size_t)qa * dim, gq, k, row_mask, ent, c->d_retry, nullptr);
+          c->scan_ns.fetch_add((int64_t)((now_us() - t0) * 1e3), std::memory_order_relaxed);
+          if (again_rc) again_err = g_err;
+        }
+        tl.retry_scan_us += now_us() - t_r;
+        if (again_rc) g_err = again_err;
+        go = GroupOut();
+        rc = comm_exchange_group(c, shard, c->d_retry, again_rc, queries + (size_t)qa * dim, gq, k, thr, ent,
+                                 out_ids + (size_t)qa * k, out_dist + (size_t)qa * k, out_count + qa, &go);
+        tl.groups++;
+      }
+      if (rc) {
+        std::string keep = g_err;
+        end_stream();
+        g_err = keep;
+        return rc;
+      }
     }
-    if (rc == TSH_OK && lookahead_lost && g + 1 < n_groups) c->helper->post([&, g] { scan(g + 1, (g + 1) & 1, entries); });
-    if (rc) {
-      c->helper->wait();  // nothing of this call may still run when it returns
-      return rc;
-    }
+    end_stream();
+    w0 += wn;
   }
   if (trace_batch())
-    fprintf(stderr, "[tsh sharded] rank %d nq=%d groups of %d: %.0f us\n", c->rank, nq, G, now_us() - t_in);
+    fprintf(stderr, "[tsh sharded] rank %d nq=%d in %d groups (first %d, last %d): %.0f us\n", c->rank, nq, (int)sizes.size(),
+            sizes.front(), sizes.back(), now_us() - t_in);
   return TSH_OK;
 }
 

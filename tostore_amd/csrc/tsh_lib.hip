@@ -301,6 +301,16 @@ struct DeviceStreams {
   hipStream_t upload = nullptr;                 // a batched call's queries on their way in, beside the call before it
   bool cu_split = false;
   std::mutex scan_mu;                           // one enqueue sequence (scan + hand-off + tail) at a time
+  // small shards run their scans on two streams: which scans of either are still out (guarded by scan_mu).  A new
+  // scan goes to the stream with fewer of them -- two scans side by side do not share the HBM evenly, and with strict
+  // alternation one stream ended a call a scan or two behind the other, which sat idle meanwhile
+  struct ScanOut {
+    const void *owner;  // the context whose job this scan belongs to
+    hipEvent_t ev;      // rides on the scan's dispatch packet
+    int which;
+  };
+  std::vector<ScanOut> scan_out;
+  int scans_out[2] = {0, 0};
   int rc = TSH_OK;
   std::string err;
   int users = 0;                                // shards alive on this device (device_streams / device_streams_release)
@@ -359,6 +369,7 @@ struct Shard {
   hipStream_t batch_stream = nullptr;  // matrix-core batches: compute-bound, so all CUs (no mask)
   hipStream_t upload_stream = nullptr;  // H2D copies of a batched call's inputs (they overlap the call in front)
   std::mutex *scan_mu = nullptr;  // the device's (DeviceStreams): streams are shared by its shards
+  DeviceStreams *dstreams = nullptr;
   std::atomic<int> inflight{0};
 
   RwLock mu;  // search: shared; append/delete: exclusive
@@ -527,6 +538,7 @@ int shard_init(Shard *s) {
   s->cu_split = ds->cu_split;
   s->cus = ds->cus;
   s->scan_mu = &ds->scan_mu;
+  s->dstreams = ds;
   s->holds_streams = true;
   HIPCHK(hipMalloc(&s->d_stats, sizeof(IngestStats)));
   HIPCHK(hipMemset(s->d_stats, 0, sizeof(IngestStats)));
@@ -765,6 +777,18 @@ Ctx *ctx_acquire(Shard *s, bool block) {
   }
 }
 void ctx_release(Shard *s, Ctx *c) {
+  if (s->dstreams) {  // whatever the device still books under this context's events is over (or given up)
+    std::lock_guard<std::mutex> lk(*s->scan_mu);
+    std::vector<DeviceStreams::ScanOut> &so = s->dstreams->scan_out;
+    for (size_t i = 0; i < so.size();)
+      if (so[i].owner == c) {
+        s->dstreams->scans_out[so[i].which]--;
+        so[i] = so.back();
+        so.pop_back();
+      } else {
+        ++i;
+      }
+  }
   {
     std::lock_guard<std::mutex> lk(s->ctx_mu);
     s->ctx_free.push_back(c);
@@ -941,7 +965,7 @@ bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles,
 
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
                 const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target, int64_t rows_est = 0,
-                const RowList *list = nullptr) {
+                const RowList *list = nullptr, bool more_coming = false, bool last_of_call = false) {
   Ctx *c = j->c;
   int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
   if (rc) return rc;
@@ -1019,13 +1043,15 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   ra.dim = s->dim;
   ra.cap = entries;
   ra.metric = s->metric;
-  // with other queries already in flight the tail moves to the reserved CUs;
-  // a lone query keeps everything in order on one stream (no hand-off latency)
-  const bool overlap = s->inflight.fetch_add(1) > 0 && s->cu_split;
+  // with other queries already in flight -- or the caller about to submit more (the first query of a multi-query
+  // call: left alone it kept its select + re-rank on the pipeline stream, in front of the call's third scan) -- the
+  // tail moves to the reserved CUs; a lone query keeps everything in order on one stream (no hand-off latency)
+  const bool overlap = (s->inflight.fetch_add(1) > 0 || more_coming) && s->cu_split;
   j->counted = true;
   {
     std::lock_guard<std::mutex> lk(*s->scan_mu);
     hipStream_t ps = s->scan_stream;
+    int which = -1;  // >= 0: one of the two scan streams of a small shard, booked in DeviceStreams::scan_out
     {
       // Between two scans on one in-order stream the GPU idles for about 13 us (drain, write-back,
       // ramp-up).  That is 3 % of a 1 M-row scan but 20 % of a 125 k-row one (a shard of an 8-GPU
@@ -1038,7 +1064,21 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       const int64_t tiles_read = rows_est > 0 ? std::min<int64_t>(n_tiles, (rows_est + 63) / 64) : n_tiles;
       static const int min_tiles = getenv("TSH_TWO_STREAM_MIN_TILES") ? atoi(getenv("TSH_TWO_STREAM_MIN_TILES")) : 0;
       const bool two = forced == 2 || (forced != 1 && tiles_read < SMALL_SHARD_TILES && tiles_read >= min_tiles);
-      if (overlap && two && s->scan_stream2 && (s->scan_seq++ & 1)) ps = s->scan_stream2;
+      if (overlap && two && s->scan_stream2) {
+        DeviceStreams *ds = s->dstreams;
+        for (size_t i = 0; i < ds->scan_out.size();) {  // scans that have finished since the last look
+          if (hipEventQuery(ds->scan_out[i].ev) != hipErrorNotReady) {
+            ds->scans_out[ds->scan_out[i].which]--;
+            ds->scan_out[i] = ds->scan_out.back();
+            ds->scan_out.pop_back();
+          } else {
+            ++i;
+          }
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error)
+        which = ds->scans_out[0] != ds->scans_out[1] ? (ds->scans_out[1] < ds->scans_out[0] ? 1 : 0) : (int)(s->scan_seq++ & 1);
+        if (which) ps = s->scan_stream2;
+      }
     }
     if (upload_mask)
       HIPCHK(hipMemcpyAsync(c->d_mask, c->h_mask, (size_t)n_tiles * 8, hipMemcpyHostToDevice, ps));
@@ -1061,8 +1101,14 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     else
       launch_scan(sa, s->nch, s->metric, j->masked, ps, ev,
                   j->masked && scan_mostly_live(rows_est > 0 ? rows_est : s->rows - s->deleted, s->rows));
+    if (which >= 0 && ev.stop) {
+      s->dstreams->scan_out.push_back({c, ev.stop, which});
+      s->dstreams->scans_out[which]++;
+    }
     hipStream_t ts = ps;
-    if (overlap) {
+    // (the last query of a call: nothing follows its scan on that stream, so its tail stays there -- in order, without
+    // the ~10 us of a cross-stream event hand-off in front of the select, on the step every caller waits for)
+    if (overlap && !last_of_call) {
       // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
       // scans -- selective masks, small shards -- were then limited by)
       static const bool one_tail = getenv("TSH_ONE_TAIL") != nullptr && getenv("TSH_ONE_TAIL")[0] == '1';
@@ -1279,6 +1325,10 @@ struct SearchOut {
   // queries [q0, q1), indexed like the call's queries; what it cannot goes through on_chunk as before
   double fin_thr = std::nan("");
   std::function<void(int32_t q0, int32_t q1, const char *skip, const int64_t *ids, const double *dist, const int32_t *cnt)> on_final;
+  // single-query pipeline, device mode (progressive shard search): called once query q's block is final in
+  // d_blocks (its job finished on the host, fallback included), from whichever submitting thread ran it.  With it
+  // set the submitting threads take the queries interleaved (q = t, t + T, ...), so blocks become final in order
+  std::function<void(int32_t q)> on_done;
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1286,12 +1336,14 @@ struct SearchOut {
 // behind the next query's scan.
 int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, int32_t k, const uint64_t *mask_words,
                        uint64_t epoch, int32_t entries, SearchOut *out, int depth, int64_t rows_est,
-                       const RowList *list = nullptr) {
+                       const RowList *list = nullptr, int32_t stride = 1) {
+  // this thread's queries: q0, q0 + stride, ... below q1 (cnt of them; i-th = q0 + i * stride)
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
-  depth = std::max(1, std::min(depth, std::min(q1 - q0, MAX_CTX)));
+  const int32_t cnt = q1 > q0 ? (q1 - q0 + stride - 1) / stride : 0;
+  depth = std::max(1, std::min(depth, std::min(cnt, MAX_CTX)));
   std::vector<Job> jobs((size_t)depth);
   int rc = TSH_OK;
-  int32_t submitted = q0, finished = q0;
+  int32_t submitted = 0, finished = 0;
   auto release_all = [&]() {
     for (auto &j : jobs)
       if (j.c) {
@@ -1302,34 +1354,38 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
         j.c = nullptr;
       }
   };
-  while (finished < q1) {
-    while (submitted < q1 && submitted - finished < depth) {
+  while (finished < cnt) {
+    while (submitted < cnt && submitted - finished < depth) {
       // wait for a context only while holding none: callers that each hold some and wait for
       // more would deadlock on the shard's fixed pool
       Ctx *c = ctx_acquire(s, submitted == finished);
       if (!c) break;
-      Job &j = jobs[(size_t)((submitted - q0) % depth)];
+      Job &j = jobs[(size_t)(submitted % depth)];
       j.c = c;
-      rc = job_enqueue(s, &j, queries + (size_t)submitted * s->dim, k, entries, mask_words, epoch,
-                       out->d_blocks ? out->d_blocks + (size_t)submitted * bb : nullptr, rows_est, list);
+      const int32_t q = q0 + submitted * stride;
+      rc = job_enqueue(s, &j, queries + (size_t)q * s->dim, k, entries, mask_words, epoch,
+                       out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr, rows_est, list, cnt > 1,
+                       cnt > 1 && submitted == cnt - 1);
       if (rc) {
         release_all();
         return rc;
       }
       ++submitted;
     }
-    Job &j = jobs[(size_t)((finished - q0) % depth)];
-    std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[(size_t)finished] : nullptr;
-    std::vector<BlockEntry> *ex = out->extra ? &(*out->extra)[(size_t)finished] : nullptr;
+    Job &j = jobs[(size_t)(finished % depth)];
+    const int32_t q = q0 + finished * stride;
+    std::vector<BlockEntry> *sp = out->spill ? &(*out->spill)[(size_t)q] : nullptr;
+    std::vector<BlockEntry> *ex = out->extra ? &(*out->extra)[(size_t)q] : nullptr;
     rc = job_finish(s, &j, sp, ex);
     if (rc) {
       release_all();
       return rc;
     }
-    if (out->h_blocks) memcpy(out->h_blocks + (size_t)finished * bb, j.c->h_block, bb);
+    if (out->h_blocks) memcpy(out->h_blocks + (size_t)q * bb, j.c->h_block, bb);
     ctx_release(s, j.c);
     j.c = nullptr;
     ++finished;
+    if (out->on_done) out->on_done(q);
   }
   return TSH_OK;
 }
@@ -1370,9 +1426,12 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   std::vector<int> rcs((size_t)T, TSH_OK);
   std::vector<std::string> errs((size_t)T);
   const int per_depth = std::max(2, depth / T);
+  const bool interleave = (bool)out->on_done;  // a progressive search wants its blocks final in query order
   auto run = [&](int t) {
-    const int32_t q0 = (int32_t)((int64_t)nq * t / T), q1 = (int32_t)((int64_t)nq * (t + 1) / T);
-    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth, rows_est, lp);
+    const int32_t q0 = interleave ? t : (int32_t)((int64_t)nq * t / T);
+    const int32_t q1 = interleave ? nq : (int32_t)((int64_t)nq * (t + 1) / T);
+    rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth, rows_est, lp,
+                                        interleave ? T : 1);
     if (rcs[(size_t)t]) errs[(size_t)t] = g_err;
   };
   std::vector<std::thread> th;
@@ -1980,6 +2039,192 @@ int32_t tsh_search_shard(tsh_index *idx, const float *queries, int32_t nq, int32
   so.d_blocks = static_cast<uint8_t *>(d_out_blocks);
   so.user_stream = static_cast<hipStream_t>(stream);
   return shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
+}
+
+// ---- progressive shard search ---------------------------------------------------------------------------------
+// tsh_search_shard answers when the LAST of its queries is done; a caller that exchanges the blocks group by group
+// (tsh_search_sharded, sharded.py) then starts group g + 1's scans only after group g's have drained, and every
+// group pays the fill and the drain of the scan pipeline (measured: ~45 us per group on a 125 k-row shard, a fifth of
+// a ten-query group).  Here the scans of ALL nq queries run as ONE pipeline on a library thread -- group boundaries
+// do not exist for the GPU -- and the caller is told how many LEADING queries' blocks are final.
+struct tsh_shard_stream {
+  tsh_index *idx = nullptr;
+  const float *queries = nullptr;
+  const uint8_t *mask = nullptr;
+  std::vector<float> own_queries;  // public entry points: the caller's arrays are consumed before begin returns
+  std::vector<uint8_t> own_mask;
+  int32_t nq = 0, k = 0, entries = 0, step = 0;
+  uint8_t *d_blocks = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<char> done_q;  // single-query route: query q's block is final
+  int32_t done = 0;          // leading queries whose blocks are final
+  bool finished = false;     // the worker has returned
+  std::atomic<int32_t> done_seen{0};  // copies of the two for a caller that polls before it sleeps
+  std::atomic<bool> finished_seen{false};
+  int rc = TSH_OK;
+  std::string err;
+  double busy_us = 0;  // worker: first enqueue to last block
+  std::thread th;
+
+  void publish(int32_t upto) {  // queries [0, upto) are final
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      done = std::max(done, upto);
+      done_seen.store(done, std::memory_order_release);
+    }
+    cv.notify_all();
+  }
+  void mark(int32_t q) {
+    bool moved = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      done_q[(size_t)q] = 1;
+      while (done < nq && done_q[(size_t)done]) {
+        ++done;
+        moved = true;
+      }
+      done_seen.store(done, std::memory_order_release);
+    }
+    if (moved) cv.notify_all();
+  }
+  int body() {
+    Shard *s = idx->shards[0].get();
+    std::shared_lock<RwLock> sl = share(idx, s);
+    HIPCHK(hipSetDevice(s->device));
+    const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
+    if (s->rows == 0) {  // an empty shard contributes empty blocks
+      std::vector<uint8_t> z(bb * (size_t)nq, 0);
+      for (int32_t q = 0; q < nq; ++q) {
+        BlockHeader *h = reinterpret_cast<BlockHeader *>(z.data() + (size_t)q * bb);
+        h->entries = (uint32_t)entries;
+        h->k = (uint32_t)k;
+        h->metric = (uint32_t)s->metric;
+        h->row_base = s->row_base;
+      }
+      HIPCHK(hipMemcpy(d_blocks, z.data(), z.size(), hipMemcpyHostToDevice));
+      publish(nq);
+      return TSH_OK;
+    }
+    const int32_t min_nq = idx->batch_min_nq.load();
+    const int32_t st = step > 0 ? std::min(step, nq) : nq;
+    if (!shard_takes_batch(s, min_nq, st, k)) {  // one pipeline over all queries
+      done_q.assign((size_t)nq, 0);
+      SearchOut so;
+      so.d_blocks = d_blocks;
+      so.on_done = [this](int32_t q) { mark(q); };
+      return shard_search_blocks(s, queries, nq, k, mask, entries, &so, PIPE_DEPTH);
+    }
+    // matrix-core route: a call per step (the batched path answers a call as a whole; the next step's call overlaps
+    // the caller's work on this one as before)
+    for (int32_t q0 = 0; q0 < nq; q0 += st) {
+      const int32_t gq = std::min(st, nq - q0);
+      SearchOut so;
+      so.d_blocks = d_blocks + (size_t)q0 * bb;
+      int r = shard_search_any(s, s->batch, min_nq, queries + (size_t)q0 * s->dim, gq, k, mask, entries, &so);
+      if (r) return r;
+      publish(q0 + gq);
+    }
+    return TSH_OK;
+  }
+  void run() {
+    const double t0 = now_us();
+    int r = body();
+    std::string e = r ? g_err : std::string();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      rc = r;
+      err = e;
+      finished = true;
+      busy_us = now_us() - t0;
+      finished_seen.store(true, std::memory_order_release);
+    }
+    cv.notify_all();
+  }
+};
+
+namespace {
+int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t k, const uint8_t *row_mask,
+                       int32_t entries, void *d_out_blocks, int32_t step, bool copy_inputs, tsh_shard_stream **out) {
+  if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (!idx || idx->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle");
+  if (nq <= 0 || !queries || !d_out_blocks || k <= 0 || entries < 1 || step < 0)
+    return set_err(TSH_E_BAD_ARG, "bad nq / k / entries / step / pointers");
+  std::unique_ptr<tsh_shard_stream> st(new tsh_shard_stream());
+  st->idx = idx;
+  st->nq = nq;
+  st->k = k;
+  st->entries = entries;
+  st->step = step;
+  st->d_blocks = static_cast<uint8_t *>(d_out_blocks);
+  st->queries = queries;
+  st->mask = row_mask;
+  if (copy_inputs) {
+    Shard *s = idx->shards[0].get();
+    st->own_queries.assign(queries, queries + (size_t)nq * (size_t)s->dim);
+    st->queries = st->own_queries.data();
+    if (row_mask) {
+      int64_t bits;
+      {
+        std::shared_lock<RwLock> sl = share(idx, s);
+        bits = s->row_base + s->rows;  // the mask is global: one bit per row id below this shard's end
+      }
+      st->own_mask.assign(row_mask, row_mask + (size_t)((bits + 7) / 8));
+      st->mask = st->own_mask.data();
+    }
+  }
+  tsh_shard_stream *p = st.get();
+  try {
+    st->th = std::thread([p] { p->run(); });
+  } catch (...) {
+    return set_err(TSH_E_OOM, "could not start the search thread");
+  }
+  *out = st.release();
+  return TSH_OK;
+}
+
+// blocks until min(want, nq) leading queries are final, or the search has ended; -> its status so far
+int shard_stream_progress(tsh_shard_stream *st, int32_t want, int32_t *out_done) {
+  want = std::min(want, st->nq);
+  if (!blocking_wait()) {
+    // the caller has nothing else to do and (blocking_wait: at least three CPUs per rank) a core to do it on: poll for
+    // a few milliseconds before sleeping -- being woken through the condition variable costs 20-50 us, on the last
+    // group of a call in full view
+    const double t_end = now_us() + 3000.0;
+    while (st->done_seen.load(std::memory_order_acquire) < want && !st->finished_seen.load(std::memory_order_acquire) &&
+           now_us() < t_end)
+      __builtin_ia32_pause();
+  }
+  std::unique_lock<std::mutex> lk(st->mu);
+  st->cv.wait(lk, [&] { return st->done >= want || st->finished; });
+  if (out_done) *out_done = st->done;
+  if (st->done >= want) return TSH_OK;  // (whatever happens to later queries)
+  g_err = st->err;  // the search ended before it got there
+  return st->rc != TSH_OK ? st->rc : set_err(TSH_E_HIP, "the shard search ended early");
+}
+
+int shard_stream_end(tsh_shard_stream *st, double *busy_us = nullptr) {
+  if (st->th.joinable()) st->th.join();
+  const int rc = st->rc;
+  if (rc) g_err = st->err;
+  if (busy_us) *busy_us = st->busy_us;
+  delete st;
+  return rc;
+}
+}  // namespace
+
+int32_t tsh_search_shard_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t k, const uint8_t *row_mask,
+                               int32_t entries, void *d_out_blocks, int32_t step, tsh_shard_stream **out) {
+  return shard_stream_begin(idx, queries, nq, k, row_mask, entries, d_out_blocks, step, /*copy_inputs=*/true, out);
+}
+int32_t tsh_search_shard_progress(tsh_shard_stream *st, int32_t want, int32_t *out_done) {
+  if (!st) return set_err(TSH_E_BAD_ARG, "stream is NULL");
+  return shard_stream_progress(st, want, out_done);
+}
+int32_t tsh_search_shard_end(tsh_shard_stream *st) {
+  if (!st) return TSH_OK;
+  return shard_stream_end(st);
 }
 
 int32_t tsh_merge_candidates(int32_t metric, int32_t dim, const float *queries, int32_t nq, int32_t k,

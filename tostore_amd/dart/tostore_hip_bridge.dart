@@ -94,6 +94,14 @@ typedef _SearchShardC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int
     Int32, Pointer<Void>, Pointer<Void>);
 typedef _SearchShardD = int Function(Pointer<Void>, Pointer<Float>, int, int, Pointer<Uint8>,
     int, Pointer<Void>, Pointer<Void>);
+typedef _ShardBeginC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, Pointer<Uint8>,
+    Int32, Pointer<Void>, Int32, Pointer<Pointer<Void>>);
+typedef _ShardBeginD = int Function(Pointer<Void>, Pointer<Float>, int, int, Pointer<Uint8>,
+    int, Pointer<Void>, int, Pointer<Pointer<Void>>);
+typedef _ShardProgressC = Int32 Function(Pointer<Void>, Int32, Pointer<Int32>);
+typedef _ShardProgressD = int Function(Pointer<Void>, int, Pointer<Int32>);
+typedef _ShardEndC = Int32 Function(Pointer<Void>);
+typedef _ShardEndD = int Function(Pointer<Void>);
 typedef _MergeC = Int32 Function(Int32, Int32, Pointer<Float>, Int32, Int32, Double, Pointer<Void>,
     Int32, Int32, Pointer<Int64>, Pointer<Double>, Pointer<Int32>, Pointer<Int32>);
 typedef _MergeD = int Function(int, int, Pointer<Float>, int, int, double, Pointer<Void>,
@@ -273,6 +281,9 @@ final class HipVectorBackend {
   static late final _BlockBytesD _blockBytes;
   static late final _BlockEntriesD _blockEntries;
   static late final _SearchShardD _searchShard;
+  static late final _ShardBeginD _shardBegin;
+  static late final _ShardProgressD _shardProgress;
+  static late final _ShardEndD _shardEnd;
   static late final _MergeD _merge;
   static late final _CommIdD _commId;
   static late final _CommCreateD _commCreate;
@@ -284,7 +295,7 @@ final class HipVectorBackend {
   static late final _CommTimelineD _commTimeline;
 
   /// include/tostore_hip.h TSH_ABI_VERSION this file was written against.
-  static const int abiVersion = 3;
+  static const int abiVersion = 4;
 
   /// True when libtostore_hip.so is loadable, ABI-compatible and sees a GPU.
   static bool get available {
@@ -318,6 +329,10 @@ final class HipVectorBackend {
       _blockBytes = lib.lookupFunction<_BlockBytesC, _BlockBytesD>('tsh_candidate_block_bytes');
       _blockEntries = lib.lookupFunction<_BlockEntriesC, _BlockEntriesD>('tsh_default_block_entries');
       _searchShard = lib.lookupFunction<_SearchShardC, _SearchShardD>('tsh_search_shard');
+      _shardBegin = lib.lookupFunction<_ShardBeginC, _ShardBeginD>('tsh_search_shard_begin');
+      _shardProgress =
+          lib.lookupFunction<_ShardProgressC, _ShardProgressD>('tsh_search_shard_progress');
+      _shardEnd = lib.lookupFunction<_ShardEndC, _ShardEndD>('tsh_search_shard_end');
       _merge = lib.lookupFunction<_MergeC, _MergeD>('tsh_merge_candidates');
       _commId = lib.lookupFunction<_CommIdC, _CommIdD>('tsh_comm_unique_id');
       _commCreate = lib.lookupFunction<_CommCreateC, _CommCreateD>('tsh_comm_create');
@@ -330,7 +345,7 @@ final class HipVectorBackend {
           lib.lookupFunction<_SearchShardedC, _SearchShardedD>('tsh_search_sharded');
       _commTimeline =
           lib.lookupFunction<_CommTimelineC, _CommTimelineD>('tsh_comm_get_timeline');
-      // the structs of this file are the version-3 layouts: any other library is not used
+      // the structs of this file are the version-4 layouts: any other library is not used
       if (_abiVersion() != abiVersion || _deviceCount() < 1) return false;
       _lib = lib;
       return true;
@@ -684,6 +699,35 @@ final class HipVectorBackend {
   bool searchShard(Pointer<Float> queries, int nq, int topK, Pointer<Uint8> rowMask, int entries,
           Pointer<Void> deviceBlocks) =>
       _searchShard(_handle, queries, nq, topK, rowMask, entries, deviceBlocks, nullptr) == 0;
+
+  /// Progressive form (tsh_search_shard_begin / _progress / _end): the scans of all `nq` queries run as one
+  /// pipeline on a library thread while the host exchanges the groups whose blocks are final.  Returns the
+  /// stream handle (nullptr on failure); `step` = the host's group size.  The queries / mask are copied by the
+  /// call; `deviceBlocks` must stay valid until [shardStreamEnd].
+  Pointer<Void> shardStreamBegin(Pointer<Float> queries, int nq, int topK, Pointer<Uint8> rowMask,
+      int entries, Pointer<Void> deviceBlocks, int step) {
+    final out = calloc<Pointer<Void>>();
+    try {
+      final rc = _shardBegin(_handle, queries, nq, topK, rowMask, entries, deviceBlocks, step, out);
+      return rc == 0 ? out.value : nullptr;
+    } finally {
+      calloc.free(out);
+    }
+  }
+
+  /// Blocks until the first min(want, nq) queries' blocks are final; -1 when the search failed first,
+  /// otherwise the number of leading queries that are final.
+  static int shardStreamProgress(Pointer<Void> stream, int want) {
+    final done = calloc<Int32>();
+    try {
+      return _shardProgress(stream, want, done) == 0 ? done.value : -1;
+    } finally {
+      calloc.free(done);
+    }
+  }
+
+  /// Waits for whatever still runs and frees the stream; exactly once per [shardStreamBegin].
+  static bool shardStreamEnd(Pointer<Void> stream) => _shardEnd(stream) == 0;
 
   /// Host-side merge of `nBlocks` x nq gathered candidate blocks; false with `neededEntries`
   /// set when a block was truncated (every rank retries with that many entries).

@@ -90,9 +90,10 @@ class ShardedSearcher:
         _ffi.check(_ffi.lib().tsh_search_shard(self.index._h, q.ctypes.data_as(_ffi.p_f32), q.shape[0], int(k), mp,
                                                entries, ctypes.c_void_p(mine.data_ptr()), None))
 
-    def _exchange_merge(self, q: np.ndarray, k: int, thr, entries: int, slot: int):
+    def _exchange_merge(self, q: np.ndarray, k: int, thr, entries: int, slot: int, mine=None):
         t = self._torch
-        mine, allb, host = self._buffers(q.shape[0], entries, slot)
+        own, allb, host = self._buffers(q.shape[0], entries, slot)
+        mine = own if mine is None else mine
         if self._dist.is_initialized() and self._dist.get_backend(self.group) == "gloo":
             # test setups (several ranks on one GPU): exchange through host memory
             mine_h = mine.cpu()
@@ -110,11 +111,10 @@ class ShardedSearcher:
 
     def search_many(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None,
                     group: int = 8):
-        """A stream of independent queries in groups: while the main thread all-gathers and merges
-        group g (collectives stay on one thread, in one order on every rank), a helper thread already
-        runs group g+1's shard scans (ctypes releases the GIL).  Same results as search()."""
-        from concurrent.futures import ThreadPoolExecutor
-
+        """A stream of independent queries, exchanged in groups: this rank's scans of ALL the queries run as one
+        pipeline on a library thread (tsh_search_shard_begin: the GPU sees no group boundaries), and the calling
+        thread all-gathers and merges every group as soon as its blocks are final (collectives stay on one thread,
+        in one order on every rank).  Same results as search()."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
@@ -122,34 +122,39 @@ class ShardedSearcher:
         ids = np.full((nq, kk), -1, dtype=np.int64)
         dist = np.full((nq, kk), np.nan, dtype=np.float64)
         cnt = np.zeros(nq, dtype=np.int32)
-        entries = _ffi.lib().tsh_default_block_entries(int(k))
+        L = _ffi.lib()
+        entries = L.tsh_default_block_entries(int(k))
         row_mask, mp = self.index.mask_arg(row_mask)  # GLOBAL mask: one bit per row id below this shard's end
+        group = max(1, int(group))
         spans = [(s, min(nq, s + group)) for s in range(0, nq, group)]
         if not spans:
             return ids, dist, cnt
-        dev = self._torch.cuda.current_device()
-
-        def scan(span, slot):
-            self._torch.cuda.set_device(dev)  # the helper thread starts on device 0 otherwise
-            self._scan(q[span[0]:span[1]], k, mp, entries, slot)
-
-        with ThreadPoolExecutor(max_workers=1) as ex:
-            fut = ex.submit(scan, spans[0], 0)
+        bb = L.tsh_candidate_block_bytes(entries)
+        key = ("many", entries)
+        cur = self._bufs.get(key)
+        if cur is None or cur[0] < nq:
+            cur = (max(nq, 64), self._torch.empty(max(nq, 64) * bb, dtype=self._torch.uint8, device="cuda"))
+            self._bufs[key] = cur
+            self._torch.cuda.current_stream().synchronize()
+        mine_all = cur[1]
+        st = ctypes.c_void_p()
+        _ffi.check(L.tsh_search_shard_begin(self.index._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), mp, entries,
+                                            ctypes.c_void_p(mine_all.data_ptr()), group, ctypes.byref(st)))
+        try:
             for g, (lo, hi) in enumerate(spans):
-                fut.result()
-                if g + 1 < len(spans):
-                    fut = ex.submit(scan, spans[g + 1], (g + 1) % 2)
+                _ffi.check(L.tsh_search_shard_progress(st, hi, None))  # this group's blocks are final
                 try:
-                    i, d, c = self._exchange_merge(q[lo:hi], k, distance_threshold, entries, g % 2)
+                    i, d, c = self._exchange_merge(q[lo:hi], k, distance_threshold, entries, g % 2,
+                                                   mine_all[lo * bb: hi * bb])
                 except _ffi.TshError as e:
                     if e.code != _ffi.TSH_E_OVERFLOW:
                         raise
-                    if g + 1 < len(spans):
-                        fut.result()  # keep the helper idle while this group is redone
+                    _ffi.check(L.tsh_search_shard_progress(st, nq, None))  # nothing overlaps a retry
                     i, d, c = self.search(q[lo:hi], k, distance_threshold, row_mask)  # ties: bigger blocks
-                    if g + 1 < len(spans):
-                        fut = ex.submit(scan, spans[g + 1], (g + 1) % 2)
                 ids[lo:hi], dist[lo:hi], cnt[lo:hi] = i, d, c
+        finally:
+            rc = L.tsh_search_shard_end(st)
+        _ffi.check(rc)
         return ids, dist, cnt
 
     def search(self, queries, k: int, distance_threshold: Optional[float] = None, row_mask=None):
