@@ -332,7 +332,9 @@ class Env:
         from tostore_amd.sharded import CommSearcher, ShardedSearcher
 
         want = self.a.exchange
-        fake = bool(os.environ.get("TSH_RCCL_LIB"))  # tests/fake_rccl: the RCCL branch with ranks sharing a GPU
+        fake = bool(self.a.fake_rccl and os.environ.get("TSH_RCCL_LIB"))  # tests/fake_rccl: the RCCL branch with ranks sharing a GPU
+        if fake:  # (the library obeys the variable only in a process that asked for its test hooks)
+            self._ffi.enable_test_hooks()
         if want == "torch":
             self.exchange = "torch.distributed all_gather_into_tensor (%s) + tsh_merge_candidates" % self.a.backend
             return ShardedSearcher(idx)
@@ -708,8 +710,8 @@ def make_env(a):
     return getattr(importlib.import_module(mod), cls)(a)
 
 
-TIMELINE_MAIN = ("reserve_us", "wait_scan_us", "exchange_wait_us", "merge_us", "result_gather_us", "copy_out_us",
-                 "retry_scan_us")  # the calling thread's phases of tsh_search_sharded: they add up to call_us
+TIMELINE_MAIN = ("reserve_us", "pre_enqueue_us", "wait_scan_us", "exchange_wait_us", "merge_us", "result_gather_us",
+                 "copy_out_us", "retry_scan_us")  # the calling thread's phases of tsh_search_sharded: they add up to call_us
 
 
 def exchange_timeline(per_rank, steps_total, ms_per_step):
@@ -735,7 +737,7 @@ def exchange_timeline(per_rank, steps_total, ms_per_step):
         ranks.append(ent)
     have = [e for e in ranks if e.get("calls") is not None]
     out = {"unit": "ms per step (sums over the timed regions / timed steps), per rank",
-           "phases": "calling thread: reserve | wait_scan | exchange_wait (= block all-gather + this rank's slice to the "
+           "phases": "calling thread: reserve | pre_enqueue (the exchange's launch, ahead of its blocks) | wait_scan | exchange_wait (= block all-gather + this rank's slice to the "
                      "host) | merge | result_gather | copy_out (+ retry_scan); scan runs beside them on a helper "
                      "thread; gather + slice_d2h are the device-side split of exchange_wait",
            "ms_per_step": ms_per_step, "ranks": ranks}
@@ -1180,7 +1182,7 @@ def run_bench(a, env=None):
                          "kernel_us_back_to_back_alone": scan_alone_us,
                          "algorithmic_bytes_per_launch": shard_bytes},
         }
-        if (hi - lo + 63) // 64 < 6144 and a.inflight > 1 and os.environ.get("TSH_SCAN_STREAMS") != "1":
+        if (hi - lo + 63) // 64 < 6144 and a.inflight > 1:
             # shards below 6144 tiles alternate their scans between two streams: two scans
             # run side by side, so one launch's own duration is about twice its share of the HBM time
             out["roofline"]["scans_side_by_side"] = 2

@@ -394,9 +394,9 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *querie
 
 /* Where the time of this rank's tsh_search_sharded calls went: sums over the calls since the communicator was made
  * (or since the last reset).  On the calling thread a call is, group after group,
- *   reserve | wait_scan | exchange_wait (= all-gather of the blocks + this rank's slice to the host) | merge |
- *   result_gather | copy_out        (+ retry_scan for groups redone with larger blocks)
- * so these seven add up to call_us but for loop overhead; scan_us runs beside them on the helper thread (group g + 1
+ *   reserve | pre_enqueue | wait_scan | exchange_wait (= all-gather of the blocks + this rank's slice to the host) |
+ *   merge | result_gather | copy_out        (+ retry_scan for groups redone with larger blocks)
+ * so these eight add up to call_us but for loop overhead; scan_us runs beside them on the helper thread (group g + 1
  * is scanned while group g is exchanged), and gather_us + slice_d2h_us are the device-side split of exchange_wait_us.
  * A rank that waits for slower peers shows it in gather_us (the all-gather cannot finish before the last rank
  * joins); a rank whose own scans are the bottleneck shows it in wait_scan_us.  No reference counterpart. */
@@ -414,12 +414,15 @@ typedef struct tsh_comm_timeline {
   double wait_scan_us;     /* calling thread blocked until this rank's scans of the group were done */
   double scan_us;          /* helper thread: tsh_search_shard of the groups (overlaps the previous group's exchange) */
   double exchange_wait_us; /* from issuing the block all-gather until this rank's slice is on the host */
-  double gather_us;        /* of that: the all-gather (RCCL: device time on the communicator's stream) */
-  double slice_d2h_us;     /* of that: the slice's copy to the host */
+  double gather_us;        /* the all-gather (RCCL: device time on the communicator's stream; every fourth exchange is
+                              timed and counted four times) */
+  double slice_d2h_us;     /* the slice's copy to the host (sampled likewise) */
   double merge_us;         /* host merge of the slice (threshold, order, cut) */
   double result_gather_us; /* every slice's results to every rank: H2D + all-gather + D2H */
   double copy_out_us;      /* into the caller's arrays */
   double retry_scan_us;    /* re-scans of overflowing groups, on the calling thread */
+  double pre_enqueue_us;   /* RCCL transport: launching a group's all-gather + copy AHEAD of its blocks, behind a gate
+                              the host opens when they are final (the launch's host cost hides behind the scans) */
 } tsh_comm_timeline;
 int32_t tsh_comm_get_timeline(tsh_comm *comm, tsh_comm_timeline *out, int32_t reset);
 
@@ -471,6 +474,25 @@ int32_t tsh_probe_batch_keys(tsh_index *idx, const float *queries, int32_t nq, i
  *      with the largest row.
  * The copy is built by the first batched search and kept current across appends. */
 #define TSH_OPT_BATCH_KERNEL 2
+/* TSH_OPT_EXCHANGE_AHEAD (process-wide; idx is ignored and may be NULL; default 0): 1 = tsh_search_sharded over RCCL
+ * launches a group's all-gather as soon as the group's scans are ENQUEUED, ordered on the communicator's stream behind
+ * the events of the group's last block writers, instead of when the host has seen the blocks final -- the collective's
+ * launch (tens of microseconds of host time) then hides behind the scans.  Blocks carry a generation
+ * (their header's pad[1]) so that a block of an earlier call is never taken for an answer, and a block the host is
+ * still going to redo (ties) asks for a retry like a truncated one.  Measured on one MI355X with 125 k x 768 shards it
+ * LOSES 3-6 % (the early packets on the communicator's queue run late), hence off by default;
+ * kept for hosts whose collectives are costlier to launch.  Same value on every rank. */
+#define TSH_OPT_EXCHANGE_AHEAD 3
+/* TSH_OPT_TEST_HOOKS (process-wide; idx is ignored and may be NULL): value TSH_TEST_HOOKS_MAGIC switches the
+ * library's TEST hooks on, 0 off.  Only then does it read the environment variables that change what it loads or make
+ * it fail on purpose -- TSH_RCCL_LIB (a stand-in for librccl: tests/fake_rccl), TSH_TEST_FAIL_ALLOC_OVER (device
+ * allocations fail), TSH_SHARDS_SHARE_DEVICES (several shards of one handle on one GPU).  Without the call those
+ * variables change nothing: an embedded database must not be steerable through its environment.  Experiment
+ * switches (kernel shapes, stream layouts) exist in probe builds only (-DTSH_PROBES).  A release build reads
+ * LOCAL_WORLD_SIZE, TSH_BLOCKING_WAIT, TSH_HOST_THREADS (how the host side waits: DESIGN.md appendix B) and
+ * TSH_TRACE_BATCH (stderr diagnostics), nothing else. */
+#define TSH_OPT_TEST_HOOKS 1000
+#define TSH_TEST_HOOKS_MAGIC 0x7465737468ll /* "testh" */
 int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value);
 
 #ifdef __cplusplus

@@ -8,7 +8,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle  # noqa: E402
-from tostore_amd import HipVectorIndex  # noqa: E402
+from tostore_amd import HipVectorIndex, _ffi  # noqa: E402
+
+_ffi.enable_test_hooks()  # TSH_TEST_FAIL_ALLOC_OVER is obeyed only in a process that asked for the test hooks
 
 expect = sys.argv[1]
 rng = np.random.default_rng(5)

@@ -81,7 +81,7 @@ class FakeSearcher:
         self.groups = []
         self.tl = dict.fromkeys(("calls", "queries", "groups", "retries", "call_us", "reserve_us", "wait_scan_us", "scan_us",
                                  "exchange_wait_us", "gather_us", "slice_d2h_us", "merge_us", "result_gather_us",
-                                 "copy_out_us", "retry_scan_us"), 0)
+                                 "copy_out_us", "retry_scan_us", "pre_enqueue_us"), 0)
 
     def _book(self, nq, dt):
         t = self.tl

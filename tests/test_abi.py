@@ -286,17 +286,66 @@ def test_open_ngh_reads_meta_before_it_needs_a_device(tmp_path):
         L.tsh_index_destroy(out)
 
 
-def test_rccl_override_that_does_not_load_is_an_error():
-    """TSH_RCCL_LIB names the library tsh_comm_* loads instead of librccl (tests/fake_rccl is the one user): a path that
-    does not load is TSH_E_RCCL with the reason -- never a silent fall-back to the system's librccl.  (Read once per
-    process: a process of its own.)"""
+def _comm_id_in_a_process(env_extra, hooks):
     import subprocess
     import sys
 
-    code = ("import ctypes, sys; sys.path.insert(0, %r); from tostore_amd import _ffi; L = _ffi.lib(); "
-            "b = ctypes.create_string_buffer(128); rc = L.tsh_comm_unique_id(b); print(rc, _ffi.last_error())" % ROOT)
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TSH_RCCL_LIB="/nonexistent/librccl_stand_in.so"),
-                       capture_output=True, text=True, timeout=120)
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from tostore_amd import _ffi; L = _ffi.lib(); %s"
+            "b = ctypes.create_string_buffer(128); rc = L.tsh_comm_unique_id(b); print(rc, _ffi.last_error() if rc else '')"
+            % (ROOT, "_ffi.enable_test_hooks(); " if hooks else ""))
+    env = {k: v for k, v in os.environ.items() if k != "TSH_RCCL_LIB"}
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     rc, _, msg = p.stdout.strip().partition(" ")
-    assert int(rc) == -10 and "TSH_RCCL_LIB" in msg and "does not load" in msg, p.stdout
+    return int(rc), msg
+
+
+def test_environment_alone_cannot_steer_the_library():
+    """An embedded database must not dlopen what its environment names, or fail allocations because a variable says
+    so: TSH_RCCL_LIB / TSH_TEST_FAIL_ALLOC_OVER / TSH_SHARDS_SHARE_DEVICES are read only in a process that switched
+    the test hooks on itself (tsh_index_set_option(NULL, TSH_OPT_TEST_HOOKS, magic)).  (The RCCL library is chosen
+    once per process: processes of their own.)"""
+    bad = {"TSH_RCCL_LIB": "/nonexistent/librccl_stand_in.so", "TSH_TEST_FAIL_ALLOC_OVER": "1",
+           "TSH_SHARDS_SHARE_DEVICES": "1"}
+    plain = _comm_id_in_a_process({}, hooks=False)
+    assert _comm_id_in_a_process(bad, hooks=False) == plain, "the variables alone changed the library's behaviour"
+    assert "TSH_RCCL_LIB" not in plain[1]
+    from tostore_amd import _ffi
+
+    L = _ffi.lib()
+    assert L.tsh_index_set_option(None, _ffi.TSH_OPT_TEST_HOOKS, 12345) == _ffi.TSH_E_BAD_ARG  # wrong magic
+    assert L.tsh_index_set_option(None, _ffi.TSH_OPT_TEST_HOOKS, 0) == _ffi.TSH_OK
+
+
+def test_rccl_override_that_does_not_load_is_an_error():
+    """With the test hooks on, TSH_RCCL_LIB names the library tsh_comm_* loads instead of librccl (tests/fake_rccl is
+    the one user): a path that does not load is TSH_E_RCCL with the reason -- never a silent fall-back to the system's
+    librccl."""
+    rc, msg = _comm_id_in_a_process({"TSH_RCCL_LIB": "/nonexistent/librccl_stand_in.so"}, hooks=True)
+    assert rc == -10 and "TSH_RCCL_LIB" in msg and "does not load" in msg, (rc, msg)
+
+
+def test_release_library_reads_few_environment_variables():
+    """at most six getenv call sites in the release objects (probe switches are compiled out,
+    test hooks share one site behind the opt-in)."""
+    import re
+
+    csrc = os.path.join(ROOT, "tostore_amd", "csrc")
+    sites = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".h", ".hip")):
+            continue
+        in_probes = 0
+        for ln, line in enumerate(open(os.path.join(csrc, name)), 1):
+            t = line.strip()
+            if t.startswith("#ifdef TSH_PROBES"):
+                in_probes += 1
+            elif in_probes and t.startswith("#if"):
+                in_probes += 1
+            elif in_probes and t.startswith("#endif"):
+                in_probes -= 1
+            code = line.split("//")[0]
+            if not in_probes and re.search(r"(?<![_\w])getenv\(", code):
+                sites.append("%s:%d" % (name, ln))
+    assert len(sites) <= 6, sites

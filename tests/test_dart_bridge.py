@@ -159,7 +159,7 @@ def test_dart_timeline_struct_matches_the_header():
     body = re.search(r"final\s+class\s+TshCommTimeline\s+extends\s+Struct\s*\{(.*?)\n\}", text, flags=re.S).group(1)
     dart_fields = re.findall(r"@(\w+)\(\)\s*external\s+(\w+)\s+(\w+)\s*;", body)
     c_fields = c_struct("tsh_comm_timeline")
-    assert len(dart_fields) == len(c_fields) == 19
+    assert len(dart_fields) == len(c_fields) == 20
     snake = lambda s: re.sub(r"([A-Z])", lambda m: "_" + m.group(1).lower(), s)  # noqa: E731
     for (ann, dtype, dname), (ctype, cname) in zip(dart_fields, c_fields):
         assert ann == C2DART[ctype], f"{cname}: @{ann} vs {ctype}"

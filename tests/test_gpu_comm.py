@@ -9,8 +9,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=["exchange_when_final", "exchange_ahead"])
+def exchange_ahead(request, hip_lib):
+    """Both ways tsh_search_sharded launches a group's all-gather over real RCCL (TSH_OPT_EXCHANGE_AHEAD)."""
+    from tostore_amd import _ffi
+
+    _ffi.check(hip_lib.tsh_index_set_option(None, _ffi.TSH_OPT_EXCHANGE_AHEAD, request.param))
+    yield request.param
+    _ffi.check(hip_lib.tsh_index_set_option(None, _ffi.TSH_OPT_EXCHANGE_AHEAD, 0))
+
+
 @pytest.mark.parametrize("metric", [0, 1, 2])
-def test_world_of_one_equals_plain_search(hip_lib, oracle_mod, metric):
+def test_world_of_one_equals_plain_search(hip_lib, oracle_mod, metric, exchange_ahead):
     from tostore_amd import HipVectorIndex
     from tostore_amd.sharded import CommSearcher
 

@@ -49,6 +49,19 @@ def test_sharded_search_over_the_rccl_branch(hip_lib, world):
     assert out.count(" ok\n") == world * (3 * 11 + 2), out[-6000:]
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_exchange_ahead_over_the_rccl_branch(hip_lib, world):
+    """TSH_OPT_EXCHANGE_AHEAD = 1: every group's all-gather is launched when its scans are enqueued, stream-ordered
+    behind their block writers; blocks carry their generation, blocks the host still has to redo (the overflow case of
+    the worker) ask for a retry.  Same answers, same verdicts."""
+    rcs, outs = run_ranks(world, [os.path.join(ROOT, "tests", "_rccl_worker.py"), "40003", "@TMP@/uid"],
+                          {"WORKER_EXCHANGE_AHEAD": "1"})
+    out = "\n".join(outs)
+    assert all(rc == 0 for rc in rcs), out[-6000:]
+    assert "MISMATCH" not in out, out[-6000:]
+    assert out.count(" ok\n") == world * (3 * 11 + 2), out[-6000:]
+
+
 def test_small_slots_chunk_the_stand_in(hip_lib):
     """The stand-in itself: transfers larger than its shared-memory slot go in pieces."""
     rcs, outs = run_ranks(2, [os.path.join(ROOT, "tests", "_rccl_worker.py"), "20011", "@TMP@/uid"],

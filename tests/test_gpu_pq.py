@@ -33,9 +33,10 @@ def test_pq_codes_bit_exact(hip_lib, oracle_mod, dim, subspaces):
 
 
 def test_pq_fewer_centroids_and_shards(hip_lib, oracle_mod, monkeypatch):
-    from tostore_amd import HipVectorIndex
+    from tostore_amd import HipVectorIndex, _ffi
 
     monkeypatch.setenv("TSH_SHARDS_SHARE_DEVICES", "1")
+    _ffi.enable_test_hooks()  # (the variable is obeyed only in a process that asked for the test hooks)
     rng = np.random.default_rng(3)
     dim, M, K = 48, 6, 100
     rows = rng.standard_normal((5000, dim)).astype(np.float32)

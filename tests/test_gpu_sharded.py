@@ -88,9 +88,12 @@ def test_truncated_block_asks_every_rank_to_retry(hip_lib, oracle_mod):
 def test_in_process_multi_shard_handle(hip_lib, oracle_mod, metric, monkeypatch):
     """tsh_index_create(n_devices=3): the one-process deployment shape (a Dart server with several
     GPUs).  TSH_SHARDS_SHARE_DEVICES=1 lets the three shards share this box's single GPU."""
-    from tostore_amd import HipVectorIndex
+    from tostore_amd import HipVectorIndex, _ffi
 
     monkeypatch.setenv("TSH_SHARDS_SHARE_DEVICES", "1")
+    with pytest.raises(_ffi.TshError):  # the variable alone changes nothing: three shards need three GPUs ...
+        HipVectorIndex(40, metric, capacity_rows=100, n_devices=3)
+    _ffi.enable_test_hooks()  # ... until the process itself asks for the test hooks
     rng = np.random.default_rng(9)
     n, d, k = 10_000, 40, 25
     rows = rng.standard_normal((n, d)).astype(np.float32)
@@ -120,3 +123,4 @@ def test_in_process_multi_shard_handle(hip_lib, oracle_mod, metric, monkeypatch)
         assert np.array_equal(ids, eids) and np.array_equal(dist, edist)
         c = idx.counters()
         assert c["rows"] == n and c["deleted_rows"] == 700
+    _ffi.enable_test_hooks(False)

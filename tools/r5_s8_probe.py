@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--nq", type=int, default=20)
     ap.add_argument("--calls", type=int, default=40)
     ap.add_argument("--group", type=int, default=0)
+    ap.add_argument("--ahead", type=int, default=1)
     a = ap.parse_args()
     import torch
 
@@ -36,6 +37,8 @@ def main():
     torch.cuda.synchronize()
     idx.append_device(0, a.rows, x.data_ptr())
     idx.set_batch_min_nq(0)
+    from tostore_amd import _ffi
+    _ffi.check(_ffi.lib().tsh_index_set_option(None, _ffi.TSH_OPT_EXCHANGE_AHEAD, a.ahead))
     cs = CommSearcher(idx, 1, 0, CommSearcher.unique_id(), 0)
     rng = np.random.default_rng(2)
     qs = rng.standard_normal((a.nq * 8, a.dim)).astype(np.float32)

@@ -67,7 +67,7 @@ class TshCommTimeline(ctypes.Structure):
         ("world", c_i32), ("rank", c_i32), ("transport", c_i32), ("reserved", c_i32),
         ("call_us", c_f64), ("reserve_us", c_f64), ("wait_scan_us", c_f64), ("scan_us", c_f64),
         ("exchange_wait_us", c_f64), ("gather_us", c_f64), ("slice_d2h_us", c_f64), ("merge_us", c_f64),
-        ("result_gather_us", c_f64), ("copy_out_us", c_f64), ("retry_scan_us", c_f64),
+        ("result_gather_us", c_f64), ("copy_out_us", c_f64), ("retry_scan_us", c_f64), ("pre_enqueue_us", c_f64),
     ]
 
 
@@ -150,6 +150,17 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError("libtostore_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+TSH_OPT_EXCHANGE_AHEAD = 3
+TSH_OPT_TEST_HOOKS = 1000
+TSH_TEST_HOOKS_MAGIC = 0x7465737468
+
+
+def enable_test_hooks(on: bool = True) -> None:
+    """Tests and rehearsals only: the library obeys TSH_RCCL_LIB / TSH_TEST_FAIL_ALLOC_OVER /
+    TSH_SHARDS_SHARE_DEVICES only in a process that asked for it (include/tostore_hip.h, TSH_OPT_TEST_HOOKS)."""
+    check(lib().tsh_index_set_option(None, TSH_OPT_TEST_HOOKS, TSH_TEST_HOOKS_MAGIC if on else 0))
 
 
 def last_error() -> str:

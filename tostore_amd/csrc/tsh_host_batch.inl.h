@@ -76,11 +76,12 @@ void batch_free(BatchCtx *b) {
     if (e) hipEventDestroy(e);
 }
 
-// TSH_TEST_FAIL_ALLOC_OVER=bytes (tests): device allocations of the batched path at or above this size fail as if the
+// TSH_TEST_FAIL_ALLOC_OVER=bytes (tests; obeyed only after TSH_OPT_TEST_HOOKS, see test_env): device allocations of the batched path at or above this size fail as if the
 // device were full -- the degrade ladder of shard_search_any (planes -> f32 MFMA -> single-query scans) can then be
 // walked deterministically, beside the test that really fills the device
 inline bool alloc_fault(int64_t bytes) {
-  static const int64_t over = getenv("TSH_TEST_FAIL_ALLOC_OVER") ? atoll(getenv("TSH_TEST_FAIL_ALLOC_OVER")) : 0;
+  const char *e = test_env("TSH_TEST_FAIL_ALLOC_OVER");  // (not cached: the hooks may be switched on after the first call)
+  const int64_t over = e ? atoll(e) : 0;
   return over > 0 && bytes >= over;
 }
 
@@ -157,7 +158,7 @@ int regrow_pinned(T **host, T **dev_view, int64_t *cap, int64_t want, int64_t *b
 // and the query is redone, so a corpus that is NOT exchangeable (rows clustered by insertion time) costs time, never
 // correctness -- and a call that sees more than a few failures switches the estimate off for the next calls.
 int32_t batch_k_est(BatchCtx *b, int32_t k, int64_t rows, int64_t n_sample) {
-  static const bool off = getenv("TSH_BATCH_PROVEN_TAU") != nullptr && getenv("TSH_BATCH_PROVEN_TAU")[0] == '1';
+  static const bool off = probe_env("TSH_BATCH_PROVEN_TAU") != nullptr && probe_env("TSH_BATCH_PROVEN_TAU")[0] == '1';
   if (off || n_sample >= rows || n_sample <= 0 || k <= 8 || b->est_backoff > 0) return k;
   const double pr = (double)n_sample / (double)rows;
   if (pr > 0.5) return k;  // (most of the rows are in the sample: its k-th key is as good as proven)
@@ -177,7 +178,7 @@ int32_t batch_k_est(BatchCtx *b, int32_t k, int64_t rows, int64_t n_sample) {
 
 int64_t batch_sample_rows(int64_t rows, int32_t k) {
   if (rows <= 16384) return rows;
-  static const int64_t div = getenv("TSH_SAMPLE_DIV") ? std::max(4, atoi(getenv("TSH_SAMPLE_DIV"))) : 32;  // experiments
+  static const int64_t div = probe_env("TSH_SAMPLE_DIV") ? std::max(4, atoi(probe_env("TSH_SAMPLE_DIV"))) : 32;  // experiments
   int64_t n = std::max<int64_t>(rows / div, (int64_t)k * rows / (3000 * div / 32));
   n = std::max<int64_t>(round_up(n, 256), 8192);  // whole row tiles of either tile shape
   n = std::max<int64_t>(n, round_up((int64_t)k * 4, 256));
@@ -292,7 +293,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // Workgroup tile (queries x rows).  f32 MFMA: 128 x 128.  bf16x3: 256 x 256 for batches of more than 128 queries,
   // 128 x 128 otherwise.  f16: 256 x 256 resp. 128 x 256.  Which key kernel runs is decided below (it needs the
   // scale of the rows); the padding of the batch only depends on the query side of the tile.
-  static const int forced_tile = getenv("TSH_BATCH_TILE") ? atoi(getenv("TSH_BATCH_TILE")) : 0;  // experiments
+  static const int forced_tile = probe_env("TSH_BATCH_TILE") ? atoi(probe_env("TSH_BATCH_TILE")) : 0;  // experiments
   const int want_kernel = force_kernel >= 0 ? force_kernel : s->batch_kernel;
   const int32_t tile = (forced_tile == 128 || forced_tile == 256) && want_kernel != 0
                            ? forced_tile
@@ -586,7 +587,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.hchunks = hchunks;
       a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
 #ifdef TSH_PROBES
-      static const int f16_dbg = getenv("TSH_F16_DBG") ? atoi(getenv("TSH_F16_DBG")) : 0;  // probes: results are wrong
+      static const int f16_dbg = probe_env("TSH_F16_DBG") ? atoi(probe_env("TSH_F16_DBG")) : 0;  // probes: results are wrong
       a.dbg = f16_dbg;
       static uint64_t *d_dbg = nullptr;
       if ((f16_dbg & 32) && !d_dbg) HIPCHK(hipMalloc(&d_dbg, (4 * 96 * 12 + 16) * sizeof(uint64_t)));
@@ -715,7 +716,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       rf.out_count = b->fin_cnt_dev;
       rf.out_info = b->fin_info_dev;
       rf.k = k;
-      static const bool old_shape = getenv("TSH_RF_SHAPE") != nullptr && getenv("TSH_RF_SHAPE")[0] == '2';  // A/B: two waves, 64-float pieces
+      static const bool old_shape = probe_env("TSH_RF_SHAPE") != nullptr && probe_env("TSH_RF_SHAPE")[0] == '2';  // A/B: two waves, 64-float pieces
       if (old_shape) rerank_final_kernel<RwBig><<<(unsigned)nq, 64 * RwBig::WAVES, 0, st>>>(rf);
       else rerank_final_kernel<RwFin><<<(unsigned)nq, 64 * RwFin::WAVES, 0, st>>>(rf);
       HIPCHK(hipEventRecord(b->e_done, st));
@@ -841,7 +842,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpy(hb.data(), g_f16_dbg_buf, hb.size() * 8, hipMemcpyDeviceToHost));
     fprintf(stderr, "[pp cnt] wave tiles %llu, crowded %llu, more than two per lane %llu, hit blocks %llu\n", (unsigned long long)hb[4 * 96 * 12],
             (unsigned long long)hb[4 * 96 * 12 + 1], (unsigned long long)hb[4 * 96 * 12 + 2], (unsigned long long)hb[4 * 96 * 12 + 3]);
-    static const bool raw = getenv("TSH_F16_GEN") == nullptr || getenv("TSH_F16_GEN")[0] != '2';
+    static const bool raw = probe_env("TSH_F16_GEN") == nullptr || probe_env("TSH_F16_GEN")[0] != '2';
     if (raw) {  // ping-pong kernel: raw stamps relative to the wave's first, one line per chunk (points 0-9)
       const int wv[4] = {0, 4, 1, 5};
       for (int w = 0; w < 4; ++w) {

@@ -49,8 +49,10 @@ RcclApi *rccl() {
     void *h = nullptr;
     // TSH_RCCL_LIB: another library with the same five entry points.  tests/fake_rccl (several ranks on ONE GPU,
     // which the real library refuses) is the one user; a path that does not load is an error, not a reason to
-    // fall back to the system's librccl behind the host's back
-    if (const char *over = getenv("TSH_RCCL_LIB"); over && *over) {
+    // fall back to the system's librccl behind the host's back.  Obeyed only in a process that switched the test
+    // hooks on BEFORE its first tsh_comm_* call (TSH_OPT_TEST_HOOKS): a database's environment must not be able to
+    // make it dlopen a path
+    if (const char *over = test_env("TSH_RCCL_LIB"); over && *over) {
       h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
       if (!h) {
         const char *why = dlerror();
@@ -170,6 +172,9 @@ struct tsh_comm {
   size_t res_cap = 0;  // bytes of one rank's result slice
   int64_t *d_agree = nullptr, *h_agree = nullptr;  // (1 + world) x {status, rows of the rank's shard} (allocated with the communicator)
   int64_t rows_hint = 0;  // largest shard of any rank as of the last agreement: the same number on every rank
+  uint32_t tag_seq = 0;  // generation of this rank's blocks: one per window of a call (the same on every rank)
+  uint64_t exchanges = 0;  // block all-gathers enqueued so far
+  bool timed_now = false;  // the one in flight carries ev_t[0] / ev_t[1]
   int32_t group = 0;  // queries per exchange; 0 = by the size of the call
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};  // RCCL: before / after the block all-gather, after the slice's D2H
   tsh_comm_timeline tl = {};  // guarded by mu
@@ -335,11 +340,50 @@ struct GroupOut {
   int32_t need = 0;  // > 0: every rank retries the group with this many entries
 };
 
+// RCCL transport: the device side of a group's exchange on the communicator's stream -- [wait for the events behind
+// the group's last block writers |] all-gather of every rank's blocks | this rank's query slice of them to the host |
+// event.  With events the calls are made AHEAD, while the group's scans still run: launching a collective costs the
+// host tens of microseconds (RCCL's enqueue path), which for the LAST group of a call sat between the last block
+// becoming final and the all-gather starting; stream-ordered, the all-gather starts a few microseconds after the
+// last re-rank whatever the host is doing.  What the device cannot know is whether the HOST will accept a block as
+// final (ties that overflow a candidate list are redone by a wider pass the host starts): such a block carries
+// FLAG_LIST_OVERFLOW when it is gathered, which every rank that reads it answers like a truncated block -- the group is
+// redone with larger blocks.  And a rank whose scans fail half-way leaves blocks of an EARLIER call in place: every
+// block carries the generation it was written for (BlockHeader.pad[1]), and a block of another generation is a failed
+// peer, not an answer.
+int comm_exchange_enqueue(tsh_comm *c, const uint8_t *d_blocks, int32_t gq, int32_t entries, const hipEvent_t *after,
+                          int n_after) {
+  const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world, mine = bb * (size_t)gq;
+  const bool whole = merge_whole(W, (size_t)gq);
+  const int32_t slice_q = whole ? gq : (int32_t)(((size_t)gq + W - 1) / W);
+  const int32_t a = whole ? 0 : std::min<int32_t>(gq, c->rank * slice_q), b = std::min<int32_t>(gq, a + slice_q);
+  for (int i = 0; i < n_after; ++i) HIPCHK(hipStreamWaitEvent(c->stream, after[i], 0));
+  // (the split of the device time into all-gather and copy is sampled, every fourth exchange: each record is a packet
+  // the queue works through, a few microseconds that the last exchange of a call shows)
+  c->timed_now = (c->exchanges++ & 3) == 0;
+  if (c->timed_now) HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
+  int rc = comm_allgather_dev(c, d_blocks, c->d_all, mine);  // k' x 24 B per rank and query: latency-bound
+  if (rc) return rc;
+  if (c->timed_now) HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
+  // every query of the group (a world of one, or a small group merged whole) is one contiguous copy; the pitched
+  // form took ~30 us of device time for 60 KB
+  if (b - a == gq)
+    HIPCHK(hipMemcpyAsync(c->h_slice, c->d_all, W * mine, hipMemcpyDeviceToHost, c->stream));
+  else if (b > a)
+    HIPCHK(hipMemcpy2DAsync(c->h_slice, (size_t)(b - a) * bb, c->d_all + (size_t)a * bb, mine, (size_t)(b - a) * bb, W,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
+  return TSH_OK;
+}
+
 // Exchange + merge of one group whose blocks sit at d_blocks (device).  local_rc: what this rank's shard search said.
+// enqueued: comm_exchange_enqueue has run for this group already (stream-ordered behind the group's block writers);
+// then a rank whose scans failed cannot mark its blocks any more -- its peers see that from the blocks' generation
+// (tag: what BlockHeader.pad[1] of every block of this group must say; 0 = blocks of a synchronous shard search).
 // Collective; returns the same verdict class on every rank (own error / TSH_E_PEER / TSH_OK + need).
 int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int local_rc, const float *queries, int32_t gq,
                         int32_t k, double thr, int32_t entries, int64_t *out_ids, double *out_dist, int32_t *out_count,
-                        GroupOut *go) {
+                        GroupOut *go, bool enqueued = false, uint32_t tag = 0) {
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries), W = (size_t)c->world, mine = bb * (size_t)gq;
   const bool whole = merge_whole(W, (size_t)gq);  // (same on every rank: W and gq are)
   const int32_t slice_q = whole ? gq : (int32_t)(((size_t)gq + W - 1) / W);
@@ -347,7 +391,7 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int lo
   const size_t rec = res_rec_bytes(k), res = sizeof(ResHeader) + (size_t)slice_q * rec;
   int rc;
   tsh_comm_timeline &tl = c->tl;
-  if (local_rc != TSH_OK) {
+  if (local_rc != TSH_OK && !enqueued) {
     rc = comm_error_blocks(d_blocks, gq, entries, local_rc);
     if (rc) return rc;
   }
@@ -367,24 +411,19 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int lo
     slice_base = c->h_slice + (size_t)a * bb;
     slice_pitch = mine;
   } else {
-    HIPCHK(hipEventRecord(c->ev_t[0], c->stream));
-    rc = comm_allgather_dev(c, d_blocks, c->d_all, mine);  // k' x 24 B per rank and query: latency-bound
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(c->ev_t[1], c->stream));
-    // every query of the group (a world of one, or a small group merged whole) is one contiguous copy; the pitched
-    // form took ~30 us of device time for 60 KB
-    if (b - a == gq)
-      HIPCHK(hipMemcpyAsync(c->h_slice, c->d_all, W * mine, hipMemcpyDeviceToHost, c->stream));
-    else if (b > a)
-      HIPCHK(hipMemcpy2DAsync(c->h_slice, (size_t)(b - a) * bb, c->d_all + (size_t)a * bb, mine, (size_t)(b - a) * bb, W,
-                              hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(c->ev_t[2], c->stream));
+    if (!enqueued) {
+      rc = comm_exchange_enqueue(c, d_blocks, gq, entries, nullptr, 0);
+      if (rc) return rc;
+    }
     HIPCHK(hipEventSynchronize(c->ev_t[2]));
-    float ms_g = 0.f, ms_d = 0.f;  // device time on the communicator's stream; the all-gather's includes the wait
-    HIPCHK(hipEventElapsedTime(&ms_g, c->ev_t[0], c->ev_t[1]));  // for the slowest rank to arrive
-    HIPCHK(hipEventElapsedTime(&ms_d, c->ev_t[1], c->ev_t[2]));
-    tl.gather_us += 1e3 * ms_g;
-    tl.slice_d2h_us += 1e3 * ms_d;
+    if (c->timed_now) {
+      float ms_g = 0.f, ms_d = 0.f;  // device time on the communicator's stream; the all-gather's includes the wait
+      HIPCHK(hipEventElapsedTime(&ms_g, c->ev_t[0], c->ev_t[1]));  // for the slowest rank to arrive
+      HIPCHK(hipEventElapsedTime(&ms_d, c->ev_t[1], c->ev_t[2]));
+      tl.gather_us += 4e3 * ms_g;  // (one exchange in four is timed: scaled to all)
+      tl.slice_d2h_us += 4e3 * ms_d;
+    }
+
     slice_base = c->h_slice;
     slice_pitch = (size_t)(b - a) * bb;
   }
@@ -406,11 +445,19 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int lo
           rh->pad[1] = (int32_t)h->pad[0];
           break;
         }
+        if (h->pad[1] != tag) {  // a block of another call: rank w's scans did not get this far
+          rh->status = TSH_E_PEER;
+          rh->pad[0] = (int32_t)w;
+          rh->pad[1] = TSH_E_HIP;
+          break;
+        }
         if (h->entries != (uint32_t)entries) {
           rh->status = TSH_E_FORMAT;
           break;
         }
         if (h->count > h->entries) need = std::max(need, h->count);
+        // (gathered stream-ordered, before its rank's host had a look: the wide pass is still to come)
+        else if (h->flags & FLAG_LIST_OVERFLOW) need = std::max(need, h->entries + 64u);
       }
     if (rh->status == TSH_OK && need) rh->need = (int32_t)round_up(need, 64);
     if (rh->status == TSH_OK && !need) {
@@ -685,9 +732,13 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
     tsh_shard_stream *ss = nullptr;
     int scan_rc = local_rc;
     std::string scan_err = local_err;
+    // the generation this window's blocks carry in BlockHeader.pad[1] (never 0; the same on every rank, whatever a
+    // rank's own state: the counter moves with the windows, and those are the same everywhere)
+    if (++c->tag_seq == 0) ++c->tag_seq;
+    const uint32_t ss_tag = c->tag_seq;
     if (scan_rc == TSH_OK) {
       scan_rc = shard_stream_begin(shard, queries + (size_t)w0 * dim, wn, k, row_mask, entries, c->d_mine, sizes[gi],
-                                   /*copy_inputs=*/false, &ss);
+                                   /*copy_inputs=*/false, &ss, ss_tag);
       if (scan_rc) scan_err = g_err;
     }
     auto end_stream = [&] {  // nothing of this call may still run when it returns
@@ -699,6 +750,28 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
     };
     for (int32_t q0 = 0; gi < ge; q0 += sizes[gi], ++gi) {
       const int32_t gq = sizes[gi], qa = w0 + q0;  // qa: the group's first query in the call
+      // the device side of the group's exchange goes out as soon as the group's scans are ENQUEUED, stream-ordered
+      // behind their block writers (comm_exchange_enqueue): the collective's launch costs the host tens of
+      // microseconds, which would otherwise follow the last block
+      bool enqueued = false;
+      if (ss && scan_rc == TSH_OK && c->comm && !c->host_fn && exchange_ahead_flag().load(std::memory_order_acquire)) {
+        const double t_e = now_us();
+        hipEvent_t after[MAX_CTX];
+        const int n_after = shard_stream_enqueued(ss, q0 + gq, after, MAX_CTX);
+        if (n_after > 0) {
+          tl.wait_scan_us += now_us() - t_e;
+          const double t_l = now_us();
+          rc = comm_exchange_enqueue(c, c->d_mine + (size_t)q0 * bb, gq, entries, after, n_after);
+          tl.pre_enqueue_us += now_us() - t_l;
+          if (rc) {
+            std::string keep = g_err;
+            end_stream();
+            g_err = keep;
+            return rc;
+          }
+          enqueued = true;
+        }
+      }
       if (ss && scan_rc == TSH_OK) {
         const double t_w = now_us();
         int32_t done = 0;
@@ -709,7 +782,8 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
       if (scan_rc) g_err = scan_err;
       GroupOut go;
       rc = comm_exchange_group(c, shard, c->d_mine + (size_t)q0 * bb, scan_rc, queries + (size_t)qa * dim, gq, k, thr,
-                               entries, out_ids + (size_t)qa * k, out_dist + (size_t)qa * k, out_count + qa, &go);
+                               entries, out_ids + (size_t)qa * k, out_dist + (size_t)qa * k, out_count + qa, &go, enqueued,
+                               ss_tag);
       tl.groups++;
       for (int attempt = 0; rc == TSH_OK && go.need > 0; ++attempt) {
         // ties made a block overflow: every rank saw the same verdict and redoes this group with larger blocks, in a
@@ -726,8 +800,8 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
         tl.retries++;
         rc = comm_reserve_agreed(c, Gmax, ent, k, 0, true, my_rows, &grew);
         if (rc) break;
-        int again_rc = local_rc;
-        std::string again_err = local_err;
+        int again_rc = local_rc != TSH_OK ? local_rc : scan_rc;  // (a rank whose pipeline failed stays failed)
+        std::string again_err = local_rc != TSH_OK ? local_err : scan_err;
         if (again_rc == TSH_OK) {
           const double t0 = now_us();
           again_rc = tsh_search_shard(shard, queries + (size_t)qa * dim, gq, k, row_mask, ent, c->d_retry, nullptr);

@@ -90,6 +90,34 @@ inline unsigned cpu_quota_cpus() {
   }
   return quota;
 }
+// ---- what the environment may and may not steer -------------------------------------------------------------
+// The library lives inside a database process: its environment is not ours to obey.  Release builds read four
+// variables, all about how the HOST side waits or logs (LOCAL_WORLD_SIZE, TSH_BLOCKING_WAIT, TSH_HOST_THREADS,
+// TSH_TRACE_BATCH).  Everything else is one of two kinds:
+//   probe_env(name)  experiment switches (kernel shapes, stream layouts, sample sizes ...): exist in probe builds
+//                    only (-DTSH_PROBES, tools/build_variants.py); a release build answers "not set";
+//   test_env(name)   test hooks that change what the library loads or make it fail on purpose (TSH_RCCL_LIB,
+//                    TSH_TEST_FAIL_ALLOC_OVER, TSH_SHARDS_SHARE_DEVICES): read only after the PROCESS itself asked
+//                    for them, tsh_index_set_option(NULL, TSH_OPT_TEST_HOOKS, TSH_TEST_HOOKS_MAGIC) -- the variables
+//                    alone change nothing (tests/test_abi.py).
+inline const char *probe_env(const char *name) {
+#ifdef TSH_PROBES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+inline std::atomic<bool> &test_hooks_flag() {
+  static std::atomic<bool> on{false};
+  return on;
+}
+inline std::atomic<bool> &exchange_ahead_flag() {  // TSH_OPT_EXCHANGE_AHEAD (off: measured slower)
+  static std::atomic<bool> on{false};
+  return on;
+}
+inline const char *test_env(const char *name) { return test_hooks_flag().load(std::memory_order_acquire) ? getenv(name) : nullptr; }
+
 inline unsigned local_peers() {  // processes of this job on this node (one per GPU): torchrun / bench.py export it
   const char *p = getenv("LOCAL_WORLD_SIZE");
   return p && atoi(p) > 0 ? (unsigned)atoi(p) : 1u;
@@ -196,7 +224,7 @@ class HostPool {
     // over it, as fast as the GPU delivers chunks)
     int nt = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, hw >= 32 ? 31 : 15);
     if (const char *forced = getenv("TSH_HOST_THREADS")) nt = std::max(0, std::min(atoi(forced) - 1, 63));
-    if (const char *spin = getenv("TSH_HOST_SPIN_US")) spin_us_ = std::max(0.0, atof(spin));
+    if (const char *spin = probe_env("TSH_HOST_SPIN_US")) spin_us_ = std::max(0.0, atof(spin));
     for (int i = 0; i < nt; ++i) {
       workers_.emplace_back([this] { loop(); });
       workers_.back().detach();

@@ -518,7 +518,7 @@ struct BlockHeader {
   uint32_t metric;
   int64_t row_base;
   int64_t shard_rows;
-  uint32_t pad[4];
+  uint32_t pad[4];     // [0]: a failed rank's status (FLAG_RANK_ERROR); [1]: the block's generation (sharded calls)
 };
 static_assert(sizeof(BlockHeader) == 64, "header is 64 bytes");
 struct BlockEntry {
@@ -548,6 +548,7 @@ struct SelectArgs {
   int64_t row_base;
   int64_t shard_rows;
   const uint32_t *list;  // list scans: keys / gmin are in list order; candidate rows = list[position]
+  uint32_t tag;          // generation of the block (BlockHeader.pad[1]): 0, or what a sharded call's exchange expects
 };
 
 constexpr int SEL_THREADS = 1024;   // one whole CU; tile minima stay in registers
@@ -958,7 +959,8 @@ __device__ __forceinline__ void select_body(const SelectArgs &a) {
     hv.metric = (uint32_t)a.metric;
     hv.row_base = a.row_base;
     hv.shard_rows = a.shard_rows;
-    hv.pad[0] = hv.pad[1] = hv.pad[2] = hv.pad[3] = 0u;
+    hv.pad[0] = hv.pad[2] = hv.pad[3] = 0u;
+    hv.pad[1] = a.tag;
     *a.hdr = hv;
     if (a.hdr_host) *a.hdr_host = hv;
   }
@@ -967,6 +969,12 @@ __device__ __forceinline__ void select_body(const SelectArgs &a) {
 template <int NT, bool IN_REGS>
 __global__ void __launch_bounds__(NT) select_kernel(SelectArgs a) {
   select_body<NT, IN_REGS>(a);
+}
+
+// blocks written by the matrix-core path get their generation afterwards
+static __global__ void __launch_bounds__(64) stamp_tag_kernel(uint8_t *blocks, size_t block_bytes, int32_t n, uint32_t tag) {
+  const int32_t q = (int32_t)(blockIdx.x * 64 + threadIdx.x);
+  if (q < n) reinterpret_cast<BlockHeader *>(blocks + (size_t)q * block_bytes)->pad[1] = tag;
 }
 
 // K3a: one pass of a radix select over the WHOLE key array (fallback path, k beyond what the tile-minimum

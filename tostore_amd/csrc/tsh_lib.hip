@@ -311,6 +311,7 @@ struct DeviceStreams {
   };
   std::vector<ScanOut> scan_out;
   int scans_out[2] = {0, 0};
+  uint64_t enq_counter = 0;  // jobs enqueued on this device's streams so far (guarded by scan_mu)
   int rc = TSH_OK;
   std::string err;
   int users = 0;                                // shards alive on this device (device_streams / device_streams_release)
@@ -447,7 +448,7 @@ static void destroy_masked_streams_at_exit() {
 static hipError_t make_scan_streams(DeviceStreams *ds) {
   // CU mask bit i = CU slot i/8 of XCD i%8 on MI355X (measured, tools/cumask_probe.hip):
   // bits 0..15 = two CUs of every XCD, reserved for the tails.
-  const char *env = getenv("TSH_NO_CU_SPLIT");
+  const char *env = probe_env("TSH_NO_CU_SPLIT");
   const int cus = ds->cus;
   if (!(env && env[0] == '1') && cus >= 64 && cus % 32 == 0) {
     std::vector<uint32_t> scan_mask((size_t)cus / 32, 0xFFFFFFFFu), tail_mask((size_t)cus / 32, 0u);
@@ -887,6 +888,8 @@ struct Job {
   float eps_rel = 0.f, delta_abs = 0.f;  // this query's error band (for the fallback's own threshold)
   bool force_all = false;
   int32_t list_tiles = 0;  // > 0: a list scan -- the context's keys / gmin are in list order, that many tiles of them
+  hipStream_t last_stream = nullptr;  // where the job's last kernel was enqueued (ev_done rides on it)
+  uint64_t enq_seq = 0;               // ... and its place in the device's enqueue order (DeviceStreams::enq_counter)
   std::vector<uint32_t> quar_sel;  // entries of c->h_quar that belong to this query's candidates
 };
 
@@ -951,7 +954,7 @@ int ctx_reserve_list(Ctx *c, int64_t padded) {
 // pays below one kept row in list_div (tools/r4_list_probe.sh); TSH_LIST_DIV=0 switches it off.  -> ids filled (padded
 // with 0xFFFFFFFF to whole tiles) and true when the scan should use them.
 bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles, int64_t rows_kept, std::vector<uint32_t> *ids) {
-  static const int64_t list_div = getenv("TSH_LIST_DIV") ? atoll(getenv("TSH_LIST_DIV")) : 24;
+  static const int64_t list_div = probe_env("TSH_LIST_DIV") ? atoll(probe_env("TSH_LIST_DIV")) : 24;
   if (!mask_words || list_div <= 0 || rows_kept * list_div > s->rows || s->rows < 4096 || !scan_list_supported(s->nch, s->ld))
     return false;
   ids->clear();
@@ -965,7 +968,7 @@ bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles,
 
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
                 const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target, int64_t rows_est = 0,
-                const RowList *list = nullptr, bool more_coming = false, bool last_of_call = false) {
+                const RowList *list = nullptr, bool more_coming = false, bool last_of_call = false, uint32_t tag = 0) {
   Ctx *c = j->c;
   int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
   if (rc) return rc;
@@ -1024,6 +1027,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   se.cand_rows = c->d_cand;
   se.n_tiles = use_list ? j->list_tiles : n_tiles;
   se.list = use_list ? c->d_list : nullptr;
+  se.tag = tag;
   se.k = k;
   se.cand_cap = entries;
   se.eps_rel = band.eps_rel;
@@ -1059,10 +1063,10 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       // in as the previous one drains (+12 % queries/s at 125 k and 250 k rows).  The two scans
       // then run side by side, so each one's own duration roughly doubles; large shards keep one
       // stream, where a scan's duration is its HBM time.  TSH_SCAN_STREAMS=1 / 2 forces either.
-      static const int forced = getenv("TSH_SCAN_STREAMS") ? atoi(getenv("TSH_SCAN_STREAMS")) : 0;
+      static const int forced = probe_env("TSH_SCAN_STREAMS") ? atoi(probe_env("TSH_SCAN_STREAMS")) : 0;
       // (a selective row mask makes a big shard's scan just as short: count the rows it keeps)
       const int64_t tiles_read = rows_est > 0 ? std::min<int64_t>(n_tiles, (rows_est + 63) / 64) : n_tiles;
-      static const int min_tiles = getenv("TSH_TWO_STREAM_MIN_TILES") ? atoi(getenv("TSH_TWO_STREAM_MIN_TILES")) : 0;
+      static const int min_tiles = probe_env("TSH_TWO_STREAM_MIN_TILES") ? atoi(probe_env("TSH_TWO_STREAM_MIN_TILES")) : 0;
       const bool two = forced == 2 || (forced != 1 && tiles_read < SMALL_SHARD_TILES && tiles_read >= min_tiles);
       if (overlap && two && s->scan_stream2) {
         DeviceStreams *ds = s->dstreams;
@@ -1111,14 +1115,20 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     if (overlap && !last_of_call) {
       // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
       // scans -- selective masks, small shards -- were then limited by)
-      static const bool one_tail = getenv("TSH_ONE_TAIL") != nullptr && getenv("TSH_ONE_TAIL")[0] == '1';
-      ts = (!one_tail && s->tail_stream2 && (s->tail_seq++ & 1)) ? s->tail_stream2 : s->tail_stream;
+      static const bool one_tail = probe_env("TSH_ONE_TAIL") != nullptr && probe_env("TSH_ONE_TAIL")[0] == '1';
+      // (a small shard's two scan streams each have their tail queue: the scans of one stream end a scan's length
+      // apart, longer than a tail, so no tail queues behind another -- alternating blindly put two tails of
+      // near-simultaneous scan ends on one queue at the end of a call, 40 us in full view)
+      if (which >= 0 && !one_tail && s->tail_stream2) ts = which ? s->tail_stream2 : s->tail_stream;
+      else ts = (!one_tail && s->tail_stream2 && (s->tail_seq++ & 1)) ? s->tail_stream2 : s->tail_stream;
       HIPCHK(hipStreamWaitEvent(ts, ev.stop, 0));
     }
     // (short rows and lists, config C1: K2 + K4 as ONE dispatch, the selecting workgroup re-ranking its dozen
     // candidates a lane each, was tried -- 17 us against 9 + 4.4 for the two launches: the lone workgroup waits out
     // count -> candidate ids -> rows one after the other, which the second launch's ramp-up hides)
     launch_select(se, se.n_tiles, ts);
+    j->last_stream = ts;
+    j->enq_seq = ++s->dstreams->enq_counter;
     // the completion event rides on the re-rank's own dispatch packet unless more kernels follow (a separate
     // hipEventRecord is one more runtime call and one more barrier packet per query)
     bool done_recorded = false;
@@ -1329,6 +1339,11 @@ struct SearchOut {
   // d_blocks (its job finished on the host, fallback included), from whichever submitting thread ran it.  With it
   // set the submitting threads take the queries interleaved (q = t, t + T, ...), so blocks become final in order
   std::function<void(int32_t q)> on_done;
+  // ... and once query q's kernels are all ENQUEUED: `done` is the event behind the last writer of its block
+  // (`where`: the stream that event was recorded on -- kernels of one stream finish in order; `seq`: the job's place
+  // in the order the device's streams were fed, which with two submitting threads is not the queries' order)
+  std::function<void(int32_t q, hipEvent_t done, hipStream_t where, uint64_t seq)> on_enqueued;
+  uint32_t tag = 0;  // generation stamped into the blocks' headers (BlockHeader.pad[1])
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1365,12 +1380,13 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
       const int32_t q = q0 + submitted * stride;
       rc = job_enqueue(s, &j, queries + (size_t)q * s->dim, k, entries, mask_words, epoch,
                        out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr, rows_est, list, cnt > 1,
-                       cnt > 1 && submitted == cnt - 1);
+                       cnt > 1 && submitted == cnt - 1, out->tag);
       if (rc) {
         release_all();
         return rc;
       }
       ++submitted;
+      if (out->on_enqueued) out->on_enqueued(q, c->ev_done, j.last_stream, j.enq_seq);
     }
     Job &j = jobs[(size_t)(finished % depth)];
     const int32_t q = q0 + finished * stride;
@@ -1419,7 +1435,7 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   const uint64_t *mw = mask ? mask_words.data() : nullptr;
   // short scans (small shards, selective masks) are bound by the submitting thread's ~25 us per query: two threads
   const int64_t scan_bytes = (rows_est > 0 ? rows_est : s->rows) * s->ld * 4;
-  static const int forced_threads = getenv("TSH_SUBMIT_THREADS") ? atoi(getenv("TSH_SUBMIT_THREADS")) : 0;
+  static const int forced_threads = probe_env("TSH_SUBMIT_THREADS") ? atoi(probe_env("TSH_SUBMIT_THREADS")) : 0;
   const int want = forced_threads > 0 ? forced_threads : (scan_bytes <= (160ll << 20) ? 2 : SUBMIT_THREADS);
   const int T = std::min(want, nq / 8);
   if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est, lp);
@@ -1614,10 +1630,10 @@ int32_t tsh_index_create(int32_t dim, int32_t metric, int64_t capacity_rows, int
                          tsh_index **out) {
   int rc = check_create_args(dim, metric, capacity_rows, out);
   if (rc) return rc;
-  // TSH_SHARDS_SHARE_DEVICES=1 (testing hook): shards of a multi-device handle may share a
-  // physical device (shard g on device g % count), so the multi-shard code path -- append
+  // TSH_SHARDS_SHARE_DEVICES=1 (testing hook, obeyed only after TSH_OPT_TEST_HOOKS): shards of a multi-device
+  // handle may share a physical device (shard g on device g % count), so the multi-shard code path -- append
   // routing, one host thread per shard, host merge -- can be exercised on a one-GPU box
-  const char *share_env = getenv("TSH_SHARDS_SHARE_DEVICES");
+  const char *share_env = test_env("TSH_SHARDS_SHARE_DEVICES");
   const bool share = share_env && share_env[0] == '1';
   if (n_devices < 1 || (!share && n_devices > device_count_cached()) || n_devices > 64)
     return set_err(TSH_E_BAD_ARG, "n_devices %d outside [1,%d]", n_devices, device_count_cached());
@@ -2062,6 +2078,16 @@ struct tsh_shard_stream {
   bool finished = false;     // the worker has returned
   std::atomic<int32_t> done_seen{0};  // copies of the two for a caller that polls before it sleeps
   std::atomic<bool> finished_seen{false};
+  // single-query route: leading queries whose kernels are all enqueued, and the event behind each one's block
+  // writer -- what a caller needs to order its own stream behind a group's blocks without waiting for them
+  std::vector<char> enq_q;
+  std::vector<hipEvent_t> ev_q;
+  std::vector<hipStream_t> st_q;  // the stream ev_q[q] was recorded on
+  std::vector<uint64_t> seq_q;    // ... and when (the device's enqueue order)
+  int32_t enq = 0;
+  std::atomic<int32_t> enq_seen{0};
+  std::atomic<int> route{0};  // 0 not decided yet, 1 every query its own scan (events exist), 2 anything else
+  uint32_t tag = 0;           // generation the blocks carry (BlockHeader.pad[1])
   int rc = TSH_OK;
   std::string err;
   double busy_us = 0;  // worker: first enqueue to last block
@@ -2074,6 +2100,22 @@ struct tsh_shard_stream {
       done_seen.store(done, std::memory_order_release);
     }
     cv.notify_all();
+  }
+  void mark_enqueued(int32_t q, hipEvent_t ev, hipStream_t where, uint64_t seq) {
+    bool moved = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ev_q[(size_t)q] = ev;
+      st_q[(size_t)q] = where;
+      seq_q[(size_t)q] = seq;
+      enq_q[(size_t)q] = 1;
+      while (enq < nq && enq_q[(size_t)enq]) {
+        ++enq;
+        moved = true;
+      }
+      enq_seen.store(enq, std::memory_order_release);
+    }
+    if (moved) cv.notify_all();
   }
   void mark(int32_t q) {
     bool moved = false;
@@ -2101,7 +2143,9 @@ struct tsh_shard_stream {
         h->k = (uint32_t)k;
         h->metric = (uint32_t)s->metric;
         h->row_base = s->row_base;
+        h->pad[1] = tag;
       }
+      route.store(2, std::memory_order_release);
       HIPCHK(hipMemcpy(d_blocks, z.data(), z.size(), hipMemcpyHostToDevice));
       publish(nq);
       return TSH_OK;
@@ -2110,19 +2154,34 @@ struct tsh_shard_stream {
     const int32_t st = step > 0 ? std::min(step, nq) : nq;
     if (!shard_takes_batch(s, min_nq, st, k)) {  // one pipeline over all queries
       done_q.assign((size_t)nq, 0);
+      enq_q.assign((size_t)nq, 0);
+      ev_q.assign((size_t)nq, nullptr);
+      st_q.assign((size_t)nq, nullptr);
+      seq_q.assign((size_t)nq, 0);
       SearchOut so;
       so.d_blocks = d_blocks;
+      so.tag = tag;
       so.on_done = [this](int32_t q) { mark(q); };
+      so.on_enqueued = [this](int32_t q, hipEvent_t ev, hipStream_t where, uint64_t seq) { mark_enqueued(q, ev, where, seq); };
+      route.store(1, std::memory_order_release);
+      cv.notify_all();
       return shard_search_blocks(s, queries, nq, k, mask, entries, &so, PIPE_DEPTH);
     }
+    route.store(2, std::memory_order_release);
+    cv.notify_all();
     // matrix-core route: a call per step (the batched path answers a call as a whole; the next step's call overlaps
     // the caller's work on this one as before)
     for (int32_t q0 = 0; q0 < nq; q0 += st) {
       const int32_t gq = std::min(st, nq - q0);
       SearchOut so;
       so.d_blocks = d_blocks + (size_t)q0 * bb;
+      so.tag = tag;  // (queries the batch hands back to the single-query path carry it at once)
       int r = shard_search_any(s, s->batch, min_nq, queries + (size_t)q0 * s->dim, gq, k, mask, entries, &so);
       if (r) return r;
+      if (tag) {  // the matrix-core path's blocks get their generation now (host-synchronised: they are final)
+        stamp_tag_kernel<<<(unsigned)((gq + 63) / 64), 64, 0, s->aux_stream>>>(so.d_blocks, bb, gq, tag);
+        HIPCHK(hipStreamSynchronize(s->aux_stream));
+      }
       publish(q0 + gq);
     }
     return TSH_OK;
@@ -2137,6 +2196,7 @@ struct tsh_shard_stream {
       err = e;
       finished = true;
       busy_us = now_us() - t0;
+      if (route.load() == 0) route.store(2);
       finished_seen.store(true, std::memory_order_release);
     }
     cv.notify_all();
@@ -2145,7 +2205,8 @@ struct tsh_shard_stream {
 
 namespace {
 int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t k, const uint8_t *row_mask,
-                       int32_t entries, void *d_out_blocks, int32_t step, bool copy_inputs, tsh_shard_stream **out) {
+                       int32_t entries, void *d_out_blocks, int32_t step, bool copy_inputs, tsh_shard_stream **out,
+                       uint32_t tag = 0) {
   if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (!idx || idx->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle");
@@ -2157,6 +2218,7 @@ int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t
   st->k = k;
   st->entries = entries;
   st->step = step;
+  st->tag = tag;
   st->d_blocks = static_cast<uint8_t *>(d_out_blocks);
   st->queries = queries;
   st->mask = row_mask;
@@ -2182,6 +2244,48 @@ int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t
   }
   *out = st.release();
   return TSH_OK;
+}
+
+// Blocks until the kernels of the first min(want, nq) queries are all enqueued -- or it is clear they never will be
+// one by one (matrix-core route, an empty shard, a failure).  -> the number of events written to `after` (at most
+// `max`): the events behind the block writers of those queries that may still be running (a job further back than
+// the pipeline is deep has been finished by the host); 0 = no stream order to be had, wait for _progress instead.
+// (An event may meanwhile belong to a LATER query of the same pipeline -- its context was reused: waiting for it
+// then waits a little longer than needed, never too short.)
+int shard_stream_enqueued(tsh_shard_stream *st, int32_t want, hipEvent_t *after, int max) {
+  want = std::min(want, st->nq);
+  if (!blocking_wait()) {
+    const double t_end = now_us() + 3000.0;
+    while (st->enq_seen.load(std::memory_order_acquire) < want && st->route.load(std::memory_order_acquire) != 2 &&
+           !st->finished_seen.load(std::memory_order_acquire) && now_us() < t_end)
+      __builtin_ia32_pause();
+  }
+  std::unique_lock<std::mutex> lk(st->mu);
+  st->cv.wait(lk, [&] { return st->enq >= want || st->route.load() == 2 || st->finished; });
+  if (st->route.load() != 1 || st->enq < want) return 0;
+  // of the jobs that share a stream only the one enqueued LAST matters (a stream's kernels finish in order), so this
+  // is two or three events, not eight: every wait is a packet the consumer's queue has to work through
+  int n = 0;
+  hipStream_t seen[MAX_CTX];
+  uint64_t seen_seq[MAX_CTX];
+  for (int32_t q = want - 1; q >= std::max(0, want - (int32_t)MAX_CTX); --q) {
+    if (!st->ev_q[(size_t)q] || st->done_q[(size_t)q]) continue;
+    int at = -1;
+    for (int i = 0; i < n; ++i)
+      if (seen[i] == st->st_q[(size_t)q]) at = i;
+    if (at < 0) {
+      if (n == max) continue;  // (cannot happen: max >= MAX_CTX jobs)
+      at = n++;
+      seen[at] = st->st_q[(size_t)q];
+      seen_seq[at] = 0;
+    }
+    if (st->seq_q[(size_t)q] >= seen_seq[at]) {
+      seen_seq[at] = st->seq_q[(size_t)q];
+      after[at] = st->ev_q[(size_t)q];
+    }
+  }
+  if (n == 0) after[n++] = st->ev_q[(size_t)(want - 1)];  // (all final already: any completed event will do)
+  return n;
 }
 
 // blocks until min(want, nq) leading queries are final, or the search has ended; -> its status so far
@@ -2358,6 +2462,16 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
 }
 
 int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
+  if (option == TSH_OPT_EXCHANGE_AHEAD) {  // process-wide (idx is ignored)
+    if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "exchange ahead: 0 or 1");
+    exchange_ahead_flag().store(value != 0, std::memory_order_release);
+    return TSH_OK;
+  }
+  if (option == TSH_OPT_TEST_HOOKS) {  // process-wide (idx is ignored): see test_env, tsh_host_sync.h
+    if (value != 0 && value != TSH_TEST_HOOKS_MAGIC) return set_err(TSH_E_BAD_ARG, "test hooks: wrong magic");
+    test_hooks_flag().store(value != 0, std::memory_order_release);
+    return TSH_OK;
+  }
   if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
   if (option == TSH_OPT_BATCH_MIN_NQ) {
     if (value < 0 || value > (1 << 20)) return set_err(TSH_E_BAD_ARG, "batch_min_nq out of range");

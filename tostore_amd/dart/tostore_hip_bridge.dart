@@ -209,6 +209,8 @@ final class TshCommTimeline extends Struct {
   external double copyOutUs;
   @Double()
   external double retryScanUs;
+  @Double()
+  external double preEnqueueUs;
 }
 
 /// `tsh_ngh_info` (include/tostore_hip.h): what tsh_index_open_ngh found.  Field order and
@@ -882,6 +884,7 @@ final class HipShardComm {
         'resultGatherUs': r.resultGatherUs,
         'copyOutUs': r.copyOutUs,
         'retryScanUs': r.retryScanUs,
+        'preEnqueueUs': r.preEnqueueUs,
       };
     } finally {
       calloc.free(t);
