@@ -426,6 +426,17 @@ class Env:
 
 
 # ------------------------------------------------------------------ helpers shared by the legs
+def profiled_kernel_us(key):
+    """A kernel's average duration under rocprofv3 --kernel-trace --stats, from the committed summaries (profiles/
+    kernel_us.json: written from the profile files it names) -> dict or None.  The line's own figures come from HIP
+    events in THIS run; the profiler's stand beside them where a leg's frac has been disputed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_us.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic(rows, d):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (not measured in this run:
     counters need their own rocprofv3 passes) -> (bytes or None, source or None)."""
@@ -587,13 +598,24 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
             el = time.perf_counter() - t0
             c1 = idx.counters()
             scan_us = idx.bench_scan(queries[0], iters=20, row_mask=mask)
-        useful = float(kept) * d * 4 + n / 8
+        # which kernel scanned: tsh_counters says (selective masks are scanned as a compacted list of row ids)
+        listed = c1.get("list_scans", 0) - c0.get("list_scans", 0)
+        scans = c1["scan_launches"] - c0["scan_launches"]
+        kernel = "tsh::scan_list_kernel" if listed > 0 and listed >= scans else \
+                 ("tsh::scan_kernel<MASKED>" if listed == 0 else "tsh::scan_list_kernel / tsh::scan_kernel<MASKED>")
+        useful = float(kept) * d * 4 + (4.0 * kept if listed > 0 else n / 8)  # (the list's ids instead of the mask's words)
         ent = {"value": cnt / el, "unit": "queries/s", "ms_per_step": el / cnt * 1e3, "kept_rows": kept, "mask": kind,
                "roofline": {"bound": "hbm", "achieved": useful / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": useful / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": "tsh::scan_kernel<MASKED>", "kernel_us": scan_us,
+                            "kernel": kernel, "kernel_us": scan_us, "list_scans": int(listed), "scan_launches": int(scans),
+                            "kernel_us_source": "HIP events around back-to-back launches of the one kernel (tsh_bench_scan)",
                             "algorithmic_bytes_per_launch": useful},
                "fallback_searches": c1["fallback_searches"] - c0["fallback_searches"]}
+        prof = profiled_kernel_us("C5.keep_%g%%%s" % (keep * 100, "_range" if kind == "range" else ""))
+        if prof and prof.get("avg_us"):  # the same kernel inside real searches, under rocprofv3 (committed summary)
+            ent["roofline"]["kernel_us_rocprofv3"] = prof["avg_us"]
+            ent["roofline"]["frac_rocprofv3"] = useful / (prof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            ent["roofline"]["rocprofv3_source"] = prof.get("source")
         tail = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None
         # the same 64-query calls with the library's own choice of path (cost model: for a call of this size it
         # scores all queries in one matrix-core pass and applies the mask in the epilogue)
@@ -1178,6 +1200,7 @@ def run_bench(a, env=None):
                        "harness": "python gc held off during the timed legs"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_measured_in_run": False,  # (counters need rocprofv3 passes of their own: a committed figure)
                          "kernel": "tsh::scan_kernel", "kernel_us": scan_us, "kernel_us_samples": int(ns),
                          "kernel_us_back_to_back_alone": scan_alone_us,
                          "algorithmic_bytes_per_launch": shard_bytes},

@@ -39,7 +39,8 @@ extern "C" {
 #define TSH_ABI_VERSION 4
 /* 3: tsh_counters grew again (batch_plane_fallbacks, batch_scan_fallbacks); tsh_comm_get_timeline / tsh_comm_timeline
  * came with it.
- * 4: tsh_search_shard_begin / _progress / _end (the progressive shard search tsh_search_sharded is now built on). */
+ * 4: tsh_search_shard_begin / _progress / _end (the progressive shard search tsh_search_sharded is now built on);
+ *    tsh_counters.list_scans, tsh_comm_timeline.pre_enqueue_us; TSH_OPT_EXCHANGE_AHEAD, TSH_OPT_TEST_HOOKS. */
 
 /* status codes */
 #define TSH_OK 0
@@ -91,6 +92,8 @@ typedef struct tsh_counters {
                                     their queries with the f32 MFMA kernel on the rows as stored (no copy needed) */
   int64_t batch_scan_fallbacks;  /* calls whose batch scratch could not be allocated either and that were answered by
                                     pipelined single-query scans */
+  int64_t list_scans;            /* of scan_launches: scans of a selective row mask as a compacted list of row ids
+                                    (scan_list_kernel) instead of a walk over the tiles */
 } tsh_counters;
 
 int32_t tsh_abi_version(void);

@@ -300,8 +300,16 @@ def test_hook_call_sites_name_real_reference_lines():
     assert "_toFloat32" in span(514, 520) and "_normalizeFloat32" in span(514, 520)
     assert "_graphEngine.search(" in span(536, 551) and "lease?.release()" in span(536, 551)
     assert "return true;" in span(1154, 1158)
+    # the ef cap the hook can bring back (hipHonourEfCap): the lines it restates
+    eng = open(os.path.join(os.path.dirname(REF_VIM), "ngh_graph_engine.dart")).read().split("\n")
+    assert "meta.medoidNodeId < 0) return const []" in eng[78 - 1]
+    assert "efSearch ?? meta.efSearch" in eng[80 - 1] and "min(efRaw, max(topK * 5, 32))" in eng[82 - 1]
+    meta = open(os.path.join(os.path.dirname(os.path.dirname(REF_VIM)), "model", "ngh_index_meta.dart")).read().split("\n")
+    assert "efSearch = 64" in meta[196 - 1]
     # ... and the hook file cites exactly these
     hook = open(HOOK).read()
+    assert "hipHonourEfCap" in hook and "efSearch: efSearch" in hook and "meta.medoidNodeId < 0" in hook
+    assert "_hipAsyncAboveFloats = 1 << 28" in hook  # (256 M floats: what its comment derives)
     for cite in (":349-356", ":359,", ":368-388", ":378-388", ":401)", ":429-434", ":514-520", ":536-551", ":1154-1158", ":1192", ":1198", ":1205"):
         assert cite in hook, cite
     assert "void clearCacheForTable" in span(1192, 1192) and "void clearCacheForIndex" in span(1198, 1198)

@@ -64,17 +64,17 @@ def test_c2_single_queries_full_size(corpora, oracle_mod):
     rows_dev = corpora["dev_unit"] * corpora["scale"]  # L2 / IP corpora: norms in [0.5, 2)
     torch.cuda.synchronize()
     host = rows_dev.cpu().numpy()
-    qs = _queries(oracle_mod, 24, 0, 1)
+    qs = _queries(oracle_mod, 80, 0, 1)
     with _index(0, rows_dev) as idx:
         del rows_dev
         idx.set_batch_min_nq(0)  # every query scans on its own
         got = idx.search(qs, K)
-        ref = oracle_mod.search_heap_many_mt(host, qs[:12], 0, K)
-        assert _same(tuple(x[:12] for x in got), ref), "pipelined single-query scans vs oracle"
-        one = idx.search(qs[13], K)  # a lone query (no pipelining) gives the same answer as inside a group
-        assert np.array_equal(one[0][0], got[0][13]) and np.array_equal(one[1][0], got[1][13])
-        pend = [idx.submit(qs[i], K) for i in range(14, 18)]  # asynchronous form
-        for i, t in zip(range(14, 18), pend):
+        ref = oracle_mod.search_heap_many_mt(host, qs[:64], 0, K)  # (the pass / fail record carries the parity evidence)
+        assert _same(tuple(x[:64] for x in got), ref), "pipelined single-query scans vs oracle (64 queries)"
+        one = idx.search(qs[65], K)  # a lone query (no pipelining) gives the same answer as inside a group
+        assert np.array_equal(one[0][0], got[0][65]) and np.array_equal(one[1][0], got[1][65])
+        pend = [idx.submit(qs[i], K) for i in range(66, 70)]  # asynchronous form
+        for i, t in zip(range(66, 70), pend):
             ids, dist = idx.wait(t)
             assert np.array_equal(ids, got[0][i]) and np.array_equal(dist, got[1][i])
         # a stored row finds itself first, at distance 0
@@ -94,9 +94,9 @@ def test_c3_batch_of_1024_full_size(corpora, oracle_mod):
     with _index(2, corpora["dev_unit"]) as idx:
         got = idx.search(qs, K)  # one call: matrix-core path (auto = fp16 keys for cosine)
         assert idx.counters()["batch_kernel_last"] == 2 and idx.counters()["batch_launches"] == 1
-        sample = np.r_[0:16, 500:516, 1008:1024]
+        sample = np.r_[0:96, 464:560, 960:1024]
         ref = oracle_mod.search_heap_many_mt(host, qs[sample], 2, K)
-        assert _same(tuple(x[sample] for x in got), ref), "1024-query batch vs oracle (48 sampled queries)"
+        assert _same(tuple(x[sample] for x in got), ref), "1024-query batch vs oracle (256 sampled queries)"
         assert (got[2] == K).all()
         # every key kernel, and the single-query pipeline, give the batch's answer bit for bit
         for kern in (1, 0):
@@ -109,23 +109,32 @@ def test_c3_batch_of_1024_full_size(corpora, oracle_mod):
         assert idx.counters()["fallback_searches"] == 0
 
 
-@pytest.mark.parametrize("keep", [0.01, 0.5])
-def test_c5_row_mask_full_size(corpora, oracle_mod, keep):
+@pytest.mark.parametrize("keep,kind", [(0.01, "bernoulli"), (0.5, "bernoulli"), (1.0, "bernoulli"), (0.1, "range")])
+def test_c5_row_mask_full_size(corpora, oracle_mod, keep, kind):
     import torch
 
     rows_dev = corpora["dev_unit"] * corpora["scale"]
     torch.cuda.synchronize()
     host = rows_dev.cpu().numpy()
     rng = np.random.default_rng(int(keep * 100))
-    bits = rng.random(N) < keep
+    if kind == "range":  # WHERE id BETWEEN ...: one contiguous run of node ids
+        bits = np.zeros(N, bool)
+        start = int(rng.integers(0, N - int(N * keep)))
+        bits[start:start + int(N * keep)] = True
+    else:
+        bits = rng.random(N) < keep
     mask = np.packbits(bits, bitorder="little")
     qs = _queries(oracle_mod, 40, 0, 3)
     with _index(0, rows_dev) as idx:
         del rows_dev
         idx.set_batch_min_nq(0)
+        c0 = idx.counters()
         got = idx.search(qs, K, None, mask)  # masked scans: bytes read scale with the mask
-        ref = oracle_mod.search_heap_many_mt(host, qs[:8], 0, K, None, mask)
-        assert _same(tuple(x[:8] for x in got), ref), "masked single-query scans vs oracle"
+        c1 = idx.counters()
+        # selective masks (below one kept row in 24) are scanned as a compacted list of row ids, the others by tiles
+        assert (c1["list_scans"] - c0["list_scans"] == 40) == (keep < 1 / 24), "which scan kernel ran"
+        ref = oracle_mod.search_heap_many_mt(host, qs[:32], 0, K, None, mask)
+        assert _same(tuple(x[:32] for x in got), ref), "masked single-query scans vs oracle (32 queries)"
         assert bits[got[0]].all(), "a masked-out row came back"
         idx.set_batch_min_nq(2)  # the same calls through the matrix-core path (mask applied in its epilogue)
         assert _same(idx.search(qs, K, None, mask), got), "masked batch vs masked scans"

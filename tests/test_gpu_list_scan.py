@@ -40,7 +40,16 @@ def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d):
             c0 = idx.counters()
             _check(idx, oracle_mod, rows, qs, metric, k, mask)      # a call of several queries (one list for all)
             _check(idx, oracle_mod, rows, qs[:1], metric, k, mask)  # a lone query
-            assert idx.counters()["fallback_searches"] == c0["fallback_searches"]
+            c1 = idx.counters()
+            assert c1["fallback_searches"] == c0["fallback_searches"]
+            # the path under test is the one that ran: every one of these scans took the compacted list
+            assert c1["list_scans"] - c0["list_scans"] == c1["scan_launches"] - c0["scan_launches"] == len(qs) + 1
+        # a mild mask (one kept row in 10 > 1 in 24) walks the tiles: no list scan
+        mask = np.packbits(rng.random(n) < 0.1, bitorder="little")
+        c0 = idx.counters()
+        _check(idx, oracle_mod, rows, qs[:2], metric, k, mask)
+        c1 = idx.counters()
+        assert c1["list_scans"] == c0["list_scans"] and c1["scan_launches"] - c0["scan_launches"] == 2
         # fewer kept rows than k, and a threshold
         mask = np.zeros(n, bool)
         mask[[5, 77, 20_000, n - 1]] = True

@@ -81,6 +81,35 @@ def test_readme_example(hip_lib, oracle_mod, metric):
         m.close()
 
 
+def test_ef_cap_compatibility_of_the_hook(hip_lib, oracle_mod):
+    """the reference returns at most ef = min(efSearch ?? meta.efSearch, max(5 topK, 32)) rows
+    (/root/reference/lib/src/core/ngh_graph_engine.dart:80-82; result heap of capacity ef, :168) and none while the
+    graph has no medoid (:78).  The device path returns the k best of all rows unless the maintainer asks for the old
+    count (hipHonourEfCap in the hook, honourEfCap here): then the answer is the first min(topK, ef) of the same rows."""
+    from tostore_amd import HipVectorIndex
+    from tostore_amd.backend import HipVectorBackend
+
+    d, n = 32, 3000
+    rows = _mk(n, d, 11)
+    q = _prep_query(oracle_mod, _mk(1, d, 12)[0], L2)
+    with HipVectorIndex(d, L2) as idx:
+        idx.append(0, rows)
+        eids, edist = oracle_mod.search_heap(rows, q, L2, 100)
+        plain = HipVectorBackend(idx).search(query=q, topK=100)
+        assert [r.nodeId for r in plain] == eids.tolist() and len(plain) == 100  # no cap: all 100
+        capped = HipVectorBackend(idx, honourEfCap=True)  # meta.efSearch = 64 (model/ngh_index_meta.dart:196)
+        got = capped.search(query=q, topK=100)
+        assert len(got) == 64 and [r.nodeId for r in got] == eids[:64].tolist()
+        assert [r.distance for r in got] == edist[:64].tolist()
+        assert len(capped.search(query=q, topK=100, efSearch=200)) == 100  # the caller's ef >= topK
+        assert len(capped.search(query=q, topK=100, efSearch=10)) == 10
+        assert len(capped.search(query=q, topK=5)) == 5            # ef = min(64, max(25, 32)) = 32 >= 5
+        assert len(capped.search(query=q, topK=5, efSearch=3)) == 3
+        assert capped.search(query=q, topK=5, efSearch=0) == []
+        assert HipVectorBackend(idx, honourEfCap=True, medoidNodeId=-1).search(query=q, topK=5) == []  # :78
+        assert len(HipVectorBackend(idx, medoidNodeId=-1).search(query=q, topK=5)) == 5  # (not honoured: rows exist)
+
+
 @pytest.mark.parametrize("metric", METRICS)
 def test_ties_duplicates_and_zero_rows(hip_lib, oracle_mod, metric):
     from tostore_amd import HipVectorIndex

@@ -48,7 +48,7 @@ class TshCounters(ctypes.Structure):
         ("bytes_resident", c_i64), ("safe_mode", c_i32), ("device_id", c_i32),
         ("scan_us_sum", c_f64), ("scan_us_samples", c_i64),
         ("batch_kernel_last", c_i32), ("quarantined_rows", c_i32), ("fused_launches", c_i64),
-        ("batch_plane_fallbacks", c_i64), ("batch_scan_fallbacks", c_i64),
+        ("batch_plane_fallbacks", c_i64), ("batch_scan_fallbacks", c_i64), ("list_scans", c_i64),
     ]
 
 

@@ -248,19 +248,34 @@ class HipVectorIndex:
 class HipVectorBackend:
     """Drop-in for `NghGraphEngine.search` backed by a `HipVectorIndex`.
 
-    ref: core/ngh_graph_engine.dart:67-135.  `efSearch` is accepted and ignored:
-    the scan is exhaustive (ef -> infinity), so the k=100 / default-ef trap of
-    :80-82,168 (at most 64 rows returned) does not exist here.
+    ref: core/ngh_graph_engine.dart:67-135.  The scan is exhaustive (ef -> infinity), so by default `efSearch`
+    changes nothing and the k=100 / default-ef trap of :80-82,168 (at most 64 rows returned) does not exist here.
+    `honourEfCap=True` (the hook's `hipHonourEfCap`, tostore_amd/dart/hip_vector_hook.dart) brings the reference's
+    row COUNT back for callers that depend on it: the answer is cut to `min(topK, ef)` rows with
+    `ef = min(efSearch ?? metaEfSearch, max(5 topK, 32))` (:80-82; the result heap holds ef entries, :168), and an
+    index whose graph has no entry point (`medoidNodeId < 0`, :78) answers nothing.  The rows are still the exact
+    nearest ones -- which the reference's own ef rows need not be.
     """
 
-    def __init__(self, index: HipVectorIndex):
+    def __init__(self, index: HipVectorIndex, *, honourEfCap: bool = False, metaEfSearch: int = 64,
+                 medoidNodeId: int = 0):
         self.index = index
+        self.honourEfCap = honourEfCap
+        self.metaEfSearch = metaEfSearch  # NghIndexMeta.efSearch (model/ngh_index_meta.dart:196: default 64)
+        self.medoidNodeId = medoidNodeId  # NghIndexMeta.medoidNodeId (-1 until the first insert picked one)
 
     def search(self, *, query, topK: int, efSearch: Optional[int] = None,
                distanceThreshold: Optional[float] = None, rowMask=None) -> list:
         # ref: :78  `if (meta.totalVectors == 0 || meta.medoidNodeId < 0) return const []`
         if self.index.size == 0 or topK <= 0:
             return []
+        if self.honourEfCap:
+            if self.medoidNodeId < 0:
+                return []
+            ef = min(self.metaEfSearch if efSearch is None else efSearch, max(topK * 5, 32))  # :80-82
+            topK = min(topK, max(ef, 0))
+            if topK <= 0:
+                return []
         ids, dist, cnt = self.index.search(query, topK, distanceThreshold, rowMask)
         n = int(cnt[0])
         return [NghSearchResult(nodeId=int(ids[0, i]), distance=float(dist[0, i])) for i in range(n)]

@@ -382,6 +382,7 @@ struct Shard {
 
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   std::atomic<int64_t> c_plane_fallbacks{0}, c_scan_fallbacks{0};  // batched calls degraded by a full device
+  std::atomic<int64_t> c_list_scans{0};  // scans of a compacted row list (selective masks)
   int cus = 0;  // compute units of the shard's device (grid of the persistent key kernels)
   std::atomic<int> f16_strikes{0};      // batched calls in a row whose fp16 bands overflowed many candidate lists
   std::atomic<bool> f16_denied{false};  // auto key-kernel choice: bf16x3 instead of fp16 for this shard from now on
@@ -1157,6 +1158,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     if (!done_recorded) HIPCHK(hipEventRecord(c->ev_done, ts));
   }
   s->c_scans++;
+  if (use_list) s->c_list_scans++;
   return TSH_OK;
 }
 
@@ -2384,6 +2386,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     out->fallback_searches += s->c_fallbacks.load();
     out->batch_plane_fallbacks += s->c_plane_fallbacks.load();
     out->batch_scan_fallbacks += s->c_scan_fallbacks.load();
+    out->list_scans += s->c_list_scans.load();
     out->candidates_total += s->c_cands.load();
     int64_t b = s->bytes;
     {

@@ -52,7 +52,17 @@ mixin HipVectorHook implements HipVectorHookHost {
   /// Searches above this many stored floats use the ticket form (tsh_search_submit / _ready / _wait) so that the
   /// isolate goes back to its event loop while the GPU scans: 256 M floats ~ 1 GB ~ 0.15 ms at 7 TB/s, far inside
   /// the 8 ms client budget (model/data_store_config.dart:225-230); a 10 M x 1536 shard is 8.8 ms and must not block.
-  static const int _hipAsyncAboveFloats = 1 << 31;
+  static const int _hipAsyncAboveFloats = 1 << 28;
+
+  /// The reference caps what a search returns: `ef = min(efSearch ?? meta.efSearch, max(topK * 5, 32))`
+  /// (ngh_graph_engine.dart:80-82) is also the capacity of its result heap (:168), so k = 100 with the default
+  /// efSearch = 64 (model/ngh_index_meta.dart:196) yields at most 64 rows, and an index without a medoid yields none
+  /// (:78).  The device path has no ef -- it returns the k best of ALL rows.  A maintainer who wants the old row
+  /// COUNT back (a caller that pages on "fewer than topK rows = end of data", a test that pins the length) sets this
+  /// for the whole manager, or names single indexes in [hipHonourEfCapFor] ('table/index'): the device answer is then
+  /// cut to `min(topK, ef)` rows -- still the exact nearest ones, which the reference's own 64 need not be.
+  bool hipHonourEfCap = false;
+  final Set<String> hipHonourEfCapFor = {};
 
   String _hipKey(String tableName, String indexName) => '$tableName/$indexName';
 
@@ -101,7 +111,16 @@ mixin HipVectorHook implements HipVectorHookHost {
   /// search must answer (no device copy, or the native call failed).  `searchQuery` is the Float32List after
   /// _toFloat32 and, for cosine, _normalizeFloat32 (:514-520): the library does not normalise.
   Future<List<NghSearchResult>?> hipSearch(String tableName, String indexName, NghIndexMeta meta,
-      Float32List searchQuery, int topK, double? distanceThreshold) async {
+      Float32List searchQuery, int topK, double? distanceThreshold, {int? efSearch}) async {
+    final capped = hipHonourEfCap || hipHonourEfCapFor.contains(_hipKey(tableName, indexName));
+    // (ngh_graph_engine.dart:78: the reference answers nothing while the graph has no entry point)
+    if (capped && meta.medoidNodeId < 0) return const [];
+    if (capped) {
+      final efRaw = efSearch ?? meta.efSearch; // :80
+      final ef = efRaw < (topK * 5 > 32 ? topK * 5 : 32) ? efRaw : (topK * 5 > 32 ? topK * 5 : 32); // :82
+      if (ef < topK) topK = ef < 0 ? 0 : ef; // the reference's result heap holds ef entries (:168)
+      if (topK <= 0) return const [];
+    }
     final hip = await hipFor(tableName, indexName, meta);
     if (hip == null) return null;
     // a copy that lags the index (an append failed, see hipAfterInsert) is never searched
@@ -178,7 +197,7 @@ mixin HipVectorHook implements HipVectorHookHost {
 //
 //   1. vectorSearch(), replacing `List<NghSearchResult> results; try { results = await _graphEngine.search(` (:536-551):
 //        List<NghSearchResult>? hipResults =
-//            await hipSearch(tableName, indexName, meta, searchQuery, topK, distanceThreshold);
+//            await hipSearch(tableName, indexName, meta, searchQuery, topK, distanceThreshold, efSearch: efSearch);
 //        List<NghSearchResult> results;
 //        if (hipResults != null) { lease?.release(); results = hipResults; } else { /* the original try / finally */ }
 //

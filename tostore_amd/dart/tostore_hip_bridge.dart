@@ -166,6 +166,8 @@ final class TshCounters extends Struct {
   external int batchPlaneFallbacks;
   @Int64()
   external int batchScanFallbacks;
+  @Int64()
+  external int listScans;
 }
 
 /// `tsh_comm_timeline` (include/tostore_hip.h): where this rank's tsh_search_sharded time went.  Field order and
@@ -680,6 +682,7 @@ final class HipVectorBackend {
         'batchKernelLast': r.batchKernelLast,
         'batchPlaneFallbacks': r.batchPlaneFallbacks,
         'batchScanFallbacks': r.batchScanFallbacks,
+        'listScans': r.listScans,
       };
     } finally {
       calloc.free(c);
