@@ -454,6 +454,12 @@ int32_t tsh_bench_batch(tsh_index *idx, const float *queries, int32_t nq, int32_
 int32_t tsh_probe_scan_keys(tsh_index *idx, const float *query, float *out_keys, float *out_eps_rel, float *out_delta_abs);
 int32_t tsh_probe_batch_keys(tsh_index *idx, const float *queries, int32_t nq, int32_t k, float *out_keys,
                              float *out_delta2);
+/* The band of the last tsh_probe_batch_keys call (same nq) row by row: the fp16 keys of an L2 / inner-product index are
+ * known to alpha |v| + beta each -- the operand roundings act on the products, 2^-10 |q| |v| a row -- and the batched path
+ * widens every row's key by its own band (a short row's far less than the longest row's).  out_alpha2[q] = 2 alpha_q,
+ * out_beta2[q] = 2 * 1.0001 * beta_q: 2 |key - exact| <= out_alpha2[q] |v| + out_beta2[q] for every row v.  Key kernels
+ * and metrics with one band for all rows report alpha = 0 and out_beta2 = out_delta2. */
+int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, float *out_beta2);
 
 /* Tuning knobs (no reference counterpart).  TSH_OPT_BATCH_MIN_NQ: when tsh_search /
  * tsh_search_shard answer a multi-query call on the batched matrix-core path:

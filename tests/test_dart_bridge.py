@@ -129,7 +129,7 @@ def test_dart_native_typedefs_match_the_c_prototypes():
     # every symbol of the header is either bound or on this list of entries a Dart host has no use for
     not_for_dart = {
         "tsh_bench_scan", "tsh_bench_batch",  # measurement hooks of bench.py
-        "tsh_probe_scan_keys", "tsh_probe_batch_keys",  # error-model probes of tests/test_gpu_bands.py
+        "tsh_probe_scan_keys", "tsh_probe_batch_keys", "tsh_probe_batch_row_band",  # error-model probes of tests/test_gpu_bands.py
         "tsh_index_append_device",            # takes a device pointer: bulk loaders that already hold the column in HBM
     }
     missing = set(protos) - bound - not_for_dart

@@ -228,6 +228,67 @@ def test_band_holds_on_adversarial_rows(hip_lib, oracle_mod, path, metric, d):
                     "candidates_per_query": (c1["candidates_total"] - c0["candidates_total"]) / max(c1["searches"] - c0["searches"], 1)})
 
 
+@pytest.mark.parametrize("metric", [L2, IP])
+@pytest.mark.parametrize("d", [768, 200])
+def test_per_row_band_of_the_fp16_keys(hip_lib, oracle_mod, metric, d):
+    """Round 5: the fp16 keys of an L2 / inner-product index carry a band PER ROW, alpha_q |v| + beta_q (the operand
+    roundings act on the products: 2^-10 |q| |v| a row), and the batched path widens every row's key by its own.
+    (1) The claim, row by row, on rows whose operand roundings all err one way and whose norms span a factor 16:
+    2 |key - exact| <= alpha2 |v| + beta2.  (2) A corpus whose k-th neighbour sits in a crowd of SHORT rows a few
+    fp16 errors apart, with long rows elsewhere: ids and distances are the oracle's, no fallback, and the short rows'
+    band is a fraction of the longest row's -- which is what every row carried before."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(77 + 10 * metric + d)
+    q = _patterned(rng, d, 2, up=False)
+    base = np.stack([_patterned(rng, d, 2, up=bool(i & 1)) for i in range(4096)])
+    scale = np.ldexp(1.0, -rng.integers(0, 5, size=len(base))).astype(np.float32)  # 1, 1/2 ... 1/16: exact, pattern kept
+    rows = base * scale[:, None]
+    others = [_patterned(rng, d, 2, up=True) for _ in range(3)]
+    exact = _exact_keys(rows, q, metric)
+    nrm = np.sqrt(np.einsum("ij,ij->i", rows.astype(np.float64), rows.astype(np.float64)))
+    with _open(d, metric, rows, 2) as idx:
+        keys, d2 = idx.probe_batch_keys(np.stack([q] + others), K)
+        a2, b2 = idx.probe_batch_row_band(4)
+    err2 = 2.0 * np.abs(keys[0].astype(np.float64) - exact)
+    claim = float(a2[0]) * nrm + float(b2[0])
+    ratio = err2 / claim
+    assert ratio.max() <= 1.0, "a key is further from its exact value than its row's band: %.3f" % ratio.max()
+    assert float(d2[0]) >= claim.max() * 0.999  # the one-number bound of the old probe covers the longest row
+    short = nrm < nrm.max() / 8
+    assert claim[short].max() < 0.45 * float(d2[0]), "short rows do not carry a materially narrower band"
+    # the per-row term is what the errors follow: the worst short row uses its own band about as much as the worst long one
+    use_short, use_long = float(ratio[short].max()), float(ratio[~short].max())
+
+    # ---- (2) a crowd of short rows around the k-th key, long rows far away ------------------------------------
+    n, k = 40960, K
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    g *= rng.uniform(1.0, 2.0, size=(n, 1)).astype(np.float32)  # long rows, random directions
+    qq = rng.standard_normal(d).astype(np.float32)
+    qq /= np.linalg.norm(qq)
+    t = (qq * np.float32(0.45) if metric == L2 else qq * np.float32(2.5))  # L2: a short row near q; IP: the longest, along q
+    crowd = 400
+    pert = rng.standard_normal((crowd, d)).astype(np.float32) * np.float32(2e-4 if metric == L2 else 1e-3)
+    pos = rng.choice(n, crowd, replace=False)
+    g[pos] = t[None, :] * (1.0 + rng.uniform(-3e-4, 3e-4, size=(crowd, 1)).astype(np.float32)) + pert
+    queries = np.stack([qq] + [x / np.linalg.norm(x) for x in rng.standard_normal((3, d)).astype(np.float32)])
+    with _open(d, metric, g, 2) as idx:
+        c0 = idx.counters()
+        ids, dist, cnt = idx.search(queries, k)
+        c1 = idx.counters()
+    e_ids, e_dist, e_cnt = oracle_mod.search_heap_many_mt(g, queries, metric, k)
+    assert np.array_equal(cnt, e_cnt) and np.array_equal(ids, e_ids), "ids differ from the oracle's"
+    assert np.array_equal(dist.view(np.uint64), e_dist.view(np.uint64)), "distances differ from the oracle's"
+    assert set(ids[0].tolist()) <= set(pos.tolist())  # the neighbours of the first query are in the crowd
+    assert c1["fallback_searches"] == c0["fallback_searches"] and c1["batch_kernel_last"] == 2
+    RESULTS.append({"path": "fp16 per-row band", "metric": ["l2", "ip"][metric], "dim": d,
+                    "max_abs_err_over_bound": float(ratio.max()), "short_rows_use_of_their_band": use_short,
+                    "long_rows_use_of_their_band": use_long,
+                    "short_row_band_over_longest_row_band": float(claim[short].max() / float(d2[0])),
+                    "candidates_per_query": (c1["candidates_total"] - c0["candidates_total"]) / max(c1["searches"] - c0["searches"], 1)})
+
+
 def test_write_band_report():
     """(runs last in this file) the measured ratios, for profiles/: gpurun_out/band_ratios.json"""
     if not RESULTS:

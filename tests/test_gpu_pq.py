@@ -45,6 +45,7 @@ def test_pq_fewer_centroids_and_shards(hip_lib, oracle_mod, monkeypatch):
         idx.append(0, rows)
         got = idx.pq_encode(100, 4800, cb, M, K)  # spans both shards
         assert np.array_equal(got, oracle_mod.pq_encode(cb, M, K, 8, rows[100:4900]))
+    _ffi.enable_test_hooks(False)
 
 
 def test_pq_encode_rate(hip_lib, oracle_mod):

@@ -91,6 +91,7 @@ def test_in_process_multi_shard_handle(hip_lib, oracle_mod, metric, monkeypatch)
     from tostore_amd import HipVectorIndex, _ffi
 
     monkeypatch.setenv("TSH_SHARDS_SHARE_DEVICES", "1")
+    _ffi.enable_test_hooks(False)  # (whatever an earlier test of this process left)
     with pytest.raises(_ffi.TshError):  # the variable alone changes nothing: three shards need three GPUs ...
         HipVectorIndex(40, metric, capacity_rows=100, n_devices=3)
     _ffi.enable_test_hooks()  # ... until the process itself asks for the test hooks

@@ -115,6 +115,7 @@ SIGNATURES = {
     "tsh_bench_batch": (c_i32, [p_void, p_f32, c_i32, c_i32, c_i32, p_f64, p_f64]),
     "tsh_probe_scan_keys": (c_i32, [p_void, p_f32, p_f32, p_f32, p_f32]),
     "tsh_probe_batch_keys": (c_i32, [p_void, p_f32, c_i32, c_i32, p_f32, p_f32]),
+    "tsh_probe_batch_row_band": (c_i32, [p_void, c_i32, p_f32, p_f32]),
     "tsh_index_set_option": (c_i32, [p_void, c_i32, c_i64]),
 }
 

@@ -236,6 +236,14 @@ class HipVectorIndex:
                                                    keys.ctypes.data_as(_ffi.p_f32), d2.ctypes.data_as(_ffi.p_f32)))
         return keys, d2
 
+    def probe_batch_row_band(self, nq: int):
+        """(alpha2[nq], beta2[nq]) of the last probe_batch_keys call: 2 |key - exact| <= alpha2 |v| + beta2 per row."""
+        a2 = np.empty(nq, dtype=np.float32)
+        b2 = np.empty(nq, dtype=np.float32)
+        _ffi.check(_ffi.lib().tsh_probe_batch_row_band(self._h, int(nq), a2.ctypes.data_as(_ffi.p_f32),
+                                                       b2.ctypes.data_as(_ffi.p_f32)))
+        return a2, b2
+
     def bench_scan(self, query, iters: int = 20, row_mask=None) -> float:
         q = _f32c(query)
         out = ctypes.c_double(0)

@@ -42,6 +42,8 @@ struct BatchArgs {
   const float *qsq;       // L2: |q|^2 per query (nq_pad)
   const float *thr;       // filter mode: per-query band (float, key space); nq_pad
   const float *kmax;      // f16 ping-pong kernel, IP / cosine: the largest key a row can have for this query (nq_pad)
+  const float *alpha;     // f16 ping-pong kernel, L2 / IP (nullable): per-row part of the key's error band, the band being
+                          // alpha_q |v| + beta_q; the filtered pass tests and stores key - alpha_q |v| (nq_pad)
   const uint64_t *live;   // nullable: bit = row present & not deleted
   const uint64_t *mask;   // nullable: caller keep mask
   float *dense;           // dense mode: nq_pad x dense_ld keys of rows [row0,row1)
@@ -65,6 +67,9 @@ struct BatchArgs {
   int32_t dbg;            // f16 kernel probe (TSH_F16_DBG): 4 = no epilogue (results are wrong), 32 = timestamps
   uint64_t *dbg_buf;      // TSH_F16_DBG & 32: [wave 0 / wave 4 of workgroup 0][step][point] shader-clock stamps
 };
+
+// an upper bound of |v| from the stored |v|^2 (f32 from an f64 sum: 2^-24; the square root: one ulp)
+__device__ __forceinline__ float batch_norm_up(float sq) { return __builtin_sqrtf(sq) * 1.000001f; }
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD runs of
 // q_tiles consecutive workgroups that share one row tile (L2 reuse of V)
@@ -634,10 +639,28 @@ __device__ __forceinline__ void for_each_key(const float *keys, int n, int n4, i
   for (int j = 4 * n4 + tid; j < n; j += THREADS) fn(keys[j], j);
 }
 
+// What the selection sees of entry i: the stored key, or (fp16 keys of an L2 / inner-product index, round 5) the key
+// plus a per-entry width -- the UPPER side of a key whose error band depends on its row, key + alpha_q |v|.
+struct KeyPlain {
+  __device__ __forceinline__ float operator()(float f, int) const { return f; }
+};
+// (the sample rows' norm bounds, once per call: the sample select looks them up for the keys near its threshold)
+static __global__ void __launch_bounds__(256) sample_norms_kernel(const float *sqnorm, float *wn, int32_t n) {
+  const int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  if (i < n) wn[i] = batch_norm_up(sqnorm[i]);
+}
+struct KeyPlusRowNorm {  // entry i of a candidate list: its row is rows[i]
+  const float *sq;
+  const uint32_t *rows;
+  float alpha2;
+  __device__ __forceinline__ float operator()(float f, int i) const { return f + alpha2 * batch_norm_up(sq[rows[i]]); }
+};
+
 // k_pick <= k: which order statistic to return -- the k_pick-th smallest -- once the k smallest are known to be in
 // the list (the sample select's estimated threshold; everybody else passes k)
-template <int THREADS>
-__device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc, uint32_t k_pick) {
+template <int THREADS, typename XF = KeyPlain>
+__device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, KthScratch *sc, uint32_t k_pick,
+                                        const XF xf = XF()) {
   constexpr int BS_GPT = BS_GROUPS / THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
@@ -670,7 +693,7 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
           const f32x4 f = keys4[i];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            uint32_t x = fkey_or_dead(f[e]);
+            uint32_t x = fkey_or_dead(xf(f[e], 4 * i + e));
             lmin[u] = x < lmin[u] ? x : lmin[u];
           }
         }
@@ -681,7 +704,7 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
       for (int u = 0; u < BS_GPT; ++u) {
         int i = base + u * THREADS + tid;
         if (i < n) {
-          uint32_t x = fkey_or_dead(keys[i]);
+          uint32_t x = fkey_or_dead(xf(keys[i], i));
           lmin[u] = x < lmin[u] ? x : lmin[u];
         }
       }
@@ -694,8 +717,8 @@ __device__ uint32_t block_kth_of_floats(const float *keys, int n, uint32_t k, Kt
   }
   __syncthreads();
   const uint32_t U = sc->U;
-  for_each_key<THREADS>(keys, n, n4, tid, [&](float f, int) {
-    uint32_t x = fkey_or_dead(f);
+  for_each_key<THREADS>(keys, n, n4, tid, [&](float f, int i) {
+    uint32_t x = fkey_or_dead(xf(f, i));
     if (x <= U && x != KEY_DEAD) {
       uint32_t p = atomicAdd(&sc->n_list, 1u);
       if (p < BS_LIST) sc->list[p] = x;
@@ -735,6 +758,14 @@ struct SampleSelArgs {
   int64_t dense_ld;
   int32_t n_sample, k, cand_cap, row0;
   int32_t k_est;         // which order statistic of the sample the threshold comes from (<= k; k = the proven bound)
+  // fp16 keys of an L2 / inner-product index (nullable: every key has the one band delta2 / 2): the band of the key of
+  // (query q, row v) is alpha[q] |v| + delta2[q] / 2 + chain2 |thr'_q| / 2, thr' the threshold the filtered pass will
+  // start its accumulators from (the chain's partial sums carry it: batch_delta2)
+  const float *alpha;    // per query
+  const float *sqnorm;   // per row (the shard's |v|^2)
+  const float *wnorm;    // per sample row: an upper bound of its norm (sample_norms_kernel)
+  float chain2;          // 2 c / (1 - 2 c), rounded up (c: the chain's roundings times the unit roundoff)
+  float norm_max;        // the shard's longest row
 };
 
 // B0s: one workgroup per query.  thr[q] = band(tau), tau = the k_est-th smallest sample key; the sample rows at
@@ -750,14 +781,40 @@ struct SampleSelArgs {
 // (A variant that keeps the query's sample keys in registers and so reads them once instead of three times was
 // measured: 1024 queries 88 us against 71 -- at 181 registers only two workgroups share a CU and their serial phases
 // no longer hide behind each other; 16 queries 17.7 against 20.3 us.  Not kept.)
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelArgs a) {
+// thr' = b0 / (1 - 2 c), rounded up: the threshold that still covers b0 once the band grows by c |thr'| on either side
+__device__ __forceinline__ float widen_by_chain(float b0, float chain2) {
+  if (!(chain2 > 0.f) || !(b0 < __builtin_inff())) return b0;
+  const double w = (double)b0 + fabs((double)b0) * (double)chain2;
+  float f = (float)w;
+  if ((double)f < w) {  // next float up
+    uint32_t b = __float_as_uint(f);
+    if ((b & 0x7FFFFFFFu) == 0u) b = 1u;
+    else if (b & 0x80000000u) b -= 1u;
+    else b += 1u;
+    f = __uint_as_float(b);
+  }
+  return f;
+}
+
+template <int THREADS, bool ROWW>
+__device__ __forceinline__ void batch_sample_select_body(const SampleSelArgs &a) {
   __shared__ KthScratch sc;
   __shared__ uint32_t s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float *keys = a.dense + (int64_t)q * a.dense_ld;
+  const float *wn = ROWW ? static_cast<const float *>(__builtin_assume_aligned(a.wnorm, 16)) : nullptr;
+  const float al = ROWW ? a.alpha[q] : 0.f;
+  // tau: the k_est-th smallest sample key -- with per-row bands the dense pass wrote the keys' UPPER sides, key +
+  // alpha |v| (a square root, a load and an fma per key and pass in HERE cost a 1024-query call 46-60 us)
   uint32_t tau = block_kth_of_floats<THREADS>(keys, a.n_sample, (uint32_t)a.k, &sc, (uint32_t)a.k_est);
+  // B2 forms the same upper sides as (key - width) + 2 width, a rounding or two away from key + width: the statistic
+  // it is held to sits a few ulps of the operands above what was found here (far inside the band's own slack)
+  if (ROWW && tau < KEY_NAN) {
+    const float t = key2f(tau);
+    if (t < __builtin_inff()) tau = f2key(widen_by_chain(t + (__builtin_fabsf(t) + al * a.norm_max) * 1e-6f, 1e-6f));
+  }
   float thr = band_float(tau, a.delta2[q]);
+  if (ROWW) thr = widen_by_chain(thr, a.chain2);
   if (tid == 0) {
     a.thr[q] = thr;
     a.tau_est[q] = thr == __builtin_inff() ? KEY_NAN : tau;  // (no threshold: nothing to verify)
@@ -765,17 +822,31 @@ __global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelA
   }
   __syncthreads();
   const int n4 = (reinterpret_cast<uintptr_t>(keys) & 15) == 0 ? a.n_sample >> 2 : 0;
+  // (the lists hold the keys' LOWER sides, key - alpha |v| = upper side - 2 alpha |v|: what the filtered pass stores
+  // for its survivors.  The row's norm is only looked up for the few keys that could pass at all.)
+  const float al2 = 2.f * al, thr_any = ROWW ? thr + al2 * a.norm_max * 1.000001f : thr;
   for_each_key<THREADS>(keys, a.n_sample, n4, tid, [&](float f, int i) {
-    if (f <= thr) {  // NaN (dead) never passes
-      uint32_t p = atomicAdd(&s_cnt, 1u);
-      if (p < (uint32_t)a.cand_cap) {
-        a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(f);
-        a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)(a.row0 + i);
+    if (f <= thr_any) {  // NaN (dead) never passes
+      const float x = ROWW ? f - al2 * wn[i] : f;
+      if (x <= thr) {
+        uint32_t p = atomicAdd(&s_cnt, 1u);
+        if (p < (uint32_t)a.cand_cap) {
+          a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(x);
+          a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)(a.row0 + i);
+        }
       }
     }
   });
   __syncthreads();
   if (tid == 0) a.cand_cnt[(int64_t)q * CC_STRIDE] = s_cnt;
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) batch_sample_select_kernel(SampleSelArgs a) {
+  batch_sample_select_body<THREADS, false>(a);
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) batch_sample_select_roww_kernel(SampleSelArgs a) {
+  batch_sample_select_body<THREADS, true>(a);
 }
 
 struct FinalSelArgs {
@@ -788,12 +859,15 @@ struct FinalSelArgs {
   int64_t block_bytes;
   int64_t row_base, shard_rows;
   int32_t k, cand_cap, entries, metric;
+  // per-row bands (see SampleSelArgs; nullable): the list keys are LOWER sides, key - alpha |v|
+  const float *alpha, *sqnorm, *thr, *kmax;
+  float chain2;
 };
 
 // B2: one workgroup per query: exact k-th smallest key of the candidate list,
 // widened by the band; survivors are the rows the f64 rerank will score.
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArgs a) {
+template <int THREADS, bool ROWW>
+__device__ __forceinline__ void batch_final_select_body(const FinalSelArgs &a) {
   __shared__ KthScratch sc;
   __shared__ uint32_t s_cnt;
   const int q = blockIdx.x, tid = threadIdx.x;
@@ -802,11 +876,23 @@ __global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArg
   const int n = (int)(over_in ? (uint32_t)a.cand_cap : total);
   const float *keys = reinterpret_cast<const float *>(a.cand_key + (int64_t)q * a.cand_cap);
   const uint32_t *rows = a.cand_row + (int64_t)q * a.cand_cap;
-  uint32_t tau = block_kth_of_floats<THREADS>(keys, n, (uint32_t)a.k, &sc, (uint32_t)a.k);
-  float band = band_float(tau, a.delta2[q]);
-  // The list holds every row with key <= tau_est + band.  It holds the whole top k only if the k-th smallest key
-  // overall is <= tau_est, i.e. if at least k of its entries are: tau (their k-th smallest) <= tau_est.  An estimated
-  // threshold (SampleSelArgs::k_est < k) that turns out too tight fails exactly this test.
+  // Per-row bands: the list holds LOWER sides x = key - alpha |v|; a row can be among the true k nearest only if its
+  // lower side is at or below the k-th smallest UPPER side (x + 2 alpha |v|, + 2 beta for both), which bounds the k-th
+  // smallest exact key from above.  With one band for all keys (alpha = 0) that is the old rule, tau + 2 delta.
+  uint32_t tau;
+  float d2 = a.delta2[q];
+  if (ROWW) {
+    tau = block_kth_of_floats<THREADS>(keys, n, (uint32_t)a.k, &sc, (uint32_t)a.k,
+                                       KeyPlusRowNorm{a.sqnorm, rows, 2.f * a.alpha[q]});
+    const float thr_c = __builtin_fminf(a.thr[q], a.kmax[q]);  // the filtered pass's start threshold (capped)
+    if (thr_c < __builtin_inff()) d2 = d2 + __builtin_fabsf(thr_c) * a.chain2 * 1.000001f;
+  } else {
+    tau = block_kth_of_floats<THREADS>(keys, n, (uint32_t)a.k, &sc, (uint32_t)a.k);
+  }
+  float band = band_float(tau, d2);
+  // The list holds every row whose (lower) key is <= tau_est + band width.  It holds the whole top k only if the k-th
+  // smallest (upper) key overall is <= tau_est, i.e. if at least k of its entries are: tau (their k-th smallest) <=
+  // tau_est.  An estimated threshold (SampleSelArgs::k_est < k) that turns out too tight fails exactly this test.
   const uint32_t te = a.tau_est[q];
   const bool unverified = te < KEY_NAN && (tau >= KEY_NAN || tau > te);
   if (tid == 0) s_cnt = 0;
@@ -837,6 +923,14 @@ __global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArg
     *reinterpret_cast<BlockHeader *>(a.blocks + (int64_t)q * a.block_bytes) = hv;
     if (a.blocks_host) *reinterpret_cast<BlockHeader *>(a.blocks_host + (int64_t)q * a.block_bytes) = hv;
   }
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) batch_final_select_kernel(FinalSelArgs a) {
+  batch_final_select_body<THREADS, false>(a);
+}
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) batch_final_select_roww_kernel(FinalSelArgs a) {
+  batch_final_select_body<THREADS, true>(a);
 }
 
 // K4 over a batch: blockIdx.y = query, blockIdx.x strides over its candidates.

@@ -93,9 +93,17 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
   constexpr int QROWS = 32 * MI;                   // query rows of a wave's patch
   constexpr bool L2 = METRIC == METRIC_L2;  // (cosine planes hold unit rows: its key is -dot, as for IP)
   constexpr bool SEEDED = !DENSE;
+  // Round 5: the fp16 error band of an L2 / inner-product key is PER ROW -- alpha_q |v| + beta_q (batch_delta2) -- and
+  // the filtered pass tests and stores the key's LOWER side, key - alpha_q |v|: one more per-(query, row) term in the
+  // accumulators' start values, a v_fma where L2 had a v_sub and inner product a v_mov.
+  constexpr bool ROWW = SEEDED && METRIC != METRIC_COS;
+  // ... and the dense (sample) pass writes the key's UPPER side, key + alpha_q |v| (what the threshold is an order
+  // statistic of), when the host hands it alpha (the probes of the error model read the plain keys: no alpha there)
+  constexpr bool ROWV = METRIC != METRIC_COS;  // the rows' norms are wanted (either pass)
   __shared__ __attribute__((aligned(1024))) unsigned char ring[NST * STAGE];
   __shared__ __attribute__((aligned(16))) float s_seed[8][QROWS];  // per wave: -theta of its query rows
   __shared__ __attribute__((aligned(16))) float s_aux[8][L2 ? QROWS : 4];  // L2: thr' (filtered) resp. |q|^2 (dense)
+  __shared__ __attribute__((aligned(16))) float s_alpha[8][ROWV ? QROWS : 4];  // per wave: alpha_q (filtered pass: in accumulator units)
   __shared__ uint2 s_hits[8][F16_HITS + 64];  // + one spare slot per lane
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -269,10 +277,12 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
 
   float *my_seed = s_seed[wave];
   float *my_aux = s_aux[wave];
+  float *my_alpha = s_alpha[wave];
   uint2 *my_hits = s_hits[wave];
   // L2: c_v = |v|^2 / (2 s) of this lane's two corpus rows (column blocks j = 0, 1) of a tile; +inf past the last row
   // (nothing passes, and no read past the norms' end)
-  float cv[2] = {0.f, 0.f};
+  // ROWW: nv = an upper bound of |v| of the same two rows (0 past the last row)
+  float cv[2] = {0.f, 0.f}, nv[2] = {0.f, 0.f};
   const float half_over_s = 0.5f / a.dot_scale;  // a power of two: exact
   auto load_cv = [&](int tile) {
     int qt, nt;
@@ -281,10 +291,12 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = nb + wn * 64 + j * 32 + l31;
-      cv[j] = col < a.row1 ? a.sqnorm[col] * half_over_s : __builtin_inff();
+      const float sq = col < a.row1 ? a.sqnorm[col] : 0.f;
+      if (L2) cv[j] = col < a.row1 ? sq * half_over_s : __builtin_inff();
+      if (ROWV) nv[j] = batch_norm_up(sq);
     }
   };
-  if (L2) load_cv((int)blockIdx.x);
+  if (L2 || ROWV) load_cv((int)blockIdx.x);
 
   // ---- prologue: three chunks in flight, chunk 0 landed; group 1 starts one phase late ---------------------------
   set_src(i_tile);
@@ -323,6 +335,9 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
           th = __builtin_fminf(a.thr[q], a.kmax[q]) / a.dot_scale;
         }
         my_seed[t] = th;
+        // alpha_q in accumulator units: key units / (2 s) for L2 (acc = (thr' - key) / (2 s)), / s for -dot keys
+        if (ROWW) my_alpha[t] = (q < a.nq && a.alpha) ? a.alpha[q] * (L2 ? half_over_s : 1.0f / a.dot_scale) : 0.f;
+        if (ROWV && DENSE) my_alpha[t] = (q < a.nq && a.alpha) ? a.alpha[q] : 0.f;  // (key units)
       }
       cur_q_tile = q_tile;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a wave's own LDS traffic is in order; the compiler too)
@@ -333,10 +348,18 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
         f32x4 sd[4];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) sd[gq] = *reinterpret_cast<const f32x4 *>(&my_seed[i * 32 + 4 * half + 8 * gq]);
+        f32x4 al[4];
+        if (ROWW) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) al[gq] = *reinterpret_cast<const f32x4 *>(&my_alpha[i * 32 + 4 * half + 8 * gq]);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = L2 ? sd[r >> 2][r & 3] - cv[j] : sd[r >> 2][r & 3];
+          for (int r = 0; r < 16; ++r) {
+            const float st0 = L2 ? sd[r >> 2][r & 3] - cv[j] : sd[r >> 2][r & 3];
+            acc[i][j][r] = ROWW ? __builtin_fmaf(al[r >> 2][r & 3], nv[j], st0) : st0;
+          }
       }
     } else {
 #pragma unroll
@@ -400,7 +423,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
     }
     // L2, filtered pass: the NEXT tile's c_v, issued beside the liveness words above so that one wait covers both and
     // the rest of the epilogue hides it (this tile's went into the accumulators' start values and is not needed again)
-    if (L2 && !DENSE && tile + G < total_tiles) load_cv(tile + G);
+    if ((L2 || ROWV) && !DENSE && tile + G < total_tiles) load_cv(tile + G);
     // one survivor: into the wave's LDS list while it has room (slot = running count + rank among the passing
     // lanes; no atomics), straight into the query's global list otherwise (ties, duplicated rows: rare)
     auto append = [&](uint64_t m, bool mine, float key, int qrow, int cj) {
@@ -447,11 +470,14 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
         const bool okj = j ? col_ok[1] : col_ok[0], alj = j ? alive_l[1] : alive_l[0];
         float *dst = a.dense + (int64_t)(qbase + wm * QROWS + i * 32 + 4 * half_t) * a.dense_ld + (nbase + cj - a.row0);
         const float sq = L2 ? (j ? cv[1] : cv[0]) * (2.f * scale_w) : 0.f;  // |v|^2 back from c_v (exact scaling)
+        const float nvj = ROWV ? (j ? nv[1] : nv[0]) : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (okj) {
+            const int ql = i * 32 + 4 * half_t + (r & 3) + 8 * (r >> 2);
             float key = -(t[r] * scale_w);
-            if (L2) key = __builtin_fmaf(-2.f * scale_w, t[r], my_aux[i * 32 + 4 * half_t + (r & 3) + 8 * (r >> 2)] + sq);
+            if (L2) key = __builtin_fmaf(-2.f * scale_w, t[r], my_aux[ql] + sq);
+            if (ROWV) key = __builtin_fmaf(my_alpha[ql], nvj, key);  // (alpha = 0 without per-row bands: the key itself)
             dst[(int64_t)((r & 3) + 8 * (r >> 2)) * a.dense_ld] = alj ? key : __builtin_nanf("");
           }
       }
@@ -574,7 +600,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
       pend_qbase = qbase;
       pend_nbase = nbase;
     }
-    if (L2 && DENSE && tile + G < total_tiles) load_cv(tile + G);  // (the dense keys above still needed this tile's)
+    if ((L2 || ROWV) && DENSE && tile + G < total_tiles) load_cv(tile + G);  // (the dense keys above still needed this tile's)
     stamp(9);
     __builtin_amdgcn_sched_barrier(0);
     if (wm) __builtin_amdgcn_s_barrier();  // (group 1's barrier of the tile's last COMPUTE phase: see compute_phase)

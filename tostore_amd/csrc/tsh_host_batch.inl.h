@@ -14,6 +14,8 @@ struct BatchCtx {
   int64_t q_cap = 0, aux_cap = 0, cc_cap = 0;  // element capacities
   float *d_dense = nullptr;
   int64_t dense_cap = 0;  // floats
+  float *d_wnorm = nullptr;  // upper bounds of the sample rows' norms (per-row bands of the fp16 keys)
+  int64_t wnorm_cap = 0;
   uint32_t *d_ck = nullptr, *d_cr = nullptr, *d_cc = nullptr;
   int64_t ck_cap = 0, cr_cap = 0;  // elements (nq * cand_cap wanted)
   uint8_t *d_blocks = nullptr, *h_blocks = nullptr;
@@ -56,6 +58,7 @@ void batch_free(BatchCtx *b) {
   hipFree(b->d_qaux);
   hipHostFree(b->h_qaux);
   hipFree(b->d_dense);
+  hipFree(b->d_wnorm);
   hipFree(b->d_ck);
   hipFree(b->d_cr);
   hipFree(b->d_cc);
@@ -210,8 +213,13 @@ void query_norms(const float *q0, int64_t stride, int dim, int n, double *qn2, f
 
 inline double hld_f16(const Shard *s) { return (double)round_up(s->dim, 64); }  // padded reduction length of the fp16 planes
 
-// 2 * (error bound of the f32 MFMA key), absolute, per query.  qn2 / qmax: query_norms.
-bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, float *out_qsq) {
+// The error band of a batched key, per query.  qn2: query_norms.
+//   out_delta2   2 * (the part of the bound every key of the query shares), absolute, rounded up
+//   out_alpha    fp16 keys of an L2 / inner-product index (round 5): the bound of the key of row v is
+//                alpha |v| + delta2 / 2 + chain |thr'| -- the operand roundings act on the products, 2^-10 |q| |v| a row, so
+//                a short row's key is known that much better than a long one's; 0 where every key has the same band
+//   (chain: batch_chain(), per call; thr': the threshold the filtered pass starts its accumulators from)
+bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, float *out_qsq, float *out_alpha = nullptr) {
   const double qn = std::sqrt(qn2) * (1.0 + 1e-6), vmax = (double)s->max_norm * (1.0 + 1e-6);
   const double u2 = 1.1920928955078125e-07;        // 2^-23
   double gam = ((double)s->ld + 8.0) * u2;   // k-ordered fma chain of ld terms
@@ -226,34 +234,61 @@ bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, flo
     // sit >= 27 binades under the largest operand value after the power-of-two scaling
     const double hld = (double)round_up(s->dim, 64);
     // (a query is only batched when its largest element is within 2^8 of the batch's, see top_q)
-    // The filtered IP / cosine pass starts its accumulators at -theta (|theta| <= |q| max|v| (1 + 1e-2), capped by
+    // The filtered cosine pass starts its accumulators at -theta (|theta| <= |q| (1 + 1e-2), capped by
     // BatchArgs::kmax) instead of zero: the chain carries twice the magnitude, and the key is formed from the
     // accumulator by one more subtraction and one multiplication by a power of two (tsh_batch_f16pp.hip.h)
     gam = 2.0 * (hld + 10.0) * u2 * (1.0 + 0.01) + 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 +
           std::sqrt(hld) * 9.3e-10;
   }
-  double delta;
-  if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
+  double delta, alpha = 0.0;
+  if (kernel == 2 && s->metric != TSH_METRIC_COSINE) {
+    // fp16 keys, L2 / inner product: per-row bands (round 5).  In key units the accumulator of (q, v) runs through
+    //   L2:  thr' - |q|^2 - |v|^2 + alpha |v|  (its start)  ... + 2 q.v      inner product:  -thr' + alpha |v| ... + q.v
+    // so its hld + 12 roundings (the chain's, the start value's fma, the key's subtraction) cost at most
+    //   c P,  c = (hld + 12) u,  P = |thr'| + |q|^2 + |v|^2 + alpha |v| + 2 |q| |v| (1 + 2^-10)      (L2)
+    //                            P = |thr'| + alpha |v| + |q| |v| (1 + 2^-10)                        (inner product)
+    // and the operand roundings act on the products only: 2 e_op |q| |v| (L2), e_op |q| |v| (inner product).  Sorted
+    // by what they multiply:  alpha |v|  (alpha appears on both sides: solved for)  +  c |thr'|  (known on the device
+    // only: batch_chain)  +  the rest, the same for every row of the query.  Roundings of |q|^2, |v|^2 (f32 from f64
+    // sums), of the seed and of the select kernels' key +- width arithmetic: 14 u A + 8 u kmax.
+    const double hld = hld_f16(s), c = (hld + 12.0) * u2;
+    const double e_op = 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 + std::sqrt(hld) * 9.3e-10;
+    const double pq = qn * (1.0 + 9.765625e-04);
+    if (s->metric == TSH_METRIC_L2) {
+      const double A = qn * qn + vmax * vmax, kmax = 1.01 * (qn + vmax) * (qn + vmax);
+      alpha = (2.0 * e_op * qn + 2.0 * c * pq) / (1.0 - c);
+      delta = c * A + 14.0 * u2 * A + 8.0 * u2 * kmax;
+    } else {
+      const double kmax = 1.01 * qn * vmax;
+      alpha = (e_op * qn + c * pq) / (1.0 - c);
+      delta = 6.0 * u2 * qn * vmax + 8.0 * u2 * kmax;
+    }
+    alpha *= 1.0 + 1e-6;
+  } else if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
   else if (s->metric == TSH_METRIC_COSINE) delta = qn * (gam + 4.76837158203125e-07) * (kernel == 2 ? 1.0 + 1e-6 : 1.0);
-  else if (kernel == 2) {
-    // L2 on the fp16 kernel (round 4): key = |q|^2 + |v|^2 - 2 q.v with the accumulators of the
-    // filtered pass starting at seed_q - c_v = -(|q|^2 - thr') / (2 s) - |v|^2 / (2 s), thr' <= kmax = 1.01 (|q| +
-    // max|v|)^2.  In key units (x 2 s) the f32 chain's partial sums stay below
-    //   M = (|q|^2 + kmax + max|v|^2) / 2 + |q| max|v| (1 + 2^-10) <= 2.03 A,   A = |q|^2 + max|v|^2,
-    // so its hld + 10 roundings cost 2 (hld + 10) u M <= 4.06 (hld + 10) u A (the dense pass, which starts at zero,
-    // carries less).  The operand roundings act on the products only: 2 e_op |q| max|v| as before.  Roundings of
-    // |q|^2, |v|^2 (f32 from f64 sums), of the seed's subtraction, the start value and the key's fma: 14 u2 A.
-    const double A = qn * qn + vmax * vmax;
-    const double e_op = 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 + std::sqrt(hld_f16(s)) * 9.3e-10;
-    delta = 2.0 * e_op * qn * vmax + 4.06 * (hld_f16(s) + 10.0) * u2 * A + 14.0 * u2 * A;
-  } else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
+  else delta = 2.0 * gam * qn * vmax + 6.0 * u2 * (qn * qn + vmax * vmax);
   delta += (double)s->dim * 7.5e-37;
   double d2 = 2.0 * delta * 1.0001;
-  if (!(d2 < 1e30)) return false;
+  if (!(d2 < 1e30) || !(alpha < 1e30)) return false;
   *out_delta2 = (float)d2;
   if ((double)*out_delta2 < d2) *out_delta2 = std::nextafter(*out_delta2, INFINITY);
   *out_qsq = (float)qn2;
+  if (out_alpha) {
+    *out_alpha = (float)alpha;
+    if ((double)*out_alpha < alpha) *out_alpha = std::nextafter(*out_alpha, INFINITY);
+  }
   return true;
+}
+// fp16 keys of an L2 / inner-product index: c of batch_delta2 as the select kernels take it -- 2 c / (1 - 2 c), rounded
+// up (the filter threshold thr' must still cover the k-th key once the band has grown by c |thr'| on either side); 0
+// for every other key kernel / metric
+float batch_chain2(const Shard *s, int kernel) {
+  if (kernel != 2 || s->metric == TSH_METRIC_COSINE) return 0.f;
+  const double c = (hld_f16(s) + 12.0) * 1.1920928955078125e-07;
+  const double v = 2.0 * c / (1.0 - 2.0 * c) * (1.0 + 1e-6);
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafter(f, INFINITY);
+  return f;
 }
 
 inline bool trace_batch() {
@@ -266,7 +301,8 @@ inline bool trace_batch() {
 // *redo and answered by the single-query path.  Caller holds s->mu shared.
 // force_kernel >= 0: that key kernel instead of the handle's choice (0 = f32 MFMA on the rows as stored, the one that
 // needs no converted copy: shard_search_any falls to it when the copy cannot be allocated).  An allocation failure
-// returns TSH_E_OOM before anything was enqueued or written: the caller may retry or answer another way.
+// returns TSH_E_OOM with nothing of the call left in flight and nothing written: the caller may retry or answer
+// another way.
 int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
                        const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo,
                        int force_kernel = -1) {
@@ -315,8 +351,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
-  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 5, &b->bytes))) return rc;  // + thr, tau_est, kmax
+  if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 6, &b->bytes))) return rc;  // + thr, tau_est, kmax, alpha
   if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
+  if ((rc = regrow(&b->d_wnorm, (float **)nullptr, &b->wnorm_cap, n_sample, &b->bytes))) return rc;
   {
     // (each buffer keeps its own capacity: one that failed to grow must read as empty on the next call)
     const int64_t want = (int64_t)nq * cand_cap;
@@ -335,7 +372,14 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // band that is narrow against ANY data; IP / L2 bands scale with the largest row norm, where bf16x3's
   // 25x tighter error keeps the candidate lists short when norms vary widely
   // -- unless the rows are nearly equal in norm (the usual normalised embeddings), when f16 serves them too
-  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm && !s->f16_denied.load();
+  // (a shard whose fp16 lists kept overflowing is served bf16x3 keys for a while -- F16_DENIAL_CALLS batched calls --
+  // and then tried again: the corpus, or the calls' masks, may have changed)
+  bool f16_ok = true;
+  if (want_kernel == 3 && s->f16_denied_calls.load() > 0) {
+    f16_ok = false;
+    if (s->f16_denied_calls.fetch_sub(1) == 1) s->f16_strikes.store(0);
+  }
+  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm && f16_ok;
   int kern = want_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : want_kernel;
   int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
   if (kern == 2) {
@@ -358,6 +402,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad, *h_kmax = b->h_qaux + 4 * (size_t)nq_pad;
+  float *h_alpha = b->h_qaux + 5 * (size_t)nq_pad;  // per-row part of the band (fp16 keys, L2 / inner product; else 0)
   // the largest key a row can have (IP: -dot <= |q| max|v|; cosine planes hold unit rows; L2: (|q| + max|v|)^2): caps
   // the thresholds of the fp16 kernel's filtered pass.  1 % above it: a row AT the largest key still passes an
   // "everything passes" threshold with its key's error (<= 0.13 % of that scale) on top
@@ -372,7 +417,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     for (int32_t q = g0; q < g1; ++q) {
       float *dst = b->h_Q + (size_t)q * ld;
       h_kmax[q] = 0.f;
-      if (q < nq && ok[q - g0] && batch_delta2(s, kern, b->mag_a[(size_t)q], &h_d2[q], &h_qsq[q])) {
+      h_alpha[q] = 0.f;
+      if (q < nq && ok[q - g0] && batch_delta2(s, kern, b->mag_a[(size_t)q], &h_d2[q], &h_qsq[q], &h_alpha[q])) {
         memcpy(dst, queries + (size_t)q * s->dim, (size_t)s->dim * sizeof(float));
         for (int64_t i = s->dim; i < ld; ++i) dst[i] = 0.f;
         const double qn_q = std::sqrt(b->mag_a[(size_t)q]);
@@ -386,6 +432,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         memset(dst, 0, (size_t)ld * sizeof(float));
         h_d2[q] = 0.f;
         h_qsq[q] = 0.f;
+        h_alpha[q] = 0.f;
       }
     }
   });
@@ -483,7 +530,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     hipStream_t up = s->upload_stream;
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, up));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));
-    HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * sizeof(float), hipMemcpyHostToDevice, up));
+    HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));  // kmax, alpha
     if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, up));
     if (gpu_final) HIPCHK(hipMemcpyAsync(b->d_sqrt_mag, b->h_sqrt_mag, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, up));
     HIPCHK(hipEventRecord(b->e_up, up));
@@ -502,14 +549,16 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         s->split_cap = 0;
         s->split_valid = 0;
         const int64_t prow = round_up(s->cap, PLANE_GROUP);  // whole 256-row groups (plane_piece)
-        // (nothing of this call has been launched yet: a device too full for the copy is the caller's cue to score
-        // with the f32 kernel instead, shard_search_any)
+        // (no kernel of this call has been launched yet: a device too full for the copy is the caller's cue to score
+        // with the f32 kernel instead, shard_search_any.  The call's inputs ARE on their way -- H2D copies out of the
+        // pinned buffers the retry will rewrite -- so they are waited for before this call gives up)
         const hipError_t pe = alloc_fault(prow * row_bytes) || !device_has_room(prow * row_bytes)
                                   ? hipErrorOutOfMemory
                                   : hipMalloc(&s->d_split, (size_t)prow * (size_t)row_bytes);
         if (pe != hipSuccess) {
           s->d_split = nullptr;
           (void)hipGetLastError();
+          (void)hipEventSynchronize(b->e_up);
           return set_err(pe == hipErrorOutOfMemory ? TSH_E_OOM : TSH_E_HIP, "hipMalloc of the %s copy of the rows (%lld bytes) failed: %s",
                          use_f16 ? "fp16" : "bf16x3", (long long)(prow * row_bytes), hipGetErrorString(pe));
         }
@@ -603,6 +652,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.qsq = d_qsq;
     a.thr = d_thr;
     a.kmax = b->d_qaux + 4 * (size_t)nq_pad;
+    // per-row bands: fp16 keys of an L2 / inner-product index (batch_delta2)
+    // (the error-model probes, last_sample_force, read the dense pass's keys as they are: no widths there -- what that
+    // call answers is discarded)
+    const bool roww = use_f16 && s->metric != TSH_METRIC_COSINE && !b->last_sample_force;
+    const float chain2 = batch_chain2(s, kern);
+    a.alpha = roww ? b->d_qaux + 5 * (size_t)nq_pad : nullptr;
     a.live = s->all_live ? nullptr : s->d_live;
     a.mask = mask ? b->d_mask : nullptr;
     a.dense = b->d_dense;
@@ -640,11 +695,22 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     ss.tau_est = d_tau_est;
     ss.cand_cap = cand_cap;
     ss.row0 = (int32_t)s0;
+    ss.alpha = a.alpha;
+    ss.sqnorm = s->d_sqnorm;
+    ss.chain2 = chain2;
+    ss.norm_max = s->max_norm;
+    if (roww) {  // the sample rows' norms, once per call
+      sample_norms_kernel<<<(unsigned)((n_sample + 255) / 256), 256, 0, st>>>(s->d_sqnorm + s0, b->d_wnorm, (int32_t)n_sample);
+      ss.wnorm = b->d_wnorm;
+    }
     // one workgroup per query: a small batch leaves most CUs empty, so its workgroups get sixteen waves instead of
     // four (128 queries: 76 -> 54 and 58 -> 50 us); with a thousand workgroups the wide shape loses (the one-wave
     // bisect phases idle fifteen waves: 103 -> 235 us)
     const bool wide_select = nq <= 256;
-    if (wide_select) batch_sample_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(ss);
+    if (roww) {
+      if (wide_select) batch_sample_select_roww_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(ss);
+      else batch_sample_select_roww_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(ss);
+    } else if (wide_select) batch_sample_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(ss);
     else batch_sample_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(ss);
     // B1: everything else, filtered
     if (timed) HIPCHK(hipEventRecord(b->e2, st));
@@ -683,7 +749,15 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     fs.cand_cap = cand_cap;
     fs.entries = entries;
     fs.metric = s->metric;
-    if (wide_select) batch_final_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(fs);
+    fs.alpha = a.alpha;
+    fs.sqnorm = s->d_sqnorm;
+    fs.thr = d_thr;
+    fs.kmax = a.kmax;
+    fs.chain2 = chain2;
+    if (roww) {
+      if (wide_select) batch_final_select_roww_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(fs);
+      else batch_final_select_roww_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(fs);
+    } else if (wide_select) batch_final_select_kernel<BS_THREADS_WIDE><<<nq, BS_THREADS_WIDE, 0, st>>>(fs);
     else batch_final_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(fs);
     RerankBatchArgs rb{};
     rb.rows = s->d_rows;
@@ -754,7 +828,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if ((out->on_chunk || gpu_final) && b->last_wait_us > 0 && b->last_wait_us < 900.0)
     HostPool::get().stay_awake_until(t_enq + b->last_wait_us * 1.1 + 50.0);
   std::vector<char> skip((size_t)nq, 0);
-  int32_t n_unverified = 0;
+  int32_t n_unverified = 0, n_band_over = 0;
   double t_gpu = 0;
   // From the end of the key passes on the pool gets a job every few dozen microseconds (one per chunk of the tail):
   // the long wait blocks, then the workers are woken and poll until the call is over
@@ -779,6 +853,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       const uint32_t h_count = gpu_final ? b->h_fin_info[q] & 0xFFFFFFu : h->count;
       if (bad[(size_t)q] || (h_flags & FLAG_LIST_OVERFLOW)) {
         if (h_flags & FLAG_TAU_UNVERIFIED) ++n_unverified;
+        else if (!bad[(size_t)q]) ++n_band_over;  // a threshold existed and held: the band itself was too wide for the list
         redo->push_back(q);
         skip[(size_t)q] = 1;
       } else {
@@ -810,11 +885,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   }
   // auto mode: fp16 keys whose band keeps overflowing the lists of this corpus (every overflow is a whole scan) give
   // way to bf16x3 ones, 25 x narrower, after two such calls (cosine keys are scale-free: never)
-  if (kern == 2 && want_kernel == 3 && s->metric != TSH_METRIC_COSINE && entries >= RF_MAX) {  // (at the widest lists only)
-    const int32_t n_over = (int32_t)redo->size() - n_unverified;
-    if (n_over > std::max(2, nq / 16)) {
-      if (s->f16_strikes.fetch_add(1) + 1 >= 2) s->f16_denied.store(true);
-    } else if (n_over == 0) {
+  // Counted: queries whose threshold held and whose list still overflowed.  Not counted: queries the error model
+  // rejected (bad[]), failed estimates, and calls with a caller mask (a mask that leaves the sample fewer than k kept
+  // rows has no threshold at all: every kept row survives, whatever the key kernel).
+  if (kern == 2 && want_kernel == 3 && s->metric != TSH_METRIC_COSINE && entries >= RF_MAX && !mask && !b->last_sample_force) {  // (at the widest lists only)
+    if (n_band_over > std::max(2, nq / 16)) {
+      if (s->f16_strikes.fetch_add(1) + 1 >= 2) s->f16_denied_calls.store(F16_DENIAL_CALLS);
+    } else if (n_band_over == 0) {
       s->f16_strikes.store(0);
     }
   }

@@ -72,6 +72,7 @@ int device_count_cached() {
 
 constexpr int MAX_CTX = 8;            // contexts (queries in flight) per shard
 constexpr int PIPE_DEPTH = 8;         // queries a multi-query call keeps in flight
+constexpr int F16_DENIAL_CALLS = 256; // batched calls a shard stays off fp16 keys after its lists kept overflowing
 constexpr uint32_t QUARANTINE_MAX = 1024;  // quarantined rows per shard; beyond that the shard goes to safe mode
 constexpr int SUBMIT_THREADS = 1;     // host threads that submit a multi-query call (more did not help: the pipeline is GPU-bound)
 constexpr int MAX_DIM_SCAN = 4096;    // register-resident query (NCH <= 16; the reference's f32 pages hold d <= 4073)
@@ -385,7 +386,7 @@ struct Shard {
   std::atomic<int64_t> c_list_scans{0};  // scans of a compacted row list (selective masks)
   int cus = 0;  // compute units of the shard's device (grid of the persistent key kernels)
   std::atomic<int> f16_strikes{0};      // batched calls in a row whose fp16 bands overflowed many candidate lists
-  std::atomic<bool> f16_denied{false};  // auto key-kernel choice: bf16x3 instead of fp16 for this shard from now on
+  std::atomic<int> f16_denied_calls{0};  // auto key-kernel choice: bf16x3 instead of fp16 for this many more batched calls
   std::atomic<int> planes_denied{0};  // batched calls left that go straight to the f32 kernel (the copy did not fit)
   double scan_us_sum = 0;  // guarded by ctx_mu
   int64_t scan_us_samples = 0;
@@ -2580,7 +2581,28 @@ int32_t tsh_probe_batch_keys(tsh_index *idx, const float *queries, int32_t nq, i
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipMemcpy2D(out_keys, (size_t)s->rows * 4, b->d_dense, (size_t)b->last_sample * 4, (size_t)s->rows * 4, (size_t)nq,
                      hipMemcpyDeviceToHost));
-  memcpy(out_delta2, b->h_qaux + b->last_nq_pad, (size_t)nq * sizeof(float));
+  // one bound for every row of the query: the shared part + the per-row part at the longest row
+  const float *d2 = b->h_qaux + b->last_nq_pad, *al = b->h_qaux + 5 * (size_t)b->last_nq_pad;
+  for (int32_t q = 0; q < nq; ++q) {
+    const double v = (double)d2[q] + 2.0 * (double)al[q] * (double)s->max_norm * (1.0 + 1e-6);
+    out_delta2[q] = (float)v;
+    if ((double)out_delta2[q] < v) out_delta2[q] = std::nextafter(out_delta2[q], INFINITY);
+  }
+  return TSH_OK;
+}
+
+int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, float *out_beta2) {
+  if (!idx || idx->shards.size() != 1 || nq <= 0 || !out_alpha2 || !out_beta2) return set_err(TSH_E_BAD_ARG, "bad arguments");
+  Shard *s = idx->shards[0].get();
+  std::shared_lock<RwLock> sl = share(idx, s);
+  BatchCtx *b = s->batch;
+  std::lock_guard<std::mutex> lk(b->mu);
+  if (b->last_nq != nq || !b->h_qaux) return set_err(TSH_E_BUSY, "no batched call of that many queries to report on");
+  const float *d2 = b->h_qaux + b->last_nq_pad, *al = b->h_qaux + 5 * (size_t)b->last_nq_pad;
+  for (int32_t q = 0; q < nq; ++q) {
+    out_alpha2[q] = 2.f * al[q];
+    out_beta2[q] = d2[q];
+  }
   return TSH_OK;
 }
 
