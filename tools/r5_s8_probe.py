@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--nq", type=int, default=20)
     ap.add_argument("--calls", type=int, default=40)
     ap.add_argument("--group", type=int, default=0)
-    ap.add_argument("--ahead", type=int, default=1)
+    ap.add_argument("--ahead", type=int, default=0)
     a = ap.parse_args()
     import torch
 

@@ -176,6 +176,7 @@ struct tsh_comm {
   uint64_t exchanges = 0;  // block all-gathers enqueued so far
   bool timed_now = false;  // the one in flight carries ev_t[0] / ev_t[1]
   int32_t group = 0;  // queries per exchange; 0 = by the size of the call
+  std::unique_ptr<OneWorker> worker;  // runs the calls' progressive shard searches (one call at a time: mu)
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};  // RCCL: before / after the block all-gather, after the slice's D2H
   tsh_comm_timeline tl = {};  // guarded by mu
   std::atomic<int64_t> scan_ns{0};  // the scanning thread's busy time (+ retries' scans)
@@ -542,12 +543,14 @@ int comm_common_create(tsh_comm *c, int32_t world, int32_t rank, int32_t device)
   const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0u;
   HIPCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming | wait_flag));
   for (auto &e : c->ev_t) HIPCHK(hipEventCreateWithFlags(&e, wait_flag));  // timed: the exchange's phases
+  c->worker.reset(new OneWorker(blocking_wait() ? 0.0 : 300.0));  // (CPUs to spare: it polls 0.3 ms for the next call)
   HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_agree), 16 * (size_t)(world + 1)));
   HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&c->h_agree), 16 * (size_t)(world + 1), hipHostMallocDefault));
   return TSH_OK;
 }
 
 void comm_free(tsh_comm *c) {
+  c->worker.reset();
   hipSetDevice(c->device);
   if (c->comm) rccl()->CommDestroy(c->comm);
   hipFree(c->d_mine);
@@ -738,7 +741,7 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
     const uint32_t ss_tag = c->tag_seq;
     if (scan_rc == TSH_OK) {
       scan_rc = shard_stream_begin(shard, queries + (size_t)w0 * dim, wn, k, row_mask, entries, c->d_mine, sizes[gi],
-                                   /*copy_inputs=*/false, &ss, ss_tag);
+                                   /*copy_inputs=*/false, &ss, ss_tag, c->worker.get());
       if (scan_rc) scan_err = g_err;
     }
     auto end_stream = [&] {  // nothing of this call may still run when it returns

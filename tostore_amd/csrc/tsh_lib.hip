@@ -909,7 +909,11 @@ void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
   // them -- from registers only while they fit a workgroup's: 64 tiles for four waves, 256 for sixteen.  A list scan
   // of a few thousand kept rows lands exactly there: 79 tiles, k = 100 took 85 us per query instead of 30)
   const bool all_hit = n_tiles < se.k && n_tiles > 64;
-  if (n_tiles <= 512 && se.k <= 256 && !all_hit) select_kernel<256, true><<<1, 256, 0, st>>>(se);
+  // (a list scan's tile minima bound the k-th key loosely -- its tiles hold the kept rows in id order, every one of them
+  // a mix of near and far rows: a 1 % mask of 1 M rows is 157 tiles of which ~100 are hits, and step (f) bisects over
+  // them from registers only with sixteen waves)
+  const bool list_many_hits = se.list != nullptr && n_tiles > 64;
+  if (n_tiles <= 512 && se.k <= 256 && !all_hit && !list_many_hits) select_kernel<256, true><<<1, 256, 0, st>>>(se);
   else if (n_tiles <= SEL_VPT * SEL_THREADS) select_kernel<SEL_THREADS, true><<<1, SEL_THREADS, 0, st>>>(se);
   else select_kernel<SEL_THREADS, false><<<1, SEL_THREADS, 0, st>>>(se);
 }
@@ -2094,7 +2098,9 @@ struct tsh_shard_stream {
   int rc = TSH_OK;
   std::string err;
   double busy_us = 0;  // worker: first enqueue to last block
-  std::thread th;
+  std::thread th;              // the search's own thread ...
+  OneWorker *exec = nullptr;   // ... or the caller's persistent one (tsh_search_sharded: starting a thread costs a
+                               // 20-query call on a 125 k-row shard 30-40 us before its first scan is enqueued)
 
   void publish(int32_t upto) {  // queries [0, upto) are final
     {
@@ -2209,7 +2215,7 @@ struct tsh_shard_stream {
 namespace {
 int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t k, const uint8_t *row_mask,
                        int32_t entries, void *d_out_blocks, int32_t step, bool copy_inputs, tsh_shard_stream **out,
-                       uint32_t tag = 0) {
+                       uint32_t tag = 0, OneWorker *exec = nullptr) {
   if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (!idx || idx->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle");
@@ -2240,10 +2246,15 @@ int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t
     }
   }
   tsh_shard_stream *p = st.get();
-  try {
-    st->th = std::thread([p] { p->run(); });
-  } catch (...) {
-    return set_err(TSH_E_OOM, "could not start the search thread");
+  if (exec) {
+    st->exec = exec;
+    exec->post([p] { p->run(); });
+  } else {
+    try {
+      st->th = std::thread([p] { p->run(); });
+    } catch (...) {
+      return set_err(TSH_E_OOM, "could not start the search thread");
+    }
   }
   *out = st.release();
   return TSH_OK;
@@ -2312,7 +2323,8 @@ int shard_stream_progress(tsh_shard_stream *st, int32_t want, int32_t *out_done)
 }
 
 int shard_stream_end(tsh_shard_stream *st, double *busy_us = nullptr) {
-  if (st->th.joinable()) st->th.join();
+  if (st->exec) st->exec->wait();
+  else if (st->th.joinable()) st->th.join();
   const int rc = st->rc;
   if (rc) g_err = st->err;
   if (busy_us) *busy_us = st->busy_us;
