@@ -165,3 +165,25 @@ def test_the_oracle_is_out_of_reach_of_timed_code(oracle_mod):
     assert os.environ.get("TSH_BENCH_TIMED") is None
     importlib.reload(bench_check)
     assert bench_check.oracle_answers(rows, rows[:1], 0, 2)[2][0] == 2
+
+
+def test_shard_of_8_leg(oracle_mod):
+    """side.shard_of_8: one rank's share of the headline at N = 8 through the sharded entry
+    point, in the driver's shape -- regions of --steps queries, fenced -- with its exchange_timeline and the speed-up it
+    bounds."""
+    a = _args("--steps", "20", "--warmup", "5", "--side", "s8")
+    env = FakeEnv(oracle_mod)
+    out = json.loads(bench.run_bench(a, env))
+    s8 = out["side"]["shard_of_8"]
+    assert "error" not in s8, s8
+    assert s8["steps"] == 20 and s8["us_per_query"] > 0 and abs(s8["ms_per_step"] * 1e3 - s8["us_per_query"]) < 1e-9
+    assert abs(s8["upper_bound_speedup"] - out["ms_per_step"] / s8["ms_per_step"]) < 1e-9
+    assert s8["timed_regions"]["count"] == len(s8["timed_regions"]["seconds"]) == bench.auto_repeats(20)
+    assert s8["workload"].startswith("one rank's share of C2 at N = 8: 375x32")  # rows / 8 of the test's 3000 x 32 corpus
+    assert s8["roofline"]["algorithmic_bytes_per_launch"] == 375 * 32 * 4
+    assert s8["exchange_timeline"]["ranks"][0]["calls"] == bench.auto_repeats(20)
+    assert s8["ids_and_distances_bit_exact"] is True and s8["recall_at_k"] == 1.0 and s8["checked_queries"] == 16
+    assert sum(s8["queries_per_exchange"]) == 20 and set(s8["group_sweep_us_per_query"]) == {"1", "2", "4", "5", "10", "20"}
+    assert bench.library_schedule(20, 125_000, 768) == [10, 5, 5] and bench.library_schedule(20, 10_000, 128) == [20]
+    assert bench.library_schedule(300, 125_000, 768) == [64, 64, 64, 64, 44] and bench.library_schedule(1, 1, 1) == [1]
+    assert all(i.closed for i in env.made)
