@@ -540,6 +540,22 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
         }
       }
       stamp(1);
+#ifdef TSH_PROBES
+      if ((a.dbg & 32) && a.dbg_buf && lane == 0) {  // how often the register-by-register walk runs, and why
+        unsigned long long *cb = reinterpret_cast<unsigned long long *>(a.dbg_buf) + 4 * 96 * 12;
+        atomicAdd(cb + 0, 1ull);
+        atomicAdd(cb + 3, (unsigned long long)__builtin_popcount(hit_blocks));
+      }
+      {
+        const bool c2 = __ballot((alive_l[0] && crowded) || (alive_l[1] && crowded)) != 0;
+        const bool m2 = __ballot((alive_l[0] && cnt[0] > 2) || (alive_l[1] && cnt[1] > 2)) != 0;
+        if ((a.dbg & 32) && a.dbg_buf && lane == 0) {
+          unsigned long long *cb = reinterpret_cast<unsigned long long *>(a.dbg_buf) + 4 * 96 * 12;
+          if (c2) atomicAdd(cb + 1, 1ull);
+          if (m2) atomicAdd(cb + 2, 1ull);
+        }
+      }
+#endif
       if (__builtin_expect(__ballot((alive_l[0] && (cnt[0] > 2 || crowded)) || (alive_l[1] && (cnt[1] > 2 || crowded))) != 0, 0)) {
         while (hit_blocks) {
           const int b = __builtin_ctz(hit_blocks);
