@@ -387,7 +387,7 @@ int32_t tsh_comm_destroy(tsh_comm *comm);
 int32_t tsh_comm_world(tsh_comm *comm);
 /* queries per exchange of tsh_search_sharded; 0 (default) = the library's own schedule: calls of up to 128 queries go
  * in SHRINKING groups (half of what is left each time, never below what hides an exchange behind the scans that
- * follow -- sized by the largest shard's rows, which the ranks tell each other whenever their buffers grow -- nor below
+ * follow -- sized by the bytes a scan of the largest shard reads, which the ranks tell each other whenever their buffers grow -- nor below
  * four: 20 queries on 125 k x 768 shards as 10 + 5 + 5), because only the LAST group's exchange is exposed; 64 per
  * group up to 512 queries, 256 beyond.  n > 0: uniform groups of n.  Same value on every rank. */
 int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);

@@ -105,6 +105,18 @@ for metric in (0, 1, 2):
         verdict = e.code
     say("m%d failing rank -> %s" % (metric, verdict), verdict == (_ffi.TSH_E_BAD_ARG if rank == 1 else _ffi.TSH_E_PEER))
     say("m%d usable after a failed call" % metric, check(cs.search(qs[:4], 10), qs[:4], metric, 10))
+    # ... also when the call is cut into several groups: how it is cut must not depend on anything the failing rank
+    # knows alone (its handle is NULL: no dimension, no rows)
+    cs.set_group(7)
+    try:
+        cs.search(qs[:20], 10, shard=None if rank == world - 1 else ...)
+        verdict = "no error"
+    except _ffi.TshError as e:
+        verdict = e.code
+    cs.set_group(0)
+    say("m%d failing rank, three groups -> %s" % (metric, verdict),
+        verdict == (_ffi.TSH_E_BAD_ARG if rank == world - 1 else _ffi.TSH_E_PEER)
+        and check(cs.search(qs[:20], 10), qs[:20], metric, 10))
     cs.close()
     idx.close()
 
@@ -136,3 +148,37 @@ except _ffi.TshError as e:
 say("failing all-gather -> %s" % verdict, verdict == _ffi.TSH_E_RCCL)
 cs.close()
 idx.close()
+
+# ---- shards big enough for the library's own schedule to cut a 20-query call into 10 + 5 + 5 (a scan of >= 30 us):
+# every rank takes the same cut -- also the rank whose handle is NULL, which knows neither rows nor dimension
+if os.environ.get("WORKER_BIG_SHARDS") == "1":
+    nb = 800_000 * world
+    big = np.random.default_rng(5).standard_normal((nb, d)).astype(np.float32)
+    perb = nb // world
+    idx = HipVectorIndex(d, 0, capacity_rows=perb, shard_device=0, row_base=rank * perb)
+    idx.append(rank * perb, big[rank * perb:(rank + 1) * perb])
+    idx.set_batch_min_nq(0)
+    cs = CommSearcher(idx, world, rank, share_id("big"), 0)
+    q20 = qs_all[:20]
+
+    def check_big(got):
+        ids, dd, cnt = got
+        ok = True
+        for i in (0, 9, 10, 14, 15, 19):  # a query of every group
+            e, ed = oracle.search_exhaustive(big, q20[i], 0, 10)
+            ok &= bool(cnt[i] == len(e) and np.array_equal(ids[i, :cnt[i]], e) and np.array_equal(dd[i, :cnt[i]], ed))
+        return ok
+
+    got = cs.search(q20, 10)
+    t = cs.timeline(reset=True)
+    say("big shards: 20 queries in %d groups" % t["groups"], t["groups"] == 3 and check_big(got))
+    try:
+        cs.search(q20, 10, shard=None if rank == world - 1 else ...)
+        verdict = "no error"
+    except _ffi.TshError as e:
+        verdict = e.code
+    say("big shards: failing rank, the library's own groups -> %s" % verdict,
+        verdict == (_ffi.TSH_E_BAD_ARG if rank == world - 1 else _ffi.TSH_E_PEER))
+    say("big shards: usable afterwards", check_big(cs.search(q20, 10)))
+    cs.close()
+    idx.close()

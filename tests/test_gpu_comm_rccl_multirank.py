@@ -46,7 +46,7 @@ def test_sharded_search_over_the_rccl_branch(hip_lib, world):
     out = "\n".join(outs)
     assert all(rc == 0 for rc in rcs), out[-6000:]
     assert "MISMATCH" not in out, out[-6000:]
-    assert out.count(" ok\n") == world * (3 * 11 + 2), out[-6000:]
+    assert out.count(" ok\n") == world * (3 * 12 + 2), out[-6000:]
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -59,7 +59,19 @@ def test_exchange_ahead_over_the_rccl_branch(hip_lib, world):
     out = "\n".join(outs)
     assert all(rc == 0 for rc in rcs), out[-6000:]
     assert "MISMATCH" not in out, out[-6000:]
-    assert out.count(" ok\n") == world * (3 * 11 + 2), out[-6000:]
+    assert out.count(" ok\n") == world * (3 * 12 + 2), out[-6000:]
+
+
+def test_the_library_schedule_is_the_same_on_a_rank_without_a_handle(hip_lib):
+    """The cut of a call into groups (10 + 5 + 5 for 20 queries on shards whose scan takes >= 30 us) may depend only on
+    what the ranks agreed on: a rank whose handle is NULL knows neither rows nor dimension and must still enter the
+    same three exchanges."""
+    rcs, outs = run_ranks(2, [os.path.join(ROOT, "tests", "_rccl_worker.py"), "20011", "@TMP@/uid"],
+                          {"WORKER_BIG_SHARDS": "1"})
+    out = "\n".join(outs)
+    assert all(rc == 0 for rc in rcs), out[-6000:]
+    assert "MISMATCH" not in out and out.count("big shards") == 2 * 3, out[-3000:]
+    assert "20 queries in 3 groups ok" in out
 
 
 def test_small_slots_chunk_the_stand_in(hip_lib):

@@ -171,7 +171,9 @@ struct tsh_comm {
   uint8_t *h_res_mine = nullptr, *h_res_all = nullptr, *d_res_mine = nullptr, *d_res_all = nullptr;
   size_t res_cap = 0;  // bytes of one rank's result slice
   int64_t *d_agree = nullptr, *h_agree = nullptr;  // (1 + world) x {status, rows of the rank's shard} (allocated with the communicator)
-  int64_t rows_hint = 0;  // largest shard of any rank as of the last agreement: the same number on every rank
+  int64_t scan_bytes_hint = 0;  // bytes one query's scan reads on the largest shard of any rank, as of the last agreement:
+                                // the same number on every rank (a rank's own handle may be bad: nothing rank-local may
+                                // decide how a call is cut into groups)
   uint32_t tag_seq = 0;  // generation of this rank's blocks: one per window of a call (the same on every rank)
   uint64_t exchanges = 0;  // block all-gathers enqueued so far
   bool timed_now = false;  // the one in flight carries ev_t[0] / ev_t[1]
@@ -204,11 +206,12 @@ int comm_allgather_host(tsh_comm *c, const void *h_send, void *h_recv, size_t by
 }
 
 // every rank says whether its part of a step that may fail locally (allocations) worked; all ranks get the
-// same answer.  Collective.  The same exchange tells every rank how many rows the largest shard holds (rows_hint:
-// what the group schedule of later calls is sized by -- identical on every rank, because it only changes here).
+// same answer.  Collective.  The same exchange tells every rank how many bytes a scan of the largest shard reads
+// (scan_bytes_hint: what the group schedule of later calls is sized by -- identical on every rank, because it only
+// changes here).
 int comm_agree(tsh_comm *c, int local_rc, int64_t local_rows) {
   if (c->world == 1) {
-    c->rows_hint = local_rows;
+    c->scan_bytes_hint = local_rows;
     return local_rc;
   }
   c->h_agree[0] = local_rc;
@@ -227,7 +230,7 @@ int comm_agree(tsh_comm *c, int local_rc, int64_t local_rows) {
   }
   int64_t rows = 0;
   for (int r = 0; r < c->world; ++r) rows = std::max(rows, all[2 * r + 1]);
-  c->rows_hint = rows;
+  c->scan_bytes_hint = rows;
   if (local_rc != TSH_OK) return local_rc;
   for (int r = 0; r < c->world; ++r)
     if (all[2 * r] != TSH_OK)
@@ -692,11 +695,11 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
   // call (whole groups; 4096 queries = 25 MB at k = 100)
   const int32_t Gmax = c->group > 0 ? std::min(c->group, nq) : sharded_group_max(nq);
   const int32_t win_cap = std::min(nq, std::max(Gmax, SHARDED_WINDOW));
-  int64_t my_rows = 0;
+  int64_t my_rows = 0;  // (bytes one scan of this rank's shard reads: what the ranks tell each other)
   if (local_rc == TSH_OK) {
     Shard *s0 = shard->shards[0].get();
     std::shared_lock<RwLock> sl = share(shard, s0);
-    my_rows = s0->rows;
+    my_rows = s0->rows * s0->ld * 4;
   }
   bool grew = false;
   const double t_in = now_us();
@@ -721,8 +724,7 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
   if (c->group > 0) {
     for (int32_t q = 0; q < nq; q += Gmax) sizes.push_back(std::min(Gmax, nq - q));
   } else {
-    const double scan_us = (double)c->rows_hint * (double)round_up(std::max(dim, 1), 4) * 4.0 / 6.5e6;  // (dim: same on every rank by contract)
-    sharded_schedule(nq, scan_us, &sizes);
+    sharded_schedule(nq, (double)c->scan_bytes_hint / 6.5e6, &sizes);
   }
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   size_t gi = 0;  // next group
