@@ -242,7 +242,10 @@ def test_per_row_band_of_the_fp16_keys(hip_lib, oracle_mod, metric, d):
     rng = np.random.default_rng(77 + 10 * metric + d)
     q = _patterned(rng, d, 2, up=False)
     base = np.stack([_patterned(rng, d, 2, up=bool(i & 1)) for i in range(4096)])
-    scale = np.ldexp(1.0, -rng.integers(0, 5, size=len(base))).astype(np.float32)  # 1, 1/2 ... 1/16: exact, pattern kept
+    # 1, 1/2 ... 1/16 (exact, the rounding pattern survives), and a tail down to 2^-26 of the longest row: those rows'
+    # elements sit in fp16's subnormal steps, which are absolute -- the shared term of the band has to carry them
+    expo = np.where(rng.random(len(base)) < 0.8, rng.integers(0, 5, size=len(base)), rng.integers(5, 27, size=len(base)))
+    scale = np.ldexp(1.0, -expo).astype(np.float32)
     rows = base * scale[:, None]
     others = [_patterned(rng, d, 2, up=True) for _ in range(3)]
     exact = _exact_keys(rows, q, metric)

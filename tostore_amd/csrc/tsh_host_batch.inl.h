@@ -254,14 +254,17 @@ bool batch_delta2(const Shard *s, int kernel, double qn2, float *out_delta2, flo
     const double hld = hld_f16(s), c = (hld + 12.0) * u2;
     const double e_op = 9.765625e-04 * (1.0 + 0.001) + 4.76837158203125e-07 + std::sqrt(hld) * 9.3e-10;
     const double pq = qn * (1.0 + 9.765625e-04);
+    // (the fp16 subnormal steps are ABSOLUTE -- 2^-30 of the largest operand value, whatever the row's own norm: a short
+    // row's small elements sit in them -- so that part of e_op goes with max|v| into the shared term)
+    const double sub = std::sqrt(hld) * 9.3e-10 * qn * vmax;
     if (s->metric == TSH_METRIC_L2) {
       const double A = qn * qn + vmax * vmax, kmax = 1.01 * (qn + vmax) * (qn + vmax);
       alpha = (2.0 * e_op * qn + 2.0 * c * pq) / (1.0 - c);
-      delta = c * A + 14.0 * u2 * A + 8.0 * u2 * kmax;
+      delta = c * A + 14.0 * u2 * A + 8.0 * u2 * kmax + 2.0 * sub;
     } else {
       const double kmax = 1.01 * qn * vmax;
       alpha = (e_op * qn + c * pq) / (1.0 - c);
-      delta = 6.0 * u2 * qn * vmax + 8.0 * u2 * kmax;
+      delta = 6.0 * u2 * qn * vmax + 8.0 * u2 * kmax + sub;
     }
     alpha *= 1.0 + 1e-6;
   } else if (s->metric == TSH_METRIC_IP) delta = gam * qn * vmax;
