@@ -168,7 +168,31 @@ static void test_one_worker() {
   puts("ok one_worker");
 }
 
+// the group schedule of a sharded call, printed for tests/test_host_sync.py to hold bench.py's mirror of it to
+static void print_schedules() {
+  const int nqs[] = {1, 2, 7, 8, 9, 16, 20, 37, 64, 100, 128, 129, 300, 511, 512, 1000, 5000};
+  const double bytes[] = {0.0, 5.0e6, 3.0e7, 2.05e8, 3.84e8, 3.072e9, 7.68e9};
+  for (int nq : nqs)
+    for (double b : bytes) {
+      std::vector<int32_t> sizes;
+      tsh::sharded_schedule(nq, b / 6.5e6, &sizes);
+      printf("schedule %d %.0f :", nq, b);
+      int sum = 0, mx = 0;
+      for (int32_t g : sizes) {
+        printf(" %d", g);
+        sum += g;
+        mx = g > mx ? g : mx;
+      }
+      printf("\n");
+      if (sum != nq || mx > tsh::sharded_group_max(nq)) {
+        fprintf(stderr, "schedule of %d queries: sum %d, largest group %d > %d\n", nq, sum, mx, tsh::sharded_group_max(nq));
+        exit(1);
+      }
+    }
+}
+
 int main() {
+  print_schedules();
   test_ticket_holder_passes_waiting_writer();
   test_rwlock_exclusion_stress();
   test_pool_runs_every_item_once();

@@ -20,3 +20,16 @@ def test_host_sync_cpp(tmp_path):
     sys.stderr.write(r.stderr)
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("ok ") == 6
+    # the library's group schedule (sharded_schedule) and bench.py's mirror of it, which the bench line reports
+    sys.path.insert(0, ROOT)
+    import bench
+
+    n = 0
+    for line in r.stdout.splitlines():
+        if line.startswith("schedule "):
+            head, _, sizes = line.partition(":")
+            _, nq, nbytes = head.split()
+            rows = int(float(nbytes)) // (768 * 4)  # library_schedule takes rows x dim: bytes = rows * ld * 4
+            assert bench.library_schedule(int(nq), rows, 768) == [int(x) for x in sizes.split()], line
+            n += 1
+    assert n == 17 * 7

@@ -3,8 +3,10 @@
 // tests/test_host_sync.py can compile and exercise it with g++ on a machine without a GPU.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -371,6 +373,39 @@ class ShardWorkers {
   std::mutex owner_;
   std::vector<std::unique_ptr<Slot>> slots_;
 };
+
+// ---- how tsh_search_sharded cuts a call into groups (tsh_host_comm.inl.h) --------------------------------------
+constexpr int32_t SHARDED_WINDOW = 4096;  // queries of a call whose blocks this rank keeps at once
+// largest group any schedule of an nq-query call can contain (what the buffers are sized for: capacities must not
+// depend on anything a rank knows alone)
+inline int32_t sharded_group_max(int32_t nq) {
+  if (nq >= 512) return 256;
+  if (nq > 128) return 64;
+  return std::max(nq, 1);
+}
+// Queries per exchange, group after group.  The scans of a call run as ONE pipeline whatever the groups are, so a
+// group costs its exchange only (collective latency + copy + merge: ~0.1 ms): hidden behind the scans of the groups
+// after it, exposed for the LAST group.  Up to 128 queries the groups therefore shrink -- half of what is left each
+// time, never below what it takes to hide an exchange (scan_us: one query's scan on the largest shard, from the
+// rows the ranks told each other at their last agreement) nor below four, the rest in one piece once it is that
+// small: 20 queries on 125 k x 768 shards go as 10 + 5 + 5, on 10 k-row shards (a scan is shorter than any exchange)
+// as one group.  Bigger calls go to the matrix cores, which want big uniform groups.
+inline void sharded_schedule(int32_t nq, double scan_us, std::vector<int32_t> *sizes) {
+  sizes->clear();
+  if (nq > 128) {
+    const int32_t G = sharded_group_max(nq);
+    for (int32_t q = 0; q < nq; q += G) sizes->push_back(std::min(G, nq - q));
+    return;
+  }
+  const double exchange_us = 150.0;
+  const int32_t g_min = (int32_t)std::min(128.0, std::max(4.0, std::ceil(exchange_us / std::max(scan_us, 1.0))));
+  int32_t rem = nq;
+  while (rem > 0) {
+    const int32_t g = rem < 2 * g_min ? rem : std::max(g_min, (rem + 1) / 2);
+    sizes->push_back(g);
+    rem -= g;
+  }
+}
 
 // One persistent helper thread that runs one job at a time (the sharded search's look-ahead: group g + 1 is scanned
 // while the caller exchanges and merges group g).  post() hands it a job, wait() returns when that job is done.
