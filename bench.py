@@ -601,13 +601,17 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
         # which kernel scanned: tsh_counters says (selective masks are scanned as a compacted list of row ids)
         listed = c1.get("list_scans", 0) - c0.get("list_scans", 0)
         scans = c1["scan_launches"] - c0["scan_launches"]
+        exact = c1.get("exact_scans", 0) - c0.get("exact_scans", 0)
         kernel = "tsh::scan_list_kernel" if listed > 0 and listed >= scans else \
                  ("tsh::scan_kernel<MASKED>" if listed == 0 else "tsh::scan_list_kernel / tsh::scan_kernel<MASKED>")
+        if exact > 0 and exact >= scans:  # few enough kept rows: their exact f64 sums in one launch, no f32 keys
+            kernel = "tsh::exact_scan_kernel (+ exact_select_kernel: two dispatches per query)"
         useful = float(kept) * d * 4 + (4.0 * kept if listed > 0 else n / 8)  # (the list's ids instead of the mask's words)
         ent = {"value": cnt / el, "unit": "queries/s", "ms_per_step": el / cnt * 1e3, "kept_rows": kept, "mask": kind,
                "roofline": {"bound": "hbm", "achieved": useful / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": useful / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": kernel, "kernel_us": scan_us, "list_scans": int(listed), "scan_launches": int(scans),
+                            "kernel": kernel, "kernel_us": scan_us, "list_scans": int(listed), "exact_scans": int(exact),
+                            "scan_launches": int(scans),
                             "kernel_us_source": "HIP events around back-to-back launches of the one kernel (tsh_bench_scan)",
                             "algorithmic_bytes_per_launch": useful},
                "fallback_searches": c1["fallback_searches"] - c0["fallback_searches"]}

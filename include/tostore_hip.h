@@ -40,7 +40,8 @@ extern "C" {
 /* 3: tsh_counters grew again (batch_plane_fallbacks, batch_scan_fallbacks); tsh_comm_get_timeline / tsh_comm_timeline
  * came with it.
  * 4: tsh_search_shard_begin / _progress / _end (the progressive shard search tsh_search_sharded is now built on);
- *    tsh_counters.list_scans, tsh_comm_timeline.pre_enqueue_us; TSH_OPT_EXCHANGE_AHEAD, TSH_OPT_TEST_HOOKS. */
+ *    tsh_counters.list_scans, tsh_counters.exact_scans (the reserved slot of version 2), tsh_comm_timeline.pre_enqueue_us;
+ *    TSH_OPT_EXCHANGE_AHEAD, TSH_OPT_EXACT_SCAN_ROWS, TSH_OPT_TEST_HOOKS. */
 
 /* status codes */
 #define TSH_OK 0
@@ -86,7 +87,10 @@ typedef struct tsh_counters {
   int32_t batch_kernel_last; /* TSH_OPT_BATCH_KERNEL variant the last batched search ran (0/1/2; -1 none yet) */
   int32_t quarantined_rows;  /* live rows outside the f32 error model (non-finite or > 1e15 elements; cosine: norm
                                 below 2^-50) that are kept out of the scan and re-ranked exactly on every search */
-  int64_t fused_launches;    /* reserved (0): counted a single-dispatch experiment of round 2 that was removed */
+  int64_t exact_scans;       /* of scan_launches: searches with at most TSH_OPT_EXACT_SCAN_ROWS rows to look at (a
+                                selective mask's list, a small index or shard), answered by the exact f64 sums of all of
+                                them and a select among the exact distances -- two dispatches, no f32 keys, no band.
+                                (The slot was "fused_launches", reserved and 0, before ABI 4.) */
   /* A batched call whose device allocations fail degrades instead of failing (results are identical on every path): */
   int64_t batch_plane_fallbacks; /* calls that could not allocate the fp16 / bf16x3 copy of the rows and scored
                                     their queries with the f32 MFMA kernel on the rows as stored (no copy needed) */
@@ -492,6 +496,13 @@ int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, 
  * LOSES 3-6 % (the early packets on the communicator's queue run late), hence off by default;
  * kept for hosts whose collectives are costlier to launch.  Same value on every rank. */
 #define TSH_OPT_EXCHANGE_AHEAD 3
+/* TSH_OPT_EXACT_SCAN_ROWS (default and maximum 16384; 0 = never): a single-query search that has at most this many
+ * rows to look at -- the kept rows of a selective row mask, or all rows of a small index or shard -- computes the exact
+ * f64 sums of ALL of them in one launch (the re-rank's arithmetic, one wave per few rows) and selects the k smallest
+ * exact distances in a second: the f32 pre-filter has nothing to spare there, and its three dependent dispatches
+ * (scan, select, re-rank) are what such a search waits for.  Results are identical either way (the candidates are then
+ * exactly the k winners); counted in tsh_counters.exact_scans. */
+#define TSH_OPT_EXACT_SCAN_ROWS 4
 /* TSH_OPT_TEST_HOOKS (process-wide; idx is ignored and may be NULL): value TSH_TEST_HOOKS_MAGIC switches the
  * library's TEST hooks on, 0 off.  Only then does it read the environment variables that change what it loads or make
  * it fail on purpose -- TSH_RCCL_LIB (a stand-in for librccl: tests/fake_rccl), TSH_TEST_FAIL_ALLOC_OVER (device

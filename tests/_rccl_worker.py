@@ -125,6 +125,7 @@ same = np.tile(rows[:1], (n, 1))
 idx = HipVectorIndex(d, 0, capacity_rows=hi - lo, shard_device=0, row_base=lo)
 idx.append(lo, same[lo:hi] if rank == world - 1 else rows[lo:hi])  # only the last shard is all ties
 idx.set_batch_min_nq(0)
+idx.set_exact_scan_rows(0)  # (a shard this small would answer from its exact sums: k rows, nothing to retry)
 cs = CommSearcher(idx, world, rank, share_id("ties"), 0)
 ref_rows = rows.copy()
 lo_last = (world - 1) * per

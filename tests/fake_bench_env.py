@@ -12,7 +12,7 @@ class FakeIndex:
         self.o, self.dim, self.metric, self.rows, self.lo = oracle, d, metric, np.ascontiguousarray(rows), lo
         self.c = {"searches": 0, "scan_launches": 0, "batch_launches": 0, "fallback_searches": 0,
                   "candidates_total": 0, "scan_us_sum": 0.0, "scan_us_samples": 0, "batch_kernel_last": -1,
-                  "list_scans": 0}
+                  "list_scans": 0, "exact_scans": 0}
         self.min_nq, self.kernel, self.closed = 1, 3, False
         self.pending, self.next_ticket = {}, 0
 

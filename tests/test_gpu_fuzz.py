@@ -78,6 +78,14 @@ def _one_case(oracle, rng, case):
                 thr = float(ed[len(ed) // 2])
         if rng.random() < 0.5:
             idx.set_batch_min_nq(0)
+        # most of these indexes are small enough for the exact path (tsh_exact.hip.h): every third case keeps to the
+        # f32 pre-filter, one in five caps the exact path somewhere inside the case's size (no draw from rng: the
+        # established cases stay what they were)
+        cno = int(str(case).split("/")[-1])
+        if cno % 3 == 2:
+            idx.set_exact_scan_rows(0)
+        elif cno % 5 == 1:
+            idx.set_exact_scan_rows(max(1, n // 2))
         ids, dist, cnt = idx.search(qs, k, thr, keep)
         for i in range(nq):
             eids, edist = oracle.search_exhaustive(rows, qs[i], metric, k, thr, eff_mask)
@@ -209,6 +217,7 @@ def _sequence_case(oracle, rng, case, steps=25):
             if op == "option":
                 idx.set_batch_kernel(int(rng.integers(0, 4)))
                 idx.set_batch_min_nq(int(rng.choice([0, 1, 2, 8])))
+                idx.set_exact_scan_rows(int(rng.choice([0, 700, 16384])))
                 continue
             eff = present & alive
             keep = None

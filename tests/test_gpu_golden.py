@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("scan_path")]  # small shapes: exact sums AND the f32 pre-filter (conftest)
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 L2, IP, COS = 0, 1, 2
 

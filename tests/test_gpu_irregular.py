@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("scan_path")]  # small shapes: exact sums AND the f32 pre-filter (conftest)
 L2, IP, COS = 0, 1, 2
 METRICS = [L2, IP, COS]
 

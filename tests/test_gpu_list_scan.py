@@ -4,7 +4,7 @@ tested with, at selectivities where the list path runs (below one kept row in 24
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("scan_path")]  # small shapes: exact sums AND the f32 pre-filter (conftest)
 
 
 def _check(idx, oracle_mod, rows, qs, metric, k, mask, thr=None, base=0):
@@ -23,7 +23,7 @@ def _local(mask, base, n):
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("d", [100, 384, 768, 1000, 1536, 2048])
-def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d):
+def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d, scan_path):
     from tostore_amd import HipVectorIndex
 
     rng = np.random.default_rng(d + metric)
@@ -44,12 +44,16 @@ def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d):
             assert c1["fallback_searches"] == c0["fallback_searches"]
             # the path under test is the one that ran: every one of these scans took the compacted list
             assert c1["list_scans"] - c0["list_scans"] == c1["scan_launches"] - c0["scan_launches"] == len(qs) + 1
-        # a mild mask (one kept row in 10 > 1 in 24) walks the tiles: no list scan
+            # ... as f32 keys of the listed rows, or (the product's choice for so few rows) as their exact sums
+            assert c1["exact_scans"] - c0["exact_scans"] == (len(qs) + 1 if scan_path == "exact" else 0)
+        # a mild mask (one kept row in 10 > 1 in 24) walks the tiles: no list scan -- unless its 4000 kept rows are few
+        # enough for the exact path, which reads nothing but its list at any selectivity
         mask = np.packbits(rng.random(n) < 0.1, bitorder="little")
         c0 = idx.counters()
         _check(idx, oracle_mod, rows, qs[:2], metric, k, mask)
         c1 = idx.counters()
-        assert c1["list_scans"] == c0["list_scans"] and c1["scan_launches"] - c0["scan_launches"] == 2
+        assert c1["scan_launches"] - c0["scan_launches"] == 2
+        assert c1["list_scans"] - c0["list_scans"] == c1["exact_scans"] - c0["exact_scans"] == (2 if scan_path == "exact" else 0)
         # fewer kept rows than k, and a threshold
         mask = np.zeros(n, bool)
         mask[[5, 77, 20_000, n - 1]] = True
@@ -60,7 +64,7 @@ def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d):
         _check(idx, oracle_mod, rows, qs[:3], metric, k, mask, thr)
 
 
-def test_tombstones_ties_ranges_and_shards(hip_lib, oracle_mod):
+def test_tombstones_ties_ranges_and_shards(hip_lib, oracle_mod, scan_path):
     from tostore_amd import HipVectorIndex
 
     rng = np.random.default_rng(3)
@@ -98,7 +102,11 @@ def test_tombstones_ties_ranges_and_shards(hip_lib, oracle_mod):
         ids, dist, cnt = idx.search(rows[0], 10, None, m)
         want = np.flatnonzero(keep)[:10]
         assert cnt[0] == 10 and ids[0].tolist() == want.tolist() and np.all(dist[0] == 0.0)
-        assert idx.counters()["fallback_searches"] > c0["fallback_searches"]
+        if scan_path == "prefilter":
+            assert idx.counters()["fallback_searches"] > c0["fallback_searches"]
+        else:  # 2000 kept rows: their exact sums, the ten lowest ids of the tie
+            assert idx.counters()["fallback_searches"] == c0["fallback_searches"]
+            assert idx.counters()["exact_scans"] == c0["exact_scans"] + 1
 
 
 def test_bench_hook_measures_the_list_kernel(hip_lib):

@@ -9,7 +9,7 @@ import math
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("scan_path")]  # small shapes: exact sums AND the f32 pre-filter (conftest)
 
 L2, IP, COS = 0, 1, 2
 METRICS = [L2, IP, COS]
@@ -127,7 +127,7 @@ def test_ties_duplicates_and_zero_rows(hip_lib, oracle_mod, metric):
 
 
 @pytest.mark.parametrize("metric", METRICS)
-def test_all_rows_identical(hip_lib, oracle_mod, metric):
+def test_all_rows_identical(hip_lib, oracle_mod, metric, scan_path):
     from tostore_amd import HipVectorIndex
 
     d = 128
@@ -136,7 +136,11 @@ def test_all_rows_identical(hip_lib, oracle_mod, metric):
         idx.append(0, rows)
         q = _prep_query(oracle_mod, _mk(1, d, 10)[0], metric)
         _check(oracle_mod, idx, rows, q, metric, 100, tag="identical")
-        assert idx.counters()["fallback_searches"] >= 1  # the wide-band path ran, still on the GPU
+        c = idx.counters()
+        if scan_path == "prefilter":
+            assert c["fallback_searches"] >= 1  # the wide-band path ran, still on the GPU
+        else:  # 5000 rows: the exact sums of all of them, the k lowest ids of the tie -- no band to overflow
+            assert c["fallback_searches"] == 0 and c["exact_scans"] == 1 and c["candidates_total"] == 100
 
 
 @pytest.mark.parametrize("metric", METRICS)

@@ -205,6 +205,12 @@ class HipVectorIndex:
         queries per call on.  Results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 1, int(nq)))
 
+    def set_exact_scan_rows(self, rows: int) -> None:
+        """Single-query searches with at most `rows` rows to look at (a selective mask's kept rows, a small index) take
+        the exact sums of all of them and select among the exact distances (two dispatches, no f32 pre-filter):
+        0 never, default and maximum 16384.  Results are identical."""
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_EXACT_SCAN_ROWS, int(rows)))
+
     def set_batch_kernel(self, kind: int) -> None:
         """Batched pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (default: f16 for cosine, bf16x3
         otherwise).  Results are identical."""

@@ -1,0 +1,473 @@
+// tsh_exact.hip.h -- short searches answered in two dispatches (gfx950, wave = 64).
+//
+// A search that has only a few thousand rows to look at -- a selective row mask scanned as a list (config C5, keep
+// 1 %: 10 k of 1 M rows), a small index (config C1: 10 k x 128), a small shard -- is not bound by HBM: the scan of a
+// 1 % mask is 9-10 us, and the select (15 us, one workgroup) and the f64 re-rank (18 us) behind it are what the caller
+// waits for.  The f32 keys exist to spare the f64 arithmetic on rows that cannot win; below EX_MAX_ROWS rows there is
+// nothing to spare -- the exact sums of ALL of them take one launch of the re-rank's own arithmetic, spread over every
+// SIMD of the device:
+//   E1 exact_scan_kernel    a wave owns eight entries (rows of the list, or of the shard), eight lanes each: a lane
+//                           forms the terms of its sixteen elements of every 128-element piece of its row (every term is
+//                           one IEEE operation, so who forms it does not matter), and the row's sum walks through its
+//                           eight lanes strictly in element order 0..d-1 -- the reference's loop
+//                           (ngh_graph_engine.dart:920-946), the oracle's vs_exact_sums, rerank_kernel's arithmetic bit
+//                           for bit.  Then the distance itself (L2 sqrt, IP negate, cosine 1 - dot / (|q| |v|) with
+//                           similarity 0 for a non-positive denominator; f64 sqrt and divide are correctly rounded on
+//                           the device as on the host) as a double.compareTo order key per entry.
+//   E2 exact_select_kernel  one workgroup: the k smallest (key, position) pairs -- position = place in the ascending
+//                           list = id order, the finaliser's tie-break -- by a radix select over the 64-bit keys held
+//                           in registers (byte rounds from the first byte in which the keys differ; two more rounds
+//                           over the positions only when the k-th key is tied beyond k), and their (id, s0, s1)
+//                           entries + the block header where select_kernel + rerank_kernel leave theirs.  Exactly
+//                           min(k, live rows) entries: no band, no overflow, no fallback.
+// Everything after that (threshold, distance, sort, cut: finalize_query; the merge of shard blocks) is unchanged: it
+// receives a candidate block like any other, only one without a row that cannot be a result.
+#pragma once
+
+#include "tsh_kernels.hip.h"
+
+namespace tsh {
+
+constexpr int EX_MAX_ROWS = 16384;  // entries E2 selects among: 16 per thread of its 1024
+constexpr int EX_R = 8;             // entries per wave: eight lanes each
+constexpr int EX_C = 128;           // elements of a row per piece: sixteen per lane
+constexpr int EX_D = 6;             // pieces of a row in flight at once (768 elements; 96 registers)
+constexpr uint64_t XKEY_DEAD = ~0ull;       // no row here (list padding, tombstone, masked out)
+constexpr uint64_t XKEY_NAN = ~0ull - 1ull;  // a live row whose distance is NaN (double.compareTo: greatest, all equal)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct ExactArgs {
+  const float *rows;     // n x ld
+  const float *query;    // ld floats on the device; NULL: the query rides in the kernel-argument segment (ExactArgsQ::q)
+  float *query_out;      // nullable: workgroup 0 leaves the query here (the quarantine kernels read it)
+  const uint64_t *live;  // bit r of word t = row t*64+r present & not deleted & not quarantined
+  const uint64_t *mask;  // nullable: caller's keep mask, same layout (entries by row; a list is the mask already)
+  const uint32_t *list;  // nullable: local row ids of the entries, ascending, padded with 0xFFFFFFFF
+  uint64_t *xkey;        // per entry: order key of its distance (XKEY_DEAD: no row)
+  double *xsum;          // per entry: s0, s1
+  double sqrt_mag_a;     // cosine: sqrt of the query's sum of squares (element order, f64: query_mag_a)
+  int64_t ld;            // floats per row, multiple of 4
+  int64_t n_rows;        // rows of the shard
+  int32_t n_entries;
+  int32_t dim;
+};
+struct ExactArgsQ {
+  ExactArgs a;
+  float q[SCAN_Q_INLINE];
+};
+static_assert(sizeof(ExactArgsQ) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__device__ __forceinline__ uint64_t xkey_of(double d) {  // tsh_lib.hip dart_order_key, NaN one below the dead marker
+  if (d != d) return XKEY_NAN;
+  const uint64_t b = (uint64_t)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// a 64-bit value one lane to the right / seven lanes to the left within its row of sixteen lanes (DPP: no LDS)
+__device__ __forceinline__ double ex_dpp_shr1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ex_dpp_shl7(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x107 /* row_shl:7 */, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x107, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// E1.  A wave = eight entries x eight slots: lane 8 r + g holds, of every 128-element piece of row r, the sixteen
+// elements [16 g, 16 g + 16) -- it loads them (64 contiguous bytes), forms their terms in f64 (one IEEE operation
+// each) and keeps them in registers.  A row's sum is ONE chain of dependent adds in element order that walks through
+// its eight lanes: slot 0 adds its sixteen terms, the partial sum moves one lane to the right (DPP), slot 1 adds its
+// sixteen, ... slot 7, and seven lanes back to the left for the next piece.  Every lane executes every step (lanes
+// that do not hold the live partial sum add their terms to a value nobody reads), so the instruction stream is d adds
+// per row long whatever the lane -- the same as one lane walking the row alone, but the eight rows of a wave and the
+// waves of a SIMD run side by side, nothing goes through LDS (a first version staged the terms there and its chain
+// lanes' two-element reads kept the CU's one LDS port busy: 29 us for 16 k rows of 768 against 13 for the f32 scan),
+// and all of a row's pieces are in flight at once (EX_D: the rows of a selective mask are a page each; a piece at a
+// time waited out HBM + translation six times per row).
+template <int METRIC>
+__global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
+#pragma clang fp contract(off)
+  const ExactArgs &a = aq.a;
+  const float *qsrc = a.query;
+  if (!qsrc) {
+    typedef const char __attribute__((address_space(4))) * karg_ptr;
+    qsrc = (const float *)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(ExactArgsQ, q));
+  }
+  const int lane = threadIdx.x;
+  const int r = lane >> 3, g = lane & 7;
+  const int ld = (int)a.ld, dim = a.dim;
+  const int64_t e = (int64_t)blockIdx.x * EX_R + r;  // this lane's entry
+  if (a.query_out && blockIdx.x == 0)
+    for (int i = lane; i < ld; i += 64) a.query_out[i] = qsrc[i];
+  uint32_t my_id = 0xFFFFFFFFu;
+  bool alive = false;
+  if (e < a.n_entries) {
+    my_id = a.list ? a.list[e] : (uint32_t)e;
+    if (my_id != 0xFFFFFFFFu && (int64_t)my_id < a.n_rows) {
+      alive = (a.live[my_id >> 6] >> (my_id & 63)) & 1ull;
+      if (alive && a.mask) alive = (a.mask[my_id >> 6] >> (my_id & 63)) & 1ull;
+    }
+  }
+  const uint64_t am = __ballot(alive);
+  const bool writer = g == 7 && e < a.n_entries;  // where a row's chain ends
+  if (!am) {  // wave-uniform: nothing to read
+    if (writer) a.xkey[e] = XKEY_DEAD;
+    return;
+  }
+  // a dead entry's lanes walk the wave's first live row (valid memory; the result is dropped)
+  const uint32_t use_id = alive ? my_id : (uint32_t)__shfl((int)my_id, __builtin_ctzll(am));
+  const float *rp = a.rows + (int64_t)use_id * a.ld;
+  const int npiece = (dim + EX_C - 1) / EX_C;
+  // rows are zero-padded to ld (a multiple of 4) and so is the query: elements in [dim, ld) are terms of +0.0, and
+  // adding +0.0 changes no sum (a sum that starts at +0.0 is never -0.0).  Past ld a lane re-reads the row's first 16
+  // bytes and its terms are set to +0.0.
+  f32x4 raw[EX_D][4];
+  auto fetch = [&](f32x4 (&dst)[4], int p) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int o = p * EX_C + 16 * g + 4 * c;
+      dst[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rp + (o < ld ? o : 0)));
+    }
+  };
+  auto fetch_group = [&](int p0) {
+#pragma unroll
+    for (int dd = 0; dd < EX_D; ++dd)
+      if (p0 + dd < npiece) fetch(raw[dd], p0 + dd);  // wave-uniform
+  };
+  double s0 = 0.0, s1 = 0.0;
+  auto piece = [&](const f32x4 (&in)[4], int p, bool group_done) {
+    double t0[16], t1[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int o = p * EX_C + 16 * g + 4 * c;
+      const bool ok = o < ld;
+      const f32x4 qf = *reinterpret_cast<const f32x4 *>(qsrc + (ok ? o : 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double qd = (double)qf[i], bd = (double)in[c][i];
+        double w;
+        if (METRIC == METRIC_L2) {
+          const double df = qd - bd;
+          w = df * df;
+        } else {
+          w = qd * bd;
+        }
+        t0[4 * c + i] = ok ? w : 0.0;
+        if (METRIC == METRIC_COS) t1[4 * c + i] = ok ? bd * bd : 0.0;
+      }
+    }
+    if (group_done) fetch_group(p + 1);  // (the group's registers are free: the next group's loads, behind these terms)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s0 = s0 + t0[i];
+        if (METRIC == METRIC_COS) s1 = s1 + t1[i];
+      }
+      if (step < 7) {
+        s0 = ex_dpp_shr1(s0);
+        if (METRIC == METRIC_COS) s1 = ex_dpp_shr1(s1);
+      }
+    }
+    if (p + 1 < npiece) {  // back to slot 0 for the next piece (wave-uniform)
+      s0 = ex_dpp_shl7(s0);
+      if (METRIC == METRIC_COS) s1 = ex_dpp_shl7(s1);
+    }
+  };
+  fetch_group(0);
+  for (int p0 = 0; p0 < npiece; p0 += EX_D) {
+#pragma unroll
+    for (int dd = 0; dd < EX_D; ++dd)
+      if (p0 + dd < npiece) piece(raw[dd], p0 + dd, dd == EX_D - 1 && p0 + EX_D < npiece);  // wave-uniform
+  }
+  if (writer) {
+    double d;
+    if (METRIC == METRIC_L2) {
+      d = __builtin_sqrt(s0);
+    } else if (METRIC == METRIC_IP) {
+      d = -s0;
+    } else {
+      const double denom = a.sqrt_mag_a * __builtin_sqrt(s1);
+      const double sim = denom > 0 ? s0 / denom : 0;
+      d = 1.0 - sim;
+    }
+    a.xkey[e] = alive ? xkey_of(d) : XKEY_DEAD;
+    *reinterpret_cast<f64x2 *>(a.xsum + 2 * e) = f64x2{s0, METRIC == METRIC_COS ? s1 : 0.0};
+  }
+}
+
+struct ExactSelArgs {
+  const uint64_t *xkey;
+  const double *xsum;
+  const uint32_t *list;  // nullable (entry = row)
+  BlockHeader *hdr;
+  BlockHeader *hdr_host;  // nullable
+  BlockEntry *out;
+  int64_t row_base;
+  int64_t shard_rows;
+  int32_t n_entries;
+  int32_t k;
+  int32_t cap;  // >= k
+  int32_t metric;
+  uint32_t tag;
+};
+constexpr uint32_t FLAG_EXACT = 8u;  // informational: the block holds the exact top k (E1 + E2), not a band's candidates
+
+// one more key into a 256-bin histogram in LDS.  Keys agree in their upper bytes and in whole waves (a corpus's
+// distances share sign and exponent): up to two values that eight or more lanes name are added once per wave, the
+// rest lane by lane.  (Wave-uniform values travel through scalar registers: a first version took them by
+// ds_bpermute, an LDS round trip per key and value, and the select ran 22-31 us.)
+__device__ __forceinline__ void ex_hist_add(uint32_t *hist, bool in, uint32_t b, int lane) {
+  uint64_t act = __ballot(in);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (__popcll(act) < 8) break;  // wave-uniform
+    const int first = __builtin_ctzll(act);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, first);
+    const uint64_t m = __ballot(in && b == b0);
+    if (__popcll(m) < 8) break;
+    if (lane == first) atomicAdd(&hist[b0], (uint32_t)__popcll(m));
+    if (b == b0) in = false;
+    act &= ~m;
+  }
+  if (in) atomicAdd(&hist[b], 1u);
+}
+
+constexpr int EX_FIN = 64;  // the select finishes by ranking once at most this many (key, position) pairs are left
+
+// OR over the wave's lanes (idempotent, so every DPP step may run on all rows; no LDS): -> wave-uniform
+__device__ __forceinline__ uint32_t ex_wave_or(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xF, 0xF, true);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xF, 0xF, true);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
+  constexpr int NT = 1024, VPT = EX_MAX_ROWS / NT;
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_bin, s_k, s_ties, s_live, s_out, s_nfin, s_P;
+  __shared__ uint32_t s_or[4];  // OR of the live keys (lo, hi) and of their complements (lo, hi)
+  __shared__ unsigned long long s_K;
+  __shared__ unsigned long long s_fkey[EX_FIN];
+  __shared__ uint32_t s_fpos[EX_FIN];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = a.n_entries;
+#ifdef TSH_PROBES  // phase stamps (100 MHz) in the header's unused fields: tools/r5_exact_try.sh
+  const uint64_t pt0 = wall_clock64();
+  uint64_t pt1 = 0, pt2 = 0;
+  uint32_t prounds = 0;
+#endif
+  if (tid < 4) s_or[tid] = 0u;
+  if (tid == 0) {
+    s_live = 0;
+    s_out = 0;
+    s_nfin = 0;
+  }
+  uint64_t key[VPT];
+  uint32_t nlive = 0;  // wave-uniform
+  uint64_t o1 = 0, o0 = 0;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = tid + j * NT;
+    key[j] = i < n ? a.xkey[i] : XKEY_DEAD;
+    const bool lv = key[j] != XKEY_DEAD;
+    nlive += (uint32_t)__popcll(__ballot(lv));
+    if (lv) {
+      o1 |= key[j];
+      o0 |= ~key[j];
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t w0 = ex_wave_or((uint32_t)o1), w1 = ex_wave_or((uint32_t)(o1 >> 32));
+    const uint32_t w2 = ex_wave_or((uint32_t)o0), w3 = ex_wave_or((uint32_t)(o0 >> 32));
+    if (lane == 0 && nlive) {
+      atomicAdd(&s_live, nlive);
+      atomicOr(&s_or[0], w0);
+      atomicOr(&s_or[1], w1);
+      atomicOr(&s_or[2], w2);
+      atomicOr(&s_or[3], w3);
+    }
+  }
+  __syncthreads();
+  const uint32_t live = s_live;
+  const uint32_t k = (uint32_t)a.k;
+  const bool all = live <= k;  // no more live rows than asked for: every one of them
+#ifdef TSH_PROBES
+  pt1 = wall_clock64();
+#endif
+  uint64_t K = 0;              // the k-th smallest key
+  uint32_t P = 0;              // ... and, when by_pos, the last position taken among the rows at that key
+  bool by_pos = false;
+  if (!all) {
+    const uint64_t any1 = ((uint64_t)s_or[1] << 32) | s_or[0], any0 = ((uint64_t)s_or[3] << 32) | s_or[2];
+    const uint64_t diff = any1 & any0;  // bits in which live keys differ
+    // Digits of up to eight bits from the first differing bit down (NOT byte-aligned: a corpus's distances share sign,
+    // exponent and often the first mantissa bits -- aligned to bytes, the first round's keys fell into five bins and
+    // their LDS atomics queued up: 5 us for that one round): `up` = bits at and above it are settled in `prefix`.
+    int up = diff ? 64 - __builtin_clzll(diff) : 0;
+    uint64_t prefix = up >= 64 ? 0ull : (any1 >> up) << up;  // (above `up` every live key has any1's bits)
+    int pos_up = 14;  // then the position's bits (EX_MAX_ROWS = 2^14), only if the k-th key's ties go beyond k
+    uint32_t kk = k, ties = live, pos_prefix = 0;
+    auto member = [&](int j) {  // still in the running: live, and equal to what the rounds so far have settled
+      const uint32_t pos = (uint32_t)(tid + j * NT);
+      if (key[j] == XKEY_DEAD) return false;
+      if (up > 0) return up >= 64 || (key[j] >> up) == (prefix >> up);
+      return key[j] == prefix && (pos >> pos_up) == (pos_prefix >> pos_up);
+    };
+    bool finished = false;
+    while (up > 0 || pos_up > 0) {
+      if (up == 0 && ties == kk) break;  // every row at the k-th key is taken (the usual end without the ranking below)
+      if (ties <= (uint32_t)EX_FIN) {
+        // a handful left (after the first round, usually): wave 0 ranks them -- the kk-th smallest (key, position)
+        // pair among them is the k-th of all
+#pragma unroll
+        for (int j = 0; j < VPT; ++j)
+          if (member(j)) {
+            const uint32_t slot = atomicAdd(&s_nfin, 1u);
+            s_fkey[slot] = key[j];
+            s_fpos[slot] = (uint32_t)(tid + j * NT);
+          }
+        __syncthreads();
+        if (tid < 64) {
+          const uint32_t m = s_nfin;  // == ties
+          const unsigned long long mk = (uint32_t)lane < m ? s_fkey[lane] : ~0ull;
+          const uint32_t mp = (uint32_t)lane < m ? s_fpos[lane] : 0xFFFFFFFFu;
+          uint32_t rank = 0;
+          for (uint32_t i = 0; i < m; ++i) {
+            const unsigned long long ok = s_fkey[i];
+            const uint32_t op = s_fpos[i];
+            rank += (ok < mk) | ((ok == mk) & (op < mp));
+          }
+          if ((uint32_t)lane < m && rank == kk - 1u) {  // exactly one lane: the pairs are distinct
+            s_K = mk;
+            s_P = mp;
+          }
+        }
+        __syncthreads();
+        K = s_K;
+        P = s_P;
+        by_pos = true;
+        finished = true;
+        break;
+      }
+#ifdef TSH_PROBES
+      ++prounds;
+#endif
+      for (int i = tid; i < 256; i += NT) s_hist[i] = 0u;
+      __syncthreads();
+      const bool on_key = up > 0;
+      const int hi = on_key ? up : pos_up, lo = hi > 8 ? hi - 8 : 0;  // this round's digit: bits [lo, hi)
+      const uint32_t dmask = (1u << (hi - lo)) - 1u;
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        const uint32_t pos = (uint32_t)(tid + j * NT);
+        const uint32_t b = (on_key ? (uint32_t)(key[j] >> lo) : pos >> lo) & dmask;
+        ex_hist_add(s_hist, member(j), b, lane);
+      }
+      __syncthreads();
+      if (tid < 64) {  // wave 0: lane l owns bins 4l .. 4l+3 (block_kth_radix's scan)
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = s_hist[4 * lane + j];
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t u = (uint32_t)__shfl_up((int)incl, d);
+          if (lane >= d) incl += u;
+        }
+        uint32_t below = incl - mine;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (kk > below && kk <= below + c[j]) {  // exactly one (lane, j): 1 <= kk <= number of keys in the round
+            s_bin = (uint32_t)(4 * lane + j);
+            s_k = kk - below;
+            s_ties = c[j];
+          }
+          below += c[j];
+        }
+      }
+      __syncthreads();
+      if (on_key) {
+        prefix |= (uint64_t)s_bin << lo;
+        up = lo;
+      } else {
+        pos_prefix |= s_bin << lo;
+        pos_up = lo;
+        by_pos = true;
+      }
+      kk = s_k;
+      ties = s_ties;
+    }
+    if (!finished) {
+      K = prefix;
+      P = pos_prefix | ((1u << pos_up) - 1u);  // (position bits no round settled: every row of the last bin is taken)
+    }
+  }
+#ifdef TSH_PROBES
+  pt2 = wall_clock64();
+#endif
+  // the entries: (id, s0, s1) of every taken row, in no particular order (the finaliser sorts)
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const uint32_t pos = (uint32_t)(tid + j * NT);
+    const bool take = key[j] != XKEY_DEAD && (all || key[j] < K || (key[j] == K && (!by_pos || pos <= P)));
+    const uint64_t bm = __ballot(take);
+    if (bm) {  // wave-uniform
+      uint32_t base = 0;
+      if (lane == __builtin_ctzll(bm)) base = atomicAdd(&s_out, (uint32_t)__popcll(bm));
+      base = (uint32_t)__shfl((int)base, __builtin_ctzll(bm));
+      if (take) {
+        const uint32_t p = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+        if (p < (uint32_t)a.cap) {
+          const uint32_t row = a.list ? a.list[pos] : pos;
+          const f64x2 sv = *reinterpret_cast<const f64x2 *>(a.xsum + 2 * (int64_t)pos);
+          BlockEntry e;
+          e.id = a.row_base + (int64_t)row;
+          e.s0 = sv.x;
+          e.s1 = sv.y;
+          a.out[p] = e;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    BlockHeader hv;
+    hv.count = s_out;
+    hv.entries = (uint32_t)a.cap;
+    hv.tau_key = KEY_NAN;   // (no f32 keys exist for this block)
+    hv.band_key = KEY_NAN;
+    hv.tiles_hit = 0u;
+#ifdef TSH_PROBES
+    hv.tau_key = (uint32_t)(pt1 - pt0);               // keys in, live count, range
+    hv.band_key = (uint32_t)(pt2 - pt1);              // the select
+    hv.tiles_hit = (uint32_t)(wall_clock64() - pt2);  // the entries
+#endif
+    hv.flags = FLAG_EXACT | (s_out > (uint32_t)a.cap ? FLAG_LIST_OVERFLOW : 0u);  // (cap >= k: never)
+    hv.k = (uint32_t)a.k;
+    hv.metric = (uint32_t)a.metric;
+    hv.row_base = a.row_base;
+    hv.shard_rows = a.shard_rows;
+    hv.pad[0] = hv.pad[2] = hv.pad[3] = 0u;
+#ifdef TSH_PROBES
+    hv.pad[2] = prounds;
+    hv.pad[3] = s_nfin;
+#endif
+    hv.pad[1] = a.tag;
+    *a.hdr = hv;
+    if (a.hdr_host) *a.hdr_host = hv;
+  }
+}
+
+}  // namespace tsh

@@ -32,6 +32,7 @@
 #include "../../include/tostore_hip.h"
 #include "tsh_batch.hip.h"
 #include "tsh_batch_f16.hip.h"
+#include "tsh_exact.hip.h"
 #include "tsh_host_sync.h"
 #include "tsh_kernels.hip.h"
 #include "tsh_launch.h"
@@ -287,6 +288,10 @@ struct Ctx {
   uint32_t *d_big_count = nullptr;
   int64_t big_cap = 0;
   BlockEntry *h_quar = nullptr, *h_quar_dev = nullptr;  // pinned + mapped: sums of the quarantined rows
+  // short searches (tsh_exact.hip.h): per entry the order key of its exact distance and its two f64 sums
+  uint64_t *d_xkey = nullptr;
+  double *d_xsum = nullptr;
+  int64_t x_cap = 0;
   int64_t bytes = 0;
 };
 
@@ -384,6 +389,8 @@ struct Shard {
   std::atomic<int64_t> c_searches{0}, c_scans{0}, c_batches{0}, c_fallbacks{0}, c_cands{0};
   std::atomic<int64_t> c_plane_fallbacks{0}, c_scan_fallbacks{0};  // batched calls degraded by a full device
   std::atomic<int64_t> c_list_scans{0};  // scans of a compacted row list (selective masks)
+  std::atomic<int64_t> c_exact_scans{0};  // searches answered by the exact scan of a few thousand rows (tsh_exact.hip.h)
+  int exact_rows = EX_MAX_ROWS;  // TSH_OPT_EXACT_SCAN_ROWS: searches that look at no more rows than this take that path
   int cus = 0;  // compute units of the shard's device (grid of the persistent key kernels)
   std::atomic<int> f16_strikes{0};      // batched calls in a row whose fp16 bands overflowed many candidate lists
   std::atomic<int> f16_denied_calls{0};  // auto key-kernel choice: bf16x3 instead of fp16 for this many more batched calls
@@ -709,6 +716,8 @@ void ctx_free_all(Ctx *c) {
   hipFree(c->d_big_rows);
   hipFree(c->d_big_entries);
   hipFree(c->d_big_count);
+  hipFree(c->d_xkey);
+  hipFree(c->d_xsum);
 }
 
 int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
@@ -890,6 +899,7 @@ struct Job {
   float eps_rel = 0.f, delta_abs = 0.f;  // this query's error band (for the fallback's own threshold)
   bool force_all = false;
   int32_t list_tiles = 0;  // > 0: a list scan -- the context's keys / gmin are in list order, that many tiles of them
+  bool exact = false;      // answered by exact_scan_kernel + exact_select_kernel: the block is final, no f32 keys exist
   hipStream_t last_stream = nullptr;  // where the job's last kernel was enqueued (ev_done rides on it)
   uint64_t enq_seq = 0;               // ... and its place in the device's enqueue order (DeviceStreams::enq_counter)
   std::vector<uint32_t> quar_sel;  // entries of c->h_quar that belong to this query's candidates
@@ -959,10 +969,15 @@ int ctx_reserve_list(Ctx *c, int64_t padded) {
 // gathers the kept rows, eight per wave, instead of walking tiles that are mostly dead (tsh_kernels.hip.h).  The list
 // pays below one kept row in list_div (tools/r4_list_probe.sh); TSH_LIST_DIV=0 switches it off.  -> ids filled (padded
 // with 0xFFFFFFFF to whole tiles) and true when the scan should use them.
-bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles, int64_t rows_kept, std::vector<uint32_t> *ids) {
+bool exact_applies(const Shard *s, int64_t n_exam, int32_t k, int32_t entries);
+bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles, int64_t rows_kept, int32_t k, int32_t entries,
+                    std::vector<uint32_t> *ids) {
   static const int64_t list_div = probe_env("TSH_LIST_DIV") ? atoll(probe_env("TSH_LIST_DIV")) : 24;
-  if (!mask_words || list_div <= 0 || rows_kept * list_div > s->rows || s->rows < 4096 || !scan_list_supported(s->nch, s->ld))
-    return false;
+  if (!mask_words || list_div <= 0 || s->rows < 4096) return false;
+  // few enough kept rows for the exact path (tsh_exact.hip.h): their list is all that search reads, at any row width
+  // and any selectivity (a shard small enough for that path whole needs no list: it tests the mask row by row)
+  const bool by_exact = !exact_applies(s, s->rows, k, entries) && exact_applies(s, round_up(rows_kept, 64), k, entries);
+  if (!by_exact && (rows_kept * list_div > s->rows || !scan_list_supported(s->nch, s->ld))) return false;
   ids->clear();
   ids->reserve((size_t)round_up(rows_kept, 64));
   for (int32_t t = 0; t < n_tiles; ++t)  // (bits past the shard's last row cannot be set: slice_mask clears them)
@@ -970,6 +985,59 @@ bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles,
   if (ids->empty()) return false;
   ids->resize((size_t)round_up((int64_t)ids->size(), 64), 0xFFFFFFFFu);
   return true;
+}
+
+int ctx_reserve_exact(Ctx *c, int64_t n) {
+  if (n <= c->x_cap) return TSH_OK;
+  hipFree(c->d_xkey);
+  hipFree(c->d_xsum);
+  c->d_xkey = nullptr;
+  c->d_xsum = nullptr;
+  c->bytes -= c->x_cap * 24;
+  c->x_cap = 0;
+  const int64_t want = std::min<int64_t>(round_up(n + n / 2, 1024), EX_MAX_ROWS);
+  HIPCHK(hipMalloc(&c->d_xkey, (size_t)want * sizeof(uint64_t)));
+  HIPCHK(hipMalloc(&c->d_xsum, (size_t)want * 2 * sizeof(double)));
+  c->x_cap = want;
+  c->bytes += want * 24;
+  return TSH_OK;
+}
+
+// A search with at most TSH_OPT_EXACT_SCAN_ROWS rows to look at takes the exact path (tsh_exact.hip.h); its block must
+// have room for the k rows it will hold
+bool exact_applies(const Shard *s, int64_t n_exam, int32_t k, int32_t entries) {
+  return n_exam > 0 && n_exam <= std::min<int64_t>(s->exact_rows, EX_MAX_ROWS) && k <= entries;
+}
+// E1's arguments but for where the query is (a.query / a.query_out: the caller's); q: the query, zero-padded to ld
+void fill_exact_args(const Shard *s, const Ctx *c, bool use_list, bool dense_mask, int64_t n_exam, const float *q, ExactArgsQ *xa) {
+  ExactArgs *a = &xa->a;
+  a->rows = s->d_rows;
+  a->query = c->d_query;
+  a->query_out = nullptr;
+  a->live = s->d_live;
+  a->mask = dense_mask ? c->d_mask : nullptr;
+  a->list = use_list ? c->d_list : nullptr;
+  a->xkey = c->d_xkey;
+  a->xsum = c->d_xsum;
+  a->sqrt_mag_a = s->metric == TSH_METRIC_COSINE ? std::sqrt(query_mag_a(q, s->dim)) : 0.0;
+  a->ld = s->ld;
+  a->n_rows = s->rows;
+  a->n_entries = (int32_t)n_exam;
+  a->dim = s->dim;
+}
+
+// E1 of a short search (tsh_exact.hip.h): one wave per eight entries, the events on the kernel's own packet
+void launch_exact_scan(const ExactArgsQ &xa, int metric, hipStream_t st, const LaunchEv &ev) {
+  const unsigned grid = (unsigned)((xa.a.n_entries + EX_R - 1) / EX_R);
+#define TSH_EXACT_LAUNCH(M)                                                                                      \
+  do {                                                                                                           \
+    if (ev.start || ev.stop) hipExtLaunchKernelGGL(exact_scan_kernel<M>, dim3(grid), dim3(64), 0, st, ev.start, ev.stop, 0, xa); \
+    else exact_scan_kernel<M><<<grid, 64, 0, st>>>(xa);                                                          \
+  } while (0)
+  if (metric == TSH_METRIC_L2) TSH_EXACT_LAUNCH(METRIC_L2);
+  else if (metric == TSH_METRIC_IP) TSH_EXACT_LAUNCH(METRIC_IP);
+  else TSH_EXACT_LAUNCH(METRIC_COS);
+#undef TSH_EXACT_LAUNCH
 }
 
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
@@ -982,6 +1050,13 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   if (use_list && (rc = ctx_reserve_list(c, list->padded))) return rc;
   j->list_tiles = use_list ? list->padded / 64 : 0;
   const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
+  // A search with only a few thousand rows to look at (a selective mask's list, a small index or shard) takes their
+  // exact sums directly and selects among the exact distances: two dispatches instead of three, no f32 keys, no band
+  // (tsh_exact.hip.h).  The block must have room for the k rows it will hold.
+  const int64_t n_exam = use_list ? (int64_t)list->padded : s->rows;
+  const bool exact = exact_applies(s, n_exam, k, entries);
+  j->exact = exact;
+  if (exact && (rc = ctx_reserve_exact(c, n_exam))) return rc;
   j->k = k;
   j->entries = entries;
   j->user_mask = mask_words != nullptr;
@@ -1008,22 +1083,33 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     c->list_epoch = epoch;
   }
   static thread_local ScanArgsQ sa;  // 4 KiB: keep it off the stack of deep callers
-  fill_scan_args(s, c, j->masked, j->user_mask, &sa);
-  if (use_list) {
-    sa.a.list = c->d_list;
-    sa.a.n_tiles = j->list_tiles;
-  }
+  static thread_local ExactArgsQ xa;
   const bool inline_q = s->ld <= SCAN_Q_INLINE;
-  float *qdst = inline_q ? sa.q : c->h_query;
+  float *qdst = inline_q ? (exact ? xa.q : sa.q) : c->h_query;
   memcpy(qdst, query, (size_t)s->dim * sizeof(float));
   for (int64_t i = s->dim; i < s->ld; ++i) qdst[i] = 0.f;
-  Band band = compute_band(s, qdst);
-  j->eps_rel = band.eps_rel;
-  j->delta_abs = band.delta_abs;
-  j->force_all = band.force_all != 0;
-  if (inline_q) {
-    sa.a.query = nullptr;        // read q[] from the kernel-argument segment ...
-    sa.a.query_out = c->d_query;  // ... and leave a device copy for the rerank kernel
+  Band band;
+  if (exact) {
+    fill_exact_args(s, c, use_list, j->user_mask && !use_list, n_exam, qdst, &xa);
+    xa.a.query = inline_q ? nullptr : c->d_query;
+    // (only the quarantine kernels read the device copy of an inline query)
+    xa.a.query_out = inline_q && !j->quar_sel.empty() ? c->d_query : nullptr;
+    j->eps_rel = j->delta_abs = 0.f;
+    j->force_all = false;
+  } else {
+    fill_scan_args(s, c, j->masked, j->user_mask, &sa);
+    if (use_list) {
+      sa.a.list = c->d_list;
+      sa.a.n_tiles = j->list_tiles;
+    }
+    band = compute_band(s, qdst);
+    j->eps_rel = band.eps_rel;
+    j->delta_abs = band.delta_abs;
+    j->force_all = band.force_all != 0;
+    if (inline_q) {
+      sa.a.query = nullptr;        // read q[] from the kernel-argument segment ...
+      sa.a.query_out = c->d_query;  // ... and leave a device copy for the rerank kernel
+    }
   }
   SelectArgs se{};
   se.gmin = c->d_gmin;
@@ -1107,7 +1193,8 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     } else if (overlap) {
       ev.stop = c->ev_scanned;
     }
-    if (use_list) launch_scan_list(sa, s->nch, s->metric, ps, ev);
+    if (exact) launch_exact_scan(xa, s->metric, ps, ev);
+    else if (use_list) launch_scan_list(sa, s->nch, s->metric, ps, ev);
     else
       launch_scan(sa, s->nch, s->metric, j->masked, ps, ev,
                   j->masked && scan_mostly_live(rows_est > 0 ? rows_est : s->rows - s->deleted, s->rows));
@@ -1132,17 +1219,40 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     // (short rows and lists, config C1: K2 + K4 as ONE dispatch, the selecting workgroup re-ranking its dozen
     // candidates a lane each, was tried -- 17 us against 9 + 4.4 for the two launches: the lone workgroup waits out
     // count -> candidate ids -> rows one after the other, which the second launch's ramp-up hides)
-    launch_select(se, se.n_tiles, ts);
     j->last_stream = ts;
     j->enq_seq = ++s->dstreams->enq_counter;
-    // the completion event rides on the re-rank's own dispatch packet unless more kernels follow (a separate
+    // the completion event rides on the last kernel's own dispatch packet unless more kernels follow (a separate
     // hipEventRecord is one more runtime call and one more barrier packet per query)
     bool done_recorded = false;
-    if (j->quar_sel.empty()) {
-      hipExtLaunchKernelGGL(rerank_kernel, dim3((unsigned)std::min(entries, 1024)), dim3(64), 0, ts, nullptr, c->ev_done, 0, ra);
-      done_recorded = true;
+    if (exact) {
+      ExactSelArgs xs{};
+      xs.xkey = c->d_xkey;
+      xs.xsum = c->d_xsum;
+      xs.list = xa.a.list;
+      xs.hdr = se.hdr;
+      xs.hdr_host = se.hdr_host;
+      xs.out = ra.out;
+      xs.row_base = s->row_base;
+      xs.shard_rows = s->rows;
+      xs.n_entries = xa.a.n_entries;
+      xs.k = k;
+      xs.cap = entries;
+      xs.metric = s->metric;
+      xs.tag = tag;
+      if (j->quar_sel.empty()) {
+        hipExtLaunchKernelGGL(exact_select_kernel, dim3(1), dim3(1024), 0, ts, nullptr, c->ev_done, 0, xs);
+        done_recorded = true;
+      } else {
+        exact_select_kernel<<<1, 1024, 0, ts>>>(xs);
+      }
     } else {
-      rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
+      launch_select(se, se.n_tiles, ts);
+      if (j->quar_sel.empty()) {
+        hipExtLaunchKernelGGL(rerank_kernel, dim3((unsigned)std::min(entries, 1024)), dim3(64), 0, ts, nullptr, c->ev_done, 0, ra);
+        done_recorded = true;
+      } else {
+        rerank_kernel<<<std::min(entries, 1024), 64, 0, ts>>>(ra);
+      }
     }
     if (!j->quar_sel.empty() && dev_target) {
       launch_quarantine_append(s, c, j, ts);
@@ -1164,6 +1274,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   }
   s->c_scans++;
   if (use_list) s->c_list_scans++;
+  if (exact) s->c_exact_scans++;
   return TSH_OK;
 }
 
@@ -1305,6 +1416,11 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill, std::vector<Blo
     j->timed = false;
   }
   BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_block);
+#ifdef TSH_PROBES
+  if (j->exact && probe_env("TSH_X2_TRACE"))
+    fprintf(stderr, "[x2] keys %.2f select %.2f entries %.2f us, %u histogram rounds, %u ranked, %u out\n", h->tau_key * 0.01,
+            h->band_key * 0.01, h->tiles_hit * 0.01, h->pad[2], h->pad[3], h->count);
+#endif
   if (h->flags & FLAG_LIST_OVERFLOW) {
     int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
     if (rc) return rc;
@@ -1434,7 +1550,7 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   // (made here once for all queries of the call)
   std::vector<uint32_t> list_ids;
   RowList list;
-  if (mask && build_row_list(s, mask_words.data(), n_tiles, rows_est, &list_ids)) {
+  if (mask && build_row_list(s, mask_words.data(), n_tiles, rows_est, k, entries, &list_ids)) {
     list.ids = list_ids.data();
     list.padded = (int32_t)list_ids.size();
   }
@@ -2400,6 +2516,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     out->batch_plane_fallbacks += s->c_plane_fallbacks.load();
     out->batch_scan_fallbacks += s->c_scan_fallbacks.load();
     out->list_scans += s->c_list_scans.load();
+    out->exact_scans += s->c_exact_scans.load();
     out->candidates_total += s->c_cands.load();
     int64_t b = s->bytes;
     {
@@ -2452,7 +2569,7 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
   }
   const bool ml = masked && scan_mostly_live(live_rows, s->rows);
   std::vector<uint32_t> list_ids;  // the kernel a search with this mask would run: the list scan for selective ones
-  const bool use_list = row_mask && build_row_list(s, c->h_mask, n_tiles, live_rows, &list_ids);
+  const bool use_list = row_mask && build_row_list(s, c->h_mask, n_tiles, live_rows, 100, tsh_default_block_entries(100), &list_ids);
   if (use_list) {
     if ((rc = ctx_reserve_list(c, (int64_t)list_ids.size()))) return rc;
     memcpy(c->h_list, list_ids.data(), list_ids.size() * sizeof(uint32_t));
@@ -2461,8 +2578,17 @@ int32_t tsh_bench_scan(tsh_index *idx, const float *query, int32_t iters, const 
     sa.a.list = c->d_list;
     sa.a.n_tiles = (int32_t)(list_ids.size() / 64);
   }
+  // (a search with few enough rows to look at takes their exact sums instead: that kernel, then)
+  const int64_t n_exam = use_list ? (int64_t)list_ids.size() : s->rows;
+  const bool exact = exact_applies(s, n_exam, 100, tsh_default_block_entries(100));
+  static thread_local ExactArgsQ xa;
+  if (exact) {
+    if ((rc = ctx_reserve_exact(c, n_exam))) return rc;
+    fill_exact_args(s, c, use_list, row_mask && !use_list, n_exam, c->h_query, &xa);
+  }
   auto launch = [&]() {
-    if (use_list) launch_scan_list(sa, s->nch, s->metric, st);
+    if (exact) launch_exact_scan(xa, s->metric, st, LaunchEv());
+    else if (use_list) launch_scan_list(sa, s->nch, s->metric, st);
     else launch_scan(sa, s->nch, s->metric, masked, st, LaunchEv(), ml);
   };
   launch();  // warm
@@ -2492,6 +2618,14 @@ int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
   if (option == TSH_OPT_BATCH_MIN_NQ) {
     if (value < 0 || value > (1 << 20)) return set_err(TSH_E_BAD_ARG, "batch_min_nq out of range");
     idx->batch_min_nq = (int32_t)value;
+    return TSH_OK;
+  }
+  if (option == TSH_OPT_EXACT_SCAN_ROWS) {
+    if (value < 0 || value > EX_MAX_ROWS) return set_err(TSH_E_BAD_ARG, "exact scan rows: 0 .. %d", EX_MAX_ROWS);
+    for (auto &sh : idx->shards) {
+      std::unique_lock<RwLock> xl(sh->mu);
+      sh->exact_rows = (int)value;
+    }
     return TSH_OK;
   }
   if (option == TSH_OPT_BATCH_KERNEL) {

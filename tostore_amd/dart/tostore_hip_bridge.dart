@@ -161,7 +161,7 @@ final class TshCounters extends Struct {
   @Int32()
   external int quarantinedRows;
   @Int64()
-  external int fusedLaunches;
+  external int exactScans;
   @Int64()
   external int batchPlaneFallbacks;
   @Int64()
@@ -683,13 +683,14 @@ final class HipVectorBackend {
         'batchPlaneFallbacks': r.batchPlaneFallbacks,
         'batchScanFallbacks': r.batchScanFallbacks,
         'listScans': r.listScans,
+        'exactScans': r.exactScans,
       };
     } finally {
       calloc.free(c);
     }
   }
 
-  /// tsh_index_set_option: 1 = TSH_OPT_BATCH_MIN_NQ, 2 = TSH_OPT_BATCH_KERNEL.
+  /// tsh_index_set_option: 1 = TSH_OPT_BATCH_MIN_NQ, 2 = TSH_OPT_BATCH_KERNEL, 4 = TSH_OPT_EXACT_SCAN_ROWS.
   bool setOption(int option, int value) => _setOption(_handle, option, value) == 0;
 
   int get nativeDimensions => _dim(_handle);
