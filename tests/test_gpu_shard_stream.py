@@ -131,7 +131,7 @@ def test_stream_ties_overflow_like_the_plain_call(hip_lib, oracle_mod, scan_path
         assert all(ids[i].tolist() == list(range(1000, 1000 + k)) for i in range(9))
 
 
-def test_stream_empty_shard_and_bad_arguments(hip_lib):
+def test_stream_empty_shard_and_bad_arguments(hip_lib, scan_path):
     import torch
 
     from tostore_amd import HipVectorIndex, _ffi
@@ -160,7 +160,8 @@ def test_stream_empty_shard_and_bad_arguments(hip_lib):
     with HipVectorIndex(d, L2, capacity_rows=10, n_devices=1) as whole:  # (a plain handle has one shard: accepted)
         whole.append(0, np.ones((10, d), np.float32))
         blk, seen = _stream_blocks(torch, whole, qs, k, entries, None, step=0)
-        assert (blk.reshape(4, bb)[:, :4].view(np.uint32)[:, 0] == 10).all()
+        # (ten rows: the pre-filter offers every one of them, the exact path the k winners)
+        assert (blk.reshape(4, bb)[:, :4].view(np.uint32)[:, 0] == (k if scan_path == "exact" else 10)).all()
 
 
 def test_appends_wait_for_a_running_stream(hip_lib, oracle_mod):

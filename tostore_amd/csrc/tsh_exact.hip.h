@@ -45,6 +45,7 @@ struct ExactArgs {
   const uint64_t *live;  // bit r of word t = row t*64+r present & not deleted & not quarantined
   const uint64_t *mask;  // nullable: caller's keep mask, same layout (entries by row; a list is the mask already)
   const uint32_t *list;  // nullable: local row ids of the entries, ascending, padded with 0xFFFFFFFF
+  uint32_t *list_out;    // nullable: the list is being read from pinned host memory -- leave a device copy here (E2, later queries)
   uint64_t *xkey;        // per entry: order key of its distance (XKEY_DEAD: no row)
   double *xsum;          // per entry: s0, s1
   double sqrt_mag_a;     // cosine: sqrt of the query's sum of squares (element order, f64: query_mag_a)
@@ -77,17 +78,21 @@ __device__ __forceinline__ double ex_dpp_shl7(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// E1.  A wave = eight entries x eight slots: lane 8 r + g holds, of every 128-element piece of row r, the sixteen
-// elements [16 g, 16 g + 16) -- it loads them (64 contiguous bytes), forms their terms in f64 (one IEEE operation
-// each) and keeps them in registers.  A row's sum is ONE chain of dependent adds in element order that walks through
-// its eight lanes: slot 0 adds its sixteen terms, the partial sum moves one lane to the right (DPP), slot 1 adds its
-// sixteen, ... slot 7, and seven lanes back to the left for the next piece.  Every lane executes every step (lanes
-// that do not hold the live partial sum add their terms to a value nobody reads), so the instruction stream is d adds
-// per row long whatever the lane -- the same as one lane walking the row alone, but the eight rows of a wave and the
-// waves of a SIMD run side by side, nothing goes through LDS (a first version staged the terms there and its chain
-// lanes' two-element reads kept the CU's one LDS port busy: 29 us for 16 k rows of 768 against 13 for the f32 scan),
-// and all of a row's pieces are in flight at once (EX_D: the rows of a selective mask are a page each; a piece at a
-// time waited out HBM + translation six times per row).
+// E1.  A wave = eight entries x eight lanes: of every 32 consecutive elements of row r, lane 8 r + g holds the four
+// elements [4 g, 4 g + 4) -- a row's eight lanes load 128 contiguous bytes per instruction --, forms their terms in
+// f64 (one IEEE operation each) and keeps them in registers.  A row's sum is ONE chain of dependent adds in element
+// order that walks through its eight lanes: lane 0 adds its four terms, the partial sum moves one lane to the right
+// (DPP), lane 1 adds its four, ... lane 7, and seven lanes back to the left for the next 32 elements.  Every lane
+// executes every step (lanes that do not hold the live partial sum add their terms to a value nobody reads), so the
+// instruction stream is d adds per row long whatever the lane -- the same as one lane walking the row alone, but the
+// eight rows of a wave and the waves of a SIMD run side by side, and nothing goes through LDS.  All of a row's pieces
+// are in flight at once (EX_D: the rows of a selective mask are a page each; a piece at a time waited out HBM +
+// translation six times per row).
+// Measured on the way here (16 k rows of 768 floats, one MI355X; the f32 scan of the same rows: 13 us): the terms staged
+// in LDS and one chain lane per row reading them two at a time -- the CU's one LDS port was the limit -- 29 us; sixteen
+// consecutive elements per lane (64-byte pieces of eight rows per load instruction: 36 cache accesses per
+// instruction, SQ_WAIT_INST_ANY 10 us per wave) 26 us; a dependent v_add_f64 takes 4.1 ns, four independent ones 2.3 ns
+// each, v_cvt_f64_f32 3.8 ns (tools/ubench/dp_rate.hip).
 template <int METRIC>
 __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
 #pragma clang fp contract(off)
@@ -107,6 +112,7 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
   bool alive = false;
   if (e < a.n_entries) {
     my_id = a.list ? a.list[e] : (uint32_t)e;
+    if (a.list_out && g == 0) a.list_out[e] = my_id;
     if (my_id != 0xFFFFFFFFu && (int64_t)my_id < a.n_rows) {
       alive = (a.live[my_id >> 6] >> (my_id & 63)) & 1ull;
       if (alive && a.mask) alive = (a.mask[my_id >> 6] >> (my_id & 63)) & 1ull;
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
   auto fetch = [&](f32x4 (&dst)[4], int p) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int o = p * EX_C + 16 * g + 4 * c;
+      const int o = p * EX_C + 32 * c + 4 * g;  // a row's eight lanes read 128 contiguous bytes per load
       dst[c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(rp + (o < ld ? o : 0)));
     }
   };
@@ -143,7 +149,7 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
     double t0[16], t1[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int o = p * EX_C + 16 * g + 4 * c;
+      const int o = p * EX_C + 32 * c + 4 * g;
       const bool ok = o < ld;
       const f32x4 qf = *reinterpret_cast<const f32x4 *>(qsrc + (ok ? o : 0));
 #pragma unroll
@@ -163,20 +169,23 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
     if (group_done) fetch_group(p + 1);  // (the group's registers are free: the next group's loads, behind these terms)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int step = 0; step < 8; ++step) {
+    for (int c = 0; c < 4; ++c) {  // elements 32 c + 4 step + i: four per lane, then on to the next lane
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s0 = s0 + t0[i];
-        if (METRIC == METRIC_COS) s1 = s1 + t1[i];
+      for (int step = 0; step < 8; ++step) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s0 = s0 + t0[4 * c + i];
+          if (METRIC == METRIC_COS) s1 = s1 + t1[4 * c + i];
+        }
+        if (step < 7) {
+          s0 = ex_dpp_shr1(s0);
+          if (METRIC == METRIC_COS) s1 = ex_dpp_shr1(s1);
+        }
       }
-      if (step < 7) {
-        s0 = ex_dpp_shr1(s0);
-        if (METRIC == METRIC_COS) s1 = ex_dpp_shr1(s1);
+      if (c < 3 || p + 1 < npiece) {  // back to slot 0 for the next 32 elements (wave-uniform)
+        s0 = ex_dpp_shl7(s0);
+        if (METRIC == METRIC_COS) s1 = ex_dpp_shl7(s1);
       }
-    }
-    if (p + 1 < npiece) {  // back to slot 0 for the next piece (wave-uniform)
-      s0 = ex_dpp_shl7(s0);
-      if (METRIC == METRIC_COS) s1 = ex_dpp_shl7(s1);
     }
   };
   fetch_group(0);
@@ -343,9 +352,11 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
           const unsigned long long mk = (uint32_t)lane < m ? s_fkey[lane] : ~0ull;
           const uint32_t mp = (uint32_t)lane < m ? s_fpos[lane] : 0xFFFFFFFFu;
           uint32_t rank = 0;
-          for (uint32_t i = 0; i < m; ++i) {
-            const unsigned long long ok = s_fkey[i];
-            const uint32_t op = s_fpos[i];
+          for (uint32_t i = 0; i < m; ++i) {  // (wave-uniform i: the other pair comes through scalar registers, not LDS)
+            const unsigned long long ok =
+                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), (int)i) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, (int)i);
+            const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)mp, (int)i);
             rank += (ok < mk) | ((ok == mk) & (op < mp));
           }
           if ((uint32_t)lane < m && rank == kk - 1u) {  // exactly one lane: the pairs are distinct
