@@ -33,7 +33,9 @@ constexpr int EX_R = 8;             // entries per wave: eight lanes each
 constexpr int EX_C = 128;           // elements of a row per piece: sixteen per lane
 constexpr int EX_D = 6;             // pieces of a row in flight at once (768 elements; 96 registers)
 constexpr uint64_t XKEY_DEAD = ~0ull;       // no row here (list padding, tombstone, masked out)
-constexpr uint64_t XKEY_NAN = ~0ull - 1ull;  // a live row whose distance is NaN (double.compareTo: greatest, all equal)
+constexpr uint64_t XKEY_NAN = 0xFFFFFFFE00000000ull;  // a live row whose distance is NaN (double.compareTo: greatest, all
+                                                      // equal): above +inf's key, its upper half below the dead marker's
+constexpr uint32_t XHI_DEAD = 0xFFFFFFFFu;            // upper half of XKEY_DEAD: no live key has it
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -47,6 +49,7 @@ struct ExactArgs {
   const uint32_t *list;  // nullable: local row ids of the entries, ascending, padded with 0xFFFFFFFF
   uint32_t *list_out;    // nullable: the list is being read from pinned host memory -- leave a device copy here (E2, later queries)
   uint64_t *xkey;        // per entry: order key of its distance (XKEY_DEAD: no row)
+  uint32_t *xhi;         // per entry: the key's upper half (what E2 selects on; lower halves only among ties of these)
   double *xsum;          // per entry: s0, s1
   double sqrt_mag_a;     // cosine: sqrt of the query's sum of squares (element order, f64: query_mag_a)
   int64_t ld;            // floats per row, multiple of 4
@@ -92,7 +95,7 @@ __device__ __forceinline__ double ex_dpp_shl7(double v) {
 // in LDS and one chain lane per row reading them two at a time -- the CU's one LDS port was the limit -- 29 us; sixteen
 // consecutive elements per lane (64-byte pieces of eight rows per load instruction: 36 cache accesses per
 // instruction, SQ_WAIT_INST_ANY 10 us per wave) 26 us; a dependent v_add_f64 takes 4.1 ns, four independent ones 2.3 ns
-// each, v_cvt_f64_f32 3.8 ns (tools/ubench/dp_rate.hip).
+// each, v_cvt_f64_f32 3.8 ns (tools/micro/dp_rate.hip).
 template <int METRIC>
 __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
 #pragma clang fp contract(off)
@@ -121,7 +124,10 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
   const uint64_t am = __ballot(alive);
   const bool writer = g == 7 && e < a.n_entries;  // where a row's chain ends
   if (!am) {  // wave-uniform: nothing to read
-    if (writer) a.xkey[e] = XKEY_DEAD;
+    if (writer) {
+      a.xkey[e] = XKEY_DEAD;
+      a.xhi[e] = XHI_DEAD;
+    }
     return;
   }
   // a dead entry's lanes walk the wave's first live row (valid memory; the result is dropped)
@@ -205,13 +211,16 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
       const double sim = denom > 0 ? s0 / denom : 0;
       d = 1.0 - sim;
     }
-    a.xkey[e] = alive ? xkey_of(d) : XKEY_DEAD;
+    const uint64_t key = alive ? xkey_of(d) : XKEY_DEAD;
+    a.xkey[e] = key;
+    a.xhi[e] = (uint32_t)(key >> 32);
     *reinterpret_cast<f64x2 *>(a.xsum + 2 * e) = f64x2{s0, METRIC == METRIC_COS ? s1 : 0.0};
   }
 }
 
 struct ExactSelArgs {
   const uint64_t *xkey;
+  const uint32_t *xhi;
   const double *xsum;
   const uint32_t *list;  // nullable (entry = row)
   BlockHeader *hdr;
@@ -260,51 +269,51 @@ __device__ __forceinline__ uint32_t ex_wave_or(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// E2.  The workgroup is ONE compute unit's worth of issue slots (sixteen waves on four SIMDs), and with sixteen keys per
+// thread the kernel is bound by its own VALU instructions (a version on whole 64-bit keys: 820 per wave, 14.7 us): it
+// works on the keys' UPPER HALVES (sign, exponent, twenty mantissa bits: one register, one-instruction compares), which
+// decide all but a handful of rows; lower halves are read only for rows whose upper half equals the cut's.
 __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
   constexpr int NT = 1024, VPT = EX_MAX_ROWS / NT;
   __shared__ uint32_t s_hist[256];
-  __shared__ uint32_t s_bin, s_k, s_ties, s_live, s_out, s_nfin, s_P;
-  __shared__ uint32_t s_or[4];  // OR of the live keys (lo, hi) and of their complements (lo, hi)
-  __shared__ unsigned long long s_K;
-  __shared__ unsigned long long s_fkey[EX_FIN];
+  __shared__ uint32_t s_bin, s_k, s_ties, s_live, s_out, s_nfin;
+  __shared__ uint32_t s_or[2];   // OR of the live upper halves and of their complements
+  __shared__ uint32_t s_cut[3];  // the ranking's result: (upper half, lower half, position) of the k-th pair
   __shared__ uint32_t s_fpos[EX_FIN];
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = a.n_entries;
+  const uint32_t *xlo = reinterpret_cast<const uint32_t *>(a.xkey);  // (little endian: a key's lower half at 2 i)
 #ifdef TSH_PROBES  // phase stamps (100 MHz) in the header's unused fields: tools/r5_exact_try.sh
   const uint64_t pt0 = wall_clock64();
   uint64_t pt1 = 0, pt2 = 0;
   uint32_t prounds = 0;
 #endif
-  if (tid < 4) s_or[tid] = 0u;
+  if (tid < 2) s_or[tid] = 0u;
+  if (tid < 256) s_hist[tid] = 0u;  // (clean for the first round; wave 0 clears what it reads for the next one)
   if (tid == 0) {
     s_live = 0;
     s_out = 0;
     s_nfin = 0;
   }
-  uint64_t key[VPT];
+  uint32_t h[VPT];
   uint32_t nlive = 0;  // wave-uniform
-  uint64_t o1 = 0, o0 = 0;
+  uint32_t o1 = 0, o0 = 0;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = tid + j * NT;
-    key[j] = i < n ? a.xkey[i] : XKEY_DEAD;
-    const bool lv = key[j] != XKEY_DEAD;
+    h[j] = i < n ? a.xhi[i] : XHI_DEAD;
+    const bool lv = h[j] != XHI_DEAD;
     nlive += (uint32_t)__popcll(__ballot(lv));
-    if (lv) {
-      o1 |= key[j];
-      o0 |= ~key[j];
-    }
+    o1 |= lv ? h[j] : 0u;
+    o0 |= lv ? ~h[j] : 0u;
   }
   __syncthreads();
   {
-    const uint32_t w0 = ex_wave_or((uint32_t)o1), w1 = ex_wave_or((uint32_t)(o1 >> 32));
-    const uint32_t w2 = ex_wave_or((uint32_t)o0), w3 = ex_wave_or((uint32_t)(o0 >> 32));
+    const uint32_t w1 = ex_wave_or(o1), w0 = ex_wave_or(o0);
     if (lane == 0 && nlive) {
       atomicAdd(&s_live, nlive);
-      atomicOr(&s_or[0], w0);
-      atomicOr(&s_or[1], w1);
-      atomicOr(&s_or[2], w2);
-      atomicOr(&s_or[3], w3);
+      atomicOr(&s_or[0], w1);
+      atomicOr(&s_or[1], w0);
     }
   }
   __syncthreads();
@@ -314,43 +323,45 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
 #ifdef TSH_PROBES
   pt1 = wall_clock64();
 #endif
-  uint64_t K = 0;              // the k-th smallest key
-  uint32_t P = 0;              // ... and, when by_pos, the last position taken among the rows at that key
-  bool by_pos = false;
+  // The cut: a live row is taken iff (upper half, lower half, position) <= (Khi, Klo, P) in that order.  Bits that no
+  // round settled are filled with ones: every row of the last bin is taken.
+  uint32_t Khi = 0xFFFFFFFFu, Klo = 0xFFFFFFFFu, P = 0xFFFFFFFFu;
   if (!all) {
-    const uint64_t any1 = ((uint64_t)s_or[1] << 32) | s_or[0], any0 = ((uint64_t)s_or[3] << 32) | s_or[2];
-    const uint64_t diff = any1 & any0;  // bits in which live keys differ
     // Digits of up to eight bits from the first differing bit down (NOT byte-aligned: a corpus's distances share sign,
     // exponent and often the first mantissa bits -- aligned to bytes, the first round's keys fell into five bins and
-    // their LDS atomics queued up: 5 us for that one round): `up` = bits at and above it are settled in `prefix`.
-    int up = diff ? 64 - __builtin_clzll(diff) : 0;
-    uint64_t prefix = up >= 64 ? 0ull : (any1 >> up) << up;  // (above `up` every live key has any1's bits)
-    int pos_up = 14;  // then the position's bits (EX_MAX_ROWS = 2^14), only if the k-th key's ties go beyond k
-    uint32_t kk = k, ties = live, pos_prefix = 0;
+    // their LDS atomics queued up: 5 us for that one round).  stage 0: the upper halves, 1: the lower halves of rows
+    // whose upper half is the cut's, 2: the positions of rows at the cut's whole key; `up` = the stage's bits at and
+    // above it are settled in its prefix.
+    int stage = 0;
+    const uint32_t diff = s_or[0] & s_or[1];  // bits in which live upper halves differ
+    int up = diff ? 32 - __builtin_clz(diff) : 0;
+    uint32_t pH = up >= 32 ? 0u : (s_or[0] >> up) << up, pL = 0u, pP = 0u;  // (above `up` every live key has s_or[0]'s bits)
+    uint32_t lo[VPT];  // lower halves, loaded when stage 1 starts (rows whose upper half is the cut's: usually none)
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) lo[j] = 0u;
+    uint32_t kk = k, ties = live;
+    auto settled = [&](uint32_t v, uint32_t pf, int u) { return u >= 32 || (v >> u) == (pf >> u); };
     auto member = [&](int j) {  // still in the running: live, and equal to what the rounds so far have settled
       const uint32_t pos = (uint32_t)(tid + j * NT);
-      if (key[j] == XKEY_DEAD) return false;
-      if (up > 0) return up >= 64 || (key[j] >> up) == (prefix >> up);
-      return key[j] == prefix && (pos >> pos_up) == (pos_prefix >> pos_up);
+      if (stage == 0) return h[j] != XHI_DEAD && settled(h[j], pH, up);
+      if (h[j] != pH) return false;
+      if (stage == 1) return settled(lo[j], pL, up);
+      return lo[j] == pL && settled(pos, pP, up);
     };
-    bool finished = false;
-    while (up > 0 || pos_up > 0) {
-      if (up == 0 && ties == kk) break;  // every row at the k-th key is taken (the usual end without the ranking below)
+    bool ranked = false;
+    for (;;) {
+      if (ties == kk) break;  // every row of the bin is taken
       if (ties <= (uint32_t)EX_FIN) {
-        // a handful left (after the first round, usually): wave 0 ranks them -- the kk-th smallest (key, position)
-        // pair among them is the k-th of all
+        // a handful left (after the first round, usually): wave 0 ranks them by (whole key, position) -- the kk-th
+        // smallest pair among them is the k-th of all
 #pragma unroll
         for (int j = 0; j < VPT; ++j)
-          if (member(j)) {
-            const uint32_t slot = atomicAdd(&s_nfin, 1u);
-            s_fkey[slot] = key[j];
-            s_fpos[slot] = (uint32_t)(tid + j * NT);
-          }
+          if (member(j)) s_fpos[atomicAdd(&s_nfin, 1u)] = (uint32_t)(tid + j * NT);
         __syncthreads();
         if (tid < 64) {
           const uint32_t m = s_nfin;  // == ties
-          const unsigned long long mk = (uint32_t)lane < m ? s_fkey[lane] : ~0ull;
           const uint32_t mp = (uint32_t)lane < m ? s_fpos[lane] : 0xFFFFFFFFu;
+          const unsigned long long mk = (uint32_t)lane < m ? a.xkey[mp] : ~0ull;
           uint32_t rank = 0;
           for (uint32_t i = 0; i < m; ++i) {  // (wave-uniform i: the other pair comes through scalar registers, not LDS)
             const unsigned long long ok =
@@ -360,36 +371,47 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
             rank += (ok < mk) | ((ok == mk) & (op < mp));
           }
           if ((uint32_t)lane < m && rank == kk - 1u) {  // exactly one lane: the pairs are distinct
-            s_K = mk;
-            s_P = mp;
+            s_cut[0] = (uint32_t)(mk >> 32);
+            s_cut[1] = (uint32_t)mk;
+            s_cut[2] = mp;
           }
         }
         __syncthreads();
-        K = s_K;
-        P = s_P;
-        by_pos = true;
-        finished = true;
+        Khi = s_cut[0];
+        Klo = s_cut[1];
+        P = s_cut[2];
+        ranked = true;
         break;
+      }
+      if (up == 0) {  // this stage is settled and its ties go beyond k: on to the next one
+        if (stage == 0) {
+#pragma unroll
+          for (int j = 0; j < VPT; ++j)
+            if (h[j] == pH) lo[j] = xlo[2 * (size_t)(tid + j * NT)];
+          up = 32;
+        } else {
+          up = 14;  // positions are below EX_MAX_ROWS = 2^14; distinct, so stage 2 ends with ties == kk == 1
+        }
+        ++stage;
       }
 #ifdef TSH_PROBES
       ++prounds;
 #endif
-      for (int i = tid; i < 256; i += NT) s_hist[i] = 0u;
-      __syncthreads();
-      const bool on_key = up > 0;
-      const int hi = on_key ? up : pos_up, lo = hi > 8 ? hi - 8 : 0;  // this round's digit: bits [lo, hi)
-      const uint32_t dmask = (1u << (hi - lo)) - 1u;
+      const int lob = up > 8 ? up - 8 : 0;  // this round's digit: bits [lob, up)
+      const uint32_t dmask = (1u << (up - lob)) - 1u;
 #pragma unroll
       for (int j = 0; j < VPT; ++j) {
-        const uint32_t pos = (uint32_t)(tid + j * NT);
-        const uint32_t b = (on_key ? (uint32_t)(key[j] >> lo) : pos >> lo) & dmask;
-        ex_hist_add(s_hist, member(j), b, lane);
+        const uint32_t v = stage == 0 ? h[j] : (stage == 1 ? lo[j] : (uint32_t)(tid + j * NT));
+        ex_hist_add(s_hist, member(j), (v >> lob) & dmask, lane);
       }
       __syncthreads();
       if (tid < 64) {  // wave 0: lane l owns bins 4l .. 4l+3 (block_kth_radix's scan)
         uint32_t c[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = s_hist[4 * lane + j];
+        for (int j = 0; j < 4; ++j) {
+          c[j] = s_hist[4 * lane + j];
+          s_hist[4 * lane + j] = 0u;
+        }
         const uint32_t mine = c[0] + c[1] + c[2] + c[3];
         uint32_t incl = mine;
 #pragma unroll
@@ -409,35 +431,42 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
         }
       }
       __syncthreads();
-      if (on_key) {
-        prefix |= (uint64_t)s_bin << lo;
-        up = lo;
-      } else {
-        pos_prefix |= s_bin << lo;
-        pos_up = lo;
-        by_pos = true;
-      }
+      const uint32_t digit = s_bin << lob;
+      if (stage == 0) pH |= digit;
+      else if (stage == 1) pL |= digit;
+      else pP |= digit;
+      up = lob;
       kk = s_k;
       ties = s_ties;
     }
-    if (!finished) {
-      K = prefix;
-      P = pos_prefix | ((1u << pos_up) - 1u);  // (position bits no round settled: every row of the last bin is taken)
+    if (!ranked) {  // the cut lies behind the last bin taken: unsettled bits of its stage, and the later stages, all ones
+      const uint32_t fill = up >= 32 ? 0xFFFFFFFFu : (1u << up) - 1u;
+      Khi = stage == 0 ? pH | fill : pH;
+      Klo = stage == 0 ? 0xFFFFFFFFu : (stage == 1 ? pL | fill : pL);
+      P = stage == 2 ? pP | fill : 0xFFFFFFFFu;
     }
   }
 #ifdef TSH_PROBES
   pt2 = wall_clock64();
 #endif
   // the entries: (id, s0, s1) of every taken row, in no particular order (the finaliser sorts)
+  const bool need_lo = !(Klo == 0xFFFFFFFFu && P == 0xFFFFFFFFu);  // workgroup-uniform
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const uint32_t pos = (uint32_t)(tid + j * NT);
-    const bool take = key[j] != XKEY_DEAD && (all || key[j] < K || (key[j] == K && (!by_pos || pos <= P)));
+    const bool lv = h[j] != XHI_DEAD;
+    bool take = lv && h[j] <= Khi;
+    if (need_lo && __ballot(lv && h[j] == Khi)) {  // wave-uniform and rare: rows AT the cut's upper half
+      if (lv && h[j] == Khi) {
+        const uint32_t l = xlo[2 * (size_t)pos];
+        take = l < Klo || (l == Klo && pos <= P);
+      }
+    }
     const uint64_t bm = __ballot(take);
     if (bm) {  // wave-uniform
       uint32_t base = 0;
       if (lane == __builtin_ctzll(bm)) base = atomicAdd(&s_out, (uint32_t)__popcll(bm));
-      base = (uint32_t)__shfl((int)base, __builtin_ctzll(bm));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(bm));
       if (take) {
         const uint32_t p = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
         if (p < (uint32_t)a.cap) {
