@@ -61,7 +61,7 @@ def test_every_width_and_k(hip_lib, oracle_mod, metric, d):
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 def test_where_the_path_ends(hip_lib, oracle_mod, metric):
-    """16384 rows are the last size the exact path takes (sixteen rows per wave there); one more row, or a lower
+    """16384 rows are the last size the exact path takes (2048 waves of eight rows there); one more row, or a lower
     TSH_OPT_EXACT_SCAN_ROWS, and the pre-filter answers."""
     from tostore_amd import HipVectorIndex, _ffi
 

@@ -85,7 +85,7 @@ def _one_case(oracle, rng, case):
         if cno % 3 == 2:
             idx.set_exact_scan_rows(0)
         elif cno % 5 == 1:
-            idx.set_exact_scan_rows(max(1, n // 2))
+            idx.set_exact_scan_rows(min(16384, max(1, n // 2)))
         ids, dist, cnt = idx.search(qs, k, thr, keep)
         for i in range(nq):
             eids, edist = oracle.search_exhaustive(rows, qs[i], metric, k, thr, eff_mask)

@@ -6,20 +6,22 @@
 // waits for.  The f32 keys exist to spare the f64 arithmetic on rows that cannot win; below EX_MAX_ROWS rows there is
 // nothing to spare -- the exact sums of ALL of them take one launch of the re-rank's own arithmetic, spread over every
 // SIMD of the device:
-//   E1 exact_scan_kernel    a wave owns eight entries (rows of the list, or of the shard), eight lanes each: a lane
-//                           forms the terms of its sixteen elements of every 128-element piece of its row (every term is
-//                           one IEEE operation, so who forms it does not matter), and the row's sum walks through its
-//                           eight lanes strictly in element order 0..d-1 -- the reference's loop
+//   E1 exact_scan_kernel    a wave owns eight entries (rows of the list, or of the shard), eight lanes each: of every
+//                           32 consecutive elements of its row a lane forms the terms of four (every term is one IEEE
+//                           operation, so who forms it does not matter), and the row's sum walks through its eight
+//                           lanes strictly in element order 0..d-1 -- the reference's loop
 //                           (ngh_graph_engine.dart:920-946), the oracle's vs_exact_sums, rerank_kernel's arithmetic bit
 //                           for bit.  Then the distance itself (L2 sqrt, IP negate, cosine 1 - dot / (|q| |v|) with
 //                           similarity 0 for a non-positive denominator; f64 sqrt and divide are correctly rounded on
 //                           the device as on the host) as a double.compareTo order key per entry.
 //   E2 exact_select_kernel  one workgroup: the k smallest (key, position) pairs -- position = place in the ascending
-//                           list = id order, the finaliser's tie-break -- by a radix select over the 64-bit keys held
-//                           in registers (byte rounds from the first byte in which the keys differ; two more rounds
-//                           over the positions only when the k-th key is tied beyond k), and their (id, s0, s1)
-//                           entries + the block header where select_kernel + rerank_kernel leave theirs.  Exactly
-//                           min(k, live rows) entries: no band, no overflow, no fallback.
+//                           list = id order, the finaliser's tie-break -- by a radix select over the keys' upper
+//                           halves held in registers (digits of up to eight bits from the first BIT in which they
+//                           differ; once at most 64 pairs are left, one wave ranks them by whole key and position;
+//                           lower halves and positions get rounds of their own only when the k-th key is tied beyond
+//                           that), and their (id, s0, s1) entries + the block header where select_kernel +
+//                           rerank_kernel leave theirs.  Exactly min(k, live rows) entries: no band, no overflow, no
+//                           fallback.
 // Everything after that (threshold, distance, sort, cut: finalize_query; the merge of shard blocks) is unchanged: it
 // receives a candidate block like any other, only one without a row that cannot be a result.
 #pragma once
