@@ -51,7 +51,6 @@ struct ExactArgs {
   const uint32_t *list;  // nullable: local row ids of the entries, ascending, padded with 0xFFFFFFFF
   uint32_t *list_out;    // nullable: the list is being read from pinned host memory -- leave a device copy here (E2, later queries)
   uint64_t *xkey;        // per entry: order key of its distance (XKEY_DEAD: no row)
-  uint32_t *xhi;         // per entry: the key's upper half (what E2 selects on; lower halves only among ties of these)
   double *xsum;          // per entry: s0, s1
   double sqrt_mag_a;     // cosine: sqrt of the query's sum of squares (element order, f64: query_mag_a)
   int64_t ld;            // floats per row, multiple of 4
@@ -126,10 +125,7 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
   const uint64_t am = __ballot(alive);
   const bool writer = g == 7 && e < a.n_entries;  // where a row's chain ends
   if (!am) {  // wave-uniform: nothing to read
-    if (writer) {
-      a.xkey[e] = XKEY_DEAD;
-      a.xhi[e] = XHI_DEAD;
-    }
+    if (writer) a.xkey[e] = XKEY_DEAD;
     return;
   }
   // a dead entry's lanes walk the wave's first live row (valid memory; the result is dropped)
@@ -213,16 +209,13 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
       const double sim = denom > 0 ? s0 / denom : 0;
       d = 1.0 - sim;
     }
-    const uint64_t key = alive ? xkey_of(d) : XKEY_DEAD;
-    a.xkey[e] = key;
-    a.xhi[e] = (uint32_t)(key >> 32);
+    a.xkey[e] = alive ? xkey_of(d) : XKEY_DEAD;
     *reinterpret_cast<f64x2 *>(a.xsum + 2 * e) = f64x2{s0, METRIC == METRIC_COS ? s1 : 0.0};
   }
 }
 
 struct ExactSelArgs {
   const uint64_t *xkey;
-  const uint32_t *xhi;
   const double *xsum;
   const uint32_t *list;  // nullable (entry = row)
   BlockHeader *hdr;
@@ -271,55 +264,62 @@ __device__ __forceinline__ uint32_t ex_wave_or(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// E2.  The workgroup is ONE compute unit's worth of issue slots (sixteen waves on four SIMDs), and with sixteen keys per
-// thread the kernel is bound by its own VALU instructions (a version on whole 64-bit keys: 820 per wave, 14.7 us): it
-// works on the keys' UPPER HALVES (sign, exponent, twenty mantissa bits: one register, one-instruction compares), which
-// decide all but a handful of rows; lower halves are read only for rows whose upper half equals the cut's.
+// E2.  The workgroup is ONE compute unit's worth of issue slots (sixteen waves on four SIMDs) and its phases are chains:
+// the keys in (one global round trip), one histogram round (LDS atomics, two barriers, a scan by one wave), the ranking
+// of the handful left, the entries out (a second round trip, then stores to pinned host memory).  The rounds work on the
+// keys' UPPER HALVES (sign, exponent, twenty mantissa bits: one register, one-instruction compares), which decide all
+// but a handful of rows; the lower halves sit in registers beside them for the ranking and for rows AT the cut.
+// Measured variants, all within a microsecond of each other (14.7-18 us on average over the probe's shapes, 8-9 at
+// best): whole 64-bit keys in every round (820 VALU instructions per wave); upper halves only, lower halves fetched for
+// the ranking (a third round trip); this one.  What it waits for is latency, not issue.
 __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
   constexpr int NT = 1024, VPT = EX_MAX_ROWS / NT;
   __shared__ uint32_t s_hist[256];
-  __shared__ uint32_t s_bin, s_k, s_ties, s_live, s_out, s_nfin;
-  __shared__ uint32_t s_or[2];   // OR of the live upper halves and of their complements
-  __shared__ uint32_t s_cut[3];  // the ranking's result: (upper half, lower half, position) of the k-th pair
-  __shared__ uint32_t s_fpos[EX_FIN];
+  __shared__ uint32_t s_bin, s_k, s_ties, s_out, s_nfin;
+  __shared__ uint32_t s_part[NT / 64][3];  // per wave: live keys, OR of their upper halves, OR of the complements
+  __shared__ uint32_t s_fhi[EX_FIN], s_flo[EX_FIN], s_fpos[EX_FIN];
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = a.n_entries;
-  const uint32_t *xlo = reinterpret_cast<const uint32_t *>(a.xkey);  // (little endian: a key's lower half at 2 i)
 #ifdef TSH_PROBES  // phase stamps (100 MHz) in the header's unused fields: tools/r5_exact_try.sh
   const uint64_t pt0 = wall_clock64();
   uint64_t pt1 = 0, pt2 = 0;
   uint32_t prounds = 0;
 #endif
-  if (tid < 2) s_or[tid] = 0u;
   if (tid < 256) s_hist[tid] = 0u;  // (clean for the first round; wave 0 clears what it reads for the next one)
   if (tid == 0) {
-    s_live = 0;
     s_out = 0;
     s_nfin = 0;
   }
-  uint32_t h[VPT];
-  uint32_t nlive = 0;  // wave-uniform
+  uint32_t h[VPT], lo[VPT];  // the keys, upper and lower halves (the rounds work on the upper ones)
+  uint32_t nlive = 0;        // wave-uniform
   uint32_t o1 = 0, o0 = 0;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = tid + j * NT;
-    h[j] = i < n ? a.xhi[i] : XHI_DEAD;
+    const uint64_t key = i < n ? a.xkey[i] : XKEY_DEAD;
+    h[j] = (uint32_t)(key >> 32);
+    lo[j] = (uint32_t)key;
     const bool lv = h[j] != XHI_DEAD;
     nlive += (uint32_t)__popcll(__ballot(lv));
     o1 |= lv ? h[j] : 0u;
     o0 |= lv ? ~h[j] : 0u;
   }
-  __syncthreads();
-  {
+  {  // one barrier: every wave leaves its part, every thread reads all sixteen
     const uint32_t w1 = ex_wave_or(o1), w0 = ex_wave_or(o0);
-    if (lane == 0 && nlive) {
-      atomicAdd(&s_live, nlive);
-      atomicOr(&s_or[0], w1);
-      atomicOr(&s_or[1], w0);
+    if (lane == 0) {
+      s_part[tid >> 6][0] = nlive;
+      s_part[tid >> 6][1] = w1;
+      s_part[tid >> 6][2] = w0;
     }
   }
   __syncthreads();
-  const uint32_t live = s_live;
+  uint32_t live = 0, any1 = 0, any0 = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    live += s_part[w][0];
+    any1 |= s_part[w][1];
+    any0 |= s_part[w][2];
+  }
   const uint32_t k = (uint32_t)a.k;
   const bool all = live <= k;  // no more live rows than asked for: every one of them
 #ifdef TSH_PROBES
@@ -335,12 +335,9 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
     // whose upper half is the cut's, 2: the positions of rows at the cut's whole key; `up` = the stage's bits at and
     // above it are settled in its prefix.
     int stage = 0;
-    const uint32_t diff = s_or[0] & s_or[1];  // bits in which live upper halves differ
+    const uint32_t diff = any1 & any0;  // bits in which live upper halves differ
     int up = diff ? 32 - __builtin_clz(diff) : 0;
-    uint32_t pH = up >= 32 ? 0u : (s_or[0] >> up) << up, pL = 0u, pP = 0u;  // (above `up` every live key has s_or[0]'s bits)
-    uint32_t lo[VPT];  // lower halves, loaded when stage 1 starts (rows whose upper half is the cut's: usually none)
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) lo[j] = 0u;
+    uint32_t pH = up >= 32 ? 0u : (any1 >> up) << up, pL = 0u, pP = 0u;  // (above `up` every live key has any1's bits)
     uint32_t kk = k, ties = live;
     auto settled = [&](uint32_t v, uint32_t pf, int u) { return u >= 32 || (v >> u) == (pf >> u); };
     auto member = [&](int j) {  // still in the running: live, and equal to what the rounds so far have settled
@@ -354,42 +351,41 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
     for (;;) {
       if (ties == kk) break;  // every row of the bin is taken
       if (ties <= (uint32_t)EX_FIN) {
-        // a handful left (after the first round, usually): wave 0 ranks them by (whole key, position) -- the kk-th
-        // smallest pair among them is the k-th of all
+        // a handful left (after the first round, usually): they are ranked by (whole key, position) -- the kk-th
+        // smallest pair among them is the k-th of all.  Every wave does it for itself (sixteen times the same few
+        // hundred instructions, and no second barrier to hand the result round)
 #pragma unroll
         for (int j = 0; j < VPT; ++j)
-          if (member(j)) s_fpos[atomicAdd(&s_nfin, 1u)] = (uint32_t)(tid + j * NT);
+          if (member(j)) {
+            const uint32_t slot = atomicAdd(&s_nfin, 1u);
+            s_fhi[slot] = h[j];
+            s_flo[slot] = lo[j];
+            s_fpos[slot] = (uint32_t)(tid + j * NT);
+          }
         __syncthreads();
-        if (tid < 64) {
+        {
           const uint32_t m = s_nfin;  // == ties
+          const uint32_t mh = (uint32_t)lane < m ? s_fhi[lane] : 0xFFFFFFFFu, ml = (uint32_t)lane < m ? s_flo[lane] : 0xFFFFFFFFu;
           const uint32_t mp = (uint32_t)lane < m ? s_fpos[lane] : 0xFFFFFFFFu;
-          const unsigned long long mk = (uint32_t)lane < m ? a.xkey[mp] : ~0ull;
+          const unsigned long long mk = ((unsigned long long)mh << 32) | ml;
           uint32_t rank = 0;
           for (uint32_t i = 0; i < m; ++i) {  // (wave-uniform i: the other pair comes through scalar registers, not LDS)
-            const unsigned long long ok =
-                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), (int)i) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, (int)i);
+            const unsigned long long ok = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mh, (int)i) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)ml, (int)i);
             const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)mp, (int)i);
             rank += (ok < mk) | ((ok == mk) & (op < mp));
           }
-          if ((uint32_t)lane < m && rank == kk - 1u) {  // exactly one lane: the pairs are distinct
-            s_cut[0] = (uint32_t)(mk >> 32);
-            s_cut[1] = (uint32_t)mk;
-            s_cut[2] = mp;
-          }
+          const uint64_t hit = __ballot((uint32_t)lane < m && rank == kk - 1u);  // exactly one lane: the pairs are distinct
+          const int src = __builtin_ctzll(hit);
+          Khi = (uint32_t)__builtin_amdgcn_readlane((int)mh, src);
+          Klo = (uint32_t)__builtin_amdgcn_readlane((int)ml, src);
+          P = (uint32_t)__builtin_amdgcn_readlane((int)mp, src);
         }
-        __syncthreads();
-        Khi = s_cut[0];
-        Klo = s_cut[1];
-        P = s_cut[2];
         ranked = true;
         break;
       }
       if (up == 0) {  // this stage is settled and its ties go beyond k: on to the next one
         if (stage == 0) {
-#pragma unroll
-          for (int j = 0; j < VPT; ++j)
-            if (h[j] == pH) lo[j] = xlo[2 * (size_t)(tid + j * NT)];
           up = 32;
         } else {
           up = 14;  // positions are below EX_MAX_ROWS = 2^14; distinct, so stage 2 ends with ties == kk == 1
@@ -458,12 +454,7 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
     const uint32_t pos = (uint32_t)(tid + j * NT);
     const bool lv = h[j] != XHI_DEAD;
     bool take = lv && h[j] <= Khi;
-    if (need_lo && __ballot(lv && h[j] == Khi)) {  // wave-uniform and rare: rows AT the cut's upper half
-      if (lv && h[j] == Khi) {
-        const uint32_t l = xlo[2 * (size_t)pos];
-        take = l < Klo || (l == Klo && pos <= P);
-      }
-    }
+    if (need_lo && lv && h[j] == Khi) take = lo[j] < Klo || (lo[j] == Klo && pos <= P);  // rows AT the cut's upper half
     const uint64_t bm = __ballot(take);
     if (bm) {  // wave-uniform
       uint32_t base = 0;

@@ -291,7 +291,6 @@ struct Ctx {
   BlockEntry *h_quar = nullptr, *h_quar_dev = nullptr;  // pinned + mapped: sums of the quarantined rows
   // short searches (tsh_exact.hip.h): per entry the order key of its exact distance and its two f64 sums
   uint64_t *d_xkey = nullptr;
-  uint32_t *d_xhi = nullptr;
   double *d_xsum = nullptr;
   int64_t x_cap = 0;
   int64_t bytes = 0;
@@ -719,7 +718,6 @@ void ctx_free_all(Ctx *c) {
   hipFree(c->d_big_entries);
   hipFree(c->d_big_count);
   hipFree(c->d_xkey);
-  hipFree(c->d_xhi);
   hipFree(c->d_xsum);
 }
 
@@ -1046,19 +1044,16 @@ bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles,
 int ctx_reserve_exact(Ctx *c, int64_t n) {
   if (n <= c->x_cap) return TSH_OK;
   hipFree(c->d_xkey);
-  hipFree(c->d_xhi);
   hipFree(c->d_xsum);
   c->d_xkey = nullptr;
-  c->d_xhi = nullptr;
   c->d_xsum = nullptr;
-  c->bytes -= c->x_cap * 28;
+  c->bytes -= c->x_cap * 24;
   c->x_cap = 0;
   const int64_t want = std::min<int64_t>(round_up(n + n / 2, 1024), EX_MAX_ROWS);
   HIPCHK(hipMalloc(&c->d_xkey, (size_t)want * sizeof(uint64_t)));
-  HIPCHK(hipMalloc(&c->d_xhi, (size_t)want * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&c->d_xsum, (size_t)want * 2 * sizeof(double)));
   c->x_cap = want;
-  c->bytes += want * 28;
+  c->bytes += want * 24;
   return TSH_OK;
 }
 
@@ -1078,7 +1073,6 @@ void fill_exact_args(const Shard *s, const Ctx *c, bool use_list, bool dense_mas
   a->list = use_list ? c->d_list : nullptr;
   a->list_out = nullptr;
   a->xkey = c->d_xkey;
-  a->xhi = c->d_xhi;
   a->xsum = c->d_xsum;
   a->sqrt_mag_a = s->metric == TSH_METRIC_COSINE ? std::sqrt(query_mag_a(q, s->dim)) : 0.0;
   a->ld = s->ld;
@@ -1292,7 +1286,6 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     if (exact) {
       ExactSelArgs xs{};
       xs.xkey = c->d_xkey;
-      xs.xhi = c->d_xhi;
       xs.xsum = c->d_xsum;
       xs.list = use_list ? c->d_list : nullptr;
       xs.hdr = se.hdr;
