@@ -19,10 +19,16 @@ timeout 900 python tools/r5_exact_probe.py --rounds 3 2>&1 | grep -v amdgpu.ids 
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_x -o p -- python tools/r5_exact_probe.py --rounds 1 > $O/prof_x.log 2>&1
 python tools/rocpd_summary.py $O/prof_x/p_results.db --by-grid 2>&1 | head -26 > $O/exact_kernel_stats.txt
 rm -rf $O/prof_x
+# the other metrics' E1 (16384 x 768, one query at a time)
+for m in 1 2; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_m$m -o p -- python tools/r5_exact_one.py --metric $m > $O/prof_m$m.log 2>&1
+  python tools/rocpd_summary.py $O/prof_m$m/p_results.db 2>&1 | grep -E "exact_s" >> $O/exact_kernel_stats.txt
+  rm -rf $O/prof_m$m
+done
 V=$(ls tostore_amd/csrc/_build/v*/libtostore_hip_v*.so 2>/dev/null | head -1)
 if [ -n "$V" ]; then
   TSH_LIB_PATH=$V TSH_X2_TRACE=1 timeout 600 python tools/r5_exact_probe.py --rounds 1 2> $O/x2.err > /dev/null
-  grep "\[x2\]" $O/x2.err | awk '{k+=$3; s+=$5; e+=$7; r+=$9; f+=$12; n++} END {printf "exact_select_kernel phases over %d launches (probe build, 100 MHz stamps): keys %.2f, select %.2f, entries %.2f us; %.2f histogram rounds, %.1f ranked\n", n, k/n, s/n, e/n, r/n, f/n}' >> $O/exact_kernel_stats.txt
+  grep "\[x2\]" $O/x2.err | awk '{k+=$3; s+=$5; e+=$7; r+=$9; f+=$12; a+=$17; c+=$19; n++} END {printf "exact_select_kernel phases over %d launches (probe build, 100 MHz stamps): keys %.2f, select %.2f (the round\047s adds %.2f, its scan %.2f), entries %.2f us; %.2f histogram rounds, %.1f ranked\n", n, k/n, s/n, a/n, c/n, e/n, r/n, f/n}' >> $O/exact_kernel_stats.txt
   rm -f $O/x2.err
 fi
 cat $O/bench_driver_args.time; python3 - <<'PY'

@@ -231,24 +231,20 @@ struct ExactSelArgs {
 };
 constexpr uint32_t FLAG_EXACT = 8u;  // informational: the block holds the exact top k (E1 + E2), not a band's candidates
 
-// one more key into a 256-bin histogram in LDS.  Keys agree in their upper bytes and in whole waves (a corpus's
-// distances share sign and exponent): up to two values that eight or more lanes name are added once per wave, the
-// rest lane by lane.  (Wave-uniform values travel through scalar registers: a first version took them by
-// ds_bpermute, an LDS round trip per key and value, and the select ran 22-31 us.)
+// one more key into a 256-bin histogram in LDS: a wave whose members all name one bin (rounds among ties) adds its count
+// once, otherwise lane by lane.  (A version that took up to two popular values out of every wave spent 40-60 instructions
+// per key on finding them -- 3.9 us of the kernel for one round, tools/r5_x2_phases.sh; same-address queueing is not what
+// a round costs: four copies of the histogram changed nothing.)
 __device__ __forceinline__ void ex_hist_add(uint32_t *hist, bool in, uint32_t b, int lane) {
-  uint64_t act = __ballot(in);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    if (__popcll(act) < 8) break;  // wave-uniform
-    const int first = __builtin_ctzll(act);
-    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, first);
-    const uint64_t m = __ballot(in && b == b0);
-    if (__popcll(m) < 8) break;
-    if (lane == first) atomicAdd(&hist[b0], (uint32_t)__popcll(m));
-    if (b == b0) in = false;
-    act &= ~m;
+  const uint64_t act = __ballot(in);
+  if (!act) return;  // wave-uniform (later rounds: most waves hold no member)
+  const int first = __builtin_ctzll(act);
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, first);
+  if (__ballot(in && b == b0) == act) {
+    if (lane == first) atomicAdd(&hist[b0], (uint32_t)__popcll(act));
+  } else if (in) {
+    atomicAdd(&hist[b], 1u);
   }
-  if (in) atomicAdd(&hist[b], 1u);
 }
 
 constexpr int EX_FIN = 64;  // the select finishes by ranking once at most this many (key, position) pairs are left
@@ -274,7 +270,10 @@ __device__ __forceinline__ uint32_t ex_wave_or(uint32_t v) {
 // the ranking (a third round trip); this one.  What it waits for is latency, not issue.
 __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
   constexpr int NT = 1024, VPT = EX_MAX_ROWS / NT;
-  __shared__ uint32_t s_hist[256];
+#ifndef EX_SUBH
+#define EX_SUBH 4  // copies of the histogram a round's lanes spread their adds over (lane & (EX_SUBH - 1))
+#endif
+  __shared__ uint32_t s_hist[EX_SUBH * 256];
   __shared__ uint32_t s_bin, s_k, s_ties, s_out, s_nfin;
   __shared__ uint32_t s_part[NT / 64][3];  // per wave: live keys, OR of their upper halves, OR of the complements
   __shared__ uint32_t s_fhi[EX_FIN], s_flo[EX_FIN], s_fpos[EX_FIN];
@@ -282,10 +281,10 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
   const int n = a.n_entries;
 #ifdef TSH_PROBES  // phase stamps (100 MHz) in the header's unused fields: tools/r5_exact_try.sh
   const uint64_t pt0 = wall_clock64();
-  uint64_t pt1 = 0, pt2 = 0;
-  uint32_t prounds = 0;
+  uint64_t pt1 = 0, pt2 = 0, pa = 0, pb = 0;
+  uint32_t prounds = 0, p_adds = 0, p_scan = 0;
 #endif
-  if (tid < 256) s_hist[tid] = 0u;  // (clean for the first round; wave 0 clears what it reads for the next one)
+  for (int i = tid; i < EX_SUBH * 256; i += NT) s_hist[i] = 0u;  // (clean for the first round; wave 0 clears what it reads)
   if (tid == 0) {
     s_out = 0;
     s_nfin = 0;
@@ -293,8 +292,13 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
   uint32_t h[VPT], lo[VPT];  // the keys, upper and lower halves (the rounds work on the upper ones)
   uint32_t nlive = 0;        // wave-uniform
   uint32_t o1 = 0, o0 = 0;
+  // (every loop over a thread's keys stops at the entries there are: j * NT < n is workgroup-uniform -- 2000 entries
+  // are two turns, not sixteen)
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
+    h[j] = XHI_DEAD;
+    lo[j] = 0xFFFFFFFFu;
+    if (j * NT >= n) continue;
     const int i = tid + j * NT;
     const uint64_t key = i < n ? a.xkey[i] : XKEY_DEAD;
     h[j] = (uint32_t)(key >> 32);
@@ -356,7 +360,7 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
         // hundred instructions, and no second barrier to hand the result round)
 #pragma unroll
         for (int j = 0; j < VPT; ++j)
-          if (member(j)) {
+          if (j * NT < n && member(j)) {
             const uint32_t slot = atomicAdd(&s_nfin, 1u);
             s_fhi[slot] = h[j];
             s_flo[slot] = lo[j];
@@ -394,21 +398,31 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
       }
 #ifdef TSH_PROBES
       ++prounds;
+      pa = wall_clock64();
 #endif
       const int lob = up > 8 ? up - 8 : 0;  // this round's digit: bits [lob, up)
       const uint32_t dmask = (1u << (up - lob)) - 1u;
 #pragma unroll
       for (int j = 0; j < VPT; ++j) {
+        if (j * NT >= n) continue;
         const uint32_t v = stage == 0 ? h[j] : (stage == 1 ? lo[j] : (uint32_t)(tid + j * NT));
-        ex_hist_add(s_hist, member(j), (v >> lob) & dmask, lane);
+        ex_hist_add(s_hist + 256 * (lane & (EX_SUBH - 1)), member(j), (v >> lob) & dmask, lane);
       }
       __syncthreads();
+#ifdef TSH_PROBES
+      pb = wall_clock64();
+      p_adds += (uint32_t)(pb - pa);
+#endif
       if (tid < 64) {  // wave 0: lane l owns bins 4l .. 4l+3 (block_kth_radix's scan)
         uint32_t c[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          c[j] = s_hist[4 * lane + j];
-          s_hist[4 * lane + j] = 0u;
+          c[j] = 0u;
+#pragma unroll
+          for (int sub = 0; sub < EX_SUBH; ++sub) {
+            c[j] += s_hist[256 * sub + 4 * lane + j];
+            s_hist[256 * sub + 4 * lane + j] = 0u;
+          }
         }
         const uint32_t mine = c[0] + c[1] + c[2] + c[3];
         uint32_t incl = mine;
@@ -429,6 +443,9 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
         }
       }
       __syncthreads();
+#ifdef TSH_PROBES
+      p_scan += (uint32_t)(wall_clock64() - pb);
+#endif
       const uint32_t digit = s_bin << lob;
       if (stage == 0) pH |= digit;
       else if (stage == 1) pL |= digit;
@@ -451,6 +468,7 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
   const bool need_lo = !(Klo == 0xFFFFFFFFu && P == 0xFFFFFFFFu);  // workgroup-uniform
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
+    if (j * NT >= n) continue;
     const uint32_t pos = (uint32_t)(tid + j * NT);
     const bool lv = h[j] != XHI_DEAD;
     bool take = lv && h[j] <= Khi;
@@ -495,6 +513,7 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
     hv.pad[0] = hv.pad[2] = hv.pad[3] = 0u;
 #ifdef TSH_PROBES
     hv.pad[2] = prounds;
+    hv.pad[0] = (p_adds << 16) | (p_scan & 0xFFFFu);  // (ticks of 10 ns: the rounds' adds, their scans)
     hv.pad[3] = s_nfin;
 #endif
     hv.pad[1] = a.tag;

@@ -1477,8 +1477,8 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill, std::vector<Blo
   BlockHeader *h = reinterpret_cast<BlockHeader *>(c->h_block);
 #ifdef TSH_PROBES
   if (j->exact && probe_env("TSH_X2_TRACE"))
-    fprintf(stderr, "[x2] keys %.2f select %.2f entries %.2f us, %u histogram rounds, %u ranked, %u out\n", h->tau_key * 0.01,
-            h->band_key * 0.01, h->tiles_hit * 0.01, h->pad[2], h->pad[3], h->count);
+    fprintf(stderr, "[x2] keys %.2f select %.2f entries %.2f us, %u histogram rounds, %u ranked, %u out adds %.2f scan %.2f\n", h->tau_key * 0.01,
+            h->band_key * 0.01, h->tiles_hit * 0.01, h->pad[2], h->pad[3], h->count, (h->pad[0] >> 16) * 0.01, (h->pad[0] & 0xFFFF) * 0.01);
 #endif
   if (h->flags & FLAG_LIST_OVERFLOW) {
     int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
