@@ -1264,7 +1264,12 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     hipStream_t ts = ps;
     // (the last query of a call: nothing follows its scan on that stream, so its tail stays there -- in order, without
     // the ~10 us of a cross-stream event hand-off in front of the select, on the step every caller waits for)
-    if (overlap && !last_of_call) {
+    // (the exact path's select stays on its scan stream, in order behind its short scan, while the scan is short: no
+    // cross-stream hand-off, and the two scan streams alternate whole queries -- 64-query calls on 10 k x 128: 20.6 -> 16.2 us
+    // per query, 2 k x 768: 22 -> 16.7, 8 k x 768: 21 -> 18.4; from ~8 k rows of 768 on the tail queues win again: 16 k x
+    // 768 23 against 25; tools/r5_x_inorder.sh)
+    const bool x_inorder = exact && n_exam * s->ld <= (int64_t)6500000;
+    if (overlap && !last_of_call && !x_inorder) {
       // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
       // scans -- selective masks, small shards -- were then limited by)
       static const bool one_tail = probe_env("TSH_ONE_TAIL") != nullptr && probe_env("TSH_ONE_TAIL")[0] == '1';
