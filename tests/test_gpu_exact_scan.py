@@ -344,3 +344,30 @@ def test_narrow_rows_get_a_list_for_the_exact_path_only(hip_lib, oracle_mod, d):
             c1 = idx.counters()
             assert c1["list_scans"] - c0["list_scans"] == c1["exact_scans"] - c0["exact_scans"] == (3 if listed else 0), kept
         assert idx.counters()["fallback_searches"] == 0
+
+
+def test_ticket_api_builds_a_list_for_selective_masks(hip_lib, oracle_mod):
+    """tsh_search_submit slices the mask itself: a selective one gets its list (and with it the exact path) like in
+    tsh_search."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(17)
+    n, d, k = 120_000, 96, 30
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((6, d)).astype(np.float32)
+    with HipVectorIndex(d, L2, capacity_rows=n) as idx:
+        idx.append(0, rows)
+        for kept, listed, exact in ((1500, True, True), (4000, True, True), (30_000, False, False)):
+            keep = np.zeros(n, bool)
+            keep[rng.choice(n, kept, replace=False)] = True
+            m = np.packbits(keep, bitorder="little")
+            c0 = idx.counters()
+            tickets = [idx.submit(q, k, m) for q in qs]
+            for t, q in zip(tickets, qs):
+                ids, dist = idx.wait(t)
+                e, ed = oracle_mod.search_exhaustive(rows, q, L2, k, None, m)
+                assert np.array_equal(ids, e) and np.array_equal(dist, ed)
+            c1 = idx.counters()
+            assert c1["list_scans"] - c0["list_scans"] == (6 if listed else 0), kept
+            assert c1["exact_scans"] - c0["exact_scans"] == (6 if exact else 0), kept
+        assert idx.counters()["fallback_searches"] == 0
