@@ -191,8 +191,55 @@ static void print_schedules() {
     }
 }
 
+// a row mask as a list of row ids: the tzcnt / popcnt variant (four unconditional extractions per word) against the
+// plain loop, on masks of every density; nothing is written past the count + 4 slots it is promised
+static void test_mask_to_list() {
+  uint64_t x = 88172645463325252ull;
+  auto rnd = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+  };
+  const int per_mille[] = {0, 1, 10, 50, 300, 700, 1000};
+  const int tiles[] = {1, 2, 63, 64, 1000, 15625};
+  for (int pm : per_mille)
+    for (int n_tiles : tiles) {
+      std::vector<uint64_t> words((size_t)n_tiles);
+      for (auto &w : words) {
+        w = 0;
+        for (int b = 0; b < 64; ++b)
+          if ((int)(rnd() % 1000) < pm) w |= 1ull << b;
+      }
+      if (pm == 1000) words.back() = ~0ull;  // (a full last word: five and more bits in one word)
+      const int64_t bits = tsh::popcount_words(words.data(), words.size());
+      int64_t naive = 0;
+      for (auto w : words) naive += __builtin_popcountll(w);
+      if (bits != naive) {
+        fprintf(stderr, "popcount_words: %ld != %ld\n", (long)bits, (long)naive);
+        exit(1);
+      }
+      const uint32_t CANARY = 0xC0FFEE11u;
+      std::vector<uint32_t> a((size_t)bits + 4 + 16, CANARY), b((size_t)bits + 4 + 16, CANARY);
+      const size_t ca = tsh::list_mask_bits_base(words.data(), n_tiles, a.data());
+      size_t cb = ca;
+      if (__builtin_cpu_supports("popcnt") && __builtin_cpu_supports("bmi")) cb = tsh::list_mask_bits_hw(words.data(), n_tiles, b.data());
+      else b = a;
+      const size_t cc = tsh::list_mask_bits(words.data(), n_tiles, bits, b.data());  // (whichever the density picks)
+      bool ok = ca == (size_t)bits && cb == ca && cc == ca && std::equal(a.begin(), a.begin() + ca, b.begin());
+      for (size_t i = 1; i < ca && ok; ++i) ok = a[i] > a[i - 1];
+      for (size_t i = ca + 4; i < a.size() && ok; ++i) ok = a[i] == CANARY && b[i] == CANARY;
+      if (!ok) {
+        fprintf(stderr, "mask -> list: %d per mille, %d tiles: %zu / %zu / %zu of %ld\n", pm, n_tiles, ca, cb, cc, (long)bits);
+        exit(1);
+      }
+    }
+  printf("ok mask_to_list\n");
+}
+
 int main() {
   print_schedules();
+  test_mask_to_list();
   test_ticket_holder_passes_waiting_writer();
   test_rwlock_exclusion_stress();
   test_pool_runs_every_item_once();

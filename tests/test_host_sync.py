@@ -19,7 +19,7 @@ def test_host_sync_cpp(tmp_path):
     sys.stdout.write(r.stdout)
     sys.stderr.write(r.stderr)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.count("ok ") == 6
+    assert r.stdout.count("ok ") == 7
     # the library's group schedule (sharded_schedule) and bench.py's mirror of it, which the bench line reports
     sys.path.insert(0, ROOT)
     import bench
