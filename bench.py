@@ -117,9 +117,10 @@ def parse(argv=None):
                     help="corpus rows stay L2-normalised for every metric (the demo's own recipe; default: L2 / IP rows are "
                          "also scaled by U(0.5, 2) so that the three metrics rank differently, SURVEY.md section 8d)")
     ap.add_argument("--no-side", action="store_true", help="skip the side legs (C1 / C3 / C5)")
-    ap.add_argument("--side", default="c5,s8,c1,c3",
+    ap.add_argument("--side", default="c5,s8,c4s8,c1,c3",
                     help="side legs to run, comma separated (s8 = side.shard_of_8: one rank's share of the headline at N = 8 "
-                         "through tsh_search_sharded)")
+                         "through tsh_search_sharded; c4s8 = side.C4_shard_of_8: one rank's share of BASELINE.json's C4, "
+                         "--c4-rows-per-rank x 1536 inner product, the same way)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--exchange", choices=["auto", "torch", "capi"], default="auto",
@@ -320,9 +321,9 @@ class Env:
         self.torch.cuda.empty_cache()
         return idx, host
 
-    def oracle_chunks(self, n, d, metric):
-        """(first row id, host rows) over the WHOLE corpus, for the recall check of a sharded run."""
-        for r0, x in self.corpus_chunks(n, d, metric, 0, n):
+    def oracle_chunks(self, n, d, metric, lo=0, hi=None):
+        """(first row id, host rows) over the WHOLE corpus (or its rows [lo, hi)), for the recall check of a sharded run."""
+        for r0, x in self.corpus_chunks(n, d, metric, lo, n if hi is None else hi):
             yield r0, x.cpu().numpy()
 
     def searcher(self, idx):
@@ -644,6 +645,34 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
             ent["library_default_path"] = {"error": repr(e)}
         finally:
             idx.set_batch_min_nq(0)
+        # the same mask as a HANDLE (tsh_mask_create: uploaded once, its rows listed on the device, resident): the same
+        # pipelined 64-query calls, and one query at a time -- where the pointer form's host passes over the bitmap
+        # (slice, count, list: every call) are more than half of what the caller waits for
+        tail3 = None
+        try:
+            with idx.make_mask(mask) as mh:
+                idx.search(queries[sel[:64]], k, None, mh)
+                env.fence()
+                with timed_region():
+                    t0 = time.perf_counter()
+                    for g in range(cnt // 64):
+                        got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mh)
+                    env.fence()
+                    el3 = time.perf_counter() - t0
+                    lone = {}
+                    for form, arg in (("pointer", mask), ("handle", mh)):
+                        lat = []
+                        for i in range(200):
+                            t1 = time.perf_counter()
+                            idx.search(queries[sel[i]], k, None, arg)
+                            lat.append(time.perf_counter() - t1)
+                        lat = np.sort(np.asarray(lat)) * 1e6
+                        lone[form] = {"p50": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)])}
+                ent["mask_handle"] = {"value": cnt / el3, "unit": "queries/s", "ms_per_step": el3 / cnt * 1e3,
+                                      "one_at_a_time_us": lone}
+                tail3 = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None
+        except Exception as e:  # noqa: BLE001
+            ent["mask_handle"] = {"error": repr(e)}
         if host_rows is not None and m:
             import bench_check
 
@@ -652,6 +681,8 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
             ent["checked_queries"] = m
             if tail2 is not None:
                 ent["library_default_path"]["ids_and_distances_bit_exact"] = bench_check.compare(tail2, ref)[1]
+            if tail3 is not None:
+                ent["mask_handle"]["ids_and_distances_bit_exact"] = bench_check.compare(tail3, ref)[1]
         out["keep_%d%%%s" % (round(keep * 100), "" if kind == "bernoulli" else "_" + kind)] = ent
     return out
 
@@ -968,16 +999,25 @@ def side_c4_per_rank(env, a):
         idx.close()
 
 
-def side_shard_of_8(env, a, c2_ms_per_step):
+def side_shard_of_8(env, a, c2_ms_per_step, shape=None):
     """N = 1 line: the headline's PER-RANK load of an 8-GPU run -- rows [0, rows / 8) of the same corpus, same metric
     and k -- through tsh_search_sharded over real RCCL in a world of one, in the driver's own shape (timed regions of
     --steps single-query steps per call, fenced on both sides).  What one GPU of eight has to do per step, collective
     launch included; what it cannot show is the wait for seven peers.  upper_bound_speedup = the headline's
-    ms_per_step / this leg's: the 8-GPU speed-up if the real collective cost no more than the one-rank one."""
+    ms_per_step / this leg's: the 8-GPU speed-up if the real collective cost no more than the one-rank one.
+    shape: another configuration's share instead of the headline's -- side.C4_shard_of_8 is BASELINE.json's C4
+    (10 M x 1536, inner product, k = 100, rows split over 8 GPUs) at one rank's 1.25 M x 1536 rows: the same calls,
+    the oracle over that shard on sampled queries (the shard is 7.7 GB: regenerated chunk by chunk for it, no host
+    copy), and a 1024-query call on the shard's matrix cores."""
     d, k, metric = a.dim, a.k, METRICS[a.metric]
-    n = a.rows
+    n, cfg, mname = a.rows, a.config.upper(), a.metric
+    if shape:
+        n, d, k, mname, cfg = shape["rows"], shape["dim"], shape["k"], shape["metric"], shape["config"]
+        metric = METRICS[mname]
     per = (n + 7) // 8
-    idx, host = env.build_index(d, metric, n, 0, per, keep_host=not a.no_cpu_baseline)
+    big = float(per) * d * 4 > 4e9
+    # (no host copy of another configuration's shard -- C4's is 7.7 GB: the oracle sees it chunk by chunk, regenerated)
+    idx, host = env.build_index(d, metric, n, 0, per, keep_host=not a.no_cpu_baseline and not shape)
     cs = None
     try:
         idx.set_batch_min_nq(0)  # every query scans the shard on its own, as in the headline
@@ -1018,37 +1058,65 @@ def side_shard_of_8(env, a, c2_ms_per_step):
         mine = {"rank": 0, "timeline": tl}
         shard_bytes = float(per) * d * 4
         out = {"workload": "one rank's share of %s at N = 8: %dx%d f32, %s, k=%d, %d single-query steps per "
-                           "tsh_search_sharded call, RCCL in a world of one" % (a.config.upper(), per, d, a.metric, k, steps),
+                           "tsh_search_sharded call, RCCL in a world of one" % (cfg, per, d, mname, k, steps),
                "steps": steps, "warmup": warmup, "us_per_query": ms * 1e3, "ms_per_step": ms,
                "timed_regions": {"count": repeats, "steps_each": steps, "reported": "median",
                                  "seconds": [float(x) for x in regions]},
-               "upper_bound_speedup": c2_ms_per_step / ms if ms > 0 else None,
+               "upper_bound_speedup": c2_ms_per_step / ms if ms > 0 and c2_ms_per_step else None,
                "upper_bound_note": "headline ms_per_step / this leg's: what 8 GPUs reach if the 8-rank collective costs "
-                                   "no more than the 1-rank one and no rank waits for another",
+                                   "no more than the 1-rank one and no rank waits for another" if c2_ms_per_step else
+                                   "the whole configuration's one-GPU step is not measured in this run (61 GB of rows): none",
                "queries_per_exchange": library_schedule(steps, per, d),
+               "queries_per_exchange_source": "bench.py's mirror of the library's schedule (sharded_schedule)",
                "exchange_timeline": exchange_timeline([mine], steps * repeats, ms),
                "roofline": {"bound": "hbm", "kernel": "tsh::scan_kernel", "kernel_us": scan_us,
                             "algorithmic_bytes_per_launch": shard_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "achieved": shard_bytes / (scan_us * 1e-6) / 1e9 if scan_us == scan_us else None,
                             "frac": shard_bytes / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS if scan_us == scan_us else None,
-                            "scans_side_by_side": 2,
+                            "scans_side_by_side": 2 if (per + 63) // 64 < 6144 else 1,
                             "note": "shards below 6144 tiles alternate their scans between two streams: a launch's own "
                                     "duration is about twice its share of the HBM time"},
                "floor_us_per_query": shard_bytes / (HBM_PEAK_GBS * 1e9) * 1e6}
         # the library's group choice against its neighbours (same queries, fewer regions)
         sweep = {}
-        for g in sorted({1, 2, 4, 5, 10, steps} - {0}):
+        for g in sorted(({1, 2, 4, 5, 10, steps} if not shape else {5, 10, steps}) - {0}):
             if g > steps:
                 continue
             rg, _, _ = regions_of(g, max(3, min(repeats, 7)))
             sweep[str(g)] = float(np.median(rg)) / steps * 1e6
         out["group_sweep_us_per_query"] = sweep
-        got = call(0, min(steps, 16))
-        if host is not None:
+        n_chk = min(steps, 16) if not big else min(steps, 8)
+        got = call(0, n_chk)
+        if shape:  # 1024 queries per call: the shard's share goes to its matrix cores, through the same entry point
+            try:
+                idx.set_batch_min_nq(1)
+                qb = np.ascontiguousarray(queries[[j % nqp for j in range(1024)]])
+                cs.search(qb, k)
+                bt = []
+                with timed_region():
+                    for _ in range(3):
+                        env.fence()
+                        t0 = time.perf_counter()
+                        got_b = cs.search(qb, k)
+                        env.fence()
+                        bt.append(time.perf_counter() - t0)
+                    gemm_us, flops = idx.bench_batch(qb, k, iters=2)
+                ran = idx.counters()["batch_kernel_last"]
+                out["batch_1024"] = {"value": 1024 / float(np.median(bt)), "unit": "queries/s",
+                                     "ms_per_call": float(np.median(bt)) * 1e3, "calls": len(bt),
+                                     "batch_kernel": BATCH_KERNEL_NAME.get(ran, str(ran)),
+                                     "roofline": batch_roofline(ran, gemm_us, flops),
+                                     "single_and_batched_agree": bool(all(np.array_equal(got[j], got_b[j][:n_chk]) for j in range(3)))}
+            except Exception as e:  # noqa: BLE001
+                out["batch_1024"] = {"error": repr(e)}
+            finally:
+                idx.set_batch_min_nq(0)
+        if not a.no_cpu_baseline:
             import bench_check
 
-            sel = [j % nqp for j in range(min(steps, 16))]
-            ref = bench_check.oracle_topk_stream([(0, host)], queries[sel], metric, k)
+            sel = [j % nqp for j in range(n_chk)]
+            chunks = [(0, host)] if host is not None else env.oracle_chunks(n, d, metric, 0, per)
+            ref = bench_check.oracle_topk_stream(chunks, queries[sel], metric, k)
             out["recall_at_k"], out["ids_and_distances_bit_exact"] = bench_check.compare(got, ref)
             out["checked_queries"] = len(sel)
         return out
@@ -1296,6 +1364,12 @@ def run_bench(a, env=None):
                 side["shard_of_8"] = side_shard_of_8(env, a, elapsed / a.steps * 1e3)
             except Exception as e:  # noqa: BLE001
                 side["shard_of_8"] = {"error": repr(e)}
+        if "c4s8" in legs and a.c4_rows_per_rank > 0:
+            try:
+                side["C4_shard_of_8"] = side_shard_of_8(env, a, None, {"config": "C4", "rows": 8 * int(a.c4_rows_per_rank),
+                                                                         "dim": 1536, "k": 100, "metric": "ip"})
+            except Exception as e:  # noqa: BLE001
+                side["C4_shard_of_8"] = {"error": repr(e)}
         if "c1" in legs:
             try:
                 side["C1"] = side_c1(env, not a.no_cpu_baseline)

@@ -36,12 +36,16 @@ extern "C" {
 /* 2: tsh_counters grew (fused_launches) and tsh_ngh_info grew (pages_absent, files_absent) after version 1 shipped; a
  * host built against the version-1 structs would be written past its buffers, so the number changed with them.
  * tsh_comm_create_host / tsh_comm_set_group and TSH_E_PEER came with version 2 as well. */
-#define TSH_ABI_VERSION 4
+#define TSH_ABI_VERSION 5
 /* 3: tsh_counters grew again (batch_plane_fallbacks, batch_scan_fallbacks); tsh_comm_get_timeline / tsh_comm_timeline
  * came with it.
  * 4: tsh_search_shard_begin / _progress / _end (the progressive shard search tsh_search_sharded is now built on);
  *    tsh_counters.list_scans, tsh_counters.exact_scans (the reserved slot of version 2), tsh_comm_timeline.pre_enqueue_us;
- *    TSH_OPT_EXCHANGE_AHEAD, TSH_OPT_EXACT_SCAN_ROWS, TSH_OPT_TEST_HOOKS. */
+ *    TSH_OPT_EXCHANGE_AHEAD, TSH_OPT_EXACT_SCAN_ROWS, TSH_OPT_TEST_HOOKS.
+ * 5: mask handles (tsh_mask_create / _destroy / _kept, tsh_search_masked, tsh_search_submit_masked): a WHERE row set
+ *    that lives on the device across queries; tsh_index_open_ngh_shard (a rank cold-starts its own row range);
+ *    tsh_ngh_info grew (row_base, row_end); tsh_comm_timeline's sampled fields are scaled by exchanges / timed
+ *    exchanges instead of a constant. */
 
 /* status codes */
 #define TSH_OK 0
@@ -195,6 +199,8 @@ typedef struct tsh_ngh_info {
   int64_t pages_absent; /* raw-vector pages below nextNodeId that are not on disk (file missing or shorter): their
                            node ids are ABSENT rows; a healthy index has 0 -- a caller may refuse the handle otherwise */
   int64_t files_absent; /* raw-vector partition files below nextNodeId that are missing altogether */
+  int64_t row_base;     /* node ids [row_base, row_end) are what this handle was opened for: 0 and nextNodeId for */
+  int64_t row_end;      /* tsh_index_open_ngh, the rank's range for tsh_index_open_ngh_shard (ABI 5) */
 } tsh_ngh_info;
 
 /* Cold start from an index directory written by the reference, without Dart
@@ -216,6 +222,20 @@ typedef struct tsh_ngh_info {
  * pass the CRC but do not decode -> TSH_E_FORMAT.  info may be NULL. */
 int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices, tsh_index **out,
                            tsh_ngh_info *info);
+/* Cold start of ONE row-range shard, for the one-process-per-GPU deployment tsh_search_sharded serves: rank `rank`
+ * of `world` opens node ids [rank * per, min(nextNodeId, (rank + 1) * per)), per = ceil(nextNodeId / world), on
+ * `device` (-1 = current) as a shard handle (tsh_index_create_shard: ids stay GLOBAL).  The addressing of
+ * lib/src/model/ngh_index_meta.dart:480-490 makes that range a contiguous run of raw-vector partition files
+ * (lib/src/core/path_manager.dart:275-324) and, inside the first and the last of them, of pages: only those files
+ * are opened and only those pages read -- at BASELINE.json's C4 (10 M x 1536: 82 GB of pages) a rank of eight
+ * reads its eighth.  A range that starts or ends inside a page takes that page's slots from / up to the boundary.
+ * Tombstones come from the graph pages that hold the range's node ids (lib/src/core/ngh_page.dart:105-108,
+ * 198-213), likewise only those.  Everything else -- meta.json, page checks, absent pages and files, errors -- is
+ * tsh_index_open_ngh's; info (nullable) reports the census of THIS range (rows_loaded, tombstones, files_read,
+ * pages_absent, files_absent) and the range itself (row_base, row_end).  W shards opened this way and merged
+ * (tsh_merge_candidates / tsh_search_sharded) answer exactly what the whole-index handle answers. */
+int32_t tsh_index_open_ngh_shard(const char *ngh_dir, int32_t max_entries_per_dir, int32_t device, int32_t world,
+                                 int32_t rank, tsh_index **out, tsh_ngh_info *info);
 
 /* Write-path helper: PQ-encode resident rows
  * [first_row_id, first_row_id + n_rows) against a trained codebook -- the
@@ -275,6 +295,33 @@ int32_t tsh_index_metric(tsh_index *idx);
 int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k,
                    double distance_threshold, const uint8_t *row_mask,
                    int64_t *out_ids, double *out_dist, int32_t *out_count);
+
+/* ---- mask handles: a WHERE row set that lives on the device ------------------------------------------------------
+ * tsh_search's row_mask pointer is consumed per call: the library slices the caller's bitmap, counts it and -- for a
+ * selective one -- lists its rows, on the host, every time (three passes over 125 KB at 1 M rows: more than half of
+ * a lone masked query's latency).  A row set that serves many queries -- the rows a WHERE clause keeps, mapped from
+ * primary keys through the pk -> nodeId tree (lib/src/core/vector_index_manager.dart:1223-1378), or the complement
+ * of a tombstone set (lib/src/core/ngh_page.dart:105-108) -- is made a HANDLE instead: the bitmap is uploaded once,
+ * and when it is selective (few enough kept rows for the list scan or the exact path) compacted into the ascending
+ * list of kept row ids ON THE DEVICE (popcount per 64-row word, a prefix over the words, one thread per word writing
+ * its rows: the list never exists on the host).  Searches with the handle read both in place: no per-call copy, no
+ * host pass.
+ *   bits     GLOBAL keep bitmap, bit i (LSB first) = 1 keeps row id i, n_bytes bytes of it; rows at or beyond
+ *            8 * n_bytes are NOT kept -- rows appended after the mask was made included (the handle re-slices its
+ *            copy of the bitmap on the first search after an append; never the caller's memory again)
+ *   rows tombstoned later are dropped as always (the kernels check the live bitmap), deleted rows never come back
+ * A handle belongs to the index it was made for (any handle kind: whole index, several devices, a shard) and must be
+ * destroyed before it; destroy it only after every ticket submitted with it has been waited for.  Thread-safe: any
+ * number of searches may share one handle.  Results are identical to the pointer form's. */
+typedef struct tsh_mask tsh_mask;
+int32_t tsh_mask_create(tsh_index *idx, const uint8_t *bits, int64_t n_bytes, tsh_mask **out);
+int32_t tsh_mask_destroy(tsh_mask *mask);
+/* rows the mask keeps among the index's current row ids (tombstones not subtracted); < 0 = error */
+int64_t tsh_mask_kept(tsh_mask *mask);
+/* tsh_search / tsh_search_submit with the row set of a handle (mask may be NULL: no filter) */
+int32_t tsh_search_masked(tsh_index *idx, const float *queries, int32_t nq, int32_t k, double distance_threshold,
+                          tsh_mask *mask, int64_t *out_ids, double *out_dist, int32_t *out_count);
+int32_t tsh_search_submit_masked(tsh_index *idx, const float *query, int32_t k, tsh_mask *mask, int32_t *out_ticket);
 
 /* Asynchronous form of a single-query tsh_search, for callers that keep several
  * independent queries in flight (the reference serves concurrent vectorSearch
@@ -422,7 +469,7 @@ typedef struct tsh_comm_timeline {
   double scan_us;          /* helper thread: tsh_search_shard of the groups (overlaps the previous group's exchange) */
   double exchange_wait_us; /* from issuing the block all-gather until this rank's slice is on the host */
   double gather_us;        /* the all-gather (RCCL: device time on the communicator's stream; every fourth exchange is
-                              timed and counted four times) */
+                              timed, the sum scaled by exchanges / timed exchanges) */
   double slice_d2h_us;     /* the slice's copy to the host (sampled likewise) */
   double merge_us;         /* host merge of the slice (threshold, order, cut) */
   double result_gather_us; /* every slice's results to every rank: H2D + all-gather + D2H */

@@ -56,3 +56,50 @@ def scan_path(request, monkeypatch):
 
         monkeypatch.setattr(backend.HipVectorIndex, "__init__", patched)
     return request.param
+
+
+@pytest.fixture(params=["pointer", "handle"])
+def mask_form(request, monkeypatch):
+    """A row mask reaches the library as a POINTER (tsh_search's row_mask: sliced, counted and listed on the host, call
+    by call) or as a HANDLE (tsh_mask_create: uploaded once, listed on the device, resident).  Tests that pass masks run
+    both ways: "handle" makes HipVectorIndex.search / submit turn every mask array into a mask handle first -- one per
+    distinct bitmap and index, kept until the index is closed, so handles are also reused across calls, appends and
+    deletes exactly as the tests' pointer masks are.  Results must be identical.  A test asks for it with
+    @pytest.mark.usefixtures("mask_form")."""
+    if request.param == "handle":
+        import numpy as np
+
+        from tostore_amd import backend
+
+        cls = backend.HipVectorIndex
+        search, submit, close = cls.search, cls.submit, cls.close
+
+        def handle_for(self, row_mask):
+            if row_mask is None or isinstance(row_mask, backend.HipMask):
+                return row_mask
+            arr = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+            if arr.shape[0] < (self.size + 7) // 8:
+                return row_mask  # (too short for the pointer form: let mask_arg say so)
+            cache = self.__dict__.setdefault("_test_masks", {})
+            key = arr.tobytes()
+            if key not in cache:
+                if len(cache) >= 6:
+                    cache.pop(next(iter(cache))).close()
+                cache[key] = backend.HipMask(self, arr)
+            return cache[key]
+
+        def p_search(self, queries, k, distance_threshold=None, row_mask=None):
+            return search(self, queries, k, distance_threshold, handle_for(self, row_mask))
+
+        def p_submit(self, query, k, row_mask=None):
+            return submit(self, query, k, handle_for(self, row_mask))
+
+        def p_close(self):
+            for m in self.__dict__.pop("_test_masks", {}).values():
+                m.close()
+            close(self)
+
+        monkeypatch.setattr(cls, "search", p_search)
+        monkeypatch.setattr(cls, "submit", p_submit)
+        monkeypatch.setattr(cls, "close", p_close)
+    return request.param

@@ -7,6 +7,19 @@ import os
 import numpy as np
 
 
+class FakeMask:
+    """Stands for a HipMask: the bitmap, usable wherever a row mask is."""
+
+    def __init__(self, bits):
+        self.bits, self.closed = np.asarray(bits, np.uint8), False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.closed = True
+
+
 class FakeIndex:
     def __init__(self, oracle, d, metric, rows, lo):
         self.o, self.dim, self.metric, self.rows, self.lo = oracle, d, metric, np.ascontiguousarray(rows), lo
@@ -23,6 +36,9 @@ class FakeIndex:
     def _mask(self, row_mask):
         if row_mask is None:
             return None
+        if isinstance(row_mask, FakeMask):
+            assert not row_mask.closed
+            row_mask = row_mask.bits
         assert len(row_mask) >= (self.size + 7) // 8
         bits = np.unpackbits(np.asarray(row_mask, np.uint8), bitorder="little")[self.lo:self.lo + len(self.rows)]
         return np.packbits(bits, bitorder="little")
@@ -54,6 +70,9 @@ class FakeIndex:
     def wait(self, ticket, thr=None):
         ids, dist, cnt = self.pending.pop(ticket[0])
         return ids[0, :cnt[0]], dist[0, :cnt[0]]
+
+    def make_mask(self, bits):
+        return FakeMask(bits)
 
     def counters(self):
         return dict(self.c)
@@ -172,10 +191,11 @@ class FakeEnv:
         self._whole = FakeIndex(self.o, d, metric, corpus, 0)
         return idx, (corpus[lo:hi] if keep_host else None)
 
-    def oracle_chunks(self, n, d, metric):
+    def oracle_chunks(self, n, d, metric, lo=0, hi=None):
         corpus = self.corpus(n, d, metric)
-        for r0 in range(0, n, 1000):  # several chunks: the merge across chunks is exercised
-            yield r0, corpus[r0:r0 + 1000]
+        hi = n if hi is None else hi
+        for r0 in range(lo, hi, 1000):  # several chunks: the merge across chunks is exercised
+            yield r0, corpus[r0:min(hi, r0 + 1000)]
 
     def searcher(self, idx):
         if self.world == 1:

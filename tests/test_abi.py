@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"{n} declared in tostore_hip.h but not exported"
     assert sorted(_ffi.SIGNATURES) == names, "ctypes SIGNATURES out of sync with the header"
-    assert _ffi.lib().tsh_abi_version() == _ffi.ABI_VERSION == 4
+    assert _ffi.lib().tsh_abi_version() == _ffi.ABI_VERSION == 5
 
 
 def test_no_device_is_an_error_not_a_fallback():

@@ -55,6 +55,9 @@ def test_single_gpu_line(oracle_mod, steps, warmup):
         assert side["C5"][keep]["ids_and_distances_bit_exact"] is True, side["C5"]
         assert side["C5"][keep]["checked_queries"] == 40
         assert side["C5"][keep]["library_default_path"]["ids_and_distances_bit_exact"] is True
+        mh = side["C5"][keep]["mask_handle"]  # the same mask as a device-resident handle: pipelined and one at a time
+        assert mh["ids_and_distances_bit_exact"] is True and mh["value"] > 0
+        assert set(mh["one_at_a_time_us"]) == {"pointer", "handle"} and mh["one_at_a_time_us"]["handle"]["p50"] > 0
     assert side["C5"]["keep_10%_range"]["mask"] == "range" and side["C5"]["keep_100%"]["kept_rows"] == 3000
     assert side["C1"]["ids_and_distances_bit_exact"] is True and side["C1"]["latency_us"]["p50"] > 0
     ann = side["C1"]["reference_ann_restated"]  # context only, labelled as a restatement
@@ -66,6 +69,25 @@ def test_single_gpu_line(oracle_mod, steps, warmup):
         assert c3["ms_per_step"] <= c3["ms_per_step_p99"] <= c3["ms_per_step_max"]
         assert c3["roofline"]["bound"] == "mfma" and c3["f32_mfma_variant"]["roofline"]["peak"] == 157.3
         assert set(c3["smaller_calls"]) == {"16_queries", "128_queries"}
+    assert all(i.closed for i in env.made)
+
+
+def test_c4_shard_of_8_leg(oracle_mod):
+    """side.C4_shard_of_8: one rank's share of BASELINE.json's C4 in the N = 1 line -- the
+    sharded entry point over a world of one, the driver's regions, the oracle over that shard (streamed: no host
+    copy), and the 1024-query call on the shard's matrix cores."""
+    a = _args("--steps", "20", "--warmup", "5", "--side", "c4s8")
+    env = FakeEnv(oracle_mod)
+    out = json.loads(bench.run_bench(a, env))
+    assert set(out["side"]) == {"C4_shard_of_8", "seconds"}
+    c4 = out["side"]["C4_shard_of_8"]
+    assert "error" not in c4, c4
+    assert c4["workload"].startswith("one rank's share of C4 at N = 8: 300x1536 f32, ip, k=100, 20 single-query steps")
+    assert c4["roofline"]["algorithmic_bytes_per_launch"] == 300 * 1536 * 4 and c4["upper_bound_speedup"] is None
+    assert c4["timed_regions"]["count"] == bench.auto_repeats(20) and c4["exchange_timeline"]["ranks"][0]["calls"] >= 3
+    assert c4["ids_and_distances_bit_exact"] is True and c4["recall_at_k"] == 1.0 and c4["checked_queries"] == 16
+    b = c4["batch_1024"]
+    assert "error" not in b and b["value"] > 0 and b["single_and_batched_agree"] is True and b["roofline"]["bound"] == "mfma"
     assert all(i.closed for i in env.made)
 
 

@@ -20,6 +20,7 @@ C2DART = {
     "void*": "Pointer<Void>", "tsh_index*": "Pointer<Void>", "tsh_index**": "Pointer<Pointer<Void>>",
     "tsh_comm*": "Pointer<Void>", "tsh_comm**": "Pointer<Pointer<Void>>",
     "tsh_shard_stream*": "Pointer<Void>", "tsh_shard_stream**": "Pointer<Pointer<Void>>",
+    "tsh_mask*": "Pointer<Void>", "tsh_mask**": "Pointer<Pointer<Void>>",
     "tsh_ngh_info*": "Pointer<TshNghInfo>", "tsh_counters*": "Pointer<TshCounters>",
     "tsh_comm_timeline*": "Pointer<TshCommTimeline>",
     "tsh_allgather_fn": "Pointer<NativeFunction<TshAllgatherNative>>",
@@ -33,6 +34,7 @@ C2CTYPES = {
     "tsh_index**": ctypes.POINTER(ctypes.c_void_p), "tsh_comm*": ctypes.c_void_p,
     "tsh_comm**": ctypes.POINTER(ctypes.c_void_p), "tsh_allgather_fn": ctypes.c_void_p,
     "tsh_shard_stream*": ctypes.c_void_p, "tsh_shard_stream**": ctypes.POINTER(ctypes.c_void_p),
+    "tsh_mask*": ctypes.c_void_p, "tsh_mask**": ctypes.POINTER(ctypes.c_void_p),
 }
 
 

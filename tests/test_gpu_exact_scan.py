@@ -59,6 +59,7 @@ def test_every_width_and_k(hip_lib, oracle_mod, metric, d):
         assert idx.counters()["exact_scans"] == c1["exact_scans"]
 
 
+@pytest.mark.usefixtures("mask_form")  # the mask as a pointer, and as a device-resident handle
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 def test_where_the_path_ends(hip_lib, oracle_mod, metric):
     """16384 rows are the last size the exact path takes (2048 waves of eight rows there); one more row, or a lower
@@ -92,6 +93,7 @@ def test_where_the_path_ends(hip_lib, oracle_mod, metric):
             assert e.value.code == _ffi.TSH_E_BAD_ARG
 
 
+@pytest.mark.usefixtures("mask_form")  # the mask as a pointer, and as a device-resident handle
 @pytest.mark.parametrize("metric", [L2, IP, COS])
 def test_masks_tombstones_and_lists(hip_lib, oracle_mod, metric):
     from tostore_amd import HipVectorIndex
@@ -322,6 +324,7 @@ def test_ticket_api_and_threads(hip_lib, oracle_mod):
         assert c["exact_scans"] == c["scan_launches"] == 8 + 64 + 64 and c["fallback_searches"] == 0
 
 
+@pytest.mark.usefixtures("mask_form")
 @pytest.mark.parametrize("d", [32, 64, 128])
 def test_narrow_rows_get_a_list_for_the_exact_path_only(hip_lib, oracle_mod, d):
     """Rows of 32 / 64 / 128 floats are scanned by the packed kernels, which have no list form: a selective mask walks
@@ -346,6 +349,7 @@ def test_narrow_rows_get_a_list_for_the_exact_path_only(hip_lib, oracle_mod, d):
         assert idx.counters()["fallback_searches"] == 0
 
 
+@pytest.mark.usefixtures("mask_form")
 def test_ticket_api_builds_a_list_for_selective_masks(hip_lib, oracle_mod):
     """tsh_search_submit slices the mask itself: a selective one gets its list (and with it the exact path) like in
     tsh_search."""

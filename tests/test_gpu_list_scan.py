@@ -21,6 +21,7 @@ def _local(mask, base, n):
     return np.packbits(bits, bitorder="little")
 
 
+@pytest.mark.usefixtures("mask_form")  # the mask as a pointer, and as a device-resident handle
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("d", [100, 384, 768, 1000, 1536, 2048])
 def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d, scan_path):
@@ -64,6 +65,7 @@ def test_selective_masks_every_width(hip_lib, oracle_mod, metric, d, scan_path):
         _check(idx, oracle_mod, rows, qs[:3], metric, k, mask, thr)
 
 
+@pytest.mark.usefixtures("mask_form")
 def test_tombstones_ties_ranges_and_shards(hip_lib, oracle_mod, scan_path):
     from tostore_amd import HipVectorIndex
 

@@ -5,11 +5,11 @@ libtostore_hip.so), the ctypes binding (_ffi), and the host-side mirror of the
 reference interface around the seam (backend, vector_index_manager, sharded).
 """
 from . import _ffi  # noqa: F401
-from .backend import HipVectorBackend, HipVectorIndex, NghSearchResult  # noqa: F401
+from .backend import HipMask, HipVectorBackend, HipVectorIndex, NghSearchResult  # noqa: F401
 from .vector_index_manager import (VectorIndexManager, VectorSearchResult,  # noqa: F401
                                    distance_to_score, normalize_float32, to_float32)
 
 __all__ = [
-    "HipVectorBackend", "HipVectorIndex", "NghSearchResult", "VectorIndexManager",
+    "HipMask", "HipVectorBackend", "HipVectorIndex", "NghSearchResult", "VectorIndexManager",
     "VectorSearchResult", "distance_to_score", "normalize_float32", "to_float32",
 ]

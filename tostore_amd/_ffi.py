@@ -27,7 +27,7 @@ TSH_E_FORMAT = -8
 TSH_E_BUSY = -9
 TSH_E_RCCL = -10
 TSH_E_PEER = -11
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 
@@ -58,6 +58,7 @@ class TshNghInfo(ctypes.Structure):
         ("max_degree", c_i32), ("reserved", c_i32), ("next_node_id", c_i64), ("total_vectors", c_i64),
         ("deleted_count", c_i64), ("max_partition_file_size", c_i64), ("rows_loaded", c_i64),
         ("tombstones", c_i64), ("files_read", c_i64), ("pages_absent", c_i64), ("files_absent", c_i64),
+        ("row_base", c_i64), ("row_end", c_i64),
     ]
 
 
@@ -84,12 +85,19 @@ SIGNATURES = {
     "tsh_index_set_deleted": (c_i32, [p_void, p_i64, c_i64]),
     "tsh_index_load_rawvec_file": (c_i32, [p_void, ctypes.c_char_p, c_i32, c_i32, c_i64, c_i64, p_i64]),
     "tsh_index_open_ngh": (c_i32, [ctypes.c_char_p, c_i32, c_i32, ctypes.POINTER(p_void), ctypes.POINTER(TshNghInfo)]),
+    "tsh_index_open_ngh_shard": (c_i32, [ctypes.c_char_p, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(p_void),
+                                         ctypes.POINTER(TshNghInfo)]),
     "tsh_pq_train": (c_i32, [c_i32, p_f32, c_i64, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_int32), p_f32]),
     "tsh_index_pq_encode": (c_i32, [p_void, c_i64, c_i64, p_f32, c_i32, c_i32, p_u8]),
     "tsh_index_size": (c_i64, [p_void]),
     "tsh_index_dim": (c_i32, [p_void]),
     "tsh_index_metric": (c_i32, [p_void]),
     "tsh_search": (c_i32, [p_void, p_f32, c_i32, c_i32, c_f64, p_u8, p_i64, p_f64, p_i32]),
+    "tsh_mask_create": (c_i32, [p_void, p_u8, c_i64, ctypes.POINTER(p_void)]),
+    "tsh_mask_destroy": (c_i32, [p_void]),
+    "tsh_mask_kept": (c_i64, [p_void]),
+    "tsh_search_masked": (c_i32, [p_void, p_f32, c_i32, c_i32, c_f64, p_void, p_i64, p_f64, p_i32]),
+    "tsh_search_submit_masked": (c_i32, [p_void, p_f32, c_i32, p_void, p_i32]),
     "tsh_max_inflight": (c_i32, []),
     "tsh_search_submit": (c_i32, [p_void, p_f32, c_i32, p_u8, p_i32]),
     "tsh_search_ready": (c_i32, [p_void, c_i32]),

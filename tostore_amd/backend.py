@@ -32,6 +32,47 @@ def _f32c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class HipMask:
+    """A WHERE row set that lives on the device (`tsh_mask*`, include/tostore_hip.h): the keep bitmap is uploaded once
+    and -- when it is selective -- compacted into the list of kept row ids on the device; searches that pass the
+    handle (`HipVectorIndex.search(..., row_mask=handle)`) do no host work on the mask.  The natural row sets are the
+    ones that serve many queries in the reference: a WHERE's primary keys mapped through the pk -> nodeId tree
+    (/root/reference/lib/src/core/vector_index_manager.dart:1223-1378) and the complement of the tombstones
+    (/root/reference/lib/src/core/ngh_page.dart:105-108).  Rows appended after the mask was made are not kept; rows
+    deleted later are dropped as always.  Destroy before the index (close / context manager)."""
+
+    def __init__(self, index: "HipVectorIndex", bits):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+        self._h = ctypes.c_void_p()
+        self.index = index
+        _ffi.check(_ffi.lib().tsh_mask_create(index._h, bits.ctypes.data_as(_ffi.p_u8), bits.shape[0],
+                                              ctypes.byref(self._h)))
+
+    @property
+    def kept(self) -> int:
+        n = _ffi.lib().tsh_mask_kept(self._h)
+        if n < 0:
+            _ffi.check(int(n))
+        return int(n)
+
+    def close(self) -> None:
+        if self._h:
+            _ffi.lib().tsh_mask_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipVectorIndex:
     """Owner of one `tsh_index*`.  Destroy exactly once (close / context manager)."""
 
@@ -57,6 +98,23 @@ class HipVectorIndex:
                                                  ctypes.byref(self._h), ctypes.byref(info)))
         self.dim, self.metric, self.row_base = info.dimensions, info.metric, 0
         return self, {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
+
+    @classmethod
+    def open_ngh_shard(cls, ngh_dir: str, world: int, rank: int, device: int = -1, max_entries_per_dir: int = 500):
+        """Cold start of ONE rank's row range [rank * ceil(N / world), ...) of `<index>/ngh` as a shard handle
+        (global ids): only the partition files / pages that hold the range are read
+        (/root/reference/lib/src/model/ngh_index_meta.dart:480-490).  Returns (index, info dict)."""
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        info = _ffi.TshNghInfo()
+        _ffi.check(_ffi.lib().tsh_index_open_ngh_shard(str(ngh_dir).encode(), max_entries_per_dir, device, world, rank,
+                                                       ctypes.byref(self._h), ctypes.byref(info)))
+        self.dim, self.metric, self.row_base = info.dimensions, info.metric, info.row_base
+        return self, {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
+
+    def make_mask(self, bits) -> "HipMask":
+        """A device-resident row set for many searches (bit i of `bits`, LSB first, keeps GLOBAL row id i)."""
+        return HipMask(self, bits)
 
     # -- lifetime -----------------------------------------------------------
     def close(self) -> None:
@@ -166,6 +224,11 @@ class HipVectorIndex:
         dist = np.empty((nq, max(kk, 1)), dtype=np.float64)
         cnt = np.zeros(nq, dtype=np.int32)
         thr = math.nan if distance_threshold is None else float(distance_threshold)
+        if isinstance(row_mask, HipMask):  # a mask handle: resident on the device, nothing to prepare
+            _ffi.check(_ffi.lib().tsh_search_masked(self._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, row_mask._h,
+                                                    ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
+                                                    cnt.ctypes.data_as(_ffi.p_i32)))
+            return ids[:, :kk], dist[:, :kk], cnt
         row_mask, mp = self.mask_arg(row_mask)
         _ffi.check(_ffi.lib().tsh_search(self._h, q.ctypes.data_as(_ffi.p_f32), nq, int(k), thr, mp,
                                          ids.ctypes.data_as(_ffi.p_i64), dist.ctypes.data_as(_ffi.p_f64),
@@ -177,8 +240,12 @@ class HipVectorIndex:
         q = _f32c(query).reshape(-1)
         if q.shape[0] != self.dim:
             raise ValueError(f"query must have {self.dim} elements")
-        row_mask, mp = self.mask_arg(row_mask)
         t = ctypes.c_int32(-1)
+        if isinstance(row_mask, HipMask):
+            _ffi.check(_ffi.lib().tsh_search_submit_masked(self._h, q.ctypes.data_as(_ffi.p_f32), int(k), row_mask._h,
+                                                           ctypes.byref(t)))
+            return (t.value, int(k))
+        row_mask, mp = self.mask_arg(row_mask)
         _ffi.check(_ffi.lib().tsh_search_submit(self._h, q.ctypes.data_as(_ffi.p_f32), int(k), mp,
                                                 ctypes.byref(t)))
         return (t.value, int(k))

@@ -27,7 +27,7 @@ _KERN = ["tsh_kernels.hip.h", "tsh_batch.hip.h", "tsh_launch.h", _HDR]
 UNITS = {
     "tsh_scan_tu.hip": _KERN,
     "tsh_batch_tu.hip": _KERN + ["tsh_batch_f16.hip.h", "tsh_batch_f16pp.hip.h"],
-    "tsh_lib.hip": _KERN + ["tsh_batch_f16.hip.h", "tsh_batch_f16pp.hip.h", "tsh_exact.hip.h", "tsh_host_sync.h", "tsh_pq.hip.h",
+    "tsh_lib.hip": _KERN + ["tsh_batch_f16.hip.h", "tsh_batch_f16pp.hip.h", "tsh_exact.hip.h", "tsh_mask.hip.h", "tsh_host_sync.h", "tsh_pq.hip.h",
                             "tsh_host_batch.inl.h", "tsh_host_coldstart.inl.h", "tsh_host_pq.inl.h",
                             "tsh_host_comm.inl.h"],
 }

@@ -307,7 +307,7 @@ inline bool trace_batch() {
 // returns TSH_E_OOM with nothing of the call left in flight and nothing written: the caller may retry or answer
 // another way.
 int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, int32_t k,
-                       const uint8_t *mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo,
+                       const MaskSrc &mask, int32_t entries, SearchOut *out, std::vector<int32_t> *redo,
                        int force_kernel = -1) {
   // the shard's first scratch set stands for "either": a call that finds it taken by a concurrent call uses the second
   std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
@@ -368,7 +368,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_blocks_dev), b->h_blocks, 0));
   if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
   const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
-  if (mask && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
+  // (a mask handle's words are resident, host and device: no copy of them in this call's scratch)
+  if (mask.bytes && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
 
   // ---- bf16x3 / f16 kernels: keep the converted planes of the rows current ----------------------
   // auto: cosine keys are scale-free (unit rows, unit query), so fp16's fixed relative precision gives a
@@ -468,7 +469,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         }
     }
   }
-  if (mask) slice_mask(s, mask, b->h_mask, n_tiles_all);
+  if (mask.bytes) slice_mask(s, mask.bytes, b->h_mask, n_tiles_all);
+  const uint64_t *h_mw = mask.part ? mask.part->h_words.data() : (mask.bytes ? b->h_mask : nullptr);  // this shard's slice,
+  const uint64_t *d_mw = mask.part ? mask.part->d_words : (mask.bytes ? b->d_mask : nullptr);          // host and device
   // Where the sample sits.  The first n_sample rows serve any mask that keeps rows everywhere; a WHERE clause that
   // keeps one id RANGE leaves them without a single kept row -- no threshold, every kept row a survivor, every list
   // overflowing, every query redone by a scan of its own (1 M x 768, a 10 % range, 64-query calls: 5.5 k queries/s where
@@ -478,8 +481,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   int64_t s0 = 0;
   if (mask && n_sample < rows) {
     const int64_t wt = n_sample / 64, step = std::max<int64_t>(4, wt / 2 / 4 * 4);  // in 64-row mask words; 256-row aligned
-    std::vector<int32_t> pre((size_t)n_tiles_all + 1, 0);
-    for (int32_t t = 0; t < n_tiles_all; ++t) pre[(size_t)t + 1] = pre[(size_t)t] + __builtin_popcountll(b->h_mask[t]);
+    std::vector<int32_t> pre_own;
+    if (!mask.part) {
+      pre_own.assign((size_t)n_tiles_all + 1, 0);
+      for (int32_t t = 0; t < n_tiles_all; ++t) pre_own[(size_t)t + 1] = pre_own[(size_t)t] + __builtin_popcountll(h_mw[t]);
+    }
+    const std::vector<int32_t> &pre = mask.part ? mask.part->pre : pre_own;  // (a handle counted its words when it was made)
     int64_t best = -1;
     for (int64_t w0 = 0; w0 * 64 + n_sample <= rows; w0 += step) {
       const int64_t kept = pre[(size_t)std::min<int64_t>(w0 + wt, n_tiles_all)] - pre[(size_t)w0];
@@ -496,7 +503,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   std::vector<uint32_t> quar_sel;
   const int32_t n_quar = (int32_t)s->quar_ids.size();
   if (n_quar) {
-    quarantine_select(s, mask ? b->h_mask : nullptr, &quar_sel);
+    quarantine_select(s, h_mw, &quar_sel);
     if (!quar_sel.empty() && !out->d_blocks) {
       if (!out->extra) return set_err(TSH_E_BAD_ARG, "no room for the quarantined rows' entries");
       if ((rc = regrow(&b->d_quar_out, &b->h_quar_out, &b->quar_cap, (int64_t)nq * n_quar, &b->bytes))) return rc;
@@ -534,7 +541,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpyAsync(b->d_Q, b->h_Q, (size_t)nq_pad * ld * sizeof(float), hipMemcpyHostToDevice, up));
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));
     HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));  // kmax, alpha
-    if (mask) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, up));
+    if (mask.bytes) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, up));
     if (gpu_final) HIPCHK(hipMemcpyAsync(b->d_sqrt_mag, b->h_sqrt_mag, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, up));
     HIPCHK(hipEventRecord(b->e_up, up));
   }
@@ -662,7 +669,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     const float chain2 = batch_chain2(s, kern);
     a.alpha = roww ? b->d_qaux + 5 * (size_t)nq_pad : nullptr;
     a.live = s->all_live ? nullptr : s->d_live;
-    a.mask = mask ? b->d_mask : nullptr;
+    a.mask = d_mw;
     a.dense = b->d_dense;
     a.cand_key = b->d_ck;
     a.cand_row = b->d_cr;
@@ -807,7 +814,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         qa.rows = s->d_rows;
         qa.Q = b->d_Q + (size_t)q0 * ld;
         qa.list = s->d_quar;
-        qa.mask = mask ? b->d_mask : nullptr;
+        qa.mask = d_mw;
         qa.blocks = b->d_blocks + (size_t)q0 * bb;
         qa.ld = ld;
         qa.ldq = ld;
@@ -974,7 +981,7 @@ bool shard_takes_batch(const Shard *s, int32_t batch_min_nq, int32_t nq, int32_t
 // nq queries on one shard: matrix-core batch when it pays, single-query pipeline
 // otherwise and for whatever the batch hands back.
 int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
-                     const uint8_t *mask, int32_t entries, SearchOut *out) {
+                     const MaskSrc &mask, int32_t entries, SearchOut *out) {
   const bool use_batch = shard_takes_batch(s, batch_min_nq, nq, k);
   if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
   std::vector<int32_t> redo;

@@ -97,8 +97,10 @@ PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int 
 }
 
 // tsh_index_load_rawvec_file with the page census tsh_index_open_ngh reports
+// lo_row_id: only node ids >= lo_row_id are loaded (tsh_index_open_ngh_shard: a rank's range may begin inside a
+// partition file and inside a page); pages that hold none of them are neither read nor counted
 int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_t precision, int64_t first_row_id,
-                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages);
+                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages, int64_t lo_row_id = -1);
 
 }  // namespace
 
@@ -110,7 +112,7 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
 
 namespace {
 int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_t precision, int64_t first_row_id,
-                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages) {
+                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages, int64_t lo_row_id) {
   if (out_rows) *out_rows = 0;
   if (out_absent_pages) *out_absent_pages = 0;
   if (!idx || !path) return set_err(TSH_E_BAD_ARG, "NULL pointer");
@@ -124,6 +126,8 @@ int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_
   FILE *f = fopen(path, "rb");
   if (!f) return set_err(TSH_E_IO, "cannot open %s", path);
   int64_t n_pages = (max_rows + vpp - 1) / vpp;  // data pages needed to cover the ids
+  const int64_t lo_rel = std::max<int64_t>(0, lo_row_id - first_row_id);  // first id wanted, relative to the file's first
+  const int64_t p_first = lo_rel / vpp;                                   // ... and the data page that holds it
   const int BATCH = std::max(1, (int)((32 << 20) / ((int64_t)vpp * dim * 4)));
   // one read per block of BATCH pages, pages decoded (CRC + copy / widen) in parallel on the host pool
   std::vector<uint8_t> raw((size_t)BATCH * (size_t)page_size);
@@ -131,7 +135,7 @@ int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_
   std::vector<int> kinds((size_t)BATCH), counts((size_t)BATCH);
   int64_t loaded = 0, absent = 0;
   int rc = TSH_OK;
-  for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
+  for (int64_t p0 = p_first; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
     int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
     size_t got_total = 0;
     if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // pageNo 0 is the partition meta page
@@ -176,13 +180,14 @@ int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_
       }
       int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
       int64_t lim = std::min<int64_t>(counts[(size_t)b], max_rows - base);
-      if (lim <= 0) continue;
-      if (run_len > 0 && run_start + run_len == b * vpp) {
+      const int64_t skip = std::max<int64_t>(0, lo_rel - base);  // slots below the range's first id (its first page only)
+      if (lim <= skip) continue;
+      if (run_len > 0 && skip == 0 && run_start + run_len == b * vpp) {
         run_len += lim;
       } else {
         flush();
-        run_start = b * vpp;
-        run_len = lim;
+        run_start = b * vpp + skip;
+        run_len = lim - skip;
       }
       if (lim < vpp) flush();  // slots past vectorCount are absent rows
     }
@@ -321,8 +326,11 @@ const uint8_t *page_payload(const uint8_t *pg, size_t avail, uint32_t *plen, int
 
 }  // namespace
 
-extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices,
-                                      tsh_index **out, tsh_ngh_info *info) {
+namespace {
+// tsh_index_open_ngh (world == 0: the whole index on n_devices) and tsh_index_open_ngh_shard (world >= 1: node ids
+// [rank * per, (rank + 1) * per), per = ceil(nextNodeId / world), as a shard handle on `device`)
+int32_t open_ngh_impl(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices, int32_t device, int32_t world,
+                      int32_t rank, tsh_index **out, tsh_ngh_info *info) {
   if (out) *out = nullptr;
   if (info) memset(info, 0, sizeof *info);
   if (!ngh_dir || !out) return set_err(TSH_E_BAD_ARG, "NULL pointer");
@@ -371,18 +379,31 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
     info->deleted_count = json_int(m, "deletedCount", 0);
     info->max_partition_file_size = max_file;
   }
+  // the node ids this handle is opened for
+  int64_t lo = 0, hi = next_id;
+  if (world >= 1) {
+    const int64_t per = (next_id + world - 1) / world;
+    lo = std::min<int64_t>(next_id, (int64_t)rank * per);
+    hi = std::min<int64_t>(next_id, lo + per);
+  }
+  if (info) {
+    info->row_base = lo;
+    info->row_end = hi;
+  }
   tsh_index *idx = nullptr;
-  int32_t rc = tsh_index_create((int32_t)dim, metric, next_id, n_devices, &idx);
+  int32_t rc = world >= 1 ? tsh_index_create_shard((int32_t)dim, metric, hi - lo, device, lo, &idx)
+                          : tsh_index_create((int32_t)dim, metric, next_id, n_devices, &idx);
   if (rc != TSH_OK) return rc;
-  // raw vectors: node id -> (partition, page, slot), ngh_index_meta.dart:480-490
+  // raw vectors: node id -> (partition, page, slot), ngh_index_meta.dart:480-490.  A range of node ids is a run of
+  // partition files and, inside the first and the last, of pages: nothing else is opened or read
   int64_t rows_loaded = 0, files = 0, absent_pages = 0, absent_files = 0;
   const int64_t rows_per_part = ppp * vpp;
-  for (int64_t part = 0; rc == TSH_OK && part * rows_per_part < next_id; ++part) {
-    const int64_t first = part * rows_per_part, want = std::min(rows_per_part, next_id - first);
+  for (int64_t part = lo / rows_per_part; rc == TSH_OK && hi > lo && part * rows_per_part < hi; ++part) {
+    const int64_t first = part * rows_per_part, want = std::min(rows_per_part, hi - first);
     const std::string path = ngh_partition_path(dir, "rawvec", part, max_entries_per_dir);
     if (access(path.c_str(), R_OK) == 0) {
       int64_t got = 0, absent = 0;
-      rc = load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got, &absent);
+      rc = load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got, &absent, lo);
       rows_loaded += got;
       absent_pages += absent;
       ++files;
@@ -390,7 +411,7 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
       // A missing partition file: its ids are absent rows (see decode_rawvec_page: the reference's reader makes
       // up zero vectors here, which an exhaustive scan must not offer to every query).
       ++absent_files;
-      absent_pages += (want + vpp - 1) / vpp;
+      absent_pages += (want + vpp - 1) / vpp - std::max<int64_t>(0, lo - first) / vpp;  // (the range's pages of it)
     }
   }
   // tombstones: flags byte of each graph slot (ngh_page.dart:105-108,198-213)
@@ -402,14 +423,14 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
     std::vector<std::vector<int64_t>> found((size_t)BLOCK);  // per page, filled in parallel
     std::vector<char> bad_page((size_t)BLOCK);
     std::vector<int64_t> dead;
-    for (int64_t part = 0; rc == TSH_OK && part * ids_per_part < next_id; ++part) {
+    for (int64_t part = lo / ids_per_part; rc == TSH_OK && hi > lo && part * ids_per_part < hi; ++part) {
       const std::string path = ngh_partition_path(dir, "graph", part, max_entries_per_dir);
       FILE *f = fopen(path.c_str(), "rb");
       if (!f) continue;  // no file: every page reads as NghGraphPage.empty -> flags 0
       ++files;
       const int64_t first = part * ids_per_part;
-      const int64_t n_pages = (std::min(ids_per_part, next_id - first) + npg - 1) / npg;
-      for (int64_t p0 = 0; p0 < n_pages && rc == TSH_OK; p0 += BLOCK) {
+      const int64_t n_pages = (std::min(ids_per_part, hi - first) + npg - 1) / npg;  // ... up to the range's last id
+      for (int64_t p0 = std::max<int64_t>(0, lo - first) / npg; p0 < n_pages && rc == TSH_OK; p0 += BLOCK) {
         const int64_t nb = std::min(BLOCK, n_pages - p0);
         size_t got_total = 0;
         if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // page 0 is the partition meta page
@@ -441,8 +462,8 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
           const int64_t base = first + (p0 + b) * npg;
           for (uint32_t sl = 0; sl < slot_count && (int64_t)sl < npg; ++sl) {
             const int64_t id = base + sl;
-            if (id >= next_id) break;
-            if (pl[4 + sl * ss] & 0x01) found[(size_t)b].push_back(id);
+            if (id >= hi) break;
+            if (id >= lo && (pl[4 + sl * ss] & 0x01)) found[(size_t)b].push_back(id);
           }
         });
         for (int64_t b = 0; b < nb; ++b) {
@@ -474,5 +495,18 @@ extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_p
   }
   *out = idx;
   return TSH_OK;
+}
+}  // namespace
+
+extern "C" int32_t tsh_index_open_ngh(const char *ngh_dir, int32_t max_entries_per_dir, int32_t n_devices,
+                                      tsh_index **out, tsh_ngh_info *info) {
+  return open_ngh_impl(ngh_dir, max_entries_per_dir, n_devices, -1, 0, 0, out, info);
+}
+
+extern "C" int32_t tsh_index_open_ngh_shard(const char *ngh_dir, int32_t max_entries_per_dir, int32_t device,
+                                            int32_t world, int32_t rank, tsh_index **out, tsh_ngh_info *info) {
+  if (out) *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return set_err(TSH_E_BAD_ARG, "bad world / rank");
+  return open_ngh_impl(ngh_dir, max_entries_per_dir, 1, device, world, rank, out, info);
 }
 

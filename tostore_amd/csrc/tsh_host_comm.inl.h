@@ -146,6 +146,9 @@ struct tsh_comm {
   uint32_t tag_seq = 0;  // generation of this rank's blocks: one per window of a call (the same on every rank)
   uint64_t exchanges = 0;  // block all-gathers enqueued so far
   bool timed_now = false;  // the one in flight carries ev_t[0] / ev_t[1]
+  int64_t tl_exch = 0, tl_timed = 0;  // exchanges / timed exchanges since the timeline's last reset: gather_us and
+                                      // slice_d2h_us are sums over the TIMED ones, scaled when the timeline is read
+  int32_t calls_since_agree = 0;      // calls since the ranks last told each other their shard sizes
   int32_t group = 0;  // queries per exchange; 0 = by the size of the call
   std::unique_ptr<OneWorker> worker;  // runs the calls' progressive shard searches (one call at a time: mu)
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};  // RCCL: before / after the block all-gather, after the slice's D2H
@@ -284,10 +287,12 @@ void comm_drop_buffers(tsh_comm *c) {
   c->h_mine = c->d_all = c->h_slice = c->h_res_mine = c->h_res_all = c->d_res_mine = c->d_res_all = nullptr;
   c->h_mine_cap = c->all_cap = c->slice_cap = c->res_cap = 0;
 }
+// refresh: agree although nothing grew (the ranks' shard sizes, which size the group schedule, drift with appends:
+// tsh_search_sharded asks for it every 64th call -- the same calls on every rank, the call being collective)
 int comm_reserve_agreed(tsh_comm *c, int32_t gq, int32_t entries, int32_t k, int32_t call_q, bool retry, int64_t rows,
-                        bool *grew) {
+                        bool *grew, bool refresh = false) {
   int rc = comm_reserve(c, gq, entries, k, call_q, retry, grew);
-  if (*grew) {
+  if (*grew || refresh) {
     rc = comm_agree(c, rc, rows);
     if (rc) comm_drop_buffers(c);
   }
@@ -381,6 +386,8 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int lo
     if (rc) return rc;
     tl.slice_d2h_us += t1b - t1;  // (host transport: the rank's whole group goes to the host, not a slice)
     tl.gather_us += now_us() - t1b;
+    c->tl_exch++;
+    c->tl_timed++;
     slice_base = c->h_slice + (size_t)a * bb;
     slice_pitch = mine;
   } else {
@@ -389,12 +396,14 @@ int comm_exchange_group(tsh_comm *c, tsh_index *shard, uint8_t *d_blocks, int lo
       if (rc) return rc;
     }
     HIPCHK(hipEventSynchronize(c->ev_t[2]));
+    c->tl_exch++;
     if (c->timed_now) {
       float ms_g = 0.f, ms_d = 0.f;  // device time on the communicator's stream; the all-gather's includes the wait
       HIPCHK(hipEventElapsedTime(&ms_g, c->ev_t[0], c->ev_t[1]));  // for the slowest rank to arrive
       HIPCHK(hipEventElapsedTime(&ms_d, c->ev_t[1], c->ev_t[2]));
-      tl.gather_us += 4e3 * ms_g;  // (one exchange in four is timed: scaled to all)
-      tl.slice_d2h_us += 4e3 * ms_d;
+      tl.gather_us += 1e3 * ms_g;  // (one exchange in four is timed: tsh_comm_get_timeline scales the sums by
+      tl.slice_d2h_us += 1e3 * ms_d;  // exchanges / timed exchanges, so a run of one or two exchanges reports what it saw)
+      c->tl_timed++;
     }
 
     slice_base = c->h_slice;
@@ -628,12 +637,18 @@ int32_t tsh_comm_get_timeline(tsh_comm *c, tsh_comm_timeline *out, int32_t reset
   if (!c || !out) return set_err(TSH_E_BAD_ARG, "comm / out is NULL");
   std::lock_guard<std::mutex> lk(c->mu);  // never in the middle of a call
   *out = c->tl;
+  if (c->tl_timed > 0) {  // the sampled device-side split, scaled to all exchanges
+    const double scale = (double)c->tl_exch / (double)c->tl_timed;
+    out->gather_us *= scale;
+    out->slice_d2h_us *= scale;
+  }
   out->scan_us = 1e-3 * (double)c->scan_ns.load(std::memory_order_relaxed);
   out->world = c->world;
   out->rank = c->rank;
   out->transport = c->host_fn ? 1 : (rccl()->overridden ? 2 : 0);
   if (reset) {
     c->tl = tsh_comm_timeline{};
+    c->tl_exch = c->tl_timed = 0;
     c->scan_ns.store(0, std::memory_order_relaxed);
   }
   return TSH_OK;
@@ -683,7 +698,11 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
       tl.call_us += now_us() - t0;
     }
   } call_clock{tl, t_in, nq};
-  int rc = comm_reserve_agreed(c, Gmax, entries, k, win_cap, false, my_rows, &grew);
+  // (scan_bytes_hint sizes the schedule below: in a world of one comm_agree just takes this rank's figure; with peers
+  // it is refreshed whenever the buffers grow and on every 64th call, so it follows shards that grow or shrink)
+  const bool refresh = c->world == 1 || ++c->calls_since_agree >= 64;
+  if (refresh) c->calls_since_agree = 0;
+  int rc = comm_reserve_agreed(c, Gmax, entries, k, win_cap, false, my_rows, &grew, refresh);
   tl.reserve_us += now_us() - t_in;
   if (rc) return rc;
   const int32_t dim = local_rc == TSH_OK ? shard->dim : 0;
@@ -711,8 +730,11 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
     if (++c->tag_seq == 0) ++c->tag_seq;
     const uint32_t ss_tag = c->tag_seq;
     if (scan_rc == TSH_OK) {
+      // (launched ahead, a group's all-gather may read a block while its rank's host still looks at it: such a
+      // block is never rewritten in place -- Job::leave_overflow)
+      const bool ahead = c->comm && !c->host_fn && exchange_ahead_flag().load(std::memory_order_acquire);
       scan_rc = shard_stream_begin(shard, queries + (size_t)w0 * dim, wn, k, row_mask, entries, c->d_mine, sizes[gi],
-                                   /*copy_inputs=*/false, &ss, ss_tag, c->worker.get());
+                                   /*copy_inputs=*/false, &ss, ss_tag, c->worker.get(), ahead);
       if (scan_rc) scan_err = g_err;
     }
     auto end_stream = [&] {  // nothing of this call may still run when it returns

@@ -22,6 +22,15 @@ namespace tsh {
 inline double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// one turn of a polling loop: the x86 pause hint where there is one, a yield elsewhere (an aarch64 ROCm host builds
+// this header too)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
 
 // Reader/writer lock that may be released by a different thread than the one that took it (an asynchronous
 // search is submitted and waited independently).  Writers have preference: a reader that arrives while a writer
@@ -235,7 +244,7 @@ class HostPool {
   template <typename F>
   static void spin_until(F &&cond) {
     for (int spins = 0; !cond(); ++spins) {
-      if (spins < 20000) __builtin_ia32_pause();
+      if (spins < 20000) cpu_relax();
       else std::this_thread::yield();
     }
   }
@@ -265,7 +274,7 @@ class HostPool {
           break;
         }
         if ((i & 63) == 0 && !keep_polling(t0)) break;
-        __builtin_ia32_pause();
+        cpu_relax();
       }
       if (!got) {
         std::unique_lock<std::mutex> lk(m_);
@@ -379,6 +388,7 @@ class ShardWorkers {
 // waits for this on the host: with push_back and one loop exit per word (mispredicted every other word at 1 %) a
 // 1 M-row mask took 139 us on a 2.1 GHz core, its popcount without the instruction 39 -- now 43 and 10
 // (four unconditional extractions per word, tzcnt(0) = 64 writing a slot the next word overwrites).
+#if defined(__x86_64__)
 __attribute__((target("popcnt,bmi"))) inline size_t list_mask_bits_hw(const uint64_t *words, int32_t n_tiles, uint32_t *out) {
   uint32_t *o = out;
   for (int32_t t = 0; t < n_tiles; ++t) {
@@ -401,6 +411,7 @@ __attribute__((target("popcnt,bmi"))) inline size_t list_mask_bits_hw(const uint
   }
   return (size_t)(o - out);
 }
+#endif
 inline size_t list_mask_bits_base(const uint64_t *words, int32_t n_tiles, uint32_t *out) {
   uint32_t *o = out;
   for (int32_t t = 0; t < n_tiles; ++t)
@@ -408,19 +419,27 @@ inline size_t list_mask_bits_base(const uint64_t *words, int32_t n_tiles, uint32
   return (size_t)(o - out);
 }
 inline size_t list_mask_bits(const uint64_t *words, int32_t n_tiles, int64_t bits, uint32_t *out) {
+#if defined(__x86_64__)
   static const bool hw = __builtin_cpu_supports("popcnt") && __builtin_cpu_supports("bmi");
   // (hardly any word has a bit: the plain loop's exits are predictable and it does nothing per empty word)
   if (hw && bits * 8 > n_tiles) return list_mask_bits_hw(words, n_tiles, out);
+#else
+  (void)bits;
+#endif
   return list_mask_bits_base(words, n_tiles, out);
 }
+#if defined(__x86_64__)
 __attribute__((target("popcnt"))) inline int64_t popcount_words_hw(const uint64_t *w, size_t n) {
   int64_t r = 0;
   for (size_t i = 0; i < n; ++i) r += __builtin_popcountll(w[i]);
   return r;
 }
+#endif
 inline int64_t popcount_words(const uint64_t *w, size_t n) {
+#if defined(__x86_64__)
   static const bool hw = __builtin_cpu_supports("popcnt");
   if (hw) return popcount_words_hw(w, n);
+#endif
   int64_t r = 0;
   for (size_t i = 0; i < n; ++i) r += __builtin_popcountll(w[i]);
   return r;
@@ -468,6 +487,7 @@ class OneWorker {
   // in front of its first scan); 0 = park at once
   explicit OneWorker(double spin_us = 0) : spin_us_(spin_us), th_([this] { loop(); }) {}
   ~OneWorker() {
+    stopping_.store(true, std::memory_order_release);  // (the polling loop looks at this one: it holds no lock)
     {
       std::lock_guard<std::mutex> lk(m_);
       stop_ = true;
@@ -496,7 +516,8 @@ class OneWorker {
       if (spin_us_ > 0 && !pending_ && !stop_) {
         lk.unlock();
         const double t_end = now_us() + spin_us_;
-        while (!posted_.load(std::memory_order_acquire) && now_us() < t_end) __builtin_ia32_pause();
+        while (!posted_.load(std::memory_order_acquire) && !stopping_.load(std::memory_order_acquire) && now_us() < t_end)
+          cpu_relax();
         lk.lock();
       }
       cv_.wait(lk, [&] { return pending_ || stop_; });
@@ -514,7 +535,7 @@ class OneWorker {
   std::condition_variable cv_;
   std::function<void()> fn_;
   bool pending_ = false, stop_ = false;
-  std::atomic<bool> posted_{false};
+  std::atomic<bool> posted_{false}, stopping_{false};
   double spin_us_ = 0;
   std::thread th_;  // last member: the thread starts with everything above constructed
 };

@@ -36,6 +36,7 @@
 #include "tsh_host_sync.h"
 #include "tsh_kernels.hip.h"
 #include "tsh_launch.h"
+#include "tsh_mask.hip.h"
 #include "tsh_pq.hip.h"
 
 using namespace tsh;
@@ -176,18 +177,22 @@ inline double dart_order_key_to_double(uint64_t key) {
     }                                                                                         \
     dist[i] = d;                                                                              \
   }
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) void final_distances_avx2(int metric, const BlockEntry *e, uint32_t n, double sqrt_mag_a,
                                                           double *dist) {
   TSH_FINAL_KEYS_BODY
 }
+#endif
 void final_distances_base(int metric, const BlockEntry *e, uint32_t n, double sqrt_mag_a, double *dist) {
   TSH_FINAL_KEYS_BODY
 }
 #undef TSH_FINAL_KEYS_BODY
 inline void final_distances(int metric, const BlockEntry *e, uint32_t n, double sqrt_mag_a, double *dist) {
+#if defined(__x86_64__)
   static const bool avx2 = __builtin_cpu_supports("avx2");
-  if (avx2) final_distances_avx2(metric, e, n, sqrt_mag_a, dist);
-  else final_distances_base(metric, e, n, sqrt_mag_a, dist);
+  if (avx2) return final_distances_avx2(metric, e, n, sqrt_mag_a, dist);
+#endif
+  final_distances_base(metric, e, n, sqrt_mag_a, dist);
 }
 
 double query_mag_a(const float *q, int dim) {
@@ -900,7 +905,14 @@ struct Job {
   float eps_rel = 0.f, delta_abs = 0.f;  // this query's error band (for the fallback's own threshold)
   bool force_all = false;
   int32_t list_tiles = 0;  // > 0: a list scan -- the context's keys / gmin are in list order, that many tiles of them
+  const uint64_t *d_mask = nullptr;  // the caller's mask words on the device: the context's copy, or a mask handle's
+  const uint32_t *d_list = nullptr;  // the scanned list on the device: the context's copy, or a mask handle's
   bool exact = false;      // answered by exact_scan_kernel + exact_select_kernel: the block is final, no f32 keys exist
+  bool leave_overflow = false;  // shard mode under TSH_OPT_EXCHANGE_AHEAD: an exchange enqueued behind this job's kernels
+                                // may be reading the device block when the host looks at it -- a block whose list
+                                // overflowed is then NOT rewritten by the wide-band pass (a peer could gather a new
+                                // header over old entries); it keeps FLAG_LIST_OVERFLOW, which every rank answers by
+                                // redoing the group with larger blocks, not ahead
   hipStream_t last_stream = nullptr;  // where the job's last kernel was enqueued (ev_done rides on it)
   uint64_t enq_seq = 0;               // ... and its place in the device's enqueue order (DeviceStreams::enq_counter)
   std::vector<uint32_t> quar_sel;  // entries of c->h_quar that belong to this query's candidates
@@ -909,8 +921,41 @@ struct Job {
 // A selective caller mask as a list: local ids of the kept rows, ascending, padded with 0xFFFFFFFF to whole tiles of
 // 64.  Made once per call (shard_search_blocks) and shared by the call's queries; nullptr = scan by tiles.
 struct RowList {
-  const uint32_t *ids = nullptr;
+  const uint32_t *ids = nullptr;    // on the host: every context of the call uploads it once ...
+  const uint32_t *d_ids = nullptr;  // ... or resident on the device (a mask handle's, compacted there): read in place
   int32_t padded = 0;  // entries incl. padding (multiple of 64)
+};
+
+// ---- mask handles (tsh_mask_create, include/tostore_hip.h): one shard's part ------------------------------------
+// The caller's bitmap sliced to this shard's rows, as the kernels read it (word t bit r = local row 64 t + r), on
+// the host (the quarantined rows are matched against it there; the batched path places its sample window by it) and
+// on the device (dense masked scans, the batched epilogue); and, when the mask is selective, the ascending list of
+// its kept rows -- compacted on the device (tsh_mask.hip.h), never on the host.  Built for the rows the shard had at
+// the time; a search that finds the shard grown rebuilds it first (mask_part).
+struct MaskPart {
+  int device = 0;
+  std::atomic<int64_t> built_rows{-1};  // rows of the shard the part was built for (-1: not built)
+  int32_t n_tiles = 0;
+  int64_t kept = 0;                // set bits (tombstones not subtracted)
+  std::vector<uint64_t> h_words;   // n_tiles words
+  std::vector<int32_t> pre;        // pre[t] = kept rows in words [0, t): n_tiles + 1 entries
+  uint64_t *d_words = nullptr;
+  int64_t words_cap = 0;
+  uint32_t *d_list = nullptr;      // kept rows' local ids, ascending, padded with 0xFFFFFFFF to a multiple of 64
+  int64_t list_cap = 0;
+  int32_t list_padded = 0;         // 0: no list (the mask keeps too many rows for one to pay, or none)
+  uint32_t *d_bsum = nullptr;      // M1's per-workgroup counts + one word for M2's total
+  int64_t bsum_cap = 0;
+  int64_t bytes = 0;               // device bytes held
+};
+// the mask of a search, as the shard-level functions take it
+struct MaskSrc {
+  const uint8_t *bytes = nullptr;  // the caller's GLOBAL bitmap (pointer form: sliced, counted, listed per call) ...
+  const MaskPart *part = nullptr;  // ... or this shard's part of a mask handle (resident)
+  MaskSrc() {}
+  MaskSrc(const uint8_t *b) : bytes(b) {}  // NOLINT: the pointer form converts where a mask is passed on
+  explicit MaskSrc(const MaskPart *p) : part(p) {}
+  explicit operator bool() const { return bytes != nullptr || part != nullptr; }
 };
 
 void launch_select(const SelectArgs &se, int32_t n_tiles, hipStream_t st) {
@@ -935,7 +980,7 @@ void launch_quarantine_append(Shard *s, Ctx *c, Job *j, hipStream_t st) {
   qa.rows = s->d_rows;
   qa.Q = c->d_query;
   qa.list = s->d_quar;
-  qa.mask = j->user_mask ? c->d_mask : nullptr;
+  qa.mask = j->user_mask ? j->d_mask : nullptr;
   qa.blocks = j->dev_target;
   qa.ld = s->ld;
   qa.ldq = s->ld;
@@ -973,14 +1018,22 @@ int ctx_reserve_list(Ctx *c, int64_t padded) {
 // pays below one kept row in list_div (tools/r4_list_probe.sh); TSH_LIST_DIV=0 switches it off.  -> ids filled (padded
 // with 0xFFFFFFFF to whole tiles) and true when the scan should use them.
 bool exact_applies(const Shard *s, int64_t n_exam, int32_t k, int32_t entries);
-bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles, int64_t rows_kept, int32_t k, int32_t entries,
-                    std::vector<uint32_t> *ids) {
-  static const int64_t list_div = probe_env("TSH_LIST_DIV") ? atoll(probe_env("TSH_LIST_DIV")) : 24;
-  if (!mask_words || list_div <= 0 || s->rows < 4096) return false;
+inline int64_t mask_list_div() {
+  static const int64_t v = probe_env("TSH_LIST_DIV") ? atoll(probe_env("TSH_LIST_DIV")) : 24;
+  return v;
+}
+// does a search with this many kept rows scan them as a list?  (the rule of both forms of a mask: pointer and handle)
+bool row_list_pays(const Shard *s, int64_t rows_kept, int32_t k, int32_t entries) {
+  const int64_t list_div = mask_list_div();
+  if (list_div <= 0 || s->rows < 4096 || rows_kept <= 0) return false;
   // few enough kept rows for the exact path (tsh_exact.hip.h): their list is all that search reads, at any row width
   // and any selectivity (a shard small enough for that path whole needs no list: it tests the mask row by row)
   const bool by_exact = !exact_applies(s, s->rows, k, entries) && exact_applies(s, round_up(rows_kept, 64), k, entries);
-  if (!by_exact && (rows_kept * list_div > s->rows || !scan_list_supported(s->nch, s->ld))) return false;
+  return by_exact || (rows_kept * list_div <= s->rows && scan_list_supported(s->nch, s->ld));
+}
+bool build_row_list(const Shard *s, const uint64_t *mask_words, int32_t n_tiles, int64_t rows_kept, int32_t k, int32_t entries,
+                    std::vector<uint32_t> *ids) {
+  if (!mask_words || !row_list_pays(s, rows_kept, k, entries)) return false;
   // (bits past the shard's last row cannot be set: slice_mask clears them; rows_kept is their exact count)
   ids->resize((size_t)round_up(rows_kept, 64) + 8);
   const size_t got = list_mask_bits(mask_words, n_tiles, rows_kept, ids->data());
@@ -1047,12 +1100,18 @@ void launch_exact_scan(const ExactArgsQ &xa, int metric, hipStream_t st, const L
 
 int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries,
                 const uint64_t *mask_words, uint64_t epoch, uint8_t *dev_target, int64_t rows_est = 0,
-                const RowList *list = nullptr, bool more_coming = false, bool last_of_call = false, uint32_t tag = 0) {
+                const RowList *list = nullptr, bool more_coming = false, bool last_of_call = false, uint32_t tag = 0,
+                const MaskPart *mp = nullptr) {
+  // mp: the mask is a handle's part -- mask_words are its host words, its device words and (list->d_ids) its list
+  // are read in place: nothing of the mask is copied or uploaded here
   Ctx *c = j->c;
-  int rc = ctx_prepare(s, c, entries, mask_words != nullptr);
+  int rc = ctx_prepare(s, c, entries, mask_words != nullptr && !mp);
   if (rc) return rc;
-  const bool use_list = list && list->ids && mask_words;
-  if (use_list && (rc = ctx_reserve_list(c, list->padded))) return rc;
+  const bool use_list = list && (list->ids || list->d_ids) && mask_words;
+  const bool own_list = use_list && !list->d_ids;  // the context's copy of a host-made list
+  if (own_list && (rc = ctx_reserve_list(c, list->padded))) return rc;
+  j->d_mask = mp ? mp->d_words : c->d_mask;
+  j->d_list = use_list ? (own_list ? c->d_list : list->d_ids) : nullptr;
   j->list_tiles = use_list ? list->padded / 64 : 0;
   const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
   // A search with only a few thousand rows to look at (a selective mask's list, a small index or shard) takes their
@@ -1077,12 +1136,12 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   }
   uint8_t *dev_block = dev_target ? dev_target : c->d_block;  // where the device header lives
   // (a list scan needs the mask words on the device only where quarantined rows are matched against them)
-  const bool upload_mask = mask_words && c->mask_epoch != epoch && (!use_list || (!j->quar_sel.empty() && dev_target));
+  const bool upload_mask = mask_words && !mp && c->mask_epoch != epoch && (!use_list || (!j->quar_sel.empty() && dev_target));
   if (upload_mask) {
     memcpy(c->h_mask, mask_words, (size_t)n_tiles * 8);
     c->mask_epoch = epoch;
   }
-  const bool upload_list = use_list && c->list_epoch != epoch;
+  const bool upload_list = own_list && c->list_epoch != epoch;
   if (upload_list) {
     memcpy(c->h_list, list->ids, (size_t)list->padded * sizeof(uint32_t));
     c->list_epoch = epoch;
@@ -1096,6 +1155,8 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   Band band;
   if (exact) {
     fill_exact_args(s, c, use_list, j->user_mask && !use_list, n_exam, qdst, &xa);
+    if (xa.a.mask) xa.a.mask = j->d_mask;
+    xa.a.list = j->d_list;
     xa.a.query = inline_q ? nullptr : c->d_query;
     // (only the quarantine kernels read the device copy of an inline query)
     xa.a.query_out = inline_q && !j->quar_sel.empty() ? c->d_query : nullptr;
@@ -1107,8 +1168,9 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     j->force_all = false;
   } else {
     fill_scan_args(s, c, j->masked, j->user_mask, &sa);
+    if (sa.a.mask) sa.a.mask = j->d_mask;
     if (use_list) {
-      sa.a.list = c->d_list;
+      sa.a.list = j->d_list;
       sa.a.n_tiles = j->list_tiles;
     }
     band = compute_band(s, qdst);
@@ -1127,7 +1189,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   se.hdr_host = reinterpret_cast<BlockHeader *>(c->h_block_dev);
   se.cand_rows = c->d_cand;
   se.n_tiles = use_list ? j->list_tiles : n_tiles;
-  se.list = use_list ? c->d_list : nullptr;
+  se.list = j->d_list;
   se.tag = tag;
   se.k = k;
   se.cand_cap = entries;
@@ -1242,7 +1304,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       ExactSelArgs xs{};
       xs.xkey = c->d_xkey;
       xs.xsum = c->d_xsum;
-      xs.list = use_list ? c->d_list : nullptr;
+      xs.list = j->d_list;
       xs.hdr = se.hdr;
       xs.hdr_host = se.hdr_host;
       xs.out = ra.out;
@@ -1323,7 +1385,7 @@ int run_fallback(Shard *s, Job *j, uint32_t band_key, std::vector<BlockEntry> *s
   hipStream_t st = s->aux_stream;
   // (a list scan left its keys in list order: fewer keys, and the filter maps positions back to row ids)
   const int64_t n_keys = j->list_tiles > 0 ? (int64_t)j->list_tiles * 64 : ((s->rows + 63) / 64) * 64;
-  const uint32_t *list = j->list_tiles > 0 ? c->d_list : nullptr;
+  const uint32_t *list = j->list_tiles > 0 ? j->d_list : nullptr;
   if (s->cap > c->big_cap) {
     hipFree(c->d_big_rows);
     hipFree(c->d_big_entries);
@@ -1435,7 +1497,13 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill, std::vector<Blo
     fprintf(stderr, "[x2] keys %.2f select %.2f entries %.2f us, %u histogram rounds, %u ranked, %u out adds %.2f scan %.2f\n", h->tau_key * 0.01,
             h->band_key * 0.01, h->tiles_hit * 0.01, h->pad[2], h->pad[3], h->count, (h->pad[0] >> 16) * 0.01, (h->pad[0] & 0xFFFF) * 0.01);
 #endif
-  if (h->flags & FLAG_LIST_OVERFLOW) {
+  if ((h->flags & FLAG_LIST_OVERFLOW) && j->exact) {
+    // (exact_select_kernel writes min(k, live rows) entries into a block exact_applies sized for k: it cannot overflow.
+    // Should that invariant ever slip, the context holds no f32 keys / tile minima for the wide-band pass to filter)
+    return set_err(TSH_E_HIP, "the exact path's block overflowed (%u of %u entries): internal error", h->count, h->entries);
+  } else if ((h->flags & FLAG_LIST_OVERFLOW) && j->leave_overflow && j->dev_target) {
+    s->c_cands += std::min(h->count, h->entries);  // (the block stays as it is: see Job::leave_overflow)
+  } else if (h->flags & FLAG_LIST_OVERFLOW) {
     int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
     if (rc) return rc;
     if (!j->quar_sel.empty() && j->dev_target) {  // the fallback rewrote the device block: append again
@@ -1481,6 +1549,7 @@ struct SearchOut {
   // in the order the device's streams were fed, which with two submitting threads is not the queries' order)
   std::function<void(int32_t q, hipEvent_t done, hipStream_t where, uint64_t seq)> on_enqueued;
   uint32_t tag = 0;  // generation stamped into the blocks' headers (BlockHeader.pad[1])
+  bool leave_overflow = false;  // device mode: see Job::leave_overflow
 };
 
 // One submitting thread's share of a multi-query call: queries [q0, q1) of the call, at most
@@ -1488,7 +1557,7 @@ struct SearchOut {
 // behind the next query's scan.
 int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, int32_t k, const uint64_t *mask_words,
                        uint64_t epoch, int32_t entries, SearchOut *out, int depth, int64_t rows_est,
-                       const RowList *list = nullptr, int32_t stride = 1) {
+                       const RowList *list = nullptr, int32_t stride = 1, const MaskPart *mp = nullptr) {
   // this thread's queries: q0, q0 + stride, ... below q1 (cnt of them; i-th = q0 + i * stride)
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   const int32_t cnt = q1 > q0 ? (q1 - q0 + stride - 1) / stride : 0;
@@ -1514,10 +1583,11 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
       if (!c) break;
       Job &j = jobs[(size_t)(submitted % depth)];
       j.c = c;
+      j.leave_overflow = out->leave_overflow;
       const int32_t q = q0 + submitted * stride;
       rc = job_enqueue(s, &j, queries + (size_t)q * s->dim, k, entries, mask_words, epoch,
                        out->d_blocks ? out->d_blocks + (size_t)q * bb : nullptr, rows_est, list, cnt > 1,
-                       cnt > 1 && submitted == cnt - 1, out->tag);
+                       cnt > 1 && submitted == cnt - 1, out->tag, mp);
       if (rc) {
         release_all();
         return rc;
@@ -1547,7 +1617,7 @@ int shard_search_slice(Shard *s, const float *queries, int32_t q0, int32_t q1, i
 // launches, events, a wait); on a small shard (a row range of a multi-GPU index) that is
 // longer than the scan itself, so larger calls are submitted from a few threads at once.
 // Caller holds s->mu shared.
-int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const uint8_t *mask,
+int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, const MaskSrc &mask,
                         int32_t entries, SearchOut *out, int depth) {
   const int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
   // (the calling thread's buffers, kept between calls: a lone masked query does not pay for two allocations)
@@ -1555,28 +1625,35 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
   static thread_local std::vector<uint32_t> list_ids;
   uint64_t epoch = 0;
   int64_t rows_est = 0;
-  if (mask) {
+  const MaskPart *mp = mask.part;
+  RowList list;
+  if (mp) {  // a handle: sliced, counted and listed when it was made -- nothing to do per call
+    rows_est = std::max<int64_t>(mp->kept, 1);
+    if (mp->list_padded > 0 && row_list_pays(s, mp->kept, k, entries)) {
+      list.d_ids = mp->d_list;
+      list.padded = mp->list_padded;
+    }
+  } else if (mask) {
     if (mask_words.size() < (size_t)n_tiles) mask_words.resize((size_t)n_tiles);
-    slice_mask(s, mask, mask_words.data(), n_tiles);
+    slice_mask(s, mask.bytes, mask_words.data(), n_tiles);
     epoch = s->mask_epoch_src.fetch_add(1);
     // one pass over the mask per call: how long will each scan be?  (decides one- or two-stream pipelining)
     rows_est = popcount_words(mask_words.data(), (size_t)n_tiles);
     if (rows_est == 0) rows_est = 1;
+    // (made here once for all queries of the call)
+    if (build_row_list(s, mask_words.data(), n_tiles, rows_est, k, entries, &list_ids)) {
+      list.ids = list_ids.data();
+      list.padded = (int32_t)list_ids.size();
+    }
   }
-  // (made here once for all queries of the call)
-  RowList list;
-  if (mask && build_row_list(s, mask_words.data(), n_tiles, rows_est, k, entries, &list_ids)) {
-    list.ids = list_ids.data();
-    list.padded = (int32_t)list_ids.size();
-  }
-  const RowList *lp = list.ids ? &list : nullptr;
-  const uint64_t *mw = mask ? mask_words.data() : nullptr;
+  const RowList *lp = (list.ids || list.d_ids) ? &list : nullptr;
+  const uint64_t *mw = mp ? mp->h_words.data() : (mask ? mask_words.data() : nullptr);
   // short scans (small shards, selective masks) are bound by the submitting thread's ~25 us per query: two threads
   const int64_t scan_bytes = (rows_est > 0 ? rows_est : s->rows) * s->ld * 4;
   static const int forced_threads = probe_env("TSH_SUBMIT_THREADS") ? atoi(probe_env("TSH_SUBMIT_THREADS")) : 0;
   const int want = forced_threads > 0 ? forced_threads : (scan_bytes <= (160ll << 20) ? 2 : SUBMIT_THREADS);
   const int T = std::min(want, nq / 8);
-  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est, lp);
+  if (T <= 1) return shard_search_slice(s, queries, 0, nq, k, mw, epoch, entries, out, depth, rows_est, lp, 1, mp);
   std::vector<int> rcs((size_t)T, TSH_OK);
   std::vector<std::string> errs((size_t)T);
   const int per_depth = std::max(2, depth / T);
@@ -1585,7 +1662,7 @@ int shard_search_blocks(Shard *s, const float *queries, int32_t nq, int32_t k, c
     const int32_t q0 = interleave ? t : (int32_t)((int64_t)nq * t / T);
     const int32_t q1 = interleave ? nq : (int32_t)((int64_t)nq * (t + 1) / T);
     rcs[(size_t)t] = shard_search_slice(s, queries, q0, q1, k, mw, epoch, entries, out, per_depth, rows_est, lp,
-                                        interleave ? T : 1);
+                                        interleave ? T : 1, mp);
     if (rcs[(size_t)t]) errs[(size_t)t] = g_err;
   };
   std::vector<std::thread> th;
@@ -1745,6 +1822,122 @@ int index_append(tsh_index *idx, int64_t first, int64_t n, const float *rows, bo
     done += take;
   }
   return TSH_OK;
+}
+
+}  // namespace
+
+// ---- mask handles ---------------------------------------------------------------------------------------------
+struct tsh_mask {
+  tsh_index *idx = nullptr;
+  std::vector<uint8_t> bits;  // the caller's GLOBAL bitmap (its own copy; zero-extended as the index grows)
+  std::mutex mu;              // builds / rebuilds of the parts
+  std::vector<std::unique_ptr<MaskPart>> parts;  // one per shard of the index
+};
+
+namespace {
+
+void mask_part_free(MaskPart *p) {
+  if (hipSetDevice(p->device) != hipSuccess) return;
+  hipFree(p->d_words);
+  hipFree(p->d_list);
+  hipFree(p->d_bsum);
+  p->d_words = nullptr;
+  p->d_list = p->d_bsum = nullptr;
+  p->words_cap = p->list_cap = p->bsum_cap = 0;
+  p->bytes = 0;
+}
+
+// (Re)builds one shard's part for the rows the shard has now.  Caller holds s->mu shared (the rows cannot change) and
+// m->mu.  The words are sliced and counted on the host once -- the batched path and the quarantined rows read them
+// there --, uploaded once, and a selective mask's list is compacted on the device (tsh_mask.hip.h).
+int mask_build_part(tsh_mask *m, MaskPart *p, Shard *s) {
+  HIPCHK(hipSetDevice(s->device));
+  p->device = s->device;
+  const int64_t rows = s->rows;
+  const int32_t n_tiles = (int32_t)((rows + 63) / 64);
+  // bits at or beyond the caller's n_bytes are not kept: the handle's copy grows with zeros to what slice_mask reads
+  const size_t need = (size_t)((s->row_base + rows + 7) / 8) + 1;
+  if (m->bits.size() < need) m->bits.resize(need, 0);
+  p->h_words.assign((size_t)n_tiles, 0);
+  if (n_tiles > 0) slice_mask(s, m->bits.data(), p->h_words.data(), n_tiles);
+  p->pre.assign((size_t)n_tiles + 1, 0);
+  for (int32_t t = 0; t < n_tiles; ++t) p->pre[(size_t)t + 1] = p->pre[(size_t)t] + __builtin_popcountll(p->h_words[(size_t)t]);
+  p->kept = p->pre[(size_t)n_tiles];
+  p->n_tiles = n_tiles;
+  p->list_padded = 0;
+  hipStream_t st = s->aux_stream;
+  if (n_tiles > p->words_cap) {
+    hipFree(p->d_words);
+    p->d_words = nullptr;
+    p->bytes -= p->words_cap * 8;
+    p->words_cap = 0;
+    const int64_t want = round_up(n_tiles + n_tiles / 8, 64);
+    HIPCHK(hipMalloc(&p->d_words, (size_t)want * 8));
+    p->words_cap = want;
+    p->bytes += want * 8;
+  }
+  if (n_tiles > 0)
+    HIPCHK(hipMemcpyAsync(p->d_words, p->h_words.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+  // the list: wherever a search may scan the kept rows as one (row_list_pays: few enough for the exact path at any
+  // k and row width, or fewer than one row in list_div) -- compacted on the device, in id order
+  const int64_t padded = round_up(p->kept, 64);
+  const int64_t list_div = mask_list_div();
+  const bool want_list = p->kept > 0 && rows >= 4096 && list_div > 0 && padded < 0x7FFFFFC0ll &&
+                         (padded <= EX_MAX_ROWS || p->kept * list_div <= rows);
+  if (want_list) {
+    const int32_t n_blocks = (n_tiles + MASK_BLOCK_WORDS - 1) / MASK_BLOCK_WORDS;
+    if (n_blocks + 1 > p->bsum_cap) {
+      hipFree(p->d_bsum);
+      p->d_bsum = nullptr;
+      p->bytes -= p->bsum_cap * 4;
+      p->bsum_cap = 0;
+      const int64_t want = round_up(n_blocks + 1 + n_blocks / 8, 64);
+      HIPCHK(hipMalloc(&p->d_bsum, (size_t)want * 4));
+      p->bsum_cap = want;
+      p->bytes += want * 4;
+    }
+    if (padded > p->list_cap) {
+      hipFree(p->d_list);
+      p->d_list = nullptr;
+      p->bytes -= p->list_cap * 4;
+      p->list_cap = 0;
+      const int64_t want = round_up(padded + padded / 8, 1024);
+      HIPCHK(hipMalloc(&p->d_list, (size_t)want * 4));
+      p->list_cap = want;
+      p->bytes += want * 4;
+    }
+    uint32_t *d_total = p->d_bsum + n_blocks;
+    mask_block_count_kernel<<<n_blocks, MASK_BLOCK_WORDS, 0, st>>>(p->d_words, n_tiles, p->d_bsum);
+    mask_compact_kernel<<<n_blocks, MASK_BLOCK_WORDS, 0, st>>>(p->d_words, n_tiles, p->d_bsum, p->d_list, d_total);
+    if (padded > p->kept)
+      HIPCHK(hipMemsetAsync(p->d_list + p->kept, 0xFF, (size_t)(padded - p->kept) * 4, st));
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if ((int64_t)total != p->kept)  // (the host counted the same words: cannot differ)
+      return set_err(TSH_E_HIP, "mask compaction listed %u rows, the mask keeps %lld", total, (long long)p->kept);
+    p->list_padded = (int32_t)padded;
+  } else {
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  p->built_rows.store(rows, std::memory_order_release);
+  return TSH_OK;
+}
+
+// shard g's part of a handle, current for the rows the shard has (caller holds s->mu shared); nullptr + *rc on failure
+const MaskPart *mask_part(tsh_mask *m, size_t g, Shard *s, int *rc) {
+  *rc = TSH_OK;
+  MaskPart *p = m->parts[g].get();
+  if (p->built_rows.load(std::memory_order_acquire) == s->rows) return p;
+  // the shard grew since the part was built (appends take the shard exclusively, so no search that reads the old
+  // buffers is running: every search that started after the append passes through here first)
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (p->built_rows.load(std::memory_order_acquire) != s->rows) {
+    *rc = mask_build_part(m, p, s);
+    if (*rc) return nullptr;
+  }
+  return p;
 }
 
 }  // namespace
@@ -1914,9 +2107,11 @@ int32_t tsh_default_block_entries(int32_t k) {
   return (int32_t)std::min<int64_t>(e, 1 << 20);
 }
 
-int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, double thr,
-                   const uint8_t *row_mask, int64_t *out_ids, double *out_dist, int32_t *out_count) {
+static int32_t search_impl(tsh_index *idx, const float *queries, int32_t nq, int32_t k, double thr,
+                           const uint8_t *row_mask, tsh_mask *mask_h, int64_t *out_ids, double *out_dist,
+                           int32_t *out_count) {
   if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  if (mask_h && mask_h->idx != idx) return set_err(TSH_E_BAD_ARG, "the mask handle was made for another index");
   if (nq < 0) return set_err(TSH_E_BAD_ARG, "nq < 0");
   if (nq == 0) return TSH_OK;
   if (!queries || !out_count) return set_err(TSH_E_BAD_ARG, "queries / out_count is NULL");
@@ -1984,7 +2179,16 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
         });
       };
     }
-    rcs[g] = shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, row_mask, entries, &so);
+    MaskSrc ms(row_mask);
+    if (mask_h) {  // the handle's part for this shard: resident, rebuilt here if the shard grew since
+      const MaskPart *mp = mask_part(mask_h, g, s, &rcs[g]);
+      if (!mp) {
+        errs[g] = g_err;
+        return;
+      }
+      ms = MaskSrc(mp);
+    }
+    rcs[g] = shard_search_any(s, s->batch, idx->batch_min_nq.load(), queries, nq, k, ms, entries, &so);
     if (rcs[g]) errs[g] = g_err;
   };
   if (ns == 1) {
@@ -2030,13 +2234,79 @@ int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, 
   return TSH_OK;
 }
 
+int32_t tsh_search(tsh_index *idx, const float *queries, int32_t nq, int32_t k, double thr,
+                   const uint8_t *row_mask, int64_t *out_ids, double *out_dist, int32_t *out_count) {
+  return search_impl(idx, queries, nq, k, thr, row_mask, nullptr, out_ids, out_dist, out_count);
+}
+
+int32_t tsh_search_masked(tsh_index *idx, const float *queries, int32_t nq, int32_t k, double thr, tsh_mask *mask,
+                          int64_t *out_ids, double *out_dist, int32_t *out_count) {
+  return search_impl(idx, queries, nq, k, thr, nullptr, mask, out_ids, out_dist, out_count);
+}
+
+int32_t tsh_mask_create(tsh_index *idx, const uint8_t *bits, int64_t n_bytes, tsh_mask **out) {
+  if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (!idx) return set_err(TSH_E_BAD_ARG, "index is NULL");
+  if (n_bytes < 0 || (n_bytes > 0 && !bits)) return set_err(TSH_E_BAD_ARG, "bits is NULL / n_bytes < 0");
+  std::unique_ptr<tsh_mask> m(new tsh_mask());
+  m->idx = idx;
+  try {
+    m->bits.assign(bits, bits + n_bytes);
+  } catch (...) {
+    return set_err(TSH_E_OOM, "no memory for a %lld-byte mask", (long long)n_bytes);
+  }
+  for (size_t g = 0; g < idx->shards.size(); ++g) m->parts.emplace_back(new MaskPart());
+  // every shard's part now: a handle exists to take this work out of the searches
+  int rc = TSH_OK;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (size_t g = 0; g < idx->shards.size() && rc == TSH_OK; ++g) {
+      Shard *s = idx->shards[g].get();
+      std::shared_lock<RwLock> sl = share(idx, s);
+      rc = mask_build_part(m.get(), m->parts[g].get(), s);
+    }
+  }
+  if (rc) {
+    const std::string keep = g_err;
+    for (auto &p : m->parts) mask_part_free(p.get());
+    g_err = keep;
+    return rc;
+  }
+  *out = m.release();
+  return TSH_OK;
+}
+
+int32_t tsh_mask_destroy(tsh_mask *mask) {
+  if (!mask) return TSH_OK;
+  for (auto &p : mask->parts) mask_part_free(p.get());
+  delete mask;
+  return TSH_OK;
+}
+
+int64_t tsh_mask_kept(tsh_mask *mask) {
+  if (!mask) return set_err(TSH_E_BAD_ARG, "mask is NULL");
+  tsh_index *idx = mask->idx;
+  int64_t kept = 0;
+  for (size_t g = 0; g < idx->shards.size(); ++g) {
+    Shard *s = idx->shards[g].get();
+    std::shared_lock<RwLock> sl = share(idx, s);
+    int rc = TSH_OK;
+    const MaskPart *p = mask_part(mask, g, s, &rc);
+    if (!p) return rc;
+    kept += p->kept;
+  }
+  return kept;
+}
+
 // ---- asynchronous single-query searches ------------------------------------------
 int32_t tsh_max_inflight(void) { return MAX_CTX; }
 
-int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const uint8_t *row_mask,
-                          int32_t *out_ticket) {
+static int32_t submit_impl(tsh_index *idx, const float *query, int32_t k, const uint8_t *row_mask, tsh_mask *mask_h,
+                           int32_t *out_ticket) {
   if (!idx || !query || !out_ticket) return set_err(TSH_E_BAD_ARG, "NULL pointer");
   if (k <= 0) return set_err(TSH_E_BAD_ARG, "k <= 0");
+  if (mask_h && mask_h->idx != idx) return set_err(TSH_E_BAD_ARG, "the mask handle was made for another index");
   *out_ticket = -1;
   std::unique_ptr<Ticket> t(new Ticket());
   t->k = k;
@@ -2073,7 +2343,16 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
     RowList list;
     int64_t rows_est = 0;
     uint64_t epoch = 0;
-    if (row_mask) {
+    const MaskPart *mp = nullptr;
+    if (mask_h) {
+      mp = mask_part(mask_h, g, s, &rc);
+      if (!mp) break;
+      rows_est = std::max<int64_t>(mp->kept, 1);
+      if (mp->list_padded > 0 && row_list_pays(s, mp->kept, k, t->entries)) {
+        list.d_ids = mp->d_list;
+        list.padded = mp->list_padded;
+      }
+    } else if (row_mask) {
       int32_t n_tiles = (int32_t)((s->rows + 63) / 64);
       words.resize((size_t)n_tiles);
       slice_mask(s, row_mask, words.data(), n_tiles);
@@ -2085,8 +2364,8 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
         list.padded = (int32_t)list_ids.size();
       }
     }
-    rc = job_enqueue(s, &t->jobs[g], query, k, t->entries, row_mask ? words.data() : nullptr, epoch, nullptr, rows_est,
-                     list.ids ? &list : nullptr);
+    rc = job_enqueue(s, &t->jobs[g], query, k, t->entries, mp ? mp->h_words.data() : (row_mask ? words.data() : nullptr),
+                     epoch, nullptr, rows_est, (list.ids || list.d_ids) ? &list : nullptr, false, false, 0, mp);
   }
   if (rc != TSH_OK) {
     std::string keep = g_err;
@@ -2114,6 +2393,13 @@ int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const u
   idx->tickets_open.fetch_add(1);
   *out_ticket = slot;
   return TSH_OK;
+}
+
+int32_t tsh_search_submit(tsh_index *idx, const float *query, int32_t k, const uint8_t *row_mask, int32_t *out_ticket) {
+  return submit_impl(idx, query, k, row_mask, nullptr, out_ticket);
+}
+int32_t tsh_search_submit_masked(tsh_index *idx, const float *query, int32_t k, tsh_mask *mask, int32_t *out_ticket) {
+  return submit_impl(idx, query, k, nullptr, mask, out_ticket);
 }
 
 int32_t tsh_search_ready(tsh_index *idx, int32_t ticket) {
@@ -2236,6 +2522,7 @@ struct tsh_shard_stream {
   std::atomic<int32_t> enq_seen{0};
   std::atomic<int> route{0};  // 0 not decided yet, 1 every query its own scan (events exist), 2 anything else
   uint32_t tag = 0;           // generation the blocks carry (BlockHeader.pad[1])
+  bool leave_overflow = false;  // the caller enqueues its exchange ahead of the blocks (Job::leave_overflow)
   int rc = TSH_OK;
   std::string err;
   double busy_us = 0;  // worker: first enqueue to last block
@@ -2284,6 +2571,15 @@ struct tsh_shard_stream {
     Shard *s = idx->shards[0].get();
     std::shared_lock<RwLock> sl = share(idx, s);
     HIPCHK(hipSetDevice(s->device));
+    if (!own_mask.empty()) {
+      // _begin copied the mask for the rows the shard had THEN; rows appended between that look and this lock are
+      // beyond the caller's mask: not kept (zero bits), and never read past the copy's end
+      const size_t need = (size_t)((s->row_base + s->rows + 7) / 8);
+      if (own_mask.size() < need) {
+        own_mask.resize(need, 0);
+        mask = own_mask.data();
+      }
+    }
     const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
     if (s->rows == 0) {  // an empty shard contributes empty blocks
       std::vector<uint8_t> z(bb * (size_t)nq, 0);
@@ -2311,6 +2607,7 @@ struct tsh_shard_stream {
       SearchOut so;
       so.d_blocks = d_blocks;
       so.tag = tag;
+      so.leave_overflow = leave_overflow;
       so.on_done = [this](int32_t q) { mark(q); };
       so.on_enqueued = [this](int32_t q, hipEvent_t ev, hipStream_t where, uint64_t seq) { mark_enqueued(q, ev, where, seq); };
       route.store(1, std::memory_order_release);
@@ -2356,7 +2653,7 @@ struct tsh_shard_stream {
 namespace {
 int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t k, const uint8_t *row_mask,
                        int32_t entries, void *d_out_blocks, int32_t step, bool copy_inputs, tsh_shard_stream **out,
-                       uint32_t tag = 0, OneWorker *exec = nullptr) {
+                       uint32_t tag = 0, OneWorker *exec = nullptr, bool leave_overflow = false) {
   if (!out) return set_err(TSH_E_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (!idx || idx->shards.size() != 1) return set_err(TSH_E_BAD_ARG, "needs a single-shard handle");
@@ -2369,6 +2666,7 @@ int shard_stream_begin(tsh_index *idx, const float *queries, int32_t nq, int32_t
   st->entries = entries;
   st->step = step;
   st->tag = tag;
+  st->leave_overflow = leave_overflow;
   st->d_blocks = static_cast<uint8_t *>(d_out_blocks);
   st->queries = queries;
   st->mask = row_mask;
@@ -2413,7 +2711,7 @@ int shard_stream_enqueued(tsh_shard_stream *st, int32_t want, hipEvent_t *after,
     const double t_end = now_us() + 3000.0;
     while (st->enq_seen.load(std::memory_order_acquire) < want && st->route.load(std::memory_order_acquire) != 2 &&
            !st->finished_seen.load(std::memory_order_acquire) && now_us() < t_end)
-      __builtin_ia32_pause();
+      cpu_relax();
   }
   std::unique_lock<std::mutex> lk(st->mu);
   st->cv.wait(lk, [&] { return st->enq >= want || st->route.load() == 2 || st->finished; });
@@ -2453,7 +2751,7 @@ int shard_stream_progress(tsh_shard_stream *st, int32_t want, int32_t *out_done)
     const double t_end = now_us() + 3000.0;
     while (st->done_seen.load(std::memory_order_acquire) < want && !st->finished_seen.load(std::memory_order_acquire) &&
            now_us() < t_end)
-      __builtin_ia32_pause();
+      cpu_relax();
   }
   std::unique_lock<std::mutex> lk(st->mu);
   st->cv.wait(lk, [&] { return st->done >= want || st->finished; });

@@ -57,6 +57,22 @@ typedef _OpenNghC = Int32 Function(
     Pointer<Utf8>, Int32, Int32, Pointer<Pointer<Void>>, Pointer<TshNghInfo>);
 typedef _OpenNghD = int Function(
     Pointer<Utf8>, int, int, Pointer<Pointer<Void>>, Pointer<TshNghInfo>);
+typedef _OpenNghShardC = Int32 Function(
+    Pointer<Utf8>, Int32, Int32, Int32, Int32, Pointer<Pointer<Void>>, Pointer<TshNghInfo>);
+typedef _OpenNghShardD = int Function(
+    Pointer<Utf8>, int, int, int, int, Pointer<Pointer<Void>>, Pointer<TshNghInfo>);
+typedef _MaskCreateC = Int32 Function(Pointer<Void>, Pointer<Uint8>, Int64, Pointer<Pointer<Void>>);
+typedef _MaskCreateD = int Function(Pointer<Void>, Pointer<Uint8>, int, Pointer<Pointer<Void>>);
+typedef _MaskDestroyC = Int32 Function(Pointer<Void>);
+typedef _MaskDestroyD = int Function(Pointer<Void>);
+typedef _MaskKeptC = Int64 Function(Pointer<Void>);
+typedef _MaskKeptD = int Function(Pointer<Void>);
+typedef _SearchMaskedC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Int32, Double,
+    Pointer<Void>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _SearchMaskedD = int Function(Pointer<Void>, Pointer<Float>, int, int, double,
+    Pointer<Void>, Pointer<Int64>, Pointer<Double>, Pointer<Int32>);
+typedef _SubmitMaskedC = Int32 Function(Pointer<Void>, Pointer<Float>, Int32, Pointer<Void>, Pointer<Int32>);
+typedef _SubmitMaskedD = int Function(Pointer<Void>, Pointer<Float>, int, Pointer<Void>, Pointer<Int32>);
 typedef _PqEncodeC = Int32 Function(
     Pointer<Void>, Int64, Int64, Pointer<Float>, Int32, Int32, Pointer<Uint8>);
 typedef _PqEncodeD = int Function(
@@ -248,6 +264,10 @@ final class TshNghInfo extends Struct {
   external int pagesAbsent;
   @Int64()
   external int filesAbsent;
+  @Int64()
+  external int rowBase;
+  @Int64()
+  external int rowEnd;
 }
 
 /// One device-resident copy of an NGH index's raw-vector column.
@@ -297,9 +317,15 @@ final class HipVectorBackend {
   static late final _CommSetGroupD _commSetGroup;
   static late final _SearchShardedD _searchSharded;
   static late final _CommTimelineD _commTimeline;
+  static late final _OpenNghShardD _openNghShard;
+  static late final _MaskCreateD _maskCreate;
+  static late final _MaskDestroyD _maskDestroy;
+  static late final _MaskKeptD _maskKept;
+  static late final _SearchMaskedD _searchMasked;
+  static late final _SubmitMaskedD _submitMasked;
 
   /// include/tostore_hip.h TSH_ABI_VERSION this file was written against.
-  static const int abiVersion = 4;
+  static const int abiVersion = 5;
 
   /// True when libtostore_hip.so is loadable, ABI-compatible and sees a GPU.
   static bool get available {
@@ -349,7 +375,15 @@ final class HipVectorBackend {
           lib.lookupFunction<_SearchShardedC, _SearchShardedD>('tsh_search_sharded');
       _commTimeline =
           lib.lookupFunction<_CommTimelineC, _CommTimelineD>('tsh_comm_get_timeline');
-      // the structs of this file are the version-4 layouts: any other library is not used
+      _openNghShard =
+          lib.lookupFunction<_OpenNghShardC, _OpenNghShardD>('tsh_index_open_ngh_shard');
+      _maskCreate = lib.lookupFunction<_MaskCreateC, _MaskCreateD>('tsh_mask_create');
+      _maskDestroy = lib.lookupFunction<_MaskDestroyC, _MaskDestroyD>('tsh_mask_destroy');
+      _maskKept = lib.lookupFunction<_MaskKeptC, _MaskKeptD>('tsh_mask_kept');
+      _searchMasked = lib.lookupFunction<_SearchMaskedC, _SearchMaskedD>('tsh_search_masked');
+      _submitMasked =
+          lib.lookupFunction<_SubmitMaskedC, _SubmitMaskedD>('tsh_search_submit_masked');
+      // the structs of this file are the version-5 layouts: any other library is not used
       if (_abiVersion() != abiVersion || _deviceCount() < 1) return false;
       _lib = lib;
       return true;
@@ -421,6 +455,62 @@ final class HipVectorBackend {
     } finally {
       calloc.free(p);
       calloc.free(info);
+      calloc.free(out);
+    }
+  }
+
+  /// Cold start of ONE rank's row range of `<index>/ngh` (one Dart process per GPU, [HipShardComm]): node ids
+  /// [rank * ceil(nextNodeId / world), ...) as a shard handle with global ids -- the library opens only the
+  /// partition files and reads only the pages that hold the range (model/ngh_index_meta.dart:480-490,
+  /// core/path_manager.dart:275-324).  Null when the range has holes on disk, like [tryOpen].
+  static HipVectorBackend? tryOpenShard(String nghDir, NghIndexMeta meta, int maxEntriesPerDir,
+      int device, int world, int rank) {
+    if (!available) return null;
+    final out = calloc<Pointer<Void>>();
+    final info = calloc<TshNghInfo>();
+    final p = nghDir.toNativeUtf8();
+    try {
+      final rc = _openNghShard(p, maxEntriesPerDir, device, world, rank, out, info);
+      if (rc != 0) {
+        Logger.warn('tsh_index_open_ngh_shard failed ($rc): ${_errorText()}',
+            label: 'HipVectorBackend');
+        return null;
+      }
+      final want = info.ref.rowEnd - info.ref.rowBase;
+      if (info.ref.pagesAbsent != 0 || info.ref.rowsLoaded != want) {
+        Logger.warn(
+            'device shard $rank/$world of $nghDir not used: ${info.ref.pagesAbsent} raw-vector pages '
+            'absent, ${info.ref.rowsLoaded} of $want rows loaded',
+            label: 'HipVectorBackend');
+        _destroy(out.value);
+        return null;
+      }
+      return HipVectorBackend._(out.value, meta.dimensions, meta.distanceMetric);
+    } finally {
+      calloc.free(p);
+      calloc.free(info);
+      calloc.free(out);
+    }
+  }
+
+  /// A WHERE row set that lives on the device across queries (tsh_mask_create): bit i of `bits` (LSB first)
+  /// keeps node id i.  The bitmap crosses the FFI boundary ONCE; searches that pass the handle
+  /// ([search] / [searchAsync] `mask:`) copy nothing and do no host work on it -- the `rowMask:` form
+  /// callocs, copies and has the library slice, count and list the bitmap on every call.  Dispose the mask
+  /// before this backend.
+  HipRowMask? createMask(Uint8List bits) {
+    final buf = calloc<Uint8>(bits.isEmpty ? 1 : bits.length);
+    final out = calloc<Pointer<Void>>();
+    try {
+      buf.asTypedList(bits.length).setAll(0, bits);
+      final rc = _maskCreate(_handle, buf, bits.length, out);
+      if (rc != 0) {
+        Logger.warn('tsh_mask_create failed ($rc): ${_errorText()}', label: 'HipVectorBackend');
+        return null;
+      }
+      return HipRowMask._(out.value);
+    } finally {
+      calloc.free(buf);
       calloc.free(out);
     }
   }
@@ -535,21 +625,24 @@ final class HipVectorBackend {
   /// (vector_index_manager.dart:514-520).  Returns null on any native failure so
   /// the caller falls through to the original graph search.
   List<NghSearchResult>? search(Float32List query, int topK,
-      {double? distanceThreshold, Uint8List? rowMask}) {
+      {double? distanceThreshold, Uint8List? rowMask, HipRowMask? mask}) {
     if (topK <= 0 || size == 0) return const [];
     final q = calloc<Float>(dimensions);
     final ids = calloc<Int64>(topK);
     final dist = calloc<Double>(topK);
     final cnt = calloc<Int32>();
-    Pointer<Uint8> mask = nullptr;
+    Pointer<Uint8> maskBytes = nullptr;
     try {
       q.asTypedList(dimensions).setAll(0, query);
-      if (rowMask != null) {
-        mask = calloc<Uint8>(rowMask.length);
-        mask.asTypedList(rowMask.length).setAll(0, rowMask);
+      if (mask == null && rowMask != null) {
+        maskBytes = calloc<Uint8>(rowMask.length);
+        maskBytes.asTypedList(rowMask.length).setAll(0, rowMask);
       }
-      final rc = _search(_handle, q, 1, topK, distanceThreshold ?? double.nan, mask,
-          ids, dist, cnt);
+      final rc = mask != null
+          ? _searchMasked(_handle, q, 1, topK, distanceThreshold ?? double.nan, mask._mask,
+              ids, dist, cnt)
+          : _search(_handle, q, 1, topK, distanceThreshold ?? double.nan, maskBytes,
+              ids, dist, cnt);
       if (rc != 0) {
         Logger.warn('tsh_search failed ($rc): ${_errorText()}', label: 'HipVectorBackend');
         return null;
@@ -563,7 +656,7 @@ final class HipVectorBackend {
       calloc.free(ids);
       calloc.free(dist);
       calloc.free(cnt);
-      if (mask != nullptr) calloc.free(mask);
+      if (maskBytes != nullptr) calloc.free(maskBytes);
     }
   }
 
@@ -599,19 +692,22 @@ final class HipVectorBackend {
   /// Returns null on any native failure (TSH_E_BUSY included: the caller falls back to the
   /// synchronous path or the Dart graph search).
   Future<List<NghSearchResult>?> searchAsync(Float32List query, int topK,
-      {double? distanceThreshold, Uint8List? rowMask}) async {
+      {double? distanceThreshold, Uint8List? rowMask, HipRowMask? mask}) async {
     if (topK <= 0 || size == 0) return const [];
     final q = calloc<Float>(dimensions);
     final ticket = calloc<Int32>();
-    Pointer<Uint8> mask = nullptr;
+    Pointer<Uint8> maskBytes = nullptr;
     int t;
     try {
       q.asTypedList(dimensions).setAll(0, query);
-      if (rowMask != null) {
-        mask = calloc<Uint8>(rowMask.length);
-        mask.asTypedList(rowMask.length).setAll(0, rowMask);
+      if (mask == null && rowMask != null) {
+        maskBytes = calloc<Uint8>(rowMask.length);
+        maskBytes.asTypedList(rowMask.length).setAll(0, rowMask);
       }
-      final rc = _submit(_handle, q, topK, mask, ticket); // inputs are consumed before it returns
+      // inputs are consumed before either returns (a mask HANDLE must outlive the ticket)
+      final rc = mask != null
+          ? _submitMasked(_handle, q, topK, mask._mask, ticket)
+          : _submit(_handle, q, topK, maskBytes, ticket);
       if (rc != 0) {
         Logger.warn('tsh_search_submit failed ($rc): ${_errorText()}',
             label: 'HipVectorBackend');
@@ -621,7 +717,7 @@ final class HipVectorBackend {
     } finally {
       calloc.free(q);
       calloc.free(ticket);
-      if (mask != nullptr) calloc.free(mask);
+      if (maskBytes != nullptr) calloc.free(maskBytes);
     }
     // every ticket must be waited exactly once: from here on nothing may return before _wait ran.
     // The first polls yield with a zero delay (a short scan is over by then); after that the isolate sleeps
@@ -899,6 +995,28 @@ final class HipShardComm {
     if (_comm != nullptr) {
       HipVectorBackend._commDestroy(_comm);
       _comm = nullptr;
+    }
+  }
+}
+
+/// A device-resident WHERE row set ([HipVectorBackend.createMask], tsh_mask_create): the rows a structured
+/// filter keeps -- primary keys mapped to node ids through the pk -> nodeId tree
+/// (vector_index_manager.dart:1223-1378) -- or the complement of a tombstone set (ngh_page.dart:105-108),
+/// kept for as many queries as it serves.  Rows appended after it was made are not kept; rows deleted
+/// later are dropped by the kernels as always.  Dispose it before its backend, and only after every
+/// [HipVectorBackend.searchAsync] that used it has completed.
+final class HipRowMask {
+  Pointer<Void> _mask;
+
+  HipRowMask._(this._mask);
+
+  /// Rows the mask keeps among the index's current node ids (tombstones not subtracted); -1 on failure.
+  int get kept => _mask == nullptr ? -1 : HipVectorBackend._maskKept(_mask);
+
+  void dispose() {
+    if (_mask != nullptr) {
+      HipVectorBackend._maskDestroy(_mask);
+      _mask = nullptr;
     }
   }
 }
