@@ -1155,7 +1155,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
   Band band;
   if (exact) {
     fill_exact_args(s, c, use_list, j->user_mask && !use_list, n_exam, qdst, &xa);
-    if (xa.a.mask) xa.a.mask = j->d_mask;
+    xa.a.mask = (j->user_mask && !use_list) ? j->d_mask : nullptr;  // (the context's copy, or a handle's resident words)
     xa.a.list = j->d_list;
     xa.a.query = inline_q ? nullptr : c->d_query;
     // (only the quarantine kernels read the device copy of an inline query)
@@ -1168,7 +1168,7 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     j->force_all = false;
   } else {
     fill_scan_args(s, c, j->masked, j->user_mask, &sa);
-    if (sa.a.mask) sa.a.mask = j->d_mask;
+    sa.a.mask = (j->masked && j->user_mask) ? j->d_mask : nullptr;
     if (use_list) {
       sa.a.list = j->d_list;
       sa.a.n_tiles = j->list_tiles;
