@@ -102,6 +102,9 @@ typedef struct tsh_counters {
                                     pipelined single-query scans */
   int64_t list_scans;            /* of scan_launches: scans of a selective row mask as a compacted list of row ids
                                     (scan_list_kernel) instead of a walk over the tiles */
+  int64_t exact_redone;          /* of exact_scans: searches whose wide pick (TSH_OPT_EXACT_SELECT) met a cut bin too full
+                                    for its block -- ties by the hundred, a k-th neighbour outside the key histogram's
+                                    window -- and were finished by the one-workgroup select on the same keys (ABI 5) */
 } tsh_counters;
 
 int32_t tsh_abi_version(void);
@@ -550,6 +553,14 @@ int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, 
  * (scan, select, re-rank) are what such a search waits for.  Results are identical either way (the candidates are then
  * exactly the k winners); counted in tsh_counters.exact_scans. */
 #define TSH_OPT_EXACT_SCAN_ROWS 4
+/* TSH_OPT_EXACT_SELECT (default 1): what follows the exact scan of such a search.  1 = the wide pick: the scan leaves
+ * every wave's smallest distance, the k-th smallest of those bounds the k-th distance from above, and one workgroup per
+ * 256 rows emits every row at or below the bound -- the k winners plus a few rows that cannot win, no ranking on the
+ * device (the finaliser orders and cuts as always); a bound that lets in more rows than the block holds (ties by the
+ * hundred) is finished by the one-workgroup select, and searches with fewer than 16 k rows to look at take that select
+ * directly.  0 = always the select (round 5: exactly min(k, live rows) entries, one compute unit, 9-17 us for 2 k-10 k
+ * rows).  Results are identical. */
+#define TSH_OPT_EXACT_SELECT 5
 /* TSH_OPT_TEST_HOOKS (process-wide; idx is ignored and may be NULL): value TSH_TEST_HOOKS_MAGIC switches the
  * library's TEST hooks on, 0 off.  Only then does it read the environment variables that change what it loads or make
  * it fail on purpose -- TSH_RCCL_LIB (a stand-in for librccl: tests/fake_rccl), TSH_TEST_FAIL_ALLOC_OVER (device

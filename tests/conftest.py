@@ -38,21 +38,27 @@ def hip_lib():
     return L
 
 
-@pytest.fixture(params=["exact", "prefilter"])
+@pytest.fixture(params=["exact", "exact_select", "prefilter"])
 def scan_path(request, monkeypatch):
     """Searches that look at no more than 16384 rows answer from the exact sums of all of them (tsh_exact.hip.h);
     everything else goes through the f32 pre-filter (scan, select, re-rank).  Tests on small shapes run both ways:
     "prefilter" switches the exact path off for every index the test creates (TSH_OPT_EXACT_SCAN_ROWS = 0), so the
-    pre-filter kernels keep their coverage of small inputs, ties and edges.  A module asks for it with
+    pre-filter kernels keep their coverage of small inputs, ties and edges; "exact_select" keeps the exact scan but
+    follows it with the one-workgroup select (TSH_OPT_EXACT_SELECT = 0) instead of the wide pick, which is also what a
+    pick falls back to when its cut bin overflows.  A module asks for it with
     pytestmark = [..., pytest.mark.usefixtures("scan_path")]."""
-    if request.param == "prefilter":
+    if request.param != "exact":
         from tostore_amd import backend
 
         init = backend.HipVectorIndex.__init__
+        param = request.param
 
         def patched(self, *a, **kw):
             init(self, *a, **kw)
-            self.set_exact_scan_rows(0)
+            if param == "prefilter":
+                self.set_exact_scan_rows(0)
+            else:  # the exact scan followed by round 5's one-workgroup select instead of the wide pick
+                self.set_exact_select(False)
 
         monkeypatch.setattr(backend.HipVectorIndex, "__init__", patched)
     return request.param

@@ -33,8 +33,9 @@ def _check(idx, oracle_mod, rows, qs, metric, k, mask=None, thr=None, base=0, ef
 
 
 @pytest.mark.parametrize("metric", [L2, IP, COS])
+@pytest.mark.parametrize("wide", [True, False], ids=["pick", "select"])
 @pytest.mark.parametrize("d", [1, 3, 5, 64, 127, 128, 129, 130, 200, 768, 1000, 2048])
-def test_every_width_and_k(hip_lib, oracle_mod, metric, d):
+def test_every_width_and_k(hip_lib, oracle_mod, metric, d, wide):
     """Pieces of 128 elements: widths below, at and across a piece, rows that end inside one, queries that ride in the
     kernel arguments (ld <= 960) and queries that do not."""
     from tostore_amd import HipVectorIndex
@@ -46,14 +47,20 @@ def test_every_width_and_k(hip_lib, oracle_mod, metric, d):
     with HipVectorIndex(d, metric) as idx:
         idx.append(0, rows)
         idx.set_batch_min_nq(0)
+        idx.set_exact_select(wide)  # E2': the wide pick (default) / E2: the one-workgroup select
         c0 = idx.counters()
         for k in (1, 10, 100, n - 1, n, n + 5):
             _check(idx, oracle_mod, rows, qs, metric, k)
         c1 = idx.counters()
         assert c1["exact_scans"] - c0["exact_scans"] == c1["scan_launches"] - c0["scan_launches"] == 18
         assert c1["fallback_searches"] == 0
-        # exactly the winners are handed to the finaliser: no band's worth of extra candidates
-        assert c1["candidates_total"] - c0["candidates_total"] == 3 * (1 + 10 + 100 + (n - 1) + n + n)
+        # the winners are handed to the finaliser -- exactly them by the select, plus the few rows that share the cut bin
+        # (1/256 of an octave of distance) by the pick: no band's worth of extra candidates either way
+        extra = c1["candidates_total"] - c0["candidates_total"] - 3 * (1 + 10 + 100 + (n - 1) + n + n)
+        assert extra == 0 if not wide else 0 <= extra <= 18 * 60, extra
+        # (one-element rows under cosine are at distance 0 or 2, all of them: ties by the thousand, which the pick hands to
+        # the select -- the only shape here that does)
+        assert c1["exact_redone"] - c0["exact_redone"] == (9 if wide and d == 1 and metric == COS else 0)
         idx.set_exact_scan_rows(0)  # the same answers from the pre-filter, and the counter stands still
         _check(idx, oracle_mod, rows, qs, metric, 10)
         assert idx.counters()["exact_scans"] == c1["exact_scans"]
@@ -235,7 +242,8 @@ def test_quarantined_rows_join_the_exact_blocks(hip_lib, oracle_mod):
             assert c["quarantined_rows"] == 3 and c["safe_mode"] == 0 and c["exact_scans"] == c["scan_launches"] == 9
 
 
-def test_shard_blocks_hold_the_k_winners(hip_lib, oracle_mod):
+@pytest.mark.parametrize("wide", [True, False], ids=["pick", "select"])
+def test_shard_blocks_hold_the_k_winners(hip_lib, oracle_mod, wide):
     """Shard mode: the block a rank offers holds min(k, live rows) entries, flagged exact, with global ids; merged like
     any other block."""
     import torch
@@ -251,6 +259,7 @@ def test_shard_blocks_hold_the_k_winners(hip_lib, oracle_mod):
     with HipVectorIndex(d, L2, shard_device=0, row_base=base) as s:
         s.append(base, rows)
         s.set_batch_min_nq(0)
+        s.set_exact_select(wide)
         entries = L.tsh_default_block_entries(k)
         bb = L.tsh_candidate_block_bytes(entries)
         for mask_rows in (None, 30):
@@ -266,7 +275,11 @@ def test_shard_blocks_hold_the_k_winners(hip_lib, oracle_mod):
                                           ctypes.c_void_p(buf.data_ptr()), None))
             blk = buf.cpu().numpy()
             hdr = blk.reshape(5, bb)[:, :64].view(np.uint32)
-            assert (hdr[:, 0] == (k if not mask_rows else mask_rows)).all() and (hdr[:, 1] == entries).all()
+            if mask_rows or not wide:
+                assert (hdr[:, 0] == (k if not mask_rows else mask_rows)).all()
+            else:  # the pick: the k winners and whatever shares the cut bin with the k-th
+                assert (hdr[:, 0] >= k).all() and (hdr[:, 0] <= k + 60).all()
+            assert (hdr[:, 1] == entries).all()
             assert ((hdr[:, 5] & 8) == 8).all() and ((hdr[:, 5] & 1) == 0).all()  # FLAG_EXACT, no overflow
             ids, dist, cnt = merge_candidate_blocks(L2, d, qs, k, None, blk, 1, entries)
             om = None if bits is None else np.packbits(bits, bitorder="little")

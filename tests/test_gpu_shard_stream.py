@@ -120,7 +120,7 @@ def test_stream_ties_overflow_like_the_plain_call(hip_lib, oracle_mod, scan_path
         s.set_batch_min_nq(0)
         entries = _ffi.lib().tsh_default_block_entries(k)
         blk, _ = _stream_blocks(torch, s, qs, k, entries, None, step=3, wants=[3, 6, 9])
-        if scan_path == "exact":  # 6000 rows: the block holds the k lowest ids of the tie, nothing overflows
+        if scan_path != "prefilter":  # 6000 rows: the block holds the k lowest ids of the tie, nothing overflows
             ids, dist, cnt = merge_candidate_blocks(L2, d, qs, k, None, blk, 1, entries)
         else:
             with pytest.raises(_ffi.TshError) as e:
@@ -160,8 +160,9 @@ def test_stream_empty_shard_and_bad_arguments(hip_lib, scan_path):
     with HipVectorIndex(d, L2, capacity_rows=10, n_devices=1) as whole:  # (a plain handle has one shard: accepted)
         whole.append(0, np.ones((10, d), np.float32))
         blk, seen = _stream_blocks(torch, whole, qs, k, entries, None, step=0)
-        # (ten rows: the pre-filter offers every one of them, the exact path the k winners)
-        assert (blk.reshape(4, bb)[:, :4].view(np.uint32)[:, 0] == (k if scan_path == "exact" else 10)).all()
+        # (ten rows: the pre-filter offers every one of them, the exact path the k winners -- two waves of rows are too few
+        # for the wide pick's bound, the one-workgroup select ranks them)
+        assert (blk.reshape(4, bb)[:, :4].view(np.uint32)[:, 0] == (k if scan_path != "prefilter" else 10)).all()
 
 
 def test_appends_wait_for_a_running_stream(hip_lib, oracle_mod):

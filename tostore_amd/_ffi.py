@@ -49,6 +49,7 @@ class TshCounters(ctypes.Structure):
         ("scan_us_sum", c_f64), ("scan_us_samples", c_i64),
         ("batch_kernel_last", c_i32), ("quarantined_rows", c_i32), ("exact_scans", c_i64),
         ("batch_plane_fallbacks", c_i64), ("batch_scan_fallbacks", c_i64), ("list_scans", c_i64),
+        ("exact_redone", c_i64),
     ]
 
 
@@ -163,6 +164,7 @@ def lib() -> ctypes.CDLL:
 
 TSH_OPT_EXCHANGE_AHEAD = 3
 TSH_OPT_EXACT_SCAN_ROWS = 4
+TSH_OPT_EXACT_SELECT = 5
 TSH_OPT_TEST_HOOKS = 1000
 TSH_TEST_HOOKS_MAGIC = 0x7465737468
 

@@ -278,6 +278,12 @@ class HipVectorIndex:
         0 never, default and maximum 16384.  Results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_EXACT_SCAN_ROWS, int(rows)))
 
+    def set_exact_select(self, wide: bool) -> None:
+        """What follows the exact scan of a short search: True (default) the wide pick (one workgroup per 256 rows, the
+        cut from the scan's key histogram, k rows plus the cut bin's few others), False the one-workgroup select that
+        ranks exactly k rows.  Results are identical."""
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_EXACT_SELECT, 1 if wide else 0))
+
     def set_batch_kernel(self, kind: int) -> None:
         """Batched pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (default: f16 for cosine, bf16x3
         otherwise).  Results are identical."""

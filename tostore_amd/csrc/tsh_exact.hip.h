@@ -53,6 +53,8 @@ struct ExactArgs {
   uint64_t *xkey;        // per entry: order key of its distance (XKEY_DEAD: no row)
   double *xsum;          // per entry: s0, s1
   double sqrt_mag_a;     // cosine: sqrt of the query's sum of squares (element order, f64: query_mag_a)
+  uint64_t *wmin;        // nullable: per wave (eight entries) the smallest of its keys (XKEY_DEAD: none alive), for
+                         // exact_pick_kernel's bound on the k-th smallest key
   int64_t ld;            // floats per row, multiple of 4
   int64_t n_rows;        // rows of the shard
   int32_t n_entries;
@@ -126,6 +128,7 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
   const bool writer = g == 7 && e < a.n_entries;  // where a row's chain ends
   if (!am) {  // wave-uniform: nothing to read
     if (writer) a.xkey[e] = XKEY_DEAD;
+    if (a.wmin && lane == 0) a.wmin[blockIdx.x] = XKEY_DEAD;
     return;
   }
   // a dead entry's lanes walk the wave's first live row (valid memory; the result is dropped)
@@ -198,6 +201,7 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
     for (int dd = 0; dd < EX_D; ++dd)
       if (p0 + dd < npiece) piece(raw[dd], p0 + dd, dd == EX_D - 1 && p0 + EX_D < npiece);  // wave-uniform
   }
+  uint64_t key = XKEY_DEAD;
   if (writer) {
     double d;
     if (METRIC == METRIC_L2) {
@@ -209,8 +213,18 @@ __global__ void __launch_bounds__(64) exact_scan_kernel(ExactArgsQ aq) {
       const double sim = denom > 0 ? s0 / denom : 0;
       d = 1.0 - sim;
     }
-    a.xkey[e] = alive ? xkey_of(d) : XKEY_DEAD;
+    key = alive ? xkey_of(d) : XKEY_DEAD;
+    a.xkey[e] = key;
     *reinterpret_cast<f64x2 *>(a.xsum + 2 * e) = f64x2{s0, METRIC == METRIC_COS ? s1 : 0.0};
+  }
+  if (a.wmin) {  // the wave's smallest key: one plain store (a histogram of ALL keys in global memory was tried first --
+    // 10 k device-scope atomics, 600 of them on the most popular bin, took this kernel from 15 to 38 us)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      const uint64_t other = (uint64_t)__shfl_xor((unsigned long long)key, o);
+      key = other < key ? other : key;
+    }
+    if (lane == 7) a.wmin[blockIdx.x] = key;
   }
 }
 
@@ -516,6 +530,190 @@ __global__ void __launch_bounds__(1024) exact_select_kernel(ExactSelArgs a) {
     hv.pad[0] = (p_adds << 16) | (p_scan & 0xFFFFu);  // (ticks of 10 ns: the rounds' adds, their scans)
     hv.pad[3] = s_nfin;
 #endif
+    hv.pad[1] = a.tag;
+    *a.hdr = hv;
+    if (a.hdr_host) *a.hdr_host = hv;
+  }
+}
+
+// E2' (round 6).  exact_select_kernel above is ONE workgroup, and what it costs grows with the entries: every phase of it
+// is a loop over a thread's key slots -- 8.6 us at 2 k entries, 12.8-17 at 10 k (profiles/r06_lone_trace.txt), on one
+// compute unit of 256, behind a scan that took 6-15.  The wide pick spreads the per-entry work over one workgroup per
+// 256 entries and cuts the cross-workgroup dependency instead of synchronising over it:
+//   * a BOUND instead of the k-th key: E1 leaves every wave's smallest key (eight entries; one plain store).  The k-th
+//     smallest of those minima is at or above the k-th smallest key (k waves hold a key at or below it), and hardly
+//     above it: with G waves about 0.44 k^2 / G rows lie between the two (3.5 at k = 100 of 10 k rows).  Every workgroup
+//     finds it for itself -- up to 2048 minima, a histogram in its own LDS over eleven bits from the first bit in which
+//     the minima's upper halves differ, one scan -- and takes the cut bin's upper edge;
+//   * no ranking: every row at or below the bound is emitted -- k, the rows up to the k-th minimum, and what shares the
+//     cut bin (1/2048 of the minima's range).  The block then holds a few rows that cannot win, like a pre-filter block
+//     does, and the finaliser's threshold / sort / cut (ngh_graph_engine.dart:127,133-134) is what it always was;
+//   * ONE device-scope atomic per workgroup: a 64-bit add whose low half hands out output positions and whose high half
+//     is a ticket -- the workgroup that draws the last ticket knows the final count and writes the header.  (Per-wave
+//     position atomics, 80 of them on one address, took a 40-workgroup launch from 4.3 to 8.8 us.)
+//   * a bound that lets in more rows than the block holds (ties by the hundred; fewer live waves than k) sets
+//     FLAG_LIST_OVERFLOW, and the host finishes the search with exact_select_kernel on the same keys (job_finish).
+constexpr int EX_PICK_BINS = 2048, EX_PICK_MPT = EX_MAX_ROWS / EX_R / 256;  // minima per thread: 8
+struct ExactPickArgs {
+  const uint64_t *xkey;
+  const double *xsum;
+  const uint32_t *list;  // nullable (entry = row)
+  const uint64_t *wmin;  // E1's wave minima: n_groups of them
+  unsigned long long *ctr;  // zero between searches: low half = entries handed out, high half = workgroups done
+  BlockHeader *hdr;
+  BlockHeader *hdr_host;  // nullable
+  BlockEntry *out;
+  int64_t row_base;
+  int64_t shard_rows;
+  int32_t n_entries;
+  int32_t n_groups;
+  int32_t k;
+  int32_t cap;
+  int32_t metric;
+  uint32_t tag;
+};
+
+__global__ void __launch_bounds__(256) exact_pick_kernel(ExactPickArgs a) {
+  __shared__ uint32_t s_hist[EX_PICK_BINS];
+  __shared__ uint32_t s_part[4][3], s_tot[4], s_take[4], s_cut, s_ck, s_kk, s_base, s_final;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * 256 + tid;
+  // this thread's entry, all of it, before the bound is known (one round trip instead of two)
+  const uint64_t key = i < a.n_entries ? a.xkey[i] : XKEY_DEAD;
+  const uint32_t h = (uint32_t)(key >> 32);
+  const bool live = h != XHI_DEAD;
+  uint32_t row = (uint32_t)i;
+  f64x2 sv = f64x2{0.0, 0.0};
+  if (live) {
+    if (a.list) row = a.list[i];
+    sv = *reinterpret_cast<const f64x2 *>(a.xsum + 2 * (int64_t)i);
+  }
+  // the minima's upper halves; which bits they differ in; how many are alive
+  uint32_t m[EX_PICK_MPT];
+  uint32_t o1 = 0, o0 = 0, nl = 0;
+#pragma unroll
+  for (int j = 0; j < EX_PICK_MPT; ++j) {
+    const int g = tid + 256 * j;
+    m[j] = XHI_DEAD;
+    if (j * 256 < a.n_groups && g < a.n_groups) m[j] = (uint32_t)(a.wmin[g] >> 32);
+    const bool lv = m[j] != XHI_DEAD;
+    nl += (uint32_t)__popcll(__ballot(lv));
+    o1 |= lv ? m[j] : 0u;
+    o0 |= lv ? ~m[j] : 0u;
+    s_hist[tid + 256 * j] = 0u;  // (EX_PICK_BINS = 256 * EX_PICK_MPT)
+  }
+  {
+    const uint32_t w1 = ex_wave_or(o1), w0 = ex_wave_or(o0);
+    if (lane == 0) {
+      s_part[wave][0] = nl;
+      s_part[wave][1] = w1;
+      s_part[wave][2] = w0;
+    }
+  }
+  __syncthreads();
+  uint32_t groups = 0, any1 = 0, any0 = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    groups += s_part[w][0];
+    any1 |= s_part[w][1];
+    any0 |= s_part[w][2];
+  }
+  const uint32_t k = (uint32_t)a.k;
+  uint32_t Khi = 0xFFFFFFFEu;  // fewer live waves than k: no bound -- every live row
+  if (groups >= k) {           // (workgroup-uniform)
+    // eleven bits a round from the first bit in which the minima differ; a cut bin that still holds more than a handful
+    // of minima is refined (a corpus whose distances change sign -- inner products -- differs in the sign bit: the first
+    // round's bins are then two octaves wide, and the k-th minimum shares its bin with hundreds)
+    const uint32_t diff = any1 & any0;
+    int up = diff ? 32 - __builtin_clz(diff) : 0, lob = 0;
+    uint32_t prefix = up >= 32 ? 0u : (any1 >> up) << up, kk = k;
+    for (int round = 0;; ++round) {
+      lob = up > 11 ? up - 11 : 0;
+      const uint32_t dmask = (1u << (up - lob)) - 1u;
+      if (round) {
+#pragma unroll
+        for (int j = 0; j < EX_PICK_MPT; ++j) s_hist[tid + 256 * j] = 0u;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < EX_PICK_MPT; ++j)
+        if (m[j] != XHI_DEAD && (up >= 32 || (m[j] >> up) == (prefix >> up))) atomicAdd(&s_hist[(m[j] >> lob) & dmask], 1u);
+      __syncthreads();
+      uint32_t c[8], mine = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c[j] = s_hist[8 * tid + j];
+        mine += c[j];
+      }
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += u;
+      }
+      if (lane == 63) s_tot[wave] = incl;
+      __syncthreads();
+      uint32_t below = incl - mine;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < wave) below += s_tot[w];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (below < kk && below + c[j] >= kk) {  // exactly one (thread, j): 1 <= kk <= members of the round
+          s_cut = (uint32_t)(8 * tid + j);
+          s_ck = c[j];
+          s_kk = kk - below;
+        }
+        below += c[j];
+      }
+      __syncthreads();
+      prefix |= s_cut << lob;
+      if (lob == 0 || s_ck <= 8u) break;  // (workgroup-uniform)
+      kk = s_kk;
+      up = lob;
+    }
+    Khi = prefix | ((1u << lob) - 1u);  // the cut bin's upper edge
+  }
+  const bool take = live && h <= Khi;
+  const uint64_t bm = __ballot(take);
+  if (lane == 0) s_take[wave] = (uint32_t)__popcll(bm);
+  __syncthreads();
+  uint32_t total = 0, before = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) before += s_take[w];
+    total += s_take[w];
+  }
+  if (tid == 0) {
+    const unsigned long long old = atomicAdd(a.ctr, (1ull << 32) | (unsigned long long)total);
+    s_base = (uint32_t)old;
+    s_final = (uint32_t)(old >> 32) == gridDim.x - 1u ? (uint32_t)old + total : 0xFFFFFFFFu;
+    if ((uint32_t)(old >> 32) == gridDim.x - 1u) *a.ctr = 0ull;  // (nobody adds after the last ticket: clear for the next search)
+  }
+  __syncthreads();
+  if (take) {
+    const uint32_t p = s_base + before + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+    if (p < (uint32_t)a.cap) {
+      BlockEntry e;
+      e.id = a.row_base + (int64_t)row;
+      e.s0 = sv.x;
+      e.s1 = sv.y;
+      a.out[p] = e;
+    }
+  }
+  if (tid == 0 && s_final != 0xFFFFFFFFu) {  // the last workgroup: every other one has booked its rows
+    BlockHeader hv;
+    hv.count = s_final;
+    hv.entries = (uint32_t)a.cap;
+    hv.tau_key = KEY_NAN;  // (no f32 keys exist for this block)
+    hv.band_key = KEY_NAN;
+    hv.tiles_hit = 0u;
+    hv.flags = FLAG_EXACT | (s_final > (uint32_t)a.cap ? FLAG_LIST_OVERFLOW : 0u);
+    hv.k = (uint32_t)a.k;
+    hv.metric = (uint32_t)a.metric;
+    hv.row_base = a.row_base;
+    hv.shard_rows = a.shard_rows;
+    hv.pad[0] = hv.pad[2] = hv.pad[3] = 0u;
     hv.pad[1] = a.tag;
     *a.hdr = hv;
     if (a.hdr_host) *a.hdr_host = hv;

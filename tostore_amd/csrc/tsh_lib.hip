@@ -297,6 +297,7 @@ struct Ctx {
   // short searches (tsh_exact.hip.h): per entry the order key of its exact distance and its two f64 sums
   uint64_t *d_xkey = nullptr;
   double *d_xsum = nullptr;
+  uint64_t *d_xpick = nullptr;  // exact_pick_kernel: [0] its counter (zero between searches), [1 ..] E1's wave minima
   int64_t x_cap = 0;
   int64_t bytes = 0;
 };
@@ -397,6 +398,8 @@ struct Shard {
   std::atomic<int64_t> c_list_scans{0};  // scans of a compacted row list (selective masks)
   std::atomic<int64_t> c_exact_scans{0};  // searches answered by the exact scan of a few thousand rows (tsh_exact.hip.h)
   int exact_rows = EX_MAX_ROWS;  // TSH_OPT_EXACT_SCAN_ROWS: searches that look at no more rows than this take that path
+  bool exact_pick = true;        // TSH_OPT_EXACT_SELECT: the wide pick (exact_pick_kernel) behind the exact scan
+  std::atomic<int64_t> c_pick_redone{0};  // picks whose cut bin overflowed the block: finished by exact_select_kernel
   int cus = 0;  // compute units of the shard's device (grid of the persistent key kernels)
   std::atomic<int> f16_strikes{0};      // batched calls in a row whose fp16 bands overflowed many candidate lists
   std::atomic<int> f16_denied_calls{0};  // auto key-kernel choice: bf16x3 instead of fp16 for this many more batched calls
@@ -724,6 +727,7 @@ void ctx_free_all(Ctx *c) {
   hipFree(c->d_big_count);
   hipFree(c->d_xkey);
   hipFree(c->d_xsum);
+  hipFree(c->d_xpick);
 }
 
 int ctx_prepare(Shard *s, Ctx *c, int32_t entries, bool need_mask) {
@@ -908,6 +912,8 @@ struct Job {
   const uint64_t *d_mask = nullptr;  // the caller's mask words on the device: the context's copy, or a mask handle's
   const uint32_t *d_list = nullptr;  // the scanned list on the device: the context's copy, or a mask handle's
   bool exact = false;      // answered by exact_scan_kernel + exact_select_kernel: the block is final, no f32 keys exist
+  bool picked = false;     // ... by exact_pick_kernel instead of exact_select_kernel: a cut bin too full for the block is
+  ExactSelArgs xsel{};     // finished by exact_select_kernel on the same keys (these arguments), job_finish
   bool leave_overflow = false;  // shard mode under TSH_OPT_EXCHANGE_AHEAD: an exchange enqueued behind this job's kernels
                                 // may be reading the device block when the host looks at it -- a block whose list
                                 // overflowed is then NOT rewritten by the wide-band pass (a peer could gather a new
@@ -1055,6 +1061,11 @@ int ctx_reserve_exact(Ctx *c, int64_t n) {
   const int64_t want = std::min<int64_t>(round_up(n + n / 2, 1024), EX_MAX_ROWS);
   HIPCHK(hipMalloc(&c->d_xkey, (size_t)want * sizeof(uint64_t)));
   HIPCHK(hipMalloc(&c->d_xsum, (size_t)want * 2 * sizeof(double)));
+  if (!c->d_xpick) {
+    HIPCHK(hipMalloc(&c->d_xpick, (size_t)(1 + EX_MAX_ROWS / EX_R) * sizeof(uint64_t)));
+    HIPCHK(hipMemset(c->d_xpick, 0, sizeof(uint64_t)));
+    c->bytes += (1 + EX_MAX_ROWS / EX_R) * 8;
+  }
   c->x_cap = want;
   c->bytes += want * 24;
   return TSH_OK;
@@ -1077,6 +1088,7 @@ void fill_exact_args(const Shard *s, const Ctx *c, bool use_list, bool dense_mas
   a->list_out = nullptr;
   a->xkey = c->d_xkey;
   a->xsum = c->d_xsum;
+  a->wmin = nullptr;
   a->sqrt_mag_a = s->metric == TSH_METRIC_COSINE ? std::sqrt(query_mag_a(q, s->dim)) : 0.0;
   a->ld = s->ld;
   a->n_rows = s->rows;
@@ -1164,6 +1176,9 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       xa.a.list = c->h_list_dev;  // DMA packet in front of the scan cost a lone masked query ~8 us before anything ran
       xa.a.list_out = c->d_list;
     }
+    // E2' (the wide pick) bounds the k-th key by the k-th smallest wave minimum: it needs clearly more waves than k
+    j->picked = s->exact_pick && (n_exam + EX_R - 1) / EX_R >= 2 * (int64_t)k;
+    if (j->picked) xa.a.wmin = c->d_xpick + 1;
     j->eps_rel = j->delta_abs = 0.f;
     j->force_all = false;
   } else {
@@ -1315,7 +1330,33 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
       xs.cap = entries;
       xs.metric = s->metric;
       xs.tag = tag;
-      if (j->quar_sel.empty()) {
+      j->xsel = xs;
+      if (j->picked) {  // E2': one workgroup per 256 entries, a bound from E1's wave minima, no ranking below it
+        ExactPickArgs xp{};
+        xp.xkey = xs.xkey;
+        xp.xsum = xs.xsum;
+        xp.list = xs.list;
+        xp.wmin = c->d_xpick + 1;
+        xp.ctr = reinterpret_cast<unsigned long long *>(c->d_xpick);
+        xp.hdr = xs.hdr;
+        xp.hdr_host = xs.hdr_host;
+        xp.out = xs.out;
+        xp.row_base = xs.row_base;
+        xp.shard_rows = xs.shard_rows;
+        xp.n_entries = xs.n_entries;
+        xp.n_groups = (xs.n_entries + EX_R - 1) / EX_R;
+        xp.k = k;
+        xp.cap = entries;
+        xp.metric = s->metric;
+        xp.tag = tag;
+        const unsigned pg = (unsigned)((xs.n_entries + 255) / 256);
+        if (j->quar_sel.empty()) {
+          hipExtLaunchKernelGGL(exact_pick_kernel, dim3(pg), dim3(256), 0, ts, nullptr, c->ev_done, 0, xp);
+          done_recorded = true;
+        } else {
+          exact_pick_kernel<<<pg, 256, 0, ts>>>(xp);
+        }
+      } else if (j->quar_sel.empty()) {
         hipExtLaunchKernelGGL(exact_select_kernel, dim3(1), dim3(1024), 0, ts, nullptr, c->ev_done, 0, xs);
         done_recorded = true;
       } else {
@@ -1497,12 +1538,24 @@ int job_finish(Shard *s, Job *j, std::vector<BlockEntry> *spill, std::vector<Blo
     fprintf(stderr, "[x2] keys %.2f select %.2f entries %.2f us, %u histogram rounds, %u ranked, %u out adds %.2f scan %.2f\n", h->tau_key * 0.01,
             h->band_key * 0.01, h->tiles_hit * 0.01, h->pad[2], h->pad[3], h->count, (h->pad[0] >> 16) * 0.01, (h->pad[0] & 0xFFFF) * 0.01);
 #endif
-  if ((h->flags & FLAG_LIST_OVERFLOW) && j->exact) {
-    // (exact_select_kernel writes min(k, live rows) entries into a block exact_applies sized for k: it cannot overflow.
-    // Should that invariant ever slip, the context holds no f32 keys / tile minima for the wide-band pass to filter)
-    return set_err(TSH_E_HIP, "the exact path's block overflowed (%u of %u entries): internal error", h->count, h->entries);
-  } else if ((h->flags & FLAG_LIST_OVERFLOW) && j->leave_overflow && j->dev_target) {
+  if ((h->flags & FLAG_LIST_OVERFLOW) && j->leave_overflow && j->dev_target) {
     s->c_cands += std::min(h->count, h->entries);  // (the block stays as it is: see Job::leave_overflow)
+  } else if ((h->flags & FLAG_LIST_OVERFLOW) && j->exact) {
+    // The wide pick emits every row up to its cut bin: ties by the hundred, or a k-th neighbour outside the histogram's
+    // window, and the bin holds more rows than the block.  The keys and sums of all entries are still in the context:
+    // exact_select_kernel ranks them and writes exactly min(k, live rows) entries -- into a block exact_applies sized for
+    // k, so THAT cannot overflow (should the invariant ever slip: an error, never the wide-band pass, for which the
+    // context holds no f32 keys).
+    if (!j->picked) return set_err(TSH_E_HIP, "the exact path's block overflowed (%u of %u entries): internal error", h->count, h->entries);
+    hipStream_t st = s->aux_stream;
+    exact_select_kernel<<<1, 1024, 0, st>>>(j->xsel);
+    if (!j->quar_sel.empty() && j->dev_target) launch_quarantine_append(s, c, j, st);  // (the block's count was rewritten)
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    s->c_pick_redone++;
+    if (h->flags & FLAG_LIST_OVERFLOW)
+      return set_err(TSH_E_HIP, "the exact path's block overflowed (%u of %u entries): internal error", h->count, h->entries);
+    s->c_cands += h->count;
   } else if (h->flags & FLAG_LIST_OVERFLOW) {
     int rc = run_fallback(s, j, h->band_key, spill);  // keys[] of this query are still in the context
     if (rc) return rc;
@@ -2840,6 +2893,7 @@ int32_t tsh_get_counters(tsh_index *idx, tsh_counters *out) {
     out->batch_scan_fallbacks += s->c_scan_fallbacks.load();
     out->list_scans += s->c_list_scans.load();
     out->exact_scans += s->c_exact_scans.load();
+    out->exact_redone += s->c_pick_redone.load();
     out->candidates_total += s->c_cands.load();
     int64_t b = s->bytes;
     {
@@ -2948,6 +3002,14 @@ int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
     for (auto &sh : idx->shards) {
       std::unique_lock<RwLock> xl(sh->mu);
       sh->exact_rows = (int)value;
+    }
+    return TSH_OK;
+  }
+  if (option == TSH_OPT_EXACT_SELECT) {
+    if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "exact select: 0 (one workgroup ranks k rows) or 1 (wide pick)");
+    for (auto &sh : idx->shards) {
+      std::unique_lock<RwLock> xl(sh->mu);
+      sh->exact_pick = value != 0;
     }
     return TSH_OK;
   }

@@ -184,6 +184,8 @@ final class TshCounters extends Struct {
   external int batchScanFallbacks;
   @Int64()
   external int listScans;
+  @Int64()
+  external int exactRedone;
 }
 
 /// `tsh_comm_timeline` (include/tostore_hip.h): where this rank's tsh_search_sharded time went.  Field order and
@@ -780,6 +782,7 @@ final class HipVectorBackend {
         'batchScanFallbacks': r.batchScanFallbacks,
         'listScans': r.listScans,
         'exactScans': r.exactScans,
+        'exactRedone': r.exactRedone,
       };
     } finally {
       calloc.free(c);
