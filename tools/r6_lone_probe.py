@@ -57,12 +57,15 @@ def main():
             mh = idx.make_mask(mask)
             t_make = (time.perf_counter() - t0) * 1e6
             for r in range(a.rounds):
-                for form, arg in (("pointer", mask), ("handle", mh)):
-                    p50, p99 = lat(idx, qs, k, arg)
-                    us = piped(idx, qs, k, arg)
-                    print("keep %.1f %% %-7s: one at a time p50 %6.1f p99 %6.1f us; %6.1f us/query in 64-query calls%s"
-                          % (keep * 100, form, p50, p99, us, "  (handle made in %.0f us)" % t_make if form == "handle" else ""),
-                          flush=True)
+                for wide in (True, False):  # E2': the wide pick (shipped) | E2: round 5's one-workgroup select -- same box, alternating
+                    idx.set_exact_select(wide)
+                    for form, arg in (("pointer", mask), ("handle", mh)):
+                        p50, p99 = lat(idx, qs, k, arg)
+                        us = piped(idx, qs, k, arg)
+                        print("keep %.1f %% %-7s %-6s: one at a time p50 %6.1f p99 %6.1f us; %6.1f us/query in 64-query calls%s"
+                              % (keep * 100, form, "pick" if wide else "select", p50, p99, us,
+                                 "  (handle made in %.0f us)" % t_make if form == "handle" else ""), flush=True)
+            idx.set_exact_select(True)
             mh.close()
     d, k, n = 128, 10, 10_000
     qs = rng.standard_normal((576, d)).astype(np.float32)
@@ -70,9 +73,11 @@ def main():
         idx.append(0, rng.standard_normal((n, d)).astype(np.float32))
         idx.set_batch_min_nq(0)
         for r in range(a.rounds):
-            p50, p99 = lat(idx, qs, k, None, 1000)
-            print("C1 10k x 128         : one at a time p50 %6.1f p99 %6.1f us; %6.1f us/query in 64-query calls"
-                  % (p50, p99, piped(idx, qs, k, None)), flush=True)
+            for wide in (True, False):
+                idx.set_exact_select(wide)
+                p50, p99 = lat(idx, qs, k, None, 1000)
+                print("C1 10k x 128 %-6s       : one at a time p50 %6.1f p99 %6.1f us; %6.1f us/query in 64-query calls"
+                      % ("pick" if wide else "select", p50, p99, piped(idx, qs, k, None)), flush=True)
 
 
 if __name__ == "__main__":
