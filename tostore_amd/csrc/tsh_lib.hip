@@ -1295,7 +1295,13 @@ int job_enqueue(Shard *s, Job *j, const float *query, int32_t k, int32_t entries
     // cross-stream hand-off, and the two scan streams alternate whole queries -- 64-query calls on 10 k x 128: 20.6 -> 16.2 us
     // per query, 2 k x 768: 22 -> 16.7, 8 k x 768: 21 -> 18.4; from ~8 k rows of 768 on the tail queues win again: 16 k x
     // 768 23 against 25; tools/r5_x_inorder.sh)
-    const bool x_inorder = exact && n_exam * s->ld <= (int64_t)6500000;
+#ifndef TSH_X_INORDER_MAX
+#define TSH_X_INORDER_MAX 6500000
+#endif
+    // (round 6: behind the wide pick -- 5-6 us, one workgroup per 256 entries -- the tail queues' 16 CUs and their
+    // cross-stream hand-off, ~10 us in front of the pick under load, never pay: 10 k x 768 in 64-query calls 18.5-23.9 ->
+    // 15.8-19.2 us per query, same box, alternating, tools/r6_inorder_ab.sh)
+    const bool x_inorder = exact && (j->picked || n_exam * s->ld <= (int64_t)TSH_X_INORDER_MAX);
     if (overlap && !last_of_call && !x_inorder) {
       // (one tail queue serialises select + re-rank of consecutive queries: ~40 us per query, which is what short
       // scans -- selective masks, small shards -- were then limited by)
