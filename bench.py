@@ -139,6 +139,14 @@ def parse(argv=None):
                     help="N > 1: rows per rank of the side.C4_per_rank leg (BASELINE.json C4: 10 M x 1536 over 8 GPUs); 0 = skip")
     ap.add_argument("--c3-check", type=int, default=1024, help="side.C3: queries of one batch checked against the oracle")
     ap.add_argument("--c5-check", type=int, default=100, help="side.C5: queries checked per selectivity")
+    ap.add_argument("--in-process", action="store_true",
+                    help="--gpus N in ONE process: tsh_index_create(n_devices = N) -- row-range shards on N devices, one host "
+                         "thread per shard, candidate blocks copied back, host merge, NO collective: the deployment an embedded "
+                         "single-process database uses first (the reference searches from one isolate of one process: "
+                         "lib/src/core/vector_index_manager.dart:538).  Same line; config.sharding says which exchange ran")
+    ap.add_argument("--shards-share-gpu", action="store_true",
+                    help="testing (with --in-process): the N shards share cuda:0 (TSH_SHARDS_SHARE_DEVICES behind the library's "
+                         "test-hook opt-in): a rehearsal of the code path on a one-GPU box, not a scaling figure")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the N>1 code path (process group, all-gather, merge) even with one rank")
     a = ap.parse_args(argv)
@@ -254,7 +262,15 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = 0 if a.ranks_share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != a.gpus and self.world == 1 and a.gpus > 1:
+        if a.in_process:
+            if self.world != 1:
+                raise RuntimeError("--in-process is one process: start it without a launcher")
+            if a.shards_share_gpu:
+                os.environ["TSH_SHARDS_SHARE_DEVICES"] = "1"
+            elif torch.cuda.device_count() < a.gpus:
+                raise RuntimeError("--in-process --gpus %d: this box has %d GPU(s) (one GPU: --shards-share-gpu)"
+                                   % (a.gpus, torch.cuda.device_count()))
+        elif self.world != a.gpus and self.world == 1 and a.gpus > 1:
             raise RuntimeError("--gpus %d needs %d ranks (main() starts them when WORLD_SIZE is not set)" % (a.gpus, a.gpus))
         if torch.cuda.device_count() <= self.local_rank:
             raise RuntimeError("rank %d wants cuda:%d, this box has %d GPU(s) (one GPU: --ranks-share-gpu)"
@@ -282,6 +298,8 @@ class Env:
 
         assert _ffi.lib().tsh_device_count() >= 1, "libtostore_hip.so sees no device"
         self._ffi = _ffi
+        if a.in_process and a.shards_share_gpu:  # (the library obeys the variable only in a process that asked for its test hooks)
+            _ffi.enable_test_hooks()
 
     def corpus_chunks(self, n, d, metric, lo=0, hi=None):
         """Recipe of the reference's demo (/root/reference/example/lib/tostore_example.dart:728-747):
@@ -304,15 +322,26 @@ class Env:
             a0, a1 = max(s, lo), min(e, hi)
             yield a0, x[a0 - s:a1 - s].contiguous()
 
-    def build_index(self, d, metric, n, lo, hi, keep_host=False):
+    def build_index(self, d, metric, n, lo, hi, keep_host=False, n_devices=1):
         """Shard handle holding global rows [lo, hi) of the n-row corpus, filled chunk by chunk (device to device, on
-        the library's stream); -> (index, host copy of those rows or None)."""
+        the library's stream); -> (index, host copy of those rows or None).  n_devices > 1: ONE handle over that many
+        devices (tsh_index_create: the library routes every chunk's rows to the shard that owns them, host to device)."""
         from tostore_amd import HipVectorIndex
 
-        idx = HipVectorIndex(d, metric, capacity_rows=hi - lo, shard_device=self.local_rank, row_base=lo)
+        if n_devices > 1:
+            idx = HipVectorIndex(d, metric, capacity_rows=hi - lo, n_devices=n_devices)
+        else:
+            idx = HipVectorIndex(d, metric, capacity_rows=hi - lo, shard_device=self.local_rank, row_base=lo)
         host = np.empty((hi - lo, d), np.float32) if keep_host else None
         for r0, x in self.corpus_chunks(n, d, metric, lo, hi):
             self.torch.cuda.synchronize()  # the library copies on its own stream: the producer must be done
+            if n_devices > 1:
+                xh = x.cpu().numpy()
+                idx.append(r0, xh)
+                if host is not None:
+                    host[r0 - lo:r0 - lo + x.shape[0]] = xh
+                del x
+                continue
             idx.append_device(r0, x.shape[0], x.data_ptr())
             if host is not None:
                 host[r0 - lo:r0 - lo + x.shape[0]] = x.cpu().numpy()
@@ -1139,7 +1168,13 @@ def run_bench(a, env=None):
     # oracle sees it chunk by chunk, as in a sharded run
     big = float(n) * d * 4 > 16e9
     want_host = rank == 0 and world == 1 and not a.no_cpu_baseline and not big
-    idx, host_rows = env.build_index(d, metric, n, lo, hi, keep_host=want_host)
+    # --in-process: this one process holds all --gpus devices' shards in one handle (no ranks, no collective)
+    n_dev = a.gpus if getattr(a, "in_process", False) and a.gpus > 1 else 1
+    if n_dev > 1:
+        idx, host_rows = env.build_index(d, metric, n, lo, hi, keep_host=want_host, n_devices=n_dev)
+    else:
+        idx, host_rows = env.build_index(d, metric, n, lo, hi, keep_host=want_host)
+    per_dev = ((hi - lo + n_dev - 1) // n_dev + 63) // 64 * 64 if n_dev > 1 else hi - lo  # rows of one device's shard
 
     if a.batch > 0:
         return bench_batch(a, env, idx, host_rows, metric)
@@ -1194,11 +1229,11 @@ def run_bench(a, env=None):
     # ---- roofline of the dominant kernel (K1 scan): HIP events recorded by the library
     # around real scan launches on its pipeline stream, during the timed regions above
     ns, scan_us = m["scan_samples"], m["scan_us"]
-    with timed_region():
-        scan_alone_us = idx.bench_scan(queries[0], iters=50, row_mask=row_mask) if hi > lo else float("nan")
+    with timed_region():  # (the hook measures ONE shard's kernel: a single-device handle)
+        scan_alone_us = idx.bench_scan(queries[0], iters=50, row_mask=row_mask) if hi > lo and n_dev == 1 else float("nan")
     if not math.isfinite(scan_us):
         scan_us = scan_alone_us
-    shard_bytes = float(hi - lo) * d * 4  # algorithmic: every stored f32 read once
+    shard_bytes = float(min(per_dev, hi - lo)) * d * 4  # algorithmic: every stored f32 read once (per device: its shard)
     if row_mask is not None:  # C5: only kept rows are read, plus the mask itself
         kept = int(np.unpackbits(row_mask, bitorder="little")[lo:hi].sum())
         shard_bytes = float(kept) * d * 4 + (hi - lo) / 8
@@ -1232,7 +1267,7 @@ def run_bench(a, env=None):
     out = None
     if rank == 0:
         achieved = shard_bytes / (scan_us * 1e-6) / 1e9
-        traffic, traffic_source = pmc_traffic(hi - lo, d) if row_mask is None else (None, None)
+        traffic, traffic_source = pmc_traffic(hi - lo, d) if row_mask is None and n_dev == 1 else (None, None)
         if a.inflight <= 1:
             in_flight = 1
         elif searcher is None and a.group > 0:
@@ -1246,7 +1281,7 @@ def run_bench(a, env=None):
                       "kNN queries/sec + recall@k, %dx%d f32 brute-force (%s)" % (n, d, a.config.upper()),
             "value": a.steps / elapsed,
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": world if n_dev == 1 else n_dev,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
@@ -1267,7 +1302,11 @@ def run_bench(a, env=None):
                        "note": "every query scans the whole corpus on its own (HBM-bound kernel, no matrix-core "
                                "batching); independent queries are handed over in groups and pipelined",
                        "sharding": "row-range x%d, all-gather of top-k candidate blocks: %s" % (world, env.exchange)
-                       if searcher is not None else "single GPU",
+                       if searcher is not None else
+                       ("single GPU" if n_dev == 1 else
+                        "row-range x%d IN ONE PROCESS (tsh_index_create n_devices = %d): one host thread per shard, candidate "
+                        "blocks copied back, host merge -- no collective%s"
+                        % (n_dev, n_dev, "; the shards SHARE cuda:0 (rehearsal, not a scaling figure)" if a.shards_share_gpu else "")),
                        "exchange_note": getattr(env, "exchange_note", None),
                        "harness": "python gc held off during the timed legs"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1277,7 +1316,7 @@ def run_bench(a, env=None):
                          "kernel_us_back_to_back_alone": scan_alone_us,
                          "algorithmic_bytes_per_launch": shard_bytes},
         }
-        if (hi - lo + 63) // 64 < 6144 and a.inflight > 1:
+        if (min(per_dev, hi - lo) + 63) // 64 < 6144 and a.inflight > 1 and n_dev == 1:
             # shards below 6144 tiles alternate their scans between two streams: two scans
             # run side by side, so one launch's own duration is about twice its share of the HBM time
             out["roofline"]["scans_side_by_side"] = 2
@@ -1347,7 +1386,7 @@ def run_bench(a, env=None):
             out["batch_1024"] = {"error": repr(e)}
 
     # ---- side legs: the other BASELINE.json configurations, same process, after the headline ----
-    if world == 1 and rank == 0 and not a.no_side and a.mask_keep == 0 and searcher is None and a.config == "c2":
+    if world == 1 and rank == 0 and not a.no_side and a.mask_keep == 0 and searcher is None and a.config == "c2" and n_dev == 1:
         side = {}
         legs = [s.strip() for s in a.side.split(",") if s.strip()]
         t_side = time.perf_counter()
@@ -1497,7 +1536,7 @@ def main():
         import fake_rccl
 
         os.environ["TSH_RCCL_LIB"] = fake_rccl.build()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.force_sharded:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.force_sharded and not a.in_process:
         # started plainly: be the launcher.  Rank 0's line is handed through only when the whole job succeeded.
         rc, line = launch_ranks(a, argv, a.launch_timeout)
         if rc != 0 and a.exchange == "auto":

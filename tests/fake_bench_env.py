@@ -184,7 +184,8 @@ class FakeEnv:
             x *= (rng.random((n, 1)) * 1.5 + 0.5).astype(np.float32)
         return x
 
-    def build_index(self, d, metric, n, lo, hi, keep_host=False):
+    def build_index(self, d, metric, n, lo, hi, keep_host=False, n_devices=1):
+        self.n_devices_seen = n_devices  # (one handle over several devices: bench.py --in-process)
         corpus = self.corpus(n, d, metric)
         idx = FakeIndex(self.o, d, metric, corpus[lo:hi], lo)
         self.made.append(idx)

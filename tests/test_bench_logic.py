@@ -209,3 +209,21 @@ def test_shard_of_8_leg(oracle_mod):
     assert bench.library_schedule(20, 125_000, 768) == [10, 5, 5] and bench.library_schedule(20, 10_000, 128) == [20]
     assert bench.library_schedule(300, 125_000, 768) == [64, 64, 64, 64, 44] and bench.library_schedule(1, 1, 1) == [1]
     assert all(i.closed for i in env.made)
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+def test_in_process_multi_gpu_line(oracle_mod, n_dev):
+    """`bench.py --gpus N --in-process`: ONE process, one handle over N devices, no ranks and no
+    collective -- the same line contract, n_gpus = N, the per-device shard in the roofline, config.sharding saying which
+    exchange ran; the launcher is not involved."""
+    a = _args("--steps", "20", "--warmup", "5", "--gpus", str(n_dev), "--in-process")
+    env = FakeEnv(oracle_mod)
+    out = json.loads(bench.run_bench(a, env))
+    assert env.n_devices_seen == n_dev and env.world == 1
+    assert out["n_gpus"] == n_dev and out["value"] > 0 and out["scaling"] == "strong" and "side" not in out
+    assert "IN ONE PROCESS" in out["config"]["sharding"] and "no collective" in out["config"]["sharding"]
+    per = ((3000 + n_dev - 1) // n_dev + 63) // 64 * 64
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == min(per, 3000) * 32 * 4 and out["roofline"]["traffic"] is None
+    assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True and out["cpu_baseline"]["cores"] == 1
+    assert "exchange_timeline" not in out
+    assert all(i.closed for i in env.made)

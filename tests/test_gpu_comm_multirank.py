@@ -51,6 +51,24 @@ def test_bench_gpus_2_plain_command(hip_lib):
     assert out["roofline"]["algorithmic_bytes_per_launch"] == 100000 * 768 * 4
 
 
+def test_bench_in_process_multi_gpu(hip_lib):
+    """`python bench.py --gpus 3 --in-process`: ONE process, one handle over three devices (here they share this box's GPU:
+    --shards-share-gpu), host threads + copies + host merge, no ranks and no collective -- the same one-line contract."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--in-process", "--shards-share-gpu",
+                        "--steps", "20", "--warmup", "5", "--rows", "200000", "--cpu-seconds", "3", "--recall-queries", "100"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["steps"] == 20 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["recall_at_k"] == 1.0 and out["ids_and_distances_bit_exact"] is True and out["recall_queries"] >= 100
+    assert "IN ONE PROCESS" in out["config"]["sharding"] and "SHARE cuda:0" in out["config"]["sharding"]
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == 66688 * 768 * 4  # ceil(200 000 / 3) rounded up to whole tiles
+    assert "exchange_timeline" not in out and "side" not in out
+
+
 def test_bench_under_torch_distributed_run(hip_lib):
     """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with two ranks sharing this box's

@@ -60,6 +60,9 @@ if has 8; then  # the driver's N > 1 command rehearsed over the RCCL branch (ran
   for N in 2 8; do
     timeout -k 10 900 python3 bench.py --gpus $N --fake-rccl --steps 20 --warmup 5 --cpu-seconds 4 --c4-rows-per-rank 150000 > $O/rehearsal_fake_rccl_n$N.json 2> $O/rehearsal_fake_rccl_n$N.err
     echo "N=$N rc=$?" >> $O/rehearsal.txt
+    # ... and the single-process deployment: one handle over N devices (here sharing the one GPU), no collective
+    timeout -k 10 900 python3 bench.py --gpus $N --in-process --shards-share-gpu --steps 20 --warmup 5 --cpu-seconds 4 > $O/rehearsal_in_process_n$N.json 2> $O/rehearsal_in_process_n$N.err
+    echo "in-process N=$N rc=$?" >> $O/rehearsal.txt
   done
 fi
 if has 9; then timeout -k 10 $((60*${FUZZ_MIN:-5}+120)) python tests/probes/long_fuzz.py ${FUZZ_MIN:-5} > $O/long_fuzz.txt 2>&1; tail -3 $O/long_fuzz.txt; fi
@@ -91,6 +94,8 @@ for n in ("c3_cosine", "c3_l2", "c3_l2_unit_rows", "c3_ip"):
 for N in (2, 8):
     j = load("rehearsal_fake_rccl_n%d.json" % N)
     if j: print("rehearsal N=%d" % N, round(j["value"], 1), j["ms_per_step"], j.get("recall_at_k"), j.get("ids_and_distances_bit_exact"), j["config"]["sharding"])
+    j = load("rehearsal_in_process_n%d.json" % N)
+    if j: print("in-process N=%d" % N, round(j["value"], 1), j["ms_per_step"], j.get("recall_at_k"), j.get("ids_and_distances_bit_exact"), j["config"]["sharding"][:60])
 PY
 for f in bench_driver_args.time bench_pmc_fetch_write.txt mask_handles.txt; do [ -f $O/$f ] && cat $O/$f; done
 [ -f $O/bench_driver_args_kernel_stats.txt ] && head -14 $O/bench_driver_args_kernel_stats.txt
