@@ -116,6 +116,9 @@ def parse(argv=None):
     ap.add_argument("--unit-rows", action="store_true",
                     help="corpus rows stay L2-normalised for every metric (the demo's own recipe; default: L2 / IP rows are "
                          "also scaled by U(0.5, 2) so that the three metrics rank differently, SURVEY.md section 8d)")
+    ap.add_argument("--norm-range", default="0.5,2",
+                    help="L2 / IP corpora: row norms are U(lo, hi) (default 0.5,2: SURVEY.md section 8d); 0.1,3.2 is the 'widely "
+                         "spread norms' corpus of VERDICT round 5, item 7 (a factor 32 between the shortest and the longest row)")
     ap.add_argument("--no-side", action="store_true", help="skip the side legs (C1 / C3 / C5)")
     ap.add_argument("--side", default="c5,s8,c4s8,c1,c3",
                     help="side legs to run, comma separated (s8 = side.shard_of_8: one rank's share of the headline at N = 8 "
@@ -155,6 +158,7 @@ def parse(argv=None):
     a.dim = preset[1] if a.dim is None else a.dim
     a.k = preset[2] if a.k is None else a.k
     a.metric = preset[3] if a.metric is None else a.metric
+    a.norm_lo, a.norm_hi = (float(x) for x in a.norm_range.split(","))
     if a.fake_rccl:
         a.ranks_share_gpu = True
     if a.ranks_share_gpu and a.backend == "nccl":
@@ -318,7 +322,7 @@ class Env:
             x = torch.randn((e - s, d), generator=g, device=self.dev, dtype=torch.float32)
             x /= x.norm(dim=1, keepdim=True)
             if metric != 2 and not self.a.unit_rows:
-                x *= torch.rand((e - s, 1), generator=g, device=self.dev) * 1.5 + 0.5
+                x *= torch.rand((e - s, 1), generator=g, device=self.dev) * (self.a.norm_hi - self.a.norm_lo) + self.a.norm_lo
             a0, a1 = max(s, lo), min(e, hi)
             yield a0, x[a0 - s:a1 - s].contiguous()
 

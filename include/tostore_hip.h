@@ -531,10 +531,12 @@ int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, 
  *   2  f16: operands rounded to fp16 after an exact power-of-two scaling (cosine
  *      rows normalised first), one f16 MFMA per product (error 2^-10 |q||v|);
  *      costs a copy of 2 B per element;
- *   3  (default) auto: f16 for cosine indexes, whose keys are scale-free, and for
- *      inner-product / L2 indexes whose row norms lie within a factor of 8 of each
- *      other (normalised embeddings); bf16x3 otherwise, because those bands scale
- *      with the largest row.
+ *   3  (default) auto: f16 for cosine indexes, whose keys are scale-free, for
+ *      inner-product indexes (a row's band is its own: alpha |v| + beta) and for L2
+ *      indexes while the band's shared term, ~ c (1 + max|v|^2), stays small against
+ *      the spacing of the shortest rows' keys (~ 0.1 min|v|): norms a factor 32 apart
+ *      are served by f16, norms 2^-6 .. 2^6 by bf16x3; an index whose f16 candidate
+ *      lists overflow all the same is moved to bf16x3 for its next 256 batched calls.
  * The copy is built by the first batched search and kept current across appends. */
 #define TSH_OPT_BATCH_KERNEL 2
 /* TSH_OPT_EXCHANGE_AHEAD (process-wide; idx is ignored and may be NULL; default 0): 1 = tsh_search_sharded over RCCL

@@ -234,27 +234,30 @@ def test_bf16x3_wide_dynamic_range(hip_lib, oracle_mod):
 
 
 def test_auto_kernel_choice(hip_lib, oracle_mod):
-    """TSH_OPT_BATCH_KERNEL auto: fp16 keys for cosine and for IP / L2 corpora of nearly equal row norms,
-    bf16x3 when the norms spread widely (bands scale with the largest row) -- results exact either way."""
+    """TSH_OPT_BATCH_KERNEL auto: fp16 keys for cosine, for inner product (a row's band is its own) and for L2 corpora
+    whose band's shared term stays small against the shortest rows' key spacing (norms a factor 32 apart: yes; norms
+    2^-6 .. 2^6, or a zero row: bf16x3) -- results exact either way."""
     from tostore_amd import HipVectorIndex
 
     n, d, nq, k = 12_000, 64, 40, 20
     unit = _mk(n, d, 71)
     spread = unit * np.exp2(np.random.default_rng(72).integers(-6, 7, (n, 1))).astype(np.float32)
-    for metric, rows, want in ((COS, spread, 2), (IP, unit, 2), (L2, unit * np.float32(3.0), 2), (IP, spread, 1),
-                               (L2, spread, 1)):
+    wide = unit * np.random.default_rng(75).uniform(0.1, 3.2, (n, 1)).astype(np.float32)  # a factor 32 between the norms
+    for metric, rows, want in ((COS, spread, 2), (IP, unit, 2), (L2, unit * np.float32(3.0), 2), (IP, spread, 2),
+                               (L2, spread, 1), (L2, wide, 2), (IP, wide, 2)):
         qs = _queries(oracle_mod, nq, d, 73, metric)
         with HipVectorIndex(d, metric) as idx:
             assert idx.counters()["batch_kernel_last"] == -1
             idx.append(0, rows)
             _check_batch(oracle_mod, idx, rows, qs, metric, k, tag=f"auto m{metric}")
             assert idx.counters()["batch_kernel_last"] == want
-    with HipVectorIndex(d, IP) as idx:  # a zero row: the smallest norm is 0, so the spread is unbounded
-        rows = unit.copy()
-        rows[17] = 0.0
-        idx.append(0, rows)
-        _check_batch(oracle_mod, idx, rows, _queries(oracle_mod, nq, d, 74, IP), IP, k, tag="zero row")
-        assert idx.counters()["batch_kernel_last"] == 1
+    for metric, want in ((IP, 2), (L2, 1)):  # a zero row: the smallest norm is 0 -- L2's shortest rows have no key spacing to speak of
+        with HipVectorIndex(d, metric) as idx:
+            rows = unit.copy()
+            rows[17] = 0.0
+            idx.append(0, rows)
+            _check_batch(oracle_mod, idx, rows, _queries(oracle_mod, nq, d, 74, metric), metric, k, tag="zero row")
+            assert idx.counters()["batch_kernel_last"] == want
 
 
 def test_default_switches_to_batched_by_estimated_cost(hip_lib, oracle_mod):

@@ -383,8 +383,18 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     f16_ok = false;
     if (s->f16_denied_calls.fetch_sub(1) == 1) s->f16_strikes.store(0);
   }
-  const bool even_norms = s->min_norm > 0.f && s->max_norm <= 8.f * s->min_norm && f16_ok;
-  int kern = want_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || even_norms) ? 2 : 1) : want_kernel;
+  // Round 6: with a band PER ROW (alpha |v| + beta, batch_delta2) a row's own norm no longer
+  // widens its neighbours' bands, so the automatic choice asks what is left -- the SHARED term.  Inner product: beta is
+  // a few u |q| max|v|, nothing against the spacing of the keys that matter (the longest rows'): fp16 whatever the norms.
+  // L2: beta ~ c (|q|^2 + max|v|^2) has to stay small against the spacing of the SHORT rows' keys, ~0.1 |q| min|v| near a
+  // query's k-th neighbour: fp16 while c (1 + max|v|^2) <= 0.02 min|v| (|q| ~ 1 assumed; norms U(0.1, 3.2), a factor 32
+  // apart: 4.8e-5 against 2e-3 -- 482 k queries/s where bf16x3 gives 199 k, tools/r6_wide_norms.sh; norms 2^-6 .. 2^6:
+  // 1.2e-2 against 3e-4 -- every short row would be a candidate: bf16x3).  A shard whose fp16 lists overflow all the
+  // same is moved to bf16x3 by the denial counter above.
+  const double c_acc = (double)((s->dim + 63) / 64 + 12) * 1.1920928955078125e-07;
+  const bool l2_ok = s->min_norm > 0.f && c_acc * (1.0 + (double)s->max_norm * (double)s->max_norm) <= 0.02 * (double)s->min_norm;
+  const bool f16_fits = f16_ok && (s->metric != TSH_METRIC_L2 || l2_ok);
+  int kern = want_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || f16_fits) ? 2 : 1) : want_kernel;
   int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
   if (kern == 2) {
     const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
