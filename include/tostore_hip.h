@@ -563,6 +563,13 @@ int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, 
  * directly.  0 = always the select (round 5: exactly min(k, live rows) entries, one compute unit, 9-17 us for 2 k-10 k
  * rows).  Results are identical. */
 #define TSH_OPT_EXACT_SELECT 5
+/* TSH_OPT_BATCH_HUB (default 0): 1 = batched searches of an L2 / inner-product index on fp16 keys also score the index's
+ * HUB rows densely -- the 4096 rows whose norm alone puts them near every query: the shortest (L2) resp. the longest
+ * (inner product), kept as a gathered fp16 copy -- and take the smaller of two thresholds: the sample's (an estimate,
+ * verified) and the hub rows' k-th smallest key (a bound by construction).  Measured on one MI355X it thins the key
+ * kernel's epilogue on corpora whose neighbours are their short rows (key passes - 3 to - 5 %) and costs the call as
+ * much as it saves: off unless a host knows its corpus to be that kind.  Results are identical. */
+#define TSH_OPT_BATCH_HUB 6
 /* TSH_OPT_TEST_HOOKS (process-wide; idx is ignored and may be NULL): value TSH_TEST_HOOKS_MAGIC switches the
  * library's TEST hooks on, 0 off.  Only then does it read the environment variables that change what it loads or make
  * it fail on purpose -- TSH_RCCL_LIB (a stand-in for librccl: tests/fake_rccl), TSH_TEST_FAIL_ALLOC_OVER (device

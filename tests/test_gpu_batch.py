@@ -379,3 +379,53 @@ def test_batched_range_mask_takes_its_sample_inside_the_range(hip_lib, oracle_mo
             assert np.array_equal(dist.view(np.uint64), ref[1].view(np.uint64))
             assert c1["batch_launches"] > c0["batch_launches"]
             assert c1["scan_launches"] == c0["scan_launches"], (spans, c1["scan_launches"] - c0["scan_launches"])
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_hub_rows_bound(hip_lib, oracle_mod, metric):
+    """TSH_OPT_BATCH_HUB = 1 (round 6; off by default): the batched path also scores the index's 4096 hub rows -- the
+    shortest (L2) / the longest (inner product) -- densely, as a gathered fp16 copy, and takes the smaller of the sample's
+    threshold and their k-th smallest key, a bound by construction.  Same answers as the oracle; hub rows that are
+    tombstoned, overwritten (the copy is dropped and rebuilt) or outgrown by appends change nothing about that."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(900 + metric)
+    n, d, nq, k = 90_000, 96, 70, 60
+    rows = _mk(n + 40_000, d, 901 + metric, scale=(0.5, 2.0))
+    qs = _queries(oracle_mod, nq, d, 902, metric)
+    with HipVectorIndex(d, metric) as idx:
+        idx.append(0, rows[:n])
+        idx.set_batch_min_nq(2)
+        idx.set_batch_kernel(2)
+        off = idx.search(qs, k)
+        idx.set_batch_hub(True)
+        r0 = idx.counters()["bytes_resident"]
+        _check_batch(oracle_mod, idx, rows[:n], qs, metric, k, tag="hub")
+        on = idx.search(qs, k)
+        assert idx.counters()["bytes_resident"] - r0 >= 4096 * 4 * 64  # (the hub rows' fp16 copy exists: the bound ran)
+        assert all(np.array_equal(a, b) for a, b in zip(on, off))
+        # the most extreme rows are tombstoned: they are hub rows, and their keys must leave the bound
+        nrm = np.linalg.norm(rows[:n].astype(np.float64), axis=1)
+        order = np.argsort(nrm if metric == L2 else -nrm)
+        dead = order[:300]
+        idx.set_deleted(dead)
+        keep = np.ones(n, bool)
+        keep[dead] = False
+        ids, dist, cnt = idx.search(qs, k)
+        for i in range(0, nq, 7):
+            e, ed = oracle_mod.search_heap(rows[:n], qs[i], metric, k, None, np.packbits(keep, bitorder="little"))
+            assert np.array_equal(ids[i, :cnt[i]], e) and np.array_equal(dist[i, :cnt[i]], ed)
+        # a hub row is overwritten by a far-away one: the copy of the old contents must not bound anything
+        victim = int(order[400])
+        rows[victim] = rows[victim] * np.float32(40.0 if metric == L2 else 0.01)
+        idx.append(victim, rows[victim:victim + 1])
+        # ... and the shard grows by more than a quarter (the hub is rebuilt), with new extreme rows among the new ones
+        rows[n:n + 50] *= np.float32(0.2 if metric == L2 else 3.0)
+        idx.append(n, rows[n:])
+        keep = np.ones(len(rows), bool)
+        keep[dead] = False
+        ids, dist, cnt = idx.search(qs, k)
+        for i in range(0, nq, 7):
+            e, ed = oracle_mod.search_heap(rows, qs[i], metric, k, None, np.packbits(keep, bitorder="little"))
+            assert np.array_equal(ids[i, :cnt[i]], e) and np.array_equal(dist[i, :cnt[i]], ed)
+        assert idx.counters()["fallback_searches"] == 0

@@ -165,6 +165,7 @@ def lib() -> ctypes.CDLL:
 TSH_OPT_EXCHANGE_AHEAD = 3
 TSH_OPT_EXACT_SCAN_ROWS = 4
 TSH_OPT_EXACT_SELECT = 5
+TSH_OPT_BATCH_HUB = 6
 TSH_OPT_TEST_HOOKS = 1000
 TSH_TEST_HOOKS_MAGIC = 0x7465737468
 

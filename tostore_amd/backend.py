@@ -284,6 +284,11 @@ class HipVectorIndex:
         ranks exactly k rows.  Results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_EXACT_SELECT, 1 if wide else 0))
 
+    def set_batch_hub(self, on: bool) -> None:
+        """Batched searches (fp16 keys, L2 / inner product) also bound the k-th key by the index's hub rows -- the 4096
+        shortest (L2) / longest (inner product) -- beside the sample's estimate (default off: it pays for itself on no corpus measured).  Results are identical."""
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_BATCH_HUB, 1 if on else 0))
+
     def set_batch_kernel(self, kind: int) -> None:
         """Batched pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (default: f16 for cosine, bf16x3
         otherwise).  Results are identical."""

@@ -66,6 +66,8 @@ struct BatchArgs {
   float dot_scale;        // f16 variant: 2^-(eq + ev), undoes the power-of-two operand scales (0 = unused)
   int32_t dbg;            // f16 kernel probe (TSH_F16_DBG): 4 = no epilogue (results are wrong), 32 = timestamps
   uint64_t *dbg_buf;      // TSH_F16_DBG & 32: [wave 0 / wave 4 of workgroup 0][step][point] shader-clock stamps
+  const uint32_t *row_ids;  // f16 ping-pong kernel, nullable: the rows of this launch are a GATHERED copy (the hub rows'
+                            // dense pass): plane position p is row row_ids[p] of the shard -- where its live / mask bit is
 };
 
 // an upper bound of |v| from the stored |v|^2 (f32 from an f64 sum: 2^-24; the square root: one ulp)
@@ -766,6 +768,15 @@ struct SampleSelArgs {
   const float *wnorm;    // per sample row: an upper bound of its norm (sample_norms_kernel)
   float chain2;          // 2 c / (1 - 2 c), rounded up (c: the chain's roundings times the unit roundoff)
   float norm_max;        // the shard's longest row
+  // Round 6: the HUB rows' keys (nullable) -- the few thousand rows whose norm alone makes them near EVERY query (L2: the
+  // shortest rows, inner product: the longest), scored densely beside the sample.  Their k-th smallest key bounds the
+  // k-th smallest key overall by construction (k rows lie at or below it), like the sample's own with k_est = k; the
+  // threshold is the smaller of the two.  On a corpus whose neighbours ARE its short rows the sample's estimate lets
+  // ~480 rows per query through, all of them on the same few thousand rows -- the key kernel's epilogue then walks
+  // crowded tiles register by register --; the hub bound lets through what the final list needs.
+  const float *hub_dense;  // nq_pad x hub_ld
+  int64_t hub_ld;
+  int32_t hub_n;
 };
 
 // B0s: one workgroup per query.  thr[q] = band(tau), tau = the k_est-th smallest sample key; the sample rows at
@@ -815,6 +826,20 @@ __device__ __forceinline__ void batch_sample_select_body(const SampleSelArgs &a)
   }
   float thr = band_float(tau, a.delta2[q]);
   if (ROWW) thr = widen_by_chain(thr, a.chain2);
+  if (a.hub_dense) {  // (workgroup-uniform) the hub rows' bound: proven (k of them lie at or below it), often far tighter
+    __syncthreads();
+    uint32_t tau2 = block_kth_of_floats<THREADS>(a.hub_dense + (int64_t)q * a.hub_ld, a.hub_n, (uint32_t)a.k, &sc, (uint32_t)a.k);
+    if (ROWW && tau2 < KEY_NAN) {
+      const float t = key2f(tau2);
+      if (t < __builtin_inff()) tau2 = f2key(widen_by_chain(t + (__builtin_fabsf(t) + al * a.norm_max) * 1e-6f, 1e-6f));
+    }
+    float thr2 = band_float(tau2, a.delta2[q]);
+    if (ROWW) thr2 = widen_by_chain(thr2, a.chain2);
+    if (thr2 < thr) {
+      thr = thr2;
+      tau = tau2;
+    }
+  }
   if (tid == 0) {
     a.thr[q] = thr;
     a.tau_est[q] = thr == __builtin_inff() ? KEY_NAN : tau;  // (no threshold: nothing to verify)

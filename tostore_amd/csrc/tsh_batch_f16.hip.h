@@ -51,6 +51,7 @@ struct Half32Args {
   int64_t first, n;
   int32_t dim, kchunks;   // kchunks = ceil(dim / 32)
   float scale;            // power of two
+  const uint32_t *ids;    // nullable: a GATHERED copy -- plane row first + i holds row ids[i] of `rows` (the hub rows)
 };
 
 // one thread = 8 consecutive k of one row = one 16-byte piece
@@ -61,8 +62,9 @@ static __global__ void __launch_bounds__(256) half_rows32_kernel(Half32Args a) {
     const int64_t row = a.first + i / per_row;
     const int pp = (int)(i % per_row), kc = pp >> 2, p = pp & 3;
     const int k0 = kc * 32 + p * 8;
-    const float *src = a.rows + row * a.ld + k0;
-    const float mul = a.inv_norm ? a.inv_norm[row] * a.scale : a.scale;
+    const int64_t srow = a.ids ? (int64_t)a.ids[i / per_row] : row;
+    const float *src = a.rows + srow * a.ld + k0;
+    const float mul = a.inv_norm ? a.inv_norm[srow] * a.scale : a.scale;
     f16x8 h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = (_Float16)(k0 + e < a.dim ? src[e] * mul : 0.f);  // round to nearest even

@@ -416,8 +416,9 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
       col_ok[j] = col < a.row1;
       bool alive = col_ok[j];
       if (col_ok[j]) {
-        if (a.live) alive = (a.live[col >> 6] >> (col & 63)) & 1ull;
-        if (alive && a.mask) alive = (a.mask[col >> 6] >> (col & 63)) & 1ull;
+        const int idc = a.row_ids ? (int)a.row_ids[col] : col;  // (a gathered copy: the row this plane position holds)
+        if (a.live) alive = (a.live[idc >> 6] >> (idc & 63)) & 1ull;
+        if (alive && a.mask) alive = (a.mask[idc >> 6] >> (idc & 63)) & 1ull;
       }
       alive_l[j] = alive;
     }

@@ -24,6 +24,8 @@ struct BatchCtx {
   int64_t blocks_cap = 0, final_cap = 0;
   uint64_t *d_mask = nullptr, *h_mask = nullptr;
   int64_t mask_words = 0;
+  float *d_dense2 = nullptr;  // the hub rows' dense keys (nq_pad x HUB_ROWS)
+  int64_t dense2_cap = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
   hipEvent_t e_chunk[3] = {nullptr, nullptr, nullptr};  // tail chunks but the last
   hipEvent_t e_up = nullptr;  // the call's inputs have arrived (upload stream -> batch stream)
@@ -67,6 +69,7 @@ void batch_free(BatchCtx *b) {
   hipFree(b->d_final);
   hipFree(b->d_mask);
   hipHostFree(b->h_mask);
+  hipFree(b->d_dense2);
   hipFree(b->d_quar_out);
   hipHostFree(b->h_quar_out);
   hipHostFree(b->h_fin_ids);
@@ -299,6 +302,69 @@ inline bool trace_batch() {
   return on;
 }
 
+// ---- the hub rows (Shard::d_hub) -------------------------------------------------------------------------------------
+constexpr int HUB_ROWS = 4096;  // sixteen 256-row tiles of the key kernel: a dense pass of 1 / 250 of a 1 M-row shard
+// (Re)builds the gathered fp16 copy of the HUB_ROWS rows with the smallest (L2) / largest (inner product) norm.  Caller
+// holds batch_enq_mu and s->mu shared; everything is enqueued on `st` but the selection, which needs the norms on the
+// host once (4 MB for 1 M rows + a partial sort: a few milliseconds, at the first batched call and after the shard
+// grew by a quarter).
+int hub_build(Shard *s, hipStream_t st, int32_t hchunks, int v_exp) {
+  const int64_t rows = s->rows;
+  std::vector<float> sq((size_t)rows);
+  HIPCHK(hipMemcpyAsync(sq.data(), s->d_sqnorm, (size_t)rows * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<uint32_t> ids((size_t)rows);
+  for (int64_t i = 0; i < rows; ++i) ids[(size_t)i] = (uint32_t)i;
+  const bool shortest = s->metric == TSH_METRIC_L2;
+  // (quarantined and absent rows carry |v|^2 = 0: under L2 they would crowd the hub -- they are never live, the dense
+  // pass drops them -- so rows of norm zero go last either way)
+  auto better = [&](uint32_t x, uint32_t y) {
+    const float a = sq[x], b2 = sq[y];
+    if ((a > 0.f) != (b2 > 0.f)) return a > 0.f;
+    return shortest ? (a < b2 || (a == b2 && x < y)) : (a > b2 || (a == b2 && x < y));
+  };
+  std::nth_element(ids.begin(), ids.begin() + HUB_ROWS, ids.end(), better);
+  ids.resize(HUB_ROWS);
+  std::sort(ids.begin(), ids.end());  // (row order: neighbouring hub rows share pages)
+  std::vector<float> hsq(HUB_ROWS);
+  for (int i = 0; i < HUB_ROWS; ++i) hsq[(size_t)i] = sq[ids[(size_t)i]];
+  const int64_t bytes = (int64_t)HUB_ROWS * hchunks * 64;
+  if (!s->d_hub || s->hub_chunks != hchunks) {
+    hipFree(s->d_hub);
+    s->d_hub = nullptr;
+    s->bytes -= s->hub_bytes;
+    s->hub_bytes = 0;
+    if (alloc_fault(bytes) || !device_has_room(bytes)) return set_err(TSH_E_OOM, "no room for the hub rows' copy");
+    HIPCHK(hipMalloc(&s->d_hub, (size_t)bytes));
+    if (!s->d_hub_ids) HIPCHK(hipMalloc(&s->d_hub_ids, (size_t)HUB_ROWS * 4));
+    if (!s->d_hub_sq) HIPCHK(hipMalloc(&s->d_hub_sq, (size_t)HUB_ROWS * 4));
+    s->hub_bytes = bytes + HUB_ROWS * 8;
+    s->bytes += s->hub_bytes;
+  }
+  HIPCHK(hipMemcpyAsync(s->d_hub_ids, ids.data(), (size_t)HUB_ROWS * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->d_hub_sq, hsq.data(), (size_t)HUB_ROWS * 4, hipMemcpyHostToDevice, st));
+  Half32Args ha{};
+  ha.rows = s->d_rows;
+  ha.inv_norm = nullptr;
+  ha.out = s->d_hub;
+  ha.ld = s->ld;
+  ha.first = 0;
+  ha.n = HUB_ROWS;
+  ha.dim = s->dim;
+  ha.kchunks = hchunks;
+  ha.scale = std::ldexp(1.0f, v_exp);
+  ha.ids = s->d_hub_ids;
+  const int64_t total = (int64_t)HUB_ROWS * hchunks * 4;
+  half_rows32_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
+  HIPCHK(hipStreamSynchronize(st));  // (ids / hsq are this function's own vectors)
+  HIPCHK(hipGetLastError());
+  s->hub_rows_built = rows;
+  s->hub_n = HUB_ROWS;
+  s->hub_exp = v_exp;
+  s->hub_chunks = hchunks;
+  return TSH_OK;
+}
+
 // All nq queries in one pass over the rows on the matrix cores.  Queries the
 // error model cannot cover, or whose lists overflow (ties), are reported in
 // *redo and answered by the single-query path.  Caller holds s->mu shared.
@@ -368,6 +434,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_blocks_dev), b->h_blocks, 0));
   if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
   const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
+  // The hub rows' bound (Shard::d_hub): fp16 keys of an L2 / inner-product shard whose norms differ at all, no caller
+  // mask (the bound counts rows the mask may drop), big enough that sixteen more tiles are noise.  TSH_OPT_BATCH_HUB.
+  bool use_hub = s->batch_hub && !mask && !b->last_sample_force && s->metric != TSH_METRIC_COSINE && rows >= 16 * HUB_ROWS &&
+                 s->max_norm > 1.02f * s->min_norm && k <= HUB_ROWS / 4;
   // (a mask handle's words are resident, host and device: no copy of them in this call's scratch)
   if (mask.bytes && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
 
@@ -589,6 +659,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       s->split_mode = kern;
       s->split_exp = v_exp;
     }
+    use_hub = use_hub && use_f16;
+    if (use_hub && (s->hub_rows_built < 0 || s->hub_exp != v_exp || s->hub_chunks != hchunks ||
+                    rows - s->hub_rows_built > s->hub_rows_built / 4)) {
+      // (a device too full for the copy, or any failure on the way: the call goes without the hub bound)
+      if (hub_build(s, s->aux_stream, hchunks, v_exp) != TSH_OK) use_hub = false;
+    }
+    if (use_hub && regrow(&b->d_dense2, (float **)nullptr, &b->dense2_cap, (int64_t)nq_pad * HUB_ROWS, &b->bytes) != TSH_OK) use_hub = false;
     HIPCHK(hipStreamWaitEvent(st, b->e_up, 0));
     if (!quar_sel.empty() && !out->d_blocks) {
       QuarArgs qa{};
@@ -699,6 +776,18 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     const bool timed = b->timed || trace_batch();
     if (timed) HIPCHK(hipEventRecord(b->e0, st));
     launch_batch_score_m(s->metric, a, true, st, s->cus);
+    if (use_hub) {  // the hub rows, densely: a gathered copy with its own norms and a map back to the rows' live bits
+      BatchArgs ah = a;
+      ah.Vs = s->d_hub;
+      ah.sqnorm = s->d_hub_sq;
+      ah.row_ids = s->d_hub_ids;
+      ah.dense = b->d_dense2;
+      ah.dense_ld = HUB_ROWS;
+      ah.row0 = 0;
+      ah.row1 = HUB_ROWS;
+      ah.n_tiles = HUB_ROWS / tile_n;
+      launch_batch_score_m(s->metric, ah, true, st, s->cus);
+    }
     if (timed) HIPCHK(hipEventRecord(b->e1, st));
     // B0s: per-query threshold + the sample's own candidates
     SampleSelArgs ss{};
@@ -719,6 +808,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     ss.sqnorm = s->d_sqnorm;
     ss.chain2 = chain2;
     ss.norm_max = s->max_norm;
+    ss.hub_dense = use_hub ? b->d_dense2 : nullptr;
+    ss.hub_ld = HUB_ROWS;
+    ss.hub_n = HUB_ROWS;
     if (roww) {  // the sample rows' norms, once per call
       sample_norms_kernel<<<(unsigned)((n_sample + 255) / 256), 256, 0, st>>>(s->d_sqnorm + s0, b->d_wnorm, (int32_t)n_sample);
       ss.wnorm = b->d_wnorm;

@@ -421,10 +421,29 @@ struct Shard {
   int64_t split_cap = 0;    // rows allocated
   int64_t split_valid = 0;  // rows [0, split_valid) are converted
   int batch_kernel = 3;     // TSH_OPT_BATCH_KERNEL: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (cosine: f16, else bf16x3)
+  // TSH_OPT_BATCH_HUB: the hub rows' bound beside the sample's (fp16 keys, L2 / inner product).  OFF by default: measured
+  // on the bench's L2 corpus (norms U(0.5, 2), 1 M x 768, 1024 queries; same box, alternating, tools/r6_hub_ab.sh) it cuts
+  // the key passes 1510-1536 -> 1463-1468 us -- the 4096 shortest rows reach |v| <= 0.506, the bound lets ~300 rows per query
+  // through where the estimate lets 480 -- and the call as a whole gains nothing (520-530 k against 529-533 k queries/s):
+  // sixteen more dense tiles and a second order statistic per query cost what the thinner epilogue saves; inner product
+  // and unit-norm rows: no difference; norms U(0.1, 3.2): + 1.8 %.
+  bool batch_hub = false;
   std::atomic<int> batch_kernel_last{-1};  // variant the last batched search ran
   int split_mode = 0;       // which kernel the planes were built for (1 / 2); 0 = none
   int64_t split_bytes = 0;
   int split_exp = 0;        // f16 planes: rows were scaled by 2^split_exp
+  // The HUB rows of an L2 / inner-product shard (round 6): the few thousand rows whose norm alone puts them near every
+  // query -- the shortest (L2) resp. the longest (inner product) --, as a gathered fp16 copy beside the planes.  A batched
+  // call scores them densely beside its sample; their k-th smallest key is a PROVEN bound on the k-th key overall
+  // (SampleSelArgs::hub_dense).  Built by the first batched call that wants it (guarded by batch_enq_mu like the planes);
+  // rows appended later are simply not in it (any subset of the rows gives a valid bound) until they are a quarter of
+  // the shard; an overwrite of rows it may hold drops it.
+  u32x4 *d_hub = nullptr;
+  uint32_t *d_hub_ids = nullptr;  // plane position -> local row id
+  float *d_hub_sq = nullptr;      // |v|^2 of the hub rows, in plane order
+  int64_t hub_rows_built = -1;    // rows the shard had when it was built (-1: none)
+  int hub_n = 0, hub_exp = 0, hub_chunks = 0;
+  int64_t hub_bytes = 0;
 
   bool safe_mode() const {
     if (nonfinite_rows) return true;
@@ -701,6 +720,7 @@ int shard_append(Shard *s, int64_t first, int64_t n, const float *src, bool src_
   if (first > s->rows) s->all_live = false;  // gap of absent rows
   if (first + n > s->rows) s->rows = first + n;
   s->split_valid = std::min(s->split_valid, first);  // overwritten / new rows need re-splitting
+  if (first < s->hub_rows_built) s->hub_rows_built = -1;  // (an overwritten row may be a hub row: its copy is stale)
   return TSH_OK;
 }
 
@@ -1827,6 +1847,9 @@ void shard_destroy(Shard *s) {
   hipFree(s->d_sqnorm);
   hipFree(s->d_live);
   hipFree(s->d_split);
+  hipFree(s->d_hub);
+  hipFree(s->d_hub_ids);
+  hipFree(s->d_hub_sq);
   hipFree(s->d_stats);
   hipFree(s->d_tmp_u32);
   hipFree(s->d_del_ids);
@@ -3008,6 +3031,14 @@ int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
     for (auto &sh : idx->shards) {
       std::unique_lock<RwLock> xl(sh->mu);
       sh->exact_rows = (int)value;
+    }
+    return TSH_OK;
+  }
+  if (option == TSH_OPT_BATCH_HUB) {
+    if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "batch hub: 0 or 1");
+    for (auto &sh : idx->shards) {
+      std::unique_lock<RwLock> xl(sh->mu);
+      sh->batch_hub = value != 0;
     }
     return TSH_OK;
   }
