@@ -563,7 +563,7 @@ def measure_batch(env, idx, host_rows, metric, n, d, k, nq, steps, warm, kernel,
         mean_step = (time.perf_counter() - t0) / steps
         gemm_us, flops = idx.bench_batch(qs[:nq], k, iters=3)
         two = two_callers_batch(env, idx, qs, nq, k, steps)
-    # the container's CPU quota freezes the process for milliseconds now and then (tools/throttle_probe.py): the
+    # the container's CPU quota freezes the process for milliseconds now and then (tools/attic/throttle_probe.py): the
     # MEDIAN step is the measurement; mean, p99 and the slowest step are reported beside it
     srt = np.sort(np.asarray(per_step))
     elapsed = float(np.median(per_step)) * steps
@@ -1211,7 +1211,7 @@ def run_bench(a, env=None):
 
     # single-query latency, one at a time (not the headline value).  Round 2's line carried p99 = 42.8 ms: one
     # call in a few hundred coincided with a full (generation 2) collection of THIS harness's Python heap
-    # (37 ms with torch imported; tools/lone_stall_probe.py, gc.callbacks) -- the library was not involved.  The
+    # (37 ms with torch imported; tools/attic/lone_stall_probe.py, gc.callbacks) -- the library was not involved.  The
     # collector is held off for the duration of the leg; collections inside it would be reported.
     lat, gc_ms = [], []
 
@@ -1497,7 +1497,7 @@ def launch_ranks(a, argv, timeout):
                 MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", TSH_BENCH_RANK_PROCESS="1")
     # torch sizes its CPU thread pool by the hardware threads it sees (256 on an MI355X box), not by the container's
     # quota: N ranks waking 256 OpenMP threads each for every small host-side copy burn the whole quota and get the
-    # job throttled (tools/thread_cpu_probe.py: 300 threads per rank, 2.3 CPUs per rank doing nothing).
+    # job throttled (tools/attic/thread_cpu_probe.py: 300 threads per rank, 2.3 CPUs per rank doing nothing).
     # torch.distributed.run sets OMP_NUM_THREADS=1 for the same reason.
     if "OMP_NUM_THREADS" not in base:
         base["OMP_NUM_THREADS"] = str(max(1, host_cpus() // n))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the batched (matrix-core) path starts to beat pipelined single-query scans: time per call for
-nq = 1..128 queries with the batch path forced on / off.  python tools/batch_crossover.py [rows] [dim] [metric]"""
+nq = 1..128 queries with the batch path forced on / off.  python tools/attic/batch_crossover.py [rows] [dim] [metric]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

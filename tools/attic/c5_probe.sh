@@ -1,6 +1,6 @@
 #!/bin/bash
 # Config C5 with the per-query masked scan (batching off), keep 1 %: queries/s and a stretch of the kernel timeline.
-# usage: [KEEP=0.01] tools/c5_probe.sh
+# usage: [KEEP=0.01] tools/attic/c5_probe.sh
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/c5; rm -rf $O; mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Single-query scan at row widths that do not fill their last 1 KiB chunk (and two that do): queries/s, scan kernel time,
-# fraction of the HBM peak.  usage: [DIMS="768 384 ..."] tools/dims_probe.sh
+# fraction of the HBM peak.  usage: [DIMS="768 384 ..."] tools/attic/dims_probe.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
 for d in ${DIMS:-768 384 1000 320 512 960 1280 200}; do
   timeout 300 python bench.py --dim $d --rows ${ROWS:-1000000} --steps 200 --warmup 20 --no-side --no-cpu-baseline --recall-queries 8 2>/dev/null | python -c "

@@ -3,7 +3,7 @@
 C2-sized index, the bench's own sequence (pipelined groups first, then one query at a time), every call
 stamped: outliers are printed with their index, the time since the previous outlier, the submit / wait split
 (tsh_search_submit = host enqueue, tsh_search_wait = GPU wait + finalise) and the cgroup cpu.stat deltas
-(CFS throttling) around them.  Run on the box: gpurun -- 'python tools/lone_stall_probe.py [n] [idle_ms]'."""
+(CFS throttling) around them.  Run on the box: gpurun -- 'python tools/attic/lone_stall_probe.py [n] [idle_ms]'."""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 #!/bin/bash
 # stall / busy counters of the fp16 key kernel (tsh_batch_f16.hip.h), 1 M x 768 cosine, 1024-query batches; separate
-# rocprofv3 --pmc passes, values summed over the chip.  TSH_F16_DBG selects a probe variant (see tools/f16_probe.sh).
+# rocprofv3 --pmc passes, values summed over the chip.  TSH_F16_DBG selects a probe variant (see tools/attic/f16_probe.sh).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/f16pmc${TSH_F16_DBG:+_dbg$TSH_F16_DBG}; rm -rf $O; mkdir -p $O
 run() { # name counters...

@@ -12,7 +12,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o c -- python bench.
 python tools/rocpd_summary.py $O/prof_c3/c_results.db > $O/c3_kernel_stats.txt 2>&1
 python tools/trace_timeline.py $O/prof_c3/c_results.db 30 40 > $O/c3_timeline.txt 2>&1
 rm -rf $O/prof_c3
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c -- python tools/c1_latency.py > $O/c1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c -- python tools/attic/c1_latency.py > $O/c1.log 2>&1
 python tools/rocpd_summary.py $O/prof_c1/c_results.db > $O/c1_kernel_stats.txt 2>&1
 rm -rf $O/prof_c1
 TSH_TRACE_BATCH=1 timeout 300 python bench.py --batch 16 --metric cosine --steps 10 --warmup 3 --no-cpu-baseline > $O/c3_16.json 2> $O/c3_16.err

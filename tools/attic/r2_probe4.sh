@@ -6,9 +6,9 @@ O=gpurun_out/r2p4
 rm -rf $O && mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_fused.py -x -q 2>&1 | tail -15
 timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-python tools/c1_latency.py 2>&1 | tail -1
-python tools/c1_latency.py 2>&1 | tail -1 | sed 's/^/fused: /'
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c -- python tools/c1_latency.py > $O/c1.log 2>&1
+python tools/attic/c1_latency.py 2>&1 | tail -1
+python tools/attic/c1_latency.py 2>&1 | tail -1 | sed 's/^/fused: /'
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c -- python tools/attic/c1_latency.py > $O/c1.log 2>&1
 python tools/rocpd_summary.py $O/prof_c1/c_results.db 2>&1 | head -6
 rm -rf $O/prof_c1
 for keep in 0.01 0.1 0.5; do

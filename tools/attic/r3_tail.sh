@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3: the batched path's tail: parity tests, then the kernel durations, a stretch of the timeline, the host
 # timeline of a call and the bench line (one caller and two).
-# usage: [TESTS=0] [NQ=1024] [M=cosine] tools/r3_tail.sh
+# usage: [TESTS=0] [NQ=1024] [M=cosine] tools/attic/r3_tail.sh
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r3tail; rm -rf $O; mkdir -p $O

@@ -1,7 +1,7 @@
 """Round 5: short searches -- the exact path (tsh_exact.hip.h) against the f32 pre-filter on the same index, same box,
 alternating: a 1 M x 768 corpus behind Bernoulli masks (keep 1 % / 0.2 % / 1.6 %) and config C1's shape (10 k x 128,
 k = 10).  Per mode: microseconds per query of 64-query calls (pipelined single-query searches) and p50 / p99 of
-searches one at a time.  python tools/r5_exact_probe.py [--rows 1000000]"""
+searches one at a time.  python tools/attic/r5_exact_probe.py [--rows 1000000]"""
 import argparse
 import sys
 import time

@@ -6,7 +6,7 @@ O=gpurun_out/r5final4
 rm -rf $O && mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_exact_scan.py tests/test_gpu_shard_stream.py tests/test_gpu_list_scan.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_concurrency.py tests/test_gpu_sharded.py tests/test_gpu_comm.py -x -q -m gpu 2>&1 | tail -4 > $O/tests.log
 cat $O/tests.log
-timeout 900 python tools/r5_exact_probe.py --rounds 2 2>&1 | grep -v amdgpu.ids > $O/exact_probe.txt
+timeout 900 python tools/attic/r5_exact_probe.py --rounds 2 2>&1 | grep -v amdgpu.ids > $O/exact_probe.txt
 grep "exact  " $O/exact_probe.txt
 SECONDS=0
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err

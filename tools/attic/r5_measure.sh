@@ -36,15 +36,15 @@ rm -rf $O/prof_c5
 # 5. one rank's share of the headline at N = 8 through tsh_search_sharded (real RCCL, a world of one): the library call
 #    without bench.py around it, the two ways to launch the exchange, three group schedules
 {
-  for rep in 1 2 3; do for ah in 0 1; do for g in 0 20 10; do echo -n "exchange_ahead=$ah group=$g (0 = the library's 10 + 5 + 5): "; timeout 200 python tools/r5_s8_probe.py --group $g --ahead $ah --calls 60 2>&1 | grep "per call"; done; done; done
-  timeout 200 python tools/r5_s8_probe.py --calls 60 2>&1 | grep "_us"
+  for rep in 1 2 3; do for ah in 0 1; do for g in 0 20 10; do echo -n "exchange_ahead=$ah group=$g (0 = the library's 10 + 5 + 5): "; timeout 200 python tools/attic/r5_s8_probe.py --group $g --ahead $ah --calls 60 2>&1 | grep "per call"; done; done; done
+  timeout 200 python tools/attic/r5_s8_probe.py --calls 60 2>&1 | grep "_us"
 } > $O/shard_of_8_probe.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_s8 -- python tools/r5_s8_probe.py --calls 12 > $O/trace_s8.log 2>&1
-python tools/r5_s8_trace.py $O/trace_s8 110 > $O/shard_of_8_timeline.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_s8 -- python tools/attic/r5_s8_probe.py --calls 12 > $O/trace_s8.log 2>&1
+python tools/attic/r5_s8_trace.py $O/trace_s8 110 > $O/shard_of_8_timeline.txt 2>&1
 rm -rf $O/trace_s8
 # 6. row widths whose scan variants spill or were never measured: dense and masked (keep 80 %)
 {
-  echo "500 k rows, dense:"; DIMS="1400 1500 3072 4096" ROWS=500000 bash tools/dims_probe.sh
+  echo "500 k rows, dense:"; DIMS="1400 1500 3072 4096" ROWS=500000 bash tools/attic/dims_probe.sh
   echo "500 k rows, Bernoulli mask keeping 80 %:"
   for d in 1400 3072 4096; do
     timeout 300 python bench.py --dim $d --rows 500000 --mask-keep 0.8 --steps 200 --warmup 20 --no-side --no-cpu-baseline --recall-queries 8 2>/dev/null | python -c "

@@ -15,8 +15,8 @@ rm -rf $O/prof_drv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c -- python3 bench.py --mask-keep 0.01 --steps 200 --warmup 20 --no-cpu-baseline --recall-queries 0 --no-side > $O/prof_c5.log 2>&1
 python tools/rocpd_summary.py $O/prof_c5/c_results.db > $O/c5_keep1_kernel_stats.txt 2>&1
 rm -rf $O/prof_c5
-timeout 900 python tools/r5_exact_probe.py --rounds 3 2>&1 | grep -v amdgpu.ids > $O/exact_probe.txt
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_x -o p -- python tools/r5_exact_probe.py --rounds 1 > $O/prof_x.log 2>&1
+timeout 900 python tools/attic/r5_exact_probe.py --rounds 3 2>&1 | grep -v amdgpu.ids > $O/exact_probe.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_x -o p -- python tools/attic/r5_exact_probe.py --rounds 1 > $O/prof_x.log 2>&1
 python tools/rocpd_summary.py $O/prof_x/p_results.db --by-grid 2>&1 | head -26 > $O/exact_kernel_stats.txt
 rm -rf $O/prof_x
 # the other metrics' E1 (16384 x 768, one query at a time)
@@ -27,7 +27,7 @@ for m in 1 2; do
 done
 V=$(ls tostore_amd/csrc/_build/v*/libtostore_hip_v*.so 2>/dev/null | head -1)
 if [ -n "$V" ]; then
-  TSH_LIB_PATH=$V TSH_X2_TRACE=1 timeout 600 python tools/r5_exact_probe.py --rounds 1 2> $O/x2.err > /dev/null
+  TSH_LIB_PATH=$V TSH_X2_TRACE=1 timeout 600 python tools/attic/r5_exact_probe.py --rounds 1 2> $O/x2.err > /dev/null
   grep "\[x2\]" $O/x2.err | awk '{k+=$3; s+=$5; e+=$7; r+=$9; f+=$12; a+=$17; c+=$19; n++} END {printf "exact_select_kernel phases over %d launches (probe build, 100 MHz stamps): keys %.2f, select %.2f (the round\047s adds %.2f, its scan %.2f), entries %.2f us; %.2f histogram rounds, %.1f ranked\n", n, k/n, s/n, a/n, c/n, e/n, r/n, f/n}' >> $O/exact_kernel_stats.txt
   rm -f $O/x2.err
 fi

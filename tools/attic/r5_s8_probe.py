@@ -1,6 +1,6 @@
 """Round 5: one rank's share of the headline at N = 8 (125 k x 768, L2, k = 100) through tsh_search_sharded over real
 RCCL in a world of one, 20-query calls -- the shape of side.shard_of_8 without the rest of bench.py.  Run it under
-`rocprofv3 --kernel-trace` to see the scans of a call back to back (tools/r5_s8_trace.py reads the trace)."""
+`rocprofv3 --kernel-trace` to see the scans of a call back to back (tools/attic/r5_s8_trace.py reads the trace)."""
 import argparse
 import os
 import sys

@@ -1,4 +1,4 @@
-"""Reads a rocprofv3 --kernel-trace CSV of tools/r5_s8_probe.py and prints the kernels of the last few calls as a
+"""Reads a rocprofv3 --kernel-trace CSV of tools/attic/r5_s8_probe.py and prints the kernels of the last few calls as a
 timeline (start offset, duration, queue, name) plus the gaps between consecutive scan kernels."""
 import csv
 import glob

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Looks for one-off stalls in the batched path: traces every call and prints the calls whose GPU wait or whose
 # whole library time is far above the usual 2.1-2.5 ms, plus the sum the library accounts for.
-# usage: tools/stall_probe.sh [extra bench.py options]
+# usage: tools/attic/stall_probe.sh [extra bench.py options]
 export TSH_TRACE_BATCH=1
 timeout 600 python bench.py --batch 1024 --metric cosine --steps 20 --warmup 3 "$@" 2>&1 |
   awk '/tsh batch\] nq=/ { n++; w=$0; sub(/.*gpu wait /,"",w); sub(/ us.*/,"",w); if (w+0 > 4000) print "call", n, $0 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel durations and a stretch of the kernel timeline of a batched C3 call.
-# usage: [NQ=1024] tools/tail_kernels.sh
+# usage: [NQ=1024] tools/attic/tail_kernels.sh
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/tail_${NQ:-1024}; rm -rf $O; mkdir -p $O

@@ -1,7 +1,7 @@
 """Which threads burn the CPU in a multi-rank run?  Starts `python bench.py <args>` in the background and, while it
 runs, samples utime + stime of every thread of every rank process (/proc/<pid>/task/*/stat) twice, some seconds
 apart: prints the busiest threads with their names and kernel wait channels.
-  gpurun -- 'python tools/thread_cpu_probe.py 30 6 --gpus 2 --ranks-share-gpu --rows 131072 --steps 400 ...'
+  gpurun -- 'python tools/attic/thread_cpu_probe.py 30 6 --gpus 2 --ranks-share-gpu --rows 131072 --steps 400 ...'
   (first argument: seconds to wait before the first sample, second: seconds between the samples)"""
 import os
 import subprocess
