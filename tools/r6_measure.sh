@@ -37,6 +37,9 @@ if has 4; then  # C3 (cosine), its L2 / IP twins: kernel stats and bench lines
   timeout 600 python3 bench.py --batch 1024 --metric l2 --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_l2.json
   timeout 600 python3 bench.py --batch 1024 --metric l2 --unit-rows --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_l2_unit_rows.json
   timeout 600 python3 bench.py --batch 1024 --metric ip --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_ip.json
+  # row norms a factor 32 apart (U(0.1, 3.2)): the automatic key-kernel choice keeps fp16 (round 6)
+  timeout 600 python3 bench.py --batch 1024 --metric l2 --norm-range 0.1,3.2 --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_l2_wide_norms.json
+  timeout 600 python3 bench.py --batch 1024 --metric ip --norm-range 0.1,3.2 --steps 10 --warmup 2 2>>$O/c3.err > $O/bench_c3_ip_wide_norms.json
 fi
 if has 5; then  # selective masks: the kernels of a keep-1 % mask inside real searches (the source of profiles/kernel_us.json)
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c -- python3 bench.py --mask-keep 0.01 --steps 200 --warmup 20 --no-cpu-baseline --recall-queries 0 --no-side > $O/prof_c5.log 2>&1
@@ -88,7 +91,7 @@ if j:
     for k, e in s.get("C5", {}).items():
         if isinstance(e, dict) and "value" in e:
             print("  C5", k, round(e["value"]), e["roofline"]["kernel"][:28], round(e["roofline"]["frac"], 3), "default", round(e.get("library_default_path", {}).get("value", 0)), "handle", round((e.get("mask_handle") or {}).get("value", 0)), (e.get("mask_handle") or {}).get("one_at_a_time_us"), e.get("ids_and_distances_bit_exact"))
-for n in ("c3_cosine", "c3_l2", "c3_l2_unit_rows", "c3_ip"):
+for n in ("c3_cosine", "c3_l2", "c3_l2_unit_rows", "c3_ip", "c3_l2_wide_norms", "c3_ip_wide_norms"):
     j = load("bench_%s.json" % n)
     if j: print(n, round(j["value"]), j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["kernel_us"], j.get("ids_and_distances_bit_exact"), j["counters"])
 for N in (2, 8):
