@@ -86,10 +86,20 @@ def _one_case(oracle, rng, case):
             idx.set_exact_scan_rows(0)
         elif cno % 5 == 1:
             idx.set_exact_scan_rows(min(16384, max(1, n // 2)))
-        ids, dist, cnt = idx.search(qs, k, thr, keep)
+        # round 6, by case number as well: one case in seven ranks with the one-workgroup select instead of the wide
+        # pick; every other masked case hands its mask over as a handle (tsh_mask_create: listed on the device)
+        if cno % 7 == 3:
+            idx.set_exact_select(False)
+        handle = idx.make_mask(keep) if keep is not None and cno % 2 == 0 else None
+        try:
+            ids, dist, cnt = idx.search(qs, k, thr, handle if handle is not None else keep)
+        finally:
+            if handle is not None:
+                handle.close()
         for i in range(nq):
             eids, edist = oracle.search_exhaustive(rows, qs[i], metric, k, thr, eff_mask)
-            tag = f"case {case}: n={n} d={d} metric={metric} k={k} nq={nq} mask={keep is not None} thr={thr}"
+            tag = (f"case {case}: n={n} d={d} metric={metric} k={k} nq={nq} mask={keep is not None} "
+                   f"handle={handle is not None} thr={thr}")
             assert cnt[i] == len(eids), tag
             assert np.array_equal(ids[i, :cnt[i]], eids), tag
             a, b = dist[i, :cnt[i]], edist
@@ -150,11 +160,20 @@ def _batch_case(oracle, rng, case):
             alive[dead] = False
         eff = alive if keep is None else alive & np.unpackbits(keep, bitorder="little")[:n].astype(bool)
         eff_mask = np.packbits(eff, bitorder="little")
+        cno = int(str(case).split("/")[-1])
+        if cno % 4 == 2:
+            idx.set_batch_hub(True)  # the hub rows' bound beside the sample's (off by default; exact either way)
+        handle = idx.make_mask(keep) if keep is not None and cno % 2 == 1 else None
         before = idx.counters()["batch_launches"]
-        ids, dist, cnt = idx.search(qs, k, None, keep)
+        try:
+            ids, dist, cnt = idx.search(qs, k, None, handle if handle is not None else keep)
+        finally:
+            if handle is not None:
+                handle.close()
         assert idx.counters()["batch_launches"] > before
         eids, edist, ecnt = oracle.search_heap_many_mt(rows, qs, metric, k, None, eff_mask)
-        tag = f"batch case {case}: n={n} d={d} metric={metric} k={k} nq={nq} kernel={kernel} mask={keep is not None}"
+        tag = (f"batch case {case}: n={n} d={d} metric={metric} k={k} nq={nq} kernel={kernel} mask={keep is not None} "
+               f"handle={handle is not None}")
         assert np.array_equal(cnt, ecnt), tag
         for i in range(nq):
             assert np.array_equal(ids[i, :cnt[i]], eids[i, :cnt[i]]), tag + f" q{i}"
@@ -189,6 +208,8 @@ def _sequence_case(oracle, rng, case, steps=25):
             present = np.concatenate([present, np.zeros(n - len(present), bool)])
             alive = np.concatenate([alive, np.zeros(n - len(alive), bool)])
 
+    held = None  # (handle, its bitmap as made): kept across appends, overwrites and deletes, used by later searches
+    cno = int(str(case).split("/")[-1])
     with HipVectorIndex(d, metric, capacity_rows=cap) as idx:
         for step in range(steps):
             op = rng.choice(["append", "append", "delete", "search", "search", "multi", "option", "async"])
@@ -218,12 +239,25 @@ def _sequence_case(oracle, rng, case, steps=25):
                 idx.set_batch_kernel(int(rng.integers(0, 4)))
                 idx.set_batch_min_nq(int(rng.choice([0, 1, 2, 8])))
                 idx.set_exact_scan_rows(int(rng.choice([0, 700, 16384])))
+                idx.set_exact_select((step + cno) % 3 != 0)
+                idx.set_batch_hub((step + cno) % 2 == 0)
                 continue
             eff = present & alive
             keep = None
             if rng.random() < 0.3:
                 kb = rng.random(len(model)) < 0.5
                 keep = np.packbits(kb, bitorder="little")
+                eff = eff & kb
+                if step % 2 == 0:  # as a handle: made now and held for the searches to come
+                    if held is not None:
+                        held[0].close()
+                    held = (idx.make_mask(keep), kb)
+                    keep = held[0]
+            elif held is not None and step % 3 == 0:  # an earlier handle: rows appended since it was made are not kept
+                kb = np.zeros(len(model), bool)
+                m = min(len(model), len(held[1]))
+                kb[:m] = held[1][:m]
+                keep = held[0]
                 eff = eff & kb
             eff_mask = np.packbits(eff, bitorder="little")
             k = int(rng.choice([1, 5, 40, 300]))
@@ -242,6 +276,8 @@ def _sequence_case(oracle, rng, case, steps=25):
                 assert cnt[i] == len(eids), tag
                 assert np.array_equal(ids[i, :cnt[i]], eids), tag
                 assert np.array_equal(dist[i, :cnt[i]], edist, equal_nan=True), tag
+        if held is not None:
+            held[0].close()
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
