@@ -121,6 +121,9 @@ def parse(argv=None):
                          "spread norms' corpus of VERDICT round 5, item 7 (a factor 32 between the shortest and the longest row)")
     ap.add_argument("--hub", action="store_true",
                     help="--batch: with the hub rows' bound (TSH_OPT_BATCH_HUB = 1) beside the sample's threshold, for A/B runs")
+    ap.add_argument("--plane-in-row-order", action="store_true",
+                    help="--batch: the fp16 copy of an L2 / inner-product corpus in row order (TSH_OPT_BATCH_GROUP = 0) instead of "
+                         "grouped by norm inside blocks of 8192 rows, for A/B runs")
     ap.add_argument("--no-side", action="store_true", help="skip the side legs (C1 / C3 / C5)")
     ap.add_argument("--side", default="c5,s8,c4s8,c1,c3",
                     help="side legs to run, comma separated (s8 = side.shard_of_8: one rank's share of the headline at N = 8 "
@@ -595,13 +598,16 @@ def bench_batch(a, env, idx, host_rows, metric):
     n, d, k, nq = a.rows, a.dim, a.k, a.batch
     if a.hub and hasattr(idx, "set_batch_hub"):
         idx.set_batch_hub(True)
+    if a.plane_in_row_order and hasattr(idx, "set_batch_group"):
+        idx.set_batch_group(False)
     r = measure_batch(env, idx, host_rows, metric, n, d, k, nq, min(a.steps, 20), min(a.warmup, 3), a.batch_kernel, 128)
     out = {"metric": "kNN queries/sec, %dx%d f32 %s k=%d, %d-query batch (matrix-core path)" % (n, d, a.metric, k, nq),
            "value": r["value"], "unit": "queries/s", "n_gpus": 1, "steps": r["steps"], "warmup": r["warmup"],
            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": r["dtype"], "data": "synthetic",
            "config": {"workload": "C3: %dx%d f32, %s, k=%d, %d-query batch" % (n, d, a.metric, k, nq),
-                      "batch_kernel": r["batch_kernel"], "hub_bound": bool(a.hub)}}
+                      "batch_kernel": r["batch_kernel"], "hub_bound": bool(a.hub),
+                      "plane": "row order" if a.plane_in_row_order else "grouped by norm (L2 / inner product)"}}
     for key in ("roofline", "recall_at_k", "ids_and_distances_bit_exact", "checked_queries", "counters",
                 "key_passes_share_of_step", "callers", "two_callers", "ms_per_step_mean", "ms_per_step_p99",
                 "ms_per_step_max"):

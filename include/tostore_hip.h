@@ -570,6 +570,12 @@ int32_t tsh_probe_batch_row_band(tsh_index *idx, int32_t nq, float *out_alpha2, 
  * kernel's epilogue on corpora whose neighbours are their short rows (key passes - 3 to - 5 %) and costs the call as
  * much as it saves: off unless a host knows its corpus to be that kind.  Results are identical. */
 #define TSH_OPT_BATCH_HUB 6
+/* TSH_OPT_BATCH_GROUP (default 1): 1 = the fp16 copy of an L2 / inner-product index that batched searches score holds
+ * its rows ordered by norm inside blocks of 8192 consecutive rows (the rows every query passes -- the short ones under
+ * L2, the long ones under inner product -- then share a few tiles of the key kernel instead of slowing a quarter of
+ * them down); 0 = in row order.  Results are identical either way; the copy is rebuilt by the next batched search
+ * after a change. */
+#define TSH_OPT_BATCH_GROUP 7
 /* TSH_OPT_TEST_HOOKS (process-wide; idx is ignored and may be NULL): value TSH_TEST_HOOKS_MAGIC switches the
  * library's TEST hooks on, 0 off.  Only then does it read the environment variables that change what it loads or make
  * it fail on purpose -- TSH_RCCL_LIB (a stand-in for librccl: tests/fake_rccl), TSH_TEST_FAIL_ALLOC_OVER (device

@@ -397,6 +397,7 @@ def test_hub_rows_bound(hip_lib, oracle_mod, metric):
         idx.append(0, rows[:n])
         idx.set_batch_min_nq(2)
         idx.set_batch_kernel(2)
+        idx.set_batch_group(False)  # (the norm-grouped plane is the default cure for crowded rows: the hub bound is the other)
         off = idx.search(qs, k)
         idx.set_batch_hub(True)
         r0 = idx.counters()["bytes_resident"]
@@ -429,3 +430,79 @@ def test_hub_rows_bound(hip_lib, oracle_mod, metric):
             e, ed = oracle_mod.search_heap(rows, qs[i], metric, k, None, np.packbits(keep, bitorder="little"))
             assert np.array_equal(ids[i, :cnt[i]], e) and np.array_equal(dist[i, :cnt[i]], ed)
         assert idx.counters()["fallback_searches"] == 0
+
+
+@pytest.mark.parametrize("metric", [L2, IP])
+def test_norm_grouped_plane(hip_lib, oracle_mod, metric):
+    """TSH_OPT_BATCH_GROUP (round 6; on by default): the fp16 plane of an L2 / inner-product index holds its rows by norm
+    inside blocks of 8192 (plane_group_kernel, tsh_batch_f16.hip.h) -- the key kernel works in plane positions and lists
+    its survivors under the rows' ids.  Same answers as the oracle and as the plane in row order, through everything
+    that indexes by row: tombstones, caller masks (Bernoulli, one id range: the sample window moves in whole blocks),
+    mask handles, appends that complete a block, overwrites inside an old block, a threshold, both query-tile shapes."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(950 + metric)
+    n0, n1, d, k = 41_000, 70_000, 72, 40
+    rows = _mk(n1, d, 951 + metric, scale=(0.3, 3.0))
+    for nq in (40, 200):
+        qs = _queries(oracle_mod, nq, d, 952 + nq, metric)
+        with HipVectorIndex(d, metric) as idx:
+            idx.append(0, rows[:n0])
+            idx.set_batch_min_nq(2)
+            idx.set_batch_kernel(2)
+            r0 = idx.counters()["bytes_resident"]
+            _check_batch(oracle_mod, idx, rows[:n0], qs, metric, k, tag=f"grouped nq={nq}")
+            grouped = idx.search(qs, k)
+            r1 = idx.counters()["bytes_resident"]
+            idx.set_batch_group(False)
+            plain = idx.search(qs, k)
+            assert all(np.array_equal(a, b) for a, b in zip(grouped, plain))
+            idx.set_batch_group(True)
+            # (the two maps, 8 B per position, are part of the resident bytes)
+            assert r1 - r0 >= n0 * 8
+            # tombstones: the extreme rows of every block (they lead the grouped blocks)
+            nrm = np.linalg.norm(rows[:n0].astype(np.float64), axis=1)
+            order = np.argsort(nrm if metric == L2 else -nrm)
+            dead = order[:500]
+            idx.set_deleted(dead)
+            alive = np.ones(n1, bool)
+            alive[dead] = False
+
+            def check(nrows, keep=None, thr=None, handle=False):
+                eff = alive[:nrows] if keep is None else alive[:nrows] & keep[:nrows]
+                em = np.packbits(eff, bitorder="little")
+                bits = None if keep is None else np.packbits(keep[:nrows], bitorder="little")
+                c0 = idx.counters()
+                if handle:
+                    with idx.make_mask(bits) as m:
+                        ids, dist, cnt = idx.search(qs, k, thr, m)
+                else:
+                    ids, dist, cnt = idx.search(qs, k, thr, bits)
+                c1 = idx.counters()
+                assert c1["batch_launches"] > c0["batch_launches"] and c1["fallback_searches"] == c0["fallback_searches"]
+                ref = oracle_mod.search_heap_many_mt(rows[:nrows], qs, metric, k, thr, em)
+                assert np.array_equal(cnt, ref[2])
+                for i in range(nq):
+                    assert np.array_equal(ids[i, :cnt[i]], ref[0][i, :cnt[i]]), i
+                    assert np.array_equal(dist[i, :cnt[i]].view(np.uint64), ref[1][i, :cnt[i]].view(np.uint64)), i
+
+            check(n0)
+            keep = rng.random(n1) < 0.3
+            check(n0, keep)
+            check(n0, keep, handle=True)
+            rng_keep = np.zeros(n1, bool)
+            rng_keep[19_000:33_000] = True  # one id range that starts and ends inside blocks
+            check(n0, rng_keep)
+            check(n0, rng_keep, handle=True)
+            # appends: the tail block is completed (8 192 x 5 = 40 960 < 41 000 < 49 152) and more blocks follow
+            idx.append(n0, rows[n0:n1])
+            check(n1)
+            check(n1, keep)
+            # overwrites inside old blocks: a short row becomes a long one and the other way round
+            for victim, f in ((int(order[700]), 30.0), (int(order[-5]), 0.02)):
+                rows[victim] = rows[victim] * np.float32(f if metric == L2 else 1.0 / f)
+                idx.append(victim, rows[victim:victim + 1])
+                alive[victim] = True
+            check(n1)
+            ed = oracle_mod.search_heap(rows[:n1], qs[0], metric, k, None, np.packbits(alive, bitorder="little"))[1]
+            check(n1, None, float(ed[len(ed) // 2]))

@@ -162,7 +162,10 @@ def _batch_case(oracle, rng, case):
         eff_mask = np.packbits(eff, bitorder="little")
         cno = int(str(case).split("/")[-1])
         if cno % 4 == 2:
+            idx.set_batch_group(False)
             idx.set_batch_hub(True)  # the hub rows' bound beside the sample's (off by default; exact either way)
+        elif cno % 4 == 3:
+            idx.set_batch_group(False)  # the fp16 plane in row order (default: grouped by norm inside blocks of 8192)
         handle = idx.make_mask(keep) if keep is not None and cno % 2 == 1 else None
         before = idx.counters()["batch_launches"]
         try:
@@ -241,6 +244,7 @@ def _sequence_case(oracle, rng, case, steps=25):
                 idx.set_exact_scan_rows(int(rng.choice([0, 700, 16384])))
                 idx.set_exact_select((step + cno) % 3 != 0)
                 idx.set_batch_hub((step + cno) % 2 == 0)
+                idx.set_batch_group((step + cno) % 4 < 2)
                 continue
             eff = present & alive
             keep = None

@@ -166,6 +166,7 @@ TSH_OPT_EXCHANGE_AHEAD = 3
 TSH_OPT_EXACT_SCAN_ROWS = 4
 TSH_OPT_EXACT_SELECT = 5
 TSH_OPT_BATCH_HUB = 6
+TSH_OPT_BATCH_GROUP = 7
 TSH_OPT_TEST_HOOKS = 1000
 TSH_TEST_HOOKS_MAGIC = 0x7465737468
 

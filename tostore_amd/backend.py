@@ -289,6 +289,11 @@ class HipVectorIndex:
         shortest (L2) / longest (inner product) -- beside the sample's estimate (default off: it pays for itself on no corpus measured).  Results are identical."""
         _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_BATCH_HUB, 1 if on else 0))
 
+    def set_batch_group(self, on: bool) -> None:
+        """The fp16 copy of an L2 / inner-product index holds its rows by norm inside blocks of 8192 (default on) or in
+        row order.  Results are identical; the copy is rebuilt by the next batched search."""
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_BATCH_GROUP, 1 if on else 0))
+
     def set_batch_kernel(self, kind: int) -> None:
         """Batched pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (default: f16 for cosine, bf16x3
         otherwise).  Results are identical."""

@@ -66,8 +66,10 @@ struct BatchArgs {
   float dot_scale;        // f16 variant: 2^-(eq + ev), undoes the power-of-two operand scales (0 = unused)
   int32_t dbg;            // f16 kernel probe (TSH_F16_DBG): 4 = no epilogue (results are wrong), 32 = timestamps
   uint64_t *dbg_buf;      // TSH_F16_DBG & 32: [wave 0 / wave 4 of workgroup 0][step][point] shader-clock stamps
-  const uint32_t *row_ids;  // f16 ping-pong kernel, nullable: the rows of this launch are a GATHERED copy (the hub rows'
-                            // dense pass): plane position p is row row_ids[p] of the shard -- where its live / mask bit is
+  const uint32_t *row_ids;  // f16 ping-pong kernel, nullable: the plane holds its rows in ANOTHER ORDER than the row store
+                            // (a norm-grouped plane, plane_group_kernel; the hub rows' gathered copy): plane position p
+                            // is row row_ids[p] of the shard -- where its live / mask bit is, and the id a survivor is
+                            // listed under.  `sqnorm` is then indexed by position too.
 };
 
 // an upper bound of |v| from the stored |v|^2 (f32 from an f64 sum: 2^-24; the square root: one ulp)
@@ -777,6 +779,7 @@ struct SampleSelArgs {
   const float *hub_dense;  // nq_pad x hub_ld
   int64_t hub_ld;
   int32_t hub_n;
+  const uint32_t *row_ids;  // nullable: sample position row0 + i holds row row_ids[row0 + i] (BatchArgs::row_ids)
 };
 
 // B0s: one workgroup per query.  thr[q] = band(tau), tau = the k_est-th smallest sample key; the sample rows at
@@ -857,7 +860,7 @@ __device__ __forceinline__ void batch_sample_select_body(const SampleSelArgs &a)
         uint32_t p = atomicAdd(&s_cnt, 1u);
         if (p < (uint32_t)a.cand_cap) {
           a.cand_key[(int64_t)q * a.cand_cap + p] = __float_as_uint(x);
-          a.cand_row[(int64_t)q * a.cand_cap + p] = (uint32_t)(a.row0 + i);
+          a.cand_row[(int64_t)q * a.cand_cap + p] = a.row_ids ? a.row_ids[a.row0 + i] : (uint32_t)(a.row0 + i);
         }
       }
     }

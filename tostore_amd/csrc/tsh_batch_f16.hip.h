@@ -72,6 +72,75 @@ static __global__ void __launch_bounds__(256) half_rows32_kernel(Half32Args a) {
   }
 }
 
+// ---- the norm-grouped plane (round 6) ---------------------------------------------------------------------------------
+// Under L2 / inner product with varying norms a query's survivors are not spread over the corpus: the SHORT rows (L2;
+// the long ones under inner product) are near every query, a few thousand rows take most of the ~480 survivors of each
+// of a call's 1024 queries, and in the key kernel's epilogue a lane (= one corpus row) that holds more than two
+// survivors sends its whole wave tile through the register-by-register walk.  With those rows scattered over the
+// corpus a quarter of all wave tiles hold one (the L2 key passes ran 11-14 % behind cosine's, same MFMA work); put
+// side by side they fill one wave tile in a hundred.  So the fp16 plane of an L2 / inner-product shard holds its rows
+// in another order than the row store: inside every block of PG_ROWS consecutive rows, by norm.  A block maps onto
+// itself -- any window of whole blocks (the sample window, a mask's window) holds the same rows in either order, so
+// the sample stays an unbiased one and the masks' kept-row counts stay what they were -- and nothing downstream of a
+// candidate's row id changes: perm[position] = row travels with the plane, the key kernel reads norms by position
+// (psq) and live / mask bits and candidate ids through perm (BatchArgs::row_ids).  The sorted order is ROTATED by a
+// block-dependent number of 256-row tiles: with every block's hottest tile at the same offset the persistent key
+// kernel's workgroup b (tiles b, b + G, ...; G = 256) would meet either all of them or none (measured on a pre-sorted
+// corpus: 8 of 256 workgroups held every crowded tile, 2.2 ms instead of 1.5).  Rows of norm zero (absent /
+// quarantined: never live) go last.  The tail behind the last whole block keeps the row order.
+constexpr int PG_ROWS = 8192;
+struct PlaneGroupArgs {
+  const float *sqnorm;    // |v|^2 per row
+  uint32_t *perm;         // out, per plane position: the row it holds
+  float *psq;             // out, per plane position: that row's |v|^2
+  int64_t first;          // first position to (re)write: a multiple of PG_ROWS
+  int64_t rows;           // the shard's rows: positions [first, rows) are written
+  int32_t longest_first;  // inner product: the longest rows lead a block (L2: the shortest)
+};
+// one workgroup per block; ranks by counting (a row's rank = the rows of its block in front of it by (norm, id)): 67 M
+// compares per block, all blocks side by side -- a fraction of a millisecond, once per (re)build of the plane
+static __global__ void __launch_bounds__(1024) plane_group_kernel(PlaneGroupArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PG_ROWS];
+  constexpr int PER = PG_ROWS / 1024;
+  const int tid = threadIdx.x;
+  const int64_t b0 = a.first + (int64_t)blockIdx.x * PG_ROWS;
+  if (b0 + PG_ROWS > a.rows) {  // the tail: row order
+    for (int64_t p = b0 + tid; p < a.rows; p += 1024) {
+      a.perm[p] = (uint32_t)p;
+      a.psq[p] = a.sqnorm[p];
+    }
+    return;
+  }
+  for (int i = tid; i < PG_ROWS; i += 1024) {
+    const uint32_t u = __float_as_uint(a.sqnorm[b0 + i]);  // (a sum of squares: no sign bit, the bit patterns order like the values)
+    s_key[i] = (u == 0u || u >= 0x7F800000u) ? 0xFFFFFFFFu : (a.longest_first ? 0x7F800000u - u : u);
+  }
+  __syncthreads();
+  uint64_t own[PER];
+  uint32_t rank[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    own[u] = ((uint64_t)s_key[tid + 1024 * u] << 32) | (uint32_t)(tid + 1024 * u);
+    rank[u] = 0;
+  }
+  for (int j = 0; j < PG_ROWS; j += 4) {
+    const u32x4 k4 = *reinterpret_cast<const u32x4 *>(&s_key[j]);  // (wave-uniform address: one broadcast read)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint64_t o = ((uint64_t)k4[e] << 32) | (uint32_t)(j + e);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) rank[u] += o < own[u] ? 1u : 0u;
+    }
+  }
+  const uint32_t rot = 256u * (uint32_t)(((b0 / PG_ROWS) >> 1) & (PG_ROWS / 256 - 1));
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int64_t row = b0 + tid + 1024 * u, pos = b0 + (int64_t)((rank[u] + rot) & (uint32_t)(PG_ROWS - 1));
+    a.perm[pos] = (uint32_t)row;
+    a.psq[pos] = a.sqnorm[row];
+  }
+}
+
 // one wave's 64 x 16 B from global (per-lane address) into LDS at lds_dst + 16 * lane (wave-uniform base in M0).
 // Invisible to the compiler's s_waitcnt bookkeeping: completion is counted by hand (f16_wait_dma).
 __device__ __forceinline__ void f16_dma16(const void *gsrc, uint32_t lds_dst) {

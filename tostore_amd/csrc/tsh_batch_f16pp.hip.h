@@ -264,8 +264,9 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
   auto store = [&](int qb, int nb, uint32_t e_key, uint32_t e_loc, uint32_t p) {
     if (p < (uint32_t)a.cand_cap) {
       const int64_t o = (int64_t)(qb + (int)(e_loc >> 16)) * a.cand_cap + p;
+      const int pos = nb + (int)(e_loc & 0xFFFFu);
       a.cand_key[o] = e_key;
-      a.cand_row[o] = (uint32_t)(nb + (int)(e_loc & 0xFFFFu));
+      a.cand_row[o] = a.row_ids ? a.row_ids[pos] : (uint32_t)pos;  // (a norm-grouped plane: the row this position holds)
     }
   };
   auto settle = [&]() {  // the answers have had a whole tile's time to arrive
@@ -425,19 +426,27 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
     // L2, filtered pass: the NEXT tile's c_v, issued beside the liveness words above so that one wait covers both and
     // the rest of the epilogue hides it (this tile's went into the accumulators' start values and is not needed again)
     if ((L2 || ROWV) && !DENSE && tile + G < total_tiles) load_cv(tile + G);
-    // one survivor: into the wave's LDS list while it has room (slot = running count + rank among the passing
-    // lanes; no atomics), straight into the query's global list otherwise (ties, duplicated rows: rare)
+    // one survivor: into the wave's LDS list (slot = running count + rank among the passing lanes; no atomics).  A list
+    // that is full is handed over on the spot -- one round of slot requests for all its entries, two per lane -- and
+    // starts again empty: a tile whose rows pass for a tenth of its queries (a corpus whose short rows sit together)
+    // pays a round trip per 128 survivors, not one per append
+    auto flush = [&]() {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if ((uint32_t)(lane + 64 * h) < n_hits) {
+          const uint2 e = my_hits[lane + 64 * h];
+          store(qbase, nbase, e.x, e.y, ask(qbase, (int)(e.y >> 16)));
+        }
+      n_hits = 0;
+    };
     auto append = [&](uint64_t m, bool mine, float key, int qrow, int cj) {
+      const uint32_t np = (uint32_t)__popcll(m);
+      if (__builtin_expect(n_hits + np > (uint32_t)F16_HITS, 0)) flush();  // (wave-uniform)
       const uint32_t slot = n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       const uint32_t loc = ((uint32_t)qrow << 16) | (uint32_t)cj;
-      if (__builtin_expect(n_hits + (uint32_t)__popcll(m) <= (uint32_t)F16_HITS, 1)) {
-        const uint32_t spare = (uint32_t)F16_HITS + (uint32_t)lane;
-        my_hits[mine ? slot : spare] = uint2{__float_as_uint(key), loc};
-      } else if (mine) {
-        if (slot < (uint32_t)F16_HITS) my_hits[slot] = uint2{__float_as_uint(key), loc};
-        else store(qbase, nbase, __float_as_uint(key), loc, ask(qbase, qrow));
-      }
-      n_hits += (uint32_t)__popcll(m);
+      const uint32_t spare = (uint32_t)F16_HITS + (uint32_t)lane;
+      my_hits[mine ? slot : spare] = uint2{__float_as_uint(key), loc};
+      n_hits += np;
     };
     float scale_w = a.dot_scale;
     asm volatile("" : "+s"(scale_w));
@@ -606,7 +615,7 @@ __global__ void __launch_bounds__(512, 2) batch_score_f16pp_kernel(BatchArgs a) 
       stamp(4);
     }
     if (!DENSE) {
-      const uint32_t listed = n_hits < (uint32_t)F16_HITS ? n_hits : (uint32_t)F16_HITS;
+      const uint32_t listed = n_hits;  // (<= F16_HITS: append)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         if ((uint32_t)(lane + 64 * h) < listed) {

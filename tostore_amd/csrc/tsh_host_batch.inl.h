@@ -182,7 +182,11 @@ int32_t batch_k_est(BatchCtx *b, int32_t k, int64_t rows, int64_t n_sample) {
   return std::min(k, std::max(p + 1, 4));
 }
 
-int64_t batch_sample_rows(int64_t rows, int32_t k) {
+int64_t batch_sample_rows(int64_t rows, int32_t k, bool whole_blocks = false) {
+  if (whole_blocks) {  // a norm-grouped plane: whole blocks of PG_ROWS positions (an unbiased sample of the norms)
+    const int64_t n = round_up(batch_sample_rows(rows, k), PG_ROWS);
+    return n >= rows ? rows : n;
+  }
   if (rows <= 16384) return rows;
   static const int64_t div = probe_env("TSH_SAMPLE_DIV") ? std::max(4, atoi(probe_env("TSH_SAMPLE_DIV"))) : 32;  // experiments
   int64_t n = std::max<int64_t>(rows / div, (int64_t)k * rows / (3000 * div / 32));
@@ -406,7 +410,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const int32_t nq_pad = (int32_t)round_up(nq, tile);
   // Sample size: the filtered pass keeps about k * rows / n_sample rows per query and
   // every survivor costs an atomic append, so the sample grows with k (survivors <= ~3000).
-  const int64_t n_sample = b->last_sample_force ? rows : batch_sample_rows(rows, k);
+  // (the fp16 plane of an L2 / inner-product shard may be norm-grouped, plane_group_kernel: windows of whole blocks then.
+  // Decided here from what is known before the key kernel is -- a superset; whole blocks suit every kernel)
+  const bool want_group = s->batch_group && s->metric != TSH_METRIC_COSINE && want_kernel >= 2;
+  const int64_t n_sample = b->last_sample_force ? rows : batch_sample_rows(rows, k, want_group);
   const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
   int32_t k_est = batch_k_est(b, k, rows, n_sample);  // (with a mask: recomputed below from the KEPT rows)
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
@@ -560,7 +567,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // nothing of the sample but k kept rows inside it; an estimate it makes unrepresentative is caught by B2 as ever.
   int64_t s0 = 0;
   if (mask && n_sample < rows) {
-    const int64_t wt = n_sample / 64, step = std::max<int64_t>(4, wt / 2 / 4 * 4);  // in 64-row mask words; 256-row aligned
+    // in 64-row mask words; 256-row aligned (whole blocks of a norm-grouped plane: PG_ROWS-aligned)
+    const int64_t wa = want_group ? PG_ROWS / 64 : 4;
+    const int64_t wt = n_sample / 64, step = std::max<int64_t>(wa, wt / 2 / wa * wa);
     std::vector<int32_t> pre_own;
     if (!mask.part) {
       pre_own.assign((size_t)n_tiles_all + 1, 0);
@@ -602,6 +611,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     for (int32_t q = 0; q < nq; ++q) b->h_sqrt_mag[q] = std::sqrt(b->mag_a[(size_t)q]);
   }
   const double t_prep = now_us();
+  bool grouped = false;  // the plane this call scores is norm-grouped (decided with the plane's upkeep, below)
   int n_chunks = 1;
   // chunk c of the tail = queries [chunk_q(c), chunk_q(c + 1)): the last chunk is the small one -- its finalisation
   // is all that is left to do on the host once the GPU is done
@@ -658,8 +668,34 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       }
       s->split_mode = kern;
       s->split_exp = v_exp;
+      grouped = use_f16 && want_group;
+      if (grouped && s->perm_cap < s->split_cap) {  // (a device too full for the two maps: the plane stays in row order)
+        hipFree(s->d_perm);
+        hipFree(s->d_psq);
+        s->d_perm = nullptr;
+        s->d_psq = nullptr;
+        s->bytes -= s->perm_bytes;
+        s->perm_bytes = 0;
+        s->perm_cap = 0;
+        const int64_t prow = round_up(s->split_cap, PLANE_GROUP);
+        if (alloc_fault(prow * 8) || !device_has_room(prow * 8) || hipMalloc(&s->d_perm, (size_t)prow * 4) != hipSuccess ||
+            hipMalloc(&s->d_psq, (size_t)prow * 4) != hipSuccess) {
+          (void)hipGetLastError();
+          hipFree(s->d_perm);
+          s->d_perm = nullptr;
+          grouped = false;
+        } else {
+          s->perm_cap = s->split_cap;
+          s->perm_bytes = prow * 8;
+          s->bytes += s->perm_bytes;
+        }
+      }
+      if (s->split_grouped != grouped) {  // the other order: the whole plane again
+        s->split_valid = 0;
+        s->split_grouped = grouped;
+      }
     }
-    use_hub = use_hub && use_f16;
+    use_hub = use_hub && use_f16 && !grouped;  // (either cure for crowded rows, not both)
     if (use_hub && (s->hub_rows_built < 0 || s->hub_exp != v_exp || s->hub_chunks != hchunks ||
                     rows - s->hub_rows_built > s->hub_rows_built / 4)) {
       // (a device too full for the copy, or any failure on the way: the call goes without the hub bound)
@@ -708,8 +744,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       a.Vs = s->d_split;
       a.hchunks = hchunks;
     } else if (use_f16) {
-      auto half = [&](const float *src, const float *inv, int64_t first, int64_t n, u32x4 *dst, int e) {
+      auto half = [&](const float *src, const float *inv, int64_t first, int64_t n, u32x4 *dst, int e, const uint32_t *ids = nullptr) {
         Half32Args ha{};
+        ha.ids = ids;
         ha.rows = src;
         ha.inv_norm = inv;
         ha.out = dst;
@@ -723,8 +760,20 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         half_rows32_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
       };
       if (s->split_valid < rows) {
-        half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, s->split_valid,
-             rows - s->split_valid, s->d_split, v_exp);
+        int64_t from = s->split_valid;
+        if (grouped) {  // whole blocks again from the one the first stale row sits in: positions [from, rows) and their rows
+          from = from / PG_ROWS * PG_ROWS;
+          PlaneGroupArgs ga{};
+          ga.sqnorm = s->d_sqnorm;
+          ga.perm = s->d_perm;
+          ga.psq = s->d_psq;
+          ga.first = from;
+          ga.rows = rows;
+          ga.longest_first = s->metric == TSH_METRIC_IP ? 1 : 0;
+          plane_group_kernel<<<(unsigned)((rows - from + PG_ROWS - 1) / PG_ROWS), 1024, 0, st>>>(ga);
+        }
+        half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, from, rows - from, s->d_split, v_exp,
+             grouped ? s->d_perm + from : nullptr);
         s->split_valid = rows;
       }
       half(b->d_Q, nullptr, 0, nq_pad, b->d_Qs, q_exp);
@@ -745,7 +794,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.Q = b->d_Q;
     a.V = s->d_rows;
     a.inv_norm = use_f16 ? nullptr : s->d_inv_norm;  // f16 planes of a cosine corpus hold unit rows
-    a.sqnorm = s->d_sqnorm;
+    a.sqnorm = grouped ? s->d_psq : s->d_sqnorm;  // (by plane position, like everything the key kernel indexes by column)
+    a.row_ids = grouped ? s->d_perm : nullptr;
     a.qsq = d_qsq;
     a.thr = d_thr;
     a.kmax = b->d_qaux + 4 * (size_t)nq_pad;
@@ -811,8 +861,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     ss.hub_dense = use_hub ? b->d_dense2 : nullptr;
     ss.hub_ld = HUB_ROWS;
     ss.hub_n = HUB_ROWS;
+    ss.row_ids = a.row_ids;
     if (roww) {  // the sample rows' norms, once per call
-      sample_norms_kernel<<<(unsigned)((n_sample + 255) / 256), 256, 0, st>>>(s->d_sqnorm + s0, b->d_wnorm, (int32_t)n_sample);
+      sample_norms_kernel<<<(unsigned)((n_sample + 255) / 256), 256, 0, st>>>(a.sqnorm + s0, b->d_wnorm, (int32_t)n_sample);
       ss.wnorm = b->d_wnorm;
     }
     // one workgroup per query: a small batch leaves most CUs empty, so its workgroups get sixteen waves instead of

@@ -432,6 +432,14 @@ struct Shard {
   int split_mode = 0;       // which kernel the planes were built for (1 / 2); 0 = none
   int64_t split_bytes = 0;
   int split_exp = 0;        // f16 planes: rows were scaled by 2^split_exp
+  // TSH_OPT_BATCH_GROUP (default on): the fp16 plane of an L2 / inner-product shard holds its rows by norm inside
+  // blocks of PG_ROWS (plane_group_kernel, tsh_batch_f16.hip.h): d_perm[position] = row, d_psq[position] = that row's
+  // |v|^2.  Kept current with the plane (same guards); split_grouped = how the plane as built is ordered.
+  bool batch_group = true;
+  bool split_grouped = false;
+  uint32_t *d_perm = nullptr;
+  float *d_psq = nullptr;
+  int64_t perm_cap = 0, perm_bytes = 0;  // positions allocated
   // The HUB rows of an L2 / inner-product shard (round 6): the few thousand rows whose norm alone puts them near every
   // query -- the shortest (L2) resp. the longest (inner product) --, as a gathered fp16 copy beside the planes.  A batched
   // call scores them densely beside its sample; their k-th smallest key is a PROVEN bound on the k-th key overall
@@ -1847,6 +1855,8 @@ void shard_destroy(Shard *s) {
   hipFree(s->d_sqnorm);
   hipFree(s->d_live);
   hipFree(s->d_split);
+  hipFree(s->d_perm);
+  hipFree(s->d_psq);
   hipFree(s->d_hub);
   hipFree(s->d_hub_ids);
   hipFree(s->d_hub_sq);
@@ -3034,6 +3044,14 @@ int32_t tsh_index_set_option(tsh_index *idx, int32_t option, int64_t value) {
     }
     return TSH_OK;
   }
+  if (option == TSH_OPT_BATCH_GROUP) {
+    if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "batch group: 0 or 1");
+    for (auto &sh : idx->shards) {
+      std::unique_lock<RwLock> xl(sh->mu);
+      sh->batch_group = value != 0;
+    }
+    return TSH_OK;
+  }
   if (option == TSH_OPT_BATCH_HUB) {
     if (value != 0 && value != 1) return set_err(TSH_E_BAD_ARG, "batch hub: 0 or 1");
     for (auto &sh : idx->shards) {
@@ -3149,6 +3167,16 @@ int32_t tsh_probe_batch_keys(tsh_index *idx, const float *queries, int32_t nq, i
   HIPCHK(hipSetDevice(s->device));
   HIPCHK(hipMemcpy2D(out_keys, (size_t)s->rows * 4, b->d_dense, (size_t)b->last_sample * 4, (size_t)s->rows * 4, (size_t)nq,
                      hipMemcpyDeviceToHost));
+  if (s->split_grouped && s->batch_kernel_last.load() == 2) {  // a norm-grouped plane: the keys came out by plane position
+    std::vector<uint32_t> perm((size_t)s->rows);
+    HIPCHK(hipMemcpy(perm.data(), s->d_perm, (size_t)s->rows * 4, hipMemcpyDeviceToHost));
+    std::vector<float> byrow((size_t)s->rows);
+    for (int32_t q = 0; q < nq; ++q) {
+      float *kq = out_keys + (size_t)q * (size_t)s->rows;
+      for (int64_t p2 = 0; p2 < s->rows; ++p2) byrow[perm[(size_t)p2]] = kq[p2];
+      memcpy(kq, byrow.data(), (size_t)s->rows * 4);
+    }
+  }
   // one bound for every row of the query: the shared part + the per-row part at the longest row
   const float *d2 = b->h_qaux + b->last_nq_pad, *al = b->h_qaux + 5 * (size_t)b->last_nq_pad;
   for (int32_t q = 0; q < nq; ++q) {
