@@ -789,7 +789,8 @@ final class HipVectorBackend {
     }
   }
 
-  /// tsh_index_set_option: 1 = TSH_OPT_BATCH_MIN_NQ, 2 = TSH_OPT_BATCH_KERNEL, 4 = TSH_OPT_EXACT_SCAN_ROWS.
+  /// tsh_index_set_option: 1 = TSH_OPT_BATCH_MIN_NQ, 2 = TSH_OPT_BATCH_KERNEL, 4 = TSH_OPT_EXACT_SCAN_ROWS,
+  /// 5 = TSH_OPT_EXACT_SELECT, 6 = TSH_OPT_BATCH_HUB, 7 = TSH_OPT_BATCH_GROUP (tuning only: results never depend on them).
   bool setOption(int option, int value) => _setOption(_handle, option, value) == 0;
 
   int get nativeDimensions => _dim(_handle);
