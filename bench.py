@@ -673,14 +673,22 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
             idx.search(queries[sel[:64]], k, None, mask)
             env.fence()
             c0 = idx.counters()
+            per_call = []
             with timed_region():
                 t0 = time.perf_counter()
                 for g in range(cnt // 64):
-                    got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mask)
+                    tc = time.perf_counter()
+                    got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mask)  # (synchronous: results are back)
+                    per_call.append(time.perf_counter() - tc)
                 env.fence()
                 el2 = time.perf_counter() - t0
             c1 = idx.counters()
-            ent["library_default_path"] = {"value": cnt / el2, "unit": "queries/s", "ms_per_step": el2 / cnt * 1e3,
+            # the MEDIAN call, like side.C3's median step: sixteen calls of half a millisecond, and one of them frozen for
+            # the rest of a cgroup CPU period (host_cpu.throttled_*) moved the mean by a third in one run of this round
+            med = sorted(per_call)[len(per_call) // 2]
+            ent["library_default_path"] = {"value": 64 / med, "unit": "queries/s", "ms_per_step": med / 64 * 1e3,
+                                           "timing": "median call", "ms_per_step_mean": el2 / cnt * 1e3,
+                                           "ms_per_call_max": max(per_call) * 1e3,
                                            "batch_launches": c1["batch_launches"] - c0["batch_launches"],
                                            "scan_launches": c1["scan_launches"] - c0["scan_launches"]}
             tail2 = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r6final
 mkdir -p $O
-STEPS=${STEPS:-"1 2 3 4 5 6 7 8 9"}
+STEPS=${STEPS:-"1 2 3 4 5 6 7 8 9 10 11"}
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has 1; then  # the driver's exact command, plain (the line the round is judged on)
   SECONDS=0
@@ -69,6 +69,20 @@ if has 8; then  # the driver's N > 1 command rehearsed over the RCCL branch (ran
   done
 fi
 if has 9; then timeout -k 10 $((60*${FUZZ_MIN:-5}+120)) python tests/probes/long_fuzz.py ${FUZZ_MIN:-5} > $O/long_fuzz.txt 2>&1; tail -3 $O/long_fuzz.txt; fi
+if has 10; then  # the fp16 plane grouped by norm (default) against the plane in row order, same box, alternating; both corpora
+  O=$O/ab_tmp bash tools/r6_sorted_blocks_ab.sh > $O/grouped_plane_ab.txt 2>&1
+  NORMS=0.1,3.2 O=$O/ab_tmp bash tools/r6_sorted_blocks_ab.sh > $O/grouped_plane_ab_wide_norms.txt 2>&1
+  rm -rf $O/ab_tmp
+fi
+if has 11; then  # one query at a time through the C ABI alone (no Python in the loop): C1's shape, the headline's shard of 8
+  gcc -std=c99 -O2 -I include tools/cabi_driver.c -o /tmp/cabi_driver -L tostore_amd -ltostore_hip -Wl,-rpath,$PWD/tostore_amd -lm
+  {
+    echo "# tools/cabi_driver.c [rows dim queries k]: a host with nothing but the C ABI -- one at a time / pipelined / batched, us per query"
+    for shape in "10000 128 1000 10" "125000 768 500 100" "1000000 768 256 100"; do
+      echo "## $shape"; timeout 600 /tmp/cabi_driver $shape 2>&1 | grep -v amdgpu.ids
+    done
+  } > $O/c_abi_latency.txt
+fi
 python3 - <<'PY'
 import json, os
 O = "gpurun_out/r6final"
@@ -100,7 +114,7 @@ for N in (2, 8):
     j = load("rehearsal_in_process_n%d.json" % N)
     if j: print("in-process N=%d" % N, round(j["value"], 1), j["ms_per_step"], j.get("recall_at_k"), j.get("ids_and_distances_bit_exact"), j["config"]["sharding"][:60])
 PY
-for f in bench_driver_args.time bench_pmc_fetch_write.txt mask_handles.txt; do [ -f $O/$f ] && cat $O/$f; done
+for f in bench_driver_args.time bench_pmc_fetch_write.txt mask_handles.txt grouped_plane_ab.txt grouped_plane_ab_wide_norms.txt c_abi_latency.txt; do [ -f $O/$f ] && cat $O/$f; done
 [ -f $O/bench_driver_args_kernel_stats.txt ] && head -14 $O/bench_driver_args_kernel_stats.txt
 [ -f $O/c5_keep1_kernel_stats.txt ] && head -8 $O/c5_keep1_kernel_stats.txt
 [ -f $O/exact_scan_counters.txt ] && head -60 $O/exact_scan_counters.txt

@@ -2,7 +2,7 @@
 # A/B on one box: the C3 shape (1 M x 768, 1024-query calls) under L2 / inner product with the fp16 plane grouped by norm
 # inside blocks of 8192 rows (the default, TSH_OPT_BATCH_GROUP) and in row order; cosine beside them (same MFMA work, no
 # per-row term: what the other two are held against).  NORMS=lo,hi for another corpus (default the bench's 0.5,2).
-O=gpurun_out/sb; mkdir -p $O
+O=${O:-gpurun_out/sb}; mkdir -p $O
 NR=${NORMS:-0.5,2}
 for rep in 1 2; do
 for m in l2 ip; do

@@ -96,11 +96,96 @@ PageKind decode_rawvec_page(const uint8_t *pg, size_t avail, int page_size, int 
   return PAGE_OK;
 }
 
+// The loader as a two-stage pipeline (round 6).  A partition file is taken in batches of ~32 MB of rows:
+//   stage A, on the host pool: every worker reads ITS pages itself (pread: the copies out of the page cache run side by
+//            side, where one fread of the whole batch was one core's memcpy), checks their CRC and copies / widens their
+//            vectors into the batch's row buffer -- pinned host memory, so that
+//   stage B, on a helper thread: tsh_index_append's H2D copy of the batch runs at the link's speed and, with the norms'
+//            kernel behind it, WHILE stage A is on the next batch (two row buffers; batches are appended in order, one
+//            at a time; the pipeline runs on across the files of an index).
+// Before: fread | decode | append one after the other, 3.8 GB/s of page bytes (round 1).
+struct RawvecPipe {
+  struct Slot {
+    float *rows = nullptr;
+    bool pinned = false;
+    size_t cap = 0;  // floats
+    std::vector<uint8_t> raw;
+    std::vector<int> kinds, counts;
+  } slot[2];
+  int cur = 0;
+  std::thread helper;
+  bool has_pending = false;
+  int pending_rc = TSH_OK;
+  std::string pending_err;
+  int64_t loaded = 0;  // rows appended (written by the helper; read after wait())
+
+  float *rows_of(Slot &sl, size_t floats) {
+    if (sl.cap >= floats) return sl.rows;
+    release(sl);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, floats * sizeof(float), hipHostMallocPortable) == hipSuccess) {
+      sl.pinned = true;
+    } else {
+      (void)hipGetLastError();
+      p = malloc(floats * sizeof(float));
+      sl.pinned = false;
+    }
+    sl.rows = static_cast<float *>(p);
+    sl.cap = p ? floats : 0;
+    return sl.rows;
+  }
+  void release(Slot &sl) {
+    if (sl.rows) {
+      if (sl.pinned) (void)hipHostFree(sl.rows);
+      else free(sl.rows);
+    }
+    sl.rows = nullptr;
+    sl.cap = 0;
+  }
+  // the append in flight, if any: its status (and its message, which lives in the helper's thread otherwise)
+  int wait() {
+    if (!has_pending) return TSH_OK;
+    helper.join();
+    has_pending = false;
+    if (pending_rc != TSH_OK) g_err = pending_err;
+    return pending_rc;
+  }
+  struct Run {
+    int64_t first_id, len;
+    size_t src;  // float offset into the slot's rows
+  };
+  // appends `runs` out of slot `si` on the helper thread (the previous append must have been waited for)
+  void append_async(tsh_index *idx, int si, std::vector<Run> runs, int dim) {
+    pending_rc = TSH_OK;
+    has_pending = true;
+    helper = std::thread([this, idx, si, dim, runs = std::move(runs)]() {
+      (void)dim;
+      for (const Run &r : runs) {
+        const int rc = tsh_index_append(idx, r.first_id, r.len, slot[si].rows + r.src);
+        if (rc != TSH_OK) {
+          pending_rc = rc;
+          pending_err = g_err;
+          return;
+        }
+        loaded += r.len;
+      }
+    });
+  }
+  ~RawvecPipe() {
+    (void)wait();
+    release(slot[0]);
+    release(slot[1]);
+  }
+};
+
 // tsh_index_load_rawvec_file with the page census tsh_index_open_ngh reports
 // lo_row_id: only node ids >= lo_row_id are loaded (tsh_index_open_ngh_shard: a rank's range may begin inside a
 // partition file and inside a page); pages that hold none of them are neither read nor counted
+// pipe: the caller's pipeline (tsh_index_open_ngh: one over all files; the last batch's append is then still in flight on
+// return, *out_rows is not written, and the caller waits and reads pipe->loaded); NULL: a pipeline of this call's own
 int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_t precision, int64_t first_row_id,
-                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages, int64_t lo_row_id = -1);
+                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages, int64_t lo_row_id = -1,
+                     RawvecPipe *pipe = nullptr);
 
 }  // namespace
 
@@ -112,7 +197,7 @@ extern "C" int32_t tsh_index_load_rawvec_file(tsh_index *idx, const char *path, 
 
 namespace {
 int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_t precision, int64_t first_row_id,
-                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages, int64_t lo_row_id) {
+                     int64_t max_rows, int64_t *out_rows, int64_t *out_absent_pages, int64_t lo_row_id, RawvecPipe *pipe) {
   if (out_rows) *out_rows = 0;
   if (out_absent_pages) *out_absent_pages = 0;
   if (!idx || !path) return set_err(TSH_E_BAD_ARG, "NULL pointer");
@@ -123,54 +208,62 @@ int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_
   int usable = page_size - 20 - 8 - 64;  // ngh_page.dart:575-579
   int vpp = usable > 0 ? usable / (dim * bpe) : 0;
   if (vpp <= 0) return set_err(TSH_E_BAD_ARG, "page_size %d holds no %d-dim vector", page_size, dim);
-  FILE *f = fopen(path, "rb");
-  if (!f) return set_err(TSH_E_IO, "cannot open %s", path);
+  const int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return set_err(TSH_E_IO, "cannot open %s", path);
+  RawvecPipe own;
+  RawvecPipe *pp = pipe ? pipe : &own;
+  const int64_t loaded0 = pp->loaded;  // (a caller's pipeline: nothing of it is in flight between two files' batches but the last append)
   int64_t n_pages = (max_rows + vpp - 1) / vpp;  // data pages needed to cover the ids
   const int64_t lo_rel = std::max<int64_t>(0, lo_row_id - first_row_id);  // first id wanted, relative to the file's first
   const int64_t p_first = lo_rel / vpp;                                   // ... and the data page that holds it
   const int BATCH = std::max(1, (int)((32 << 20) / ((int64_t)vpp * dim * 4)));
-  // one read per block of BATCH pages, pages decoded (CRC + copy / widen) in parallel on the host pool
-  std::vector<uint8_t> raw((size_t)BATCH * (size_t)page_size);
-  std::vector<float> rows((size_t)BATCH * vpp * dim);
-  std::vector<int> kinds((size_t)BATCH), counts((size_t)BATCH);
-  int64_t loaded = 0, absent = 0;
+  int64_t absent = 0;
   int rc = TSH_OK;
   for (int64_t p0 = p_first; p0 < n_pages && rc == TSH_OK; p0 += BATCH) {
-    int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
-    size_t got_total = 0;
-    if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // pageNo 0 is the partition meta page
-      got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
+    const int64_t nb = std::min<int64_t>(BATCH, n_pages - p0);
+    const int si = pp->cur;
+    RawvecPipe::Slot &sl = pp->slot[si];  // (free: the append that read it was waited for before the last one was started)
+    // (sized for the batches this file has: 16 MB partition files never fill a 32 MB batch, and pinning is not free)
+    float *rows = pp->rows_of(sl, (size_t)std::min<int64_t>(BATCH, n_pages - p_first) * vpp * dim);
+    if (!rows) {
+      rc = set_err(TSH_E_OOM, "no host memory for a batch of rows");
+      break;
+    }
+    if (sl.raw.size() < (size_t)nb * (size_t)page_size) sl.raw.resize((size_t)nb * (size_t)page_size);
+    if (sl.kinds.size() < (size_t)nb) {
+      sl.kinds.resize((size_t)nb);
+      sl.counts.resize((size_t)nb);
+    }
+    // stage A: pages read and decoded (CRC + copy / widen) in parallel on the host pool
     parallel_for((int32_t)nb, [&](int32_t b) {
-      const size_t off = (size_t)b * (size_t)page_size;
-      const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
+      uint8_t *pg = sl.raw.data() + (size_t)b * (size_t)page_size;
+      size_t got = 0;
+      const off_t at = (off_t)(1 + p0 + b) * page_size;  // pageNo 0 is the partition meta page
+      while (got < (size_t)page_size) {
+        const ssize_t r = pread(fd, pg + got, (size_t)page_size - got, at + (off_t)got);
+        if (r <= 0) break;  // (the end of the file, or an error: what is missing reads as absent / a bad page)
+        got += (size_t)r;
+      }
       int vc = 0;
-      kinds[(size_t)b] = (int)decode_rawvec_page(raw.data() + off, got, page_size, dim, vpp,
-                                                 rows.data() + (size_t)b * vpp * dim, &vc);
-      counts[(size_t)b] = vc;
+      sl.kinds[(size_t)b] = (int)decode_rawvec_page(pg, got, page_size, dim, vpp, rows + (size_t)b * vpp * dim, &vc);
+      sl.counts[(size_t)b] = vc;
     });
     // runs of consecutive present rows inside the batch are appended together; the ids of absent pages and of
     // slots past a page's vectorCount stay absent rows
+    std::vector<RawvecPipe::Run> runs;
     int64_t run_start = -1, run_len = 0;
     auto flush = [&]() {
-      if (run_len > 0 && rc == TSH_OK) {
-        rc = tsh_index_append(idx, first_row_id + p0 * vpp + run_start, run_len,
-                              rows.data() + (size_t)run_start * dim);
-        if (rc == TSH_OK) loaded += run_len;
-      }
+      if (run_len > 0) runs.push_back(RawvecPipe::Run{first_row_id + p0 * vpp + run_start, run_len, (size_t)run_start * (size_t)dim});
       run_start = -1;
       run_len = 0;
     };
-    for (int64_t b = 0; b < nb && rc == TSH_OK; ++b) {
-      const int kind = kinds[(size_t)b];
-      if (kind == (int)PAGE_ERROR || kind == (int)PAGE_UNDECODABLE) {
-        flush();
-        if (rc != TSH_OK) break;
-        if (kind == (int)PAGE_ERROR)
-          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / type / CRC / dimension", path,
-                       (long long)(1 + p0 + b));
-        else
-          rc = set_err(TSH_E_FORMAT, "%s: page %lld passes its CRC but is no raw-vector payload -- an index written "
-                       "with encryptVectorIndex cannot be opened without Dart", path, (long long)(1 + p0 + b));
+    int bad_kind = 0;
+    int64_t bad_page = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      const int kind = sl.kinds[(size_t)b];
+      if (kind == (int)PAGE_ERROR || kind == (int)PAGE_UNDECODABLE) {  // the rows in front of it are still appended
+        bad_kind = kind;
+        bad_page = 1 + p0 + b;
         break;
       }
       if (kind == (int)PAGE_ABSENT) {
@@ -179,7 +272,7 @@ int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_
         continue;
       }
       int64_t base = (p0 + b) * vpp;  // id offset of this page's slot 0
-      int64_t lim = std::min<int64_t>(counts[(size_t)b], max_rows - base);
+      int64_t lim = std::min<int64_t>(sl.counts[(size_t)b], max_rows - base);
       const int64_t skip = std::max<int64_t>(0, lo_rel - base);  // slots below the range's first id (its first page only)
       if (lim <= skip) continue;
       if (run_len > 0 && skip == 0 && run_start + run_len == b * vpp) {
@@ -192,9 +285,31 @@ int load_rawvec_file(tsh_index *idx, const char *path, int32_t page_size, int32_
       if (lim < vpp) flush();  // slots past vectorCount are absent rows
     }
     flush();
+    // stage B: the previous batch's append must be through (order, and its status); then this batch's starts
+    rc = pp->wait();
+    if (rc == TSH_OK && !runs.empty()) {
+      pp->append_async(idx, si, std::move(runs), dim);
+      pp->cur ^= 1;
+    }
+    if (rc == TSH_OK && bad_kind) {
+      rc = pp->wait();
+      if (rc == TSH_OK) {
+        if (bad_kind == (int)PAGE_ERROR)
+          rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / type / CRC / dimension", path, (long long)bad_page);
+        else
+          rc = set_err(TSH_E_FORMAT, "%s: page %lld passes its CRC but is no raw-vector payload -- an index written "
+                       "with encryptVectorIndex cannot be opened without Dart", path, (long long)bad_page);
+      }
+    }
   }
-  fclose(f);
-  if (out_rows) *out_rows = loaded;
+  close(fd);
+  if (!pipe || rc != TSH_OK) {  // this call's own pipeline (or a failure): nothing stays in flight
+    const std::string keep = g_err;
+    const int wrc = pp->wait();
+    if (rc == TSH_OK) rc = wrc;
+    else g_err = keep;
+    if (out_rows) *out_rows = pp->loaded - loaded0;
+  }
   if (out_absent_pages) *out_absent_pages = absent;
   return rc;
 }
@@ -398,13 +513,13 @@ int32_t open_ngh_impl(const char *ngh_dir, int32_t max_entries_per_dir, int32_t 
   // partition files and, inside the first and the last, of pages: nothing else is opened or read
   int64_t rows_loaded = 0, files = 0, absent_pages = 0, absent_files = 0;
   const int64_t rows_per_part = ppp * vpp;
+  RawvecPipe pipe;  // one pipeline over all files: a file's last append runs while the next file's pages are read
   for (int64_t part = lo / rows_per_part; rc == TSH_OK && hi > lo && part * rows_per_part < hi; ++part) {
     const int64_t first = part * rows_per_part, want = std::min(rows_per_part, hi - first);
     const std::string path = ngh_partition_path(dir, "rawvec", part, max_entries_per_dir);
     if (access(path.c_str(), R_OK) == 0) {
-      int64_t got = 0, absent = 0;
-      rc = load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, &got, &absent, lo);
-      rows_loaded += got;
+      int64_t absent = 0;
+      rc = load_rawvec_file(idx, path.c_str(), (int32_t)page_size, precision, first, want, nullptr, &absent, lo, &pipe);
       absent_pages += absent;
       ++files;
     } else {
@@ -414,6 +529,13 @@ int32_t open_ngh_impl(const char *ngh_dir, int32_t max_entries_per_dir, int32_t 
       absent_pages += (want + vpp - 1) / vpp - std::max<int64_t>(0, lo - first) / vpp;  // (the range's pages of it)
     }
   }
+  if (rc == TSH_OK) rc = pipe.wait();
+  else {
+    const std::string keep = g_err;
+    (void)pipe.wait();
+    g_err = keep;
+  }
+  rows_loaded = pipe.loaded;
   // tombstones: flags byte of each graph slot (ngh_page.dart:105-108,198-213)
   int64_t tombstones = 0;
   if (rc == TSH_OK && npg > 0) {
@@ -425,22 +547,26 @@ int32_t open_ngh_impl(const char *ngh_dir, int32_t max_entries_per_dir, int32_t 
     std::vector<int64_t> dead;
     for (int64_t part = lo / ids_per_part; rc == TSH_OK && hi > lo && part * ids_per_part < hi; ++part) {
       const std::string path = ngh_partition_path(dir, "graph", part, max_entries_per_dir);
-      FILE *f = fopen(path.c_str(), "rb");
-      if (!f) continue;  // no file: every page reads as NghGraphPage.empty -> flags 0
+      const int gfd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+      if (gfd < 0) continue;  // no file: every page reads as NghGraphPage.empty -> flags 0
       ++files;
       const int64_t first = part * ids_per_part;
       const int64_t n_pages = (std::min(ids_per_part, hi - first) + npg - 1) / npg;  // ... up to the range's last id
       for (int64_t p0 = std::max<int64_t>(0, lo - first) / npg; p0 < n_pages && rc == TSH_OK; p0 += BLOCK) {
         const int64_t nb = std::min(BLOCK, n_pages - p0);
-        size_t got_total = 0;
-        if (fseeko(f, (off_t)(1 + p0) * page_size, SEEK_SET) == 0)  // page 0 is the partition meta page
-          got_total = fread(raw.data(), 1, (size_t)nb * (size_t)page_size, f);
-        if (got_total == 0) break;  // past the end of the file: empty pages from here on
-        parallel_for((int32_t)nb, [&](int32_t b) {
+        std::atomic<int> any_bytes{0};
+        parallel_for((int32_t)nb, [&](int32_t b) {  // (every worker reads its own pages: as in load_rawvec_file)
           found[(size_t)b].clear();
           bad_page[(size_t)b] = 0;
           const size_t off = (size_t)b * (size_t)page_size;
-          const size_t got = got_total > off ? std::min((size_t)page_size, got_total - off) : 0;
+          size_t got = 0;
+          const off_t at = (off_t)(1 + p0 + b) * page_size;  // page 0 is the partition meta page
+          while (got < (size_t)page_size) {
+            const ssize_t r = pread(gfd, raw.data() + off + got, (size_t)page_size - got, at + (off_t)got);
+            if (r <= 0) break;
+            got += (size_t)r;
+          }
+          if (got) any_bytes.store(1, std::memory_order_relaxed);
           uint32_t plen = 0;
           int type = 0;
           bool bad = false;
@@ -466,6 +592,7 @@ int32_t open_ngh_impl(const char *ngh_dir, int32_t max_entries_per_dir, int32_t 
             if (id >= lo && (pl[4 + sl * ss] & 0x01)) found[(size_t)b].push_back(id);
           }
         });
+        if (!any_bytes.load()) break;  // past the end of the file: empty pages from here on
         for (int64_t b = 0; b < nb; ++b) {
           if (bad_page[(size_t)b]) {
             rc = set_err(TSH_E_FORMAT, "%s: page %lld has a bad header / CRC", path.c_str(), (long long)(1 + p0 + b));
@@ -474,7 +601,7 @@ int32_t open_ngh_impl(const char *ngh_dir, int32_t max_entries_per_dir, int32_t 
           dead.insert(dead.end(), found[(size_t)b].begin(), found[(size_t)b].end());
         }
       }
-      fclose(f);
+      close(gfd);
     }
     if (rc == TSH_OK && !dead.empty()) {
       rc = tsh_index_set_deleted(idx, dead.data(), (int64_t)dead.size());

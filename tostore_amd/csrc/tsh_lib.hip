@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
 #include <unistd.h>
 
 #include "../../include/tostore_hip.h"
