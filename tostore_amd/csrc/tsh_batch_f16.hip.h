@@ -97,8 +97,8 @@ struct PlaneGroupArgs {
   int64_t rows;           // the shard's rows: positions [first, rows) are written
   int32_t longest_first;  // inner product: the longest rows lead a block (L2: the shortest)
 };
-// one workgroup per block; ranks by counting (a row's rank = the rows of its block in front of it by (norm, id)): 67 M
-// compares per block, all blocks side by side -- a fraction of a millisecond, once per (re)build of the plane
+// one workgroup per block; ranks by counting (a row's rank = the rows of its block in front of it by (norm, place)): 67 M
+// compares per block, all blocks side by side -- about a millisecond, once per (re)build of a block
 static __global__ void __launch_bounds__(1024) plane_group_kernel(PlaneGroupArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_key[PG_ROWS];
   constexpr int PER = PG_ROWS / 1024;
@@ -111,25 +111,27 @@ static __global__ void __launch_bounds__(1024) plane_group_kernel(PlaneGroupArgs
     }
     return;
   }
+  // the order key: the norm's leading 19 bits (sign, exponent, 10 of the mantissa: grouping needs no more) above the row's
+  // place in the block -- distinct per row, so the ranks are a permutation, and one 32-bit compare per pair
+  static_assert(PG_ROWS == 8192, "13 bits of the order key are the row's place in its block");
   for (int i = tid; i < PG_ROWS; i += 1024) {
     const uint32_t u = __float_as_uint(a.sqnorm[b0 + i]);  // (a sum of squares: no sign bit, the bit patterns order like the values)
-    s_key[i] = (u == 0u || u >= 0x7F800000u) ? 0xFFFFFFFFu : (a.longest_first ? 0x7F800000u - u : u);
+    const uint32_t kk = (u == 0u || u >= 0x7F800000u) ? 0xFFFFFFFFu : (a.longest_first ? 0x7F800000u - u : u);
+    s_key[i] = (kk & 0xFFFFE000u) | (uint32_t)i;
   }
   __syncthreads();
-  uint64_t own[PER];
-  uint32_t rank[PER];
+  uint32_t own[PER], rank[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    own[u] = ((uint64_t)s_key[tid + 1024 * u] << 32) | (uint32_t)(tid + 1024 * u);
+    own[u] = s_key[tid + 1024 * u];
     rank[u] = 0;
   }
   for (int j = 0; j < PG_ROWS; j += 4) {
     const u32x4 k4 = *reinterpret_cast<const u32x4 *>(&s_key[j]);  // (wave-uniform address: one broadcast read)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const uint64_t o = ((uint64_t)k4[e] << 32) | (uint32_t)(j + e);
 #pragma unroll
-      for (int u = 0; u < PER; ++u) rank[u] += o < own[u] ? 1u : 0u;
+      for (int u = 0; u < PER; ++u) rank[u] += k4[e] < own[u] ? 1u : 0u;
     }
   }
   const uint32_t rot = 256u * (uint32_t)(((b0 / PG_ROWS) >> 1) & (PG_ROWS / 256 - 1));
