@@ -114,7 +114,6 @@ struct RawvecPipe {
   } slot[2];
   int cur = 0;
   std::thread helper;
-  bool has_pending = false;
   int pending_rc = TSH_OK;
   std::string pending_err;
   int64_t loaded = 0;  // rows appended (written by the helper; read after wait())
@@ -142,13 +141,13 @@ struct RawvecPipe {
     sl.rows = nullptr;
     sl.cap = 0;
   }
-  // the append in flight, if any: its status (and its message, which lives in the helper's thread otherwise)
+  // the append in flight, if any: its status (and its message, which lives in the helper's thread otherwise); reported once
   int wait() {
-    if (!has_pending) return TSH_OK;
-    helper.join();
-    has_pending = false;
-    if (pending_rc != TSH_OK) g_err = pending_err;
-    return pending_rc;
+    if (helper.joinable()) helper.join();
+    const int rc = pending_rc;
+    if (rc != TSH_OK) g_err = pending_err;
+    pending_rc = TSH_OK;
+    return rc;
   }
   struct Run {
     int64_t first_id, len;
@@ -156,10 +155,9 @@ struct RawvecPipe {
   };
   // appends `runs` out of slot `si` on the helper thread (the previous append must have been waited for)
   void append_async(tsh_index *idx, int si, std::vector<Run> runs, int dim) {
+    (void)dim;
     pending_rc = TSH_OK;
-    has_pending = true;
-    helper = std::thread([this, idx, si, dim, runs = std::move(runs)]() {
-      (void)dim;
+    auto work = [this, idx, si, runs = std::move(runs)]() {
       for (const Run &r : runs) {
         const int rc = tsh_index_append(idx, r.first_id, r.len, slot[si].rows + r.src);
         if (rc != TSH_OK) {
@@ -169,7 +167,12 @@ struct RawvecPipe {
         }
         loaded += r.len;
       }
-    });
+    };
+    try {
+      helper = std::thread(work);
+    } catch (const std::system_error &) {  // no thread to be had: the append runs here; wait() reports its status all the same
+      work();
+    }
   }
   ~RawvecPipe() {
     (void)wait();
