@@ -349,3 +349,25 @@ def test_release_library_reads_few_environment_variables():
             if not in_probes and re.search(r"(?<![_\w])getenv\(", code):
                 sites.append("%s:%d" % (name, ln))
     assert len(sites) <= 6, sites
+
+
+def test_header_constants_and_the_ctypes_mirror_agree():
+    """Every `#define TSH_* <integer>` of include/tostore_hip.h that tostore_amd/_ffi.py mirrors by name carries the same value
+    there (status codes, metrics, option numbers, the test hooks' magic), and every option number of the header is mirrored."""
+    import re
+
+    from tostore_amd import _ffi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "tostore_hip.h")).read()
+    defs = {}
+    for name, val in re.findall(r"^#define (TSH_[A-Z0-9_]+) \(?(-?(?:0x[0-9a-fA-F]+|\d+))(?:ll)?\)?", text, re.M):
+        defs[name] = int(val, 0)
+    assert defs["TSH_ABI_VERSION"] == _ffi.ABI_VERSION
+    mirrored = [n for n in defs if hasattr(_ffi, n)]
+    assert len(mirrored) >= 20, mirrored
+    for n in mirrored:
+        assert getattr(_ffi, n) == defs[n], (n, getattr(_ffi, n), defs[n])
+    for n in defs:
+        if n.startswith("TSH_OPT_") or n.startswith("TSH_E_") or n.startswith("TSH_METRIC_"):
+            assert hasattr(_ffi, n) or n.startswith("TSH_METRIC_"), n + " is not mirrored in _ffi.py"

@@ -162,6 +162,8 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+TSH_OPT_BATCH_MIN_NQ = 1
+TSH_OPT_BATCH_KERNEL = 2
 TSH_OPT_EXCHANGE_AHEAD = 3
 TSH_OPT_EXACT_SCAN_ROWS = 4
 TSH_OPT_EXACT_SELECT = 5

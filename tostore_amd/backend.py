@@ -270,7 +270,7 @@ class HipVectorIndex:
     def set_batch_min_nq(self, nq: int) -> None:
         """When search() uses the batched matrix-core path: 0 never, 1 by estimated cost (default), n >= 2 from n
         queries per call on.  Results are identical."""
-        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 1, int(nq)))
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_BATCH_MIN_NQ, int(nq)))
 
     def set_exact_scan_rows(self, rows: int) -> None:
         """Single-query searches with at most `rows` rows to look at (a selective mask's kept rows, a small index) take
@@ -297,7 +297,7 @@ class HipVectorIndex:
     def set_batch_kernel(self, kind: int) -> None:
         """Batched pre-filter keys: 0 f32 MFMA, 1 bf16x3, 2 f16, 3 auto (default: f16 for cosine, bf16x3
         otherwise).  Results are identical."""
-        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, 2, int(kind)))
+        _ffi.check(_ffi.lib().tsh_index_set_option(self._h, _ffi.TSH_OPT_BATCH_KERNEL, int(kind)))
 
     def bench_batch(self, queries, k: int, iters: int = 3):
         """(avg microseconds of the matrix-core passes, algorithmic flops) for one batch."""
