@@ -84,6 +84,15 @@ def test_c2_single_queries_full_size(corpora, oracle_mod):
         # the batched path answers the same queries identically
         idx.set_batch_min_nq(2)
         assert _same(idx.search(qs, K), got), "matrix-core batch vs single-query scans (L2)"
+        # ... and as part of a 1024-query call (256-query tiles), on the fp16 plane grouped by norm (the default for L2 /
+        # inner product) and on the plane in row order: the same bits for all 1024
+        qs_big = np.concatenate([qs, _queries(oracle_mod, 944, 0, 9)])
+        big = idx.search(qs_big, K)
+        assert idx.counters()["batch_kernel_last"] == 2
+        assert _same(tuple(x[:80] for x in big), got), "the first 80 of a 1024-query L2 batch vs single-query scans"
+        idx.set_batch_group(False)
+        assert _same(idx.search(qs_big, K), big), "fp16 plane in row order vs grouped by norm (1024 queries, L2)"
+        idx.set_batch_group(True)
         c = idx.counters()
         assert c["fallback_searches"] == 0 and c["batch_launches"] > 0 and c["safe_mode"] == 0
 
