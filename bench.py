@@ -189,7 +189,7 @@ def library_schedule(nq, rows_per_shard, dim):
     """tsh_search_sharded's own schedule of queries per exchange (sharded_schedule, tsh_host_comm.inl.h), for the
     report: shrinking groups up to 128 queries, uniform ones beyond."""
     if nq > 128:
-        g = 256 if nq >= 512 else 64
+        g = 512 if nq >= 1024 else (256 if nq >= 512 else 64)
         return [min(g, nq - q) for q in range(0, nq, g)]
     scan_us = float(rows_per_shard) * ((dim + 3) // 4 * 4) * 4.0 / 6.5e6
     g_min = int(min(128.0, max(4.0, math.ceil(150.0 / max(scan_us, 1.0)))))

@@ -443,7 +443,8 @@ int32_t tsh_comm_world(tsh_comm *comm);
  * in SHRINKING groups (half of what is left each time, never below what hides an exchange behind the scans that
  * follow -- sized by the bytes a scan of the largest shard reads, which the ranks tell each other whenever their buffers grow -- nor below
  * four: 20 queries on 125 k x 768 shards as 10 + 5 + 5), because only the LAST group's exchange is exposed; 64 per
- * group up to 512 queries, 256 beyond.  n > 0: uniform groups of n.  Same value on every rank. */
+ * group up to 512 queries, 256 up to 1024, 512 beyond (a group is one matrix-core call per shard: bigger groups keep more
+ * of a big call's efficiency).  n > 0: uniform groups of n.  Same value on every rank. */
 int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
                            double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,
