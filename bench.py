@@ -185,13 +185,16 @@ def query_pool_size(steps, warmup, recall_queries, batch=0):
     return int(max(warmup + steps, 64, recall_queries, 2 * batch, 1))
 
 
-def library_schedule(nq, rows_per_shard, dim):
-    """tsh_search_sharded's own schedule of queries per exchange (sharded_schedule, tsh_host_comm.inl.h), for the
-    report: shrinking groups up to 128 queries, uniform ones beyond."""
+def library_schedule(nq, rows_per_shard, dim, batched=False):
+    """tsh_search_sharded's own schedule of queries per exchange (sharded_schedule, tsh_host_sync.h), for the
+    report: uniform groups beyond 128 queries; up to 128 shrinking groups when the shards scan query by query (batched =
+    False: the headline's TSH_OPT_BATCH_MIN_NQ = 0), one group when the ranks batch and the call pays for it."""
     if nq > 128:
-        g = 512 if nq >= 1024 else (256 if nq >= 512 else 64)
+        g = 512 if nq >= 1024 else 256
         return [min(g, nq - q) for q in range(0, nq, g)]
     scan_us = float(rows_per_shard) * ((dim + 3) // 4 * 4) * 4.0 / 6.5e6
+    if batched and nq >= 2 and nq * (scan_us + 25.0) > 300.0 + 0.825 * scan_us * ((nq + 127) // 128):
+        return [int(nq)]
     g_min = int(min(128.0, max(4.0, math.ceil(150.0 / max(scan_us, 1.0)))))
     out, rem = [], int(nq)
     while rem > 0:
@@ -983,8 +986,8 @@ def side_c4_per_rank(env, a):
     try:
         steps, warmup = max(a.steps, 20), min(max(a.warmup, 2), 10)
         queries = make_queries(max(1024, steps + warmup), d, metric, seed=20260618)
+        idx.set_batch_min_nq(0)  # (before the first sharded call: the ranks tell each other whether they batch, library_schedule)
         searcher = env.searcher(idx)
-        idx.set_batch_min_nq(0)
         repeats = max(3, min(10, auto_repeats(steps, a.repeats)))
         m = measure_single(env, a, idx, searcher, queries, k, None, steps, warmup, repeats)
         elapsed = float(np.median(m["regions"]))
@@ -1204,8 +1207,10 @@ def run_bench(a, env=None):
     pool = query_pool_size(a.steps, a.warmup, a.recall_queries if world == 1 else 0)
     queries = make_queries(pool, d, metric)
     nqp = len(queries)
+    # headline workload: every query scans the corpus on its own (no MFMA batching) -- set before the first sharded call, whose
+    # agreement tells every rank whether the ranks batch (that decides the group schedule of calls of up to 128 queries)
+    idx.set_batch_min_nq(0)
     searcher = env.searcher(idx)
-    idx.set_batch_min_nq(0)  # headline workload: every query scans the corpus on its own (no MFMA batching)
 
     row_mask = None
     if a.mask_keep > 0:  # C5 as the main line

@@ -439,12 +439,14 @@ int32_t tsh_comm_create_host(int32_t world, int32_t rank, int32_t device, tsh_al
                              tsh_comm **out);
 int32_t tsh_comm_destroy(tsh_comm *comm);
 int32_t tsh_comm_world(tsh_comm *comm);
-/* queries per exchange of tsh_search_sharded; 0 (default) = the library's own schedule: calls of up to 128 queries go
- * in SHRINKING groups (half of what is left each time, never below what hides an exchange behind the scans that
- * follow -- sized by the bytes a scan of the largest shard reads, which the ranks tell each other whenever their buffers grow -- nor below
- * four: 20 queries on 125 k x 768 shards as 10 + 5 + 5), because only the LAST group's exchange is exposed; 64 per
- * group up to 512 queries, 256 up to 1024, 512 beyond (a group is one matrix-core call per shard: bigger groups keep more
- * of a big call's efficiency).  n > 0: uniform groups of n.  Same value on every rank. */
+/* queries per exchange of tsh_search_sharded; 0 (default) = the library's own schedule.  Calls of up to 128 queries that
+ * the shards scan query by query (no rank batches -- TSH_OPT_BATCH_MIN_NQ = 0 on every handle -- or the cost model says
+ * scans) go in SHRINKING groups (half of what is left each time, never below what hides an exchange behind the scans that
+ * follow -- sized by the bytes a scan of the largest shard reads -- nor below four: 20 queries on 125 k x 768 shards as
+ * 10 + 5 + 5), because only the LAST group's exchange is exposed; calls the shards answer on their matrix cores go as ONE
+ * group (a group is one batched call per shard).  Beyond 128 queries: 256 per group, 512 from 1024 queries on.  What the
+ * ranks know of each other (shard sizes, whether they batch) they tell each other whenever their buffers grow and on every
+ * 64th call: a changed option takes that long to reach the schedule.  n > 0: uniform groups of n.  Same value on every rank. */
 int32_t tsh_comm_set_group(tsh_comm *comm, int32_t queries_per_exchange);
 int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *comm, const float *queries, int32_t nq, int32_t k,
                            double distance_threshold, const uint8_t *row_mask, int64_t *out_ids, double *out_dist,

@@ -188,6 +188,20 @@ static void print_schedules() {
         fprintf(stderr, "schedule of %d queries: sum %d, largest group %d > %d\n", nq, sum, mx, tsh::sharded_group_max(nq));
         exit(1);
       }
+      // ... and the schedule of ranks that batch (one group up to 128 queries when the call pays for a batched pass)
+      tsh::sharded_schedule(nq, b / 6.5e6, &sizes, true);
+      printf("scheduleb %d %.0f :", nq, b);
+      sum = mx = 0;
+      for (int32_t g : sizes) {
+        printf(" %d", g);
+        sum += g;
+        mx = g > mx ? g : mx;
+      }
+      printf("\n");
+      if (sum != nq || mx > tsh::sharded_group_max(nq)) {
+        fprintf(stderr, "batched schedule of %d queries: sum %d, largest group %d > %d\n", nq, sum, mx, tsh::sharded_group_max(nq));
+        exit(1);
+      }
     }
 }
 

@@ -207,7 +207,8 @@ def test_shard_of_8_leg(oracle_mod):
     assert s8["ids_and_distances_bit_exact"] is True and s8["recall_at_k"] == 1.0 and s8["checked_queries"] == 16
     assert sum(s8["queries_per_exchange"]) == 20 and set(s8["group_sweep_us_per_query"]) == {"1", "2", "4", "5", "10", "20"}
     assert bench.library_schedule(20, 125_000, 768) == [10, 5, 5] and bench.library_schedule(20, 10_000, 128) == [20]
-    assert bench.library_schedule(300, 125_000, 768) == [64, 64, 64, 64, 44] and bench.library_schedule(1, 1, 1) == [1]
+    assert bench.library_schedule(300, 125_000, 768) == [256, 44] and bench.library_schedule(1, 1, 1) == [1]
+    assert bench.library_schedule(20, 125_000, 768, batched=True) == [20] and bench.library_schedule(1500, 125_000, 768) == [512, 512, 476]
     assert all(i.closed for i in env.made)
 
 

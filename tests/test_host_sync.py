@@ -26,10 +26,10 @@ def test_host_sync_cpp(tmp_path):
 
     n = 0
     for line in r.stdout.splitlines():
-        if line.startswith("schedule "):
+        if line.startswith("schedule ") or line.startswith("scheduleb "):
             head, _, sizes = line.partition(":")
-            _, nq, nbytes = head.split()
+            kind, nq, nbytes = head.split()
             rows = int(float(nbytes)) // (768 * 4)  # library_schedule takes rows x dim: bytes = rows * ld * 4
-            assert bench.library_schedule(int(nq), rows, 768) == [int(x) for x in sizes.split()], line
+            assert bench.library_schedule(int(nq), rows, 768, kind == "scheduleb") == [int(x) for x in sizes.split()], line
             n += 1
-    assert n == 17 * 7
+    assert n == 2 * 17 * 7

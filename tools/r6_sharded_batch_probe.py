@@ -49,6 +49,16 @@ for key, v in tl.items():
         print("  %-18s %9.1f us per call" % (key, v / calls))
     else:
         print("  %-18s %s" % (key, v))
+for grp in [int(x) for x in os.environ.get("GSWEEP", "").split(",") if x]:  # uniform groups of n (tsh_comm_set_group) instead of the schedule
+    cs.set_group(grp)
+    for _ in range(2):
+        cs.search(qs, k)
+    t = time.perf_counter()
+    for _ in range(calls):
+        o2 = cs.search(qs, k)
+    print("  groups of %4d: %.3f ms per call; same answers: %s" % (grp, (time.perf_counter() - t) / calls * 1e3,
+                                                              all(np.array_equal(a, b) for a, b in zip(out, o2))))
+cs.set_group(0)
 idx.set_batch_min_nq(2)
 for _ in range(3):
     ref = idx.search(qs, k)

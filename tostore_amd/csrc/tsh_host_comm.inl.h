@@ -149,6 +149,8 @@ struct tsh_comm {
   int64_t tl_exch = 0, tl_timed = 0;  // exchanges / timed exchanges since the timeline's last reset: gather_us and
                                       // slice_d2h_us are sums over the TIMED ones, scaled when the timeline is read
   int32_t calls_since_agree = 0;      // calls since the ranks last told each other their shard sizes
+  bool batch_hint = false;            // some rank's handle sends calls to the matrix cores (TSH_OPT_BATCH_MIN_NQ != 0), as of
+                                      // the last agreement: rides in the low bit of the bytes figure (a multiple of four)
   int32_t group = 0;  // queries per exchange; 0 = by the size of the call
   std::unique_ptr<OneWorker> worker;  // runs the calls' progressive shard searches (one call at a time: mu)
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};  // RCCL: before / after the block all-gather, after the slice's D2H
@@ -183,7 +185,8 @@ int comm_allgather_host(tsh_comm *c, const void *h_send, void *h_recv, size_t by
 // changes here).
 int comm_agree(tsh_comm *c, int local_rc, int64_t local_rows) {
   if (c->world == 1) {
-    c->scan_bytes_hint = local_rows;
+    c->scan_bytes_hint = local_rows & ~(int64_t)3;
+    c->batch_hint = (local_rows & 1) != 0;
     return local_rc;
   }
   c->h_agree[0] = local_rc;
@@ -201,8 +204,13 @@ int comm_agree(tsh_comm *c, int local_rc, int64_t local_rows) {
     if (rc) return rc;
   }
   int64_t rows = 0;
-  for (int r = 0; r < c->world; ++r) rows = std::max(rows, all[2 * r + 1]);
+  bool batches = false;
+  for (int r = 0; r < c->world; ++r) {
+    rows = std::max<int64_t>(rows, all[2 * r + 1] & ~(int64_t)3);
+    batches = batches || (all[2 * r + 1] & 1) != 0;
+  }
   c->scan_bytes_hint = rows;
+  c->batch_hint = batches;
   if (local_rc != TSH_OK) return local_rc;
   for (int r = 0; r < c->world; ++r)
     if (all[2 * r] != TSH_OK)
@@ -684,6 +692,7 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
     Shard *s0 = shard->shards[0].get();
     std::shared_lock<RwLock> sl = share(shard, s0);
     my_rows = s0->rows * s0->ld * 4;
+    if (shard->batch_min_nq != 0) my_rows |= 1;  // (this rank batches: the schedule's other input, in the figure's spare low bit)
   }
   bool grew = false;
   const double t_in = now_us();
@@ -712,7 +721,7 @@ int32_t tsh_search_sharded(tsh_index *shard, tsh_comm *c, const float *queries, 
   if (c->group > 0) {
     for (int32_t q = 0; q < nq; q += Gmax) sizes.push_back(std::min(Gmax, nq - q));
   } else {
-    sharded_schedule(nq, (double)c->scan_bytes_hint / 6.5e6, &sizes);
+    sharded_schedule(nq, (double)c->scan_bytes_hint / 6.5e6, &sizes, c->batch_hint);
   }
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
   size_t gi = 0;  // next group

@@ -450,26 +450,42 @@ constexpr int32_t SHARDED_WINDOW = 4096;  // queries of a call whose blocks this
 // largest group any schedule of an nq-query call can contain (what the buffers are sized for: capacities must not
 // depend on anything a rank knows alone)
 inline int32_t sharded_group_max(int32_t nq) {
-  // (a group is one batched call on every shard, with its own sample pass, selects and re-rank: 256 queries cost 1.2 ms
-  // where 1024 in one call cost 4.0 on a 1.25 M x 1536 shard -- groups of 512 keep most of the big call's efficiency
-  // and still leave an exchange to hide behind the next group)
+  // (a group of a big call is one batched call on every shard, with its own sample pass, selects and re-rank: on a
+  // 1.25 M x 1536 shard 256 queries cost 1.2 ms where 1024 in one call cost 4.0, on 1 M x 768 five groups of 64 cost
+  // 2.6 ms where 300 queries in groups of 256 cost 1.3 -- tools/r6_sharded_batch_probe.py)
   if (nq >= 1024) return 512;
-  if (nq >= 512) return 256;
-  if (nq > 128) return 64;
+  if (nq > 128) return 256;
   return std::max(nq, 1);
 }
-// Queries per exchange, group after group.  The scans of a call run as ONE pipeline whatever the groups are, so a
-// group costs its exchange only (collective latency + copy + merge: ~0.1 ms): hidden behind the scans of the groups
-// after it, exposed for the LAST group.  Up to 128 queries the groups therefore shrink -- half of what is left each
-// time, never below what it takes to hide an exchange (scan_us: one query's scan on the largest shard, from the
-// rows the ranks told each other at their last agreement) nor below four, the rest in one piece once it is that
-// small: 20 queries on 125 k x 768 shards go as 10 + 5 + 5, on 10 k-row shards (a scan is shorter than any exchange)
-// as one group.  Bigger calls go to the matrix cores, which want big uniform groups.
-inline void sharded_schedule(int32_t nq, double scan_us, std::vector<int32_t> *sizes) {
+// Does a call of nq queries go to the matrix cores on shards whose single-query scan takes scan_us?  The schedule's
+// copy of shard_takes_batch's cost model (tsh_host_batch.inl.h: 0.30 ms + a pass over the fp16 copy at ~4 TB/s per 128
+// queries, against a pipelined scan at ~6.6 TB/s + 25 us per query), in terms of what every rank knows.
+inline bool sharded_call_batches(int32_t nq, double scan_us) {
+  if (nq < 2) return false;
+  const double t_batch = 300.0 + 0.825 * scan_us * (double)((nq + 127) / 128);
+  const double t_single = (double)nq * (scan_us + 25.0);
+  return t_single > t_batch;
+}
+// Queries per exchange, group after group.
+// Scanned one by one (batched == false: no rank batches, or the cost model says scans), the scans of a call run as ONE
+// pipeline whatever the groups are, so a group costs its exchange only (collective latency + copy + merge: ~0.1 ms):
+// hidden behind the scans of the groups after it, exposed for the LAST group.  Up to 128 queries the groups therefore
+// shrink -- half of what is left each time, never below what it takes to hide an exchange (scan_us: one query's scan on
+// the largest shard, from the bytes the ranks told each other at their last agreement) nor below four, the rest in one
+// piece once it is that small: 20 queries on 125 k x 768 shards go as 10 + 5 + 5, on 10 k-row shards (a scan is shorter
+// than any exchange) as one group.
+// On the matrix cores (batched: the ranks batch calls, and this one pays for it) a group is one batched call per shard
+// -- its own sample pass, selects and re-rank, ~0.3 ms before the first row is scored: a call of up to 128 queries is
+// ONE group (three groups of 10 + 5 + 5 would be three batched calls), bigger ones go in big uniform groups.
+inline void sharded_schedule(int32_t nq, double scan_us, std::vector<int32_t> *sizes, bool batched = false) {
   sizes->clear();
   if (nq > 128) {
     const int32_t G = sharded_group_max(nq);
     for (int32_t q = 0; q < nq; q += G) sizes->push_back(std::min(G, nq - q));
+    return;
+  }
+  if (batched && sharded_call_batches(nq, scan_us)) {
+    sizes->push_back(nq);
     return;
   }
   const double exchange_us = 150.0;
