@@ -637,12 +637,18 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
         env.fence()
         c0 = idx.counters()
         got = [None] * (cnt // 64)
+        per_call = []
         with timed_region():
             t0 = time.perf_counter()
             for g in range(cnt // 64):
-                got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mask)
+                tc = time.perf_counter()
+                got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mask)  # (synchronous: results are back)
+                per_call.append(time.perf_counter() - tc)
             env.fence()
-            el = time.perf_counter() - t0
+            el_mean = (time.perf_counter() - t0) / (cnt // 64)
+            # the MEDIAN call (side.C3 reports its median step): sixteen calls of about a millisecond, and one of them frozen
+            # for the rest of a cgroup CPU period (host_cpu.throttled_*) moved the mean by a third in runs of this round
+            el = sorted(per_call)[len(per_call) // 2] * (cnt // 64)
             c1 = idx.counters()
             scan_us = idx.bench_scan(queries[0], iters=20, row_mask=mask)
         # which kernel scanned: tsh_counters says (selective masks are scanned as a compacted list of row ids)
@@ -654,7 +660,8 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
         if exact > 0 and exact >= scans:  # few enough kept rows: their exact f64 sums in one launch, no f32 keys
             kernel = "tsh::exact_scan_kernel (+ exact_select_kernel: two dispatches per query)"
         useful = float(kept) * d * 4 + (4.0 * kept if listed > 0 else n / 8)  # (the list's ids instead of the mask's words)
-        ent = {"value": cnt / el, "unit": "queries/s", "ms_per_step": el / cnt * 1e3, "kept_rows": kept, "mask": kind,
+        ent = {"value": cnt / el, "unit": "queries/s", "ms_per_step": el / cnt * 1e3, "timing": "median call",
+               "ms_per_step_mean": el_mean / 64 * 1e3, "kept_rows": kept, "mask": kind,
                "roofline": {"bound": "hbm", "achieved": useful / (scan_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": useful / (scan_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "kernel": kernel, "kernel_us": scan_us, "list_scans": int(listed), "exact_scans": int(exact),
@@ -707,12 +714,16 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
             with idx.make_mask(mask) as mh:
                 idx.search(queries[sel[:64]], k, None, mh)
                 env.fence()
+                per_call = []
                 with timed_region():
                     t0 = time.perf_counter()
                     for g in range(cnt // 64):
+                        tc = time.perf_counter()
                         got[g] = idx.search(queries[sel[g * 64:g * 64 + 64]], k, None, mh)
+                        per_call.append(time.perf_counter() - tc)
                     env.fence()
-                    el3 = time.perf_counter() - t0
+                    el3_mean = (time.perf_counter() - t0) / (cnt // 64)
+                    el3 = sorted(per_call)[len(per_call) // 2] * (cnt // 64)  # (the median call, as the leg above)
                     lone = {}
                     for form, arg in (("pointer", mask), ("handle", mh)):
                         lat = []
@@ -723,7 +734,7 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
                         lat = np.sort(np.asarray(lat)) * 1e6
                         lone[form] = {"p50": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)])}
                 ent["mask_handle"] = {"value": cnt / el3, "unit": "queries/s", "ms_per_step": el3 / cnt * 1e3,
-                                      "one_at_a_time_us": lone}
+                                      "timing": "median call", "ms_per_step_mean": el3_mean / 64 * 1e3, "one_at_a_time_us": lone}
                 tail3 = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None
         except Exception as e:  # noqa: BLE001
             ent["mask_handle"] = {"error": repr(e)}
