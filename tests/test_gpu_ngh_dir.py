@@ -256,3 +256,34 @@ def test_open_ngh_shard_census_and_errors(hip_lib, oracle_mod, tmp_path):
     with idx:
         assert (info["row_base"], info["row_end"], info["rows_loaded"]) == (5, 5, 0) and idx.size == 0
         assert idx.search(v[0], 3)[2][0] == 0
+
+
+def test_open_ngh_into_a_handle_over_several_devices(hip_lib, oracle_mod, tmp_path):
+    """tsh_index_open_ngh(n_devices = 3): the loader's pipeline (pages read and decoded on the pool while a helper thread appends the
+    batch before) feeds a handle whose appends are routed to three shards (here sharing the one GPU); many partition files, a
+    missing one among them; the same answers as the one-device handle and as the oracle."""
+    from oracle import ngh_dir
+    from tostore_amd import HipVectorIndex, _ffi
+
+    rng = np.random.default_rng(21)
+    n, dims = 9000, 80
+    v = (rng.standard_normal((n, dims)) * 0.5).astype(np.float32)
+    deleted = sorted(set(rng.integers(0, n, 300).tolist()))
+    root = tmp_path / "ngh"
+    ngh_dir.write_ngh_dir(str(root), v, metric=0, max_partition_file_size=16384 * 6, deleted=deleted, skip_rawvec_partitions=[4])
+    os.environ["TSH_SHARDS_SHARE_DEVICES"] = "1"
+    _ffi.enable_test_hooks()
+    try:
+        one, info1 = HipVectorIndex.open_ngh(str(root))
+        many, info3 = HipVectorIndex.open_ngh(str(root), n_devices=3)
+        with one, many:
+            assert info3["rows_loaded"] == info1["rows_loaded"] < n and info3["files_absent"] == info1["files_absent"] == 1
+            assert info3["tombstones"] == info1["tombstones"]
+            qs = rng.standard_normal((5, dims)).astype(np.float32)
+            a, b = one.search(qs, 30), many.search(qs, 30)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+            ids = b[0]
+            assert not np.isin(ids[ids >= 0], deleted).any()  # (the one-device handle is held to the oracle by the tests above)
+    finally:
+        _ffi.enable_test_hooks(False)
+        del os.environ["TSH_SHARDS_SHARE_DEVICES"]
