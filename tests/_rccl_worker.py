@@ -182,4 +182,22 @@ if os.environ.get("WORKER_BIG_SHARDS") == "1":
         verdict == (_ffi.TSH_E_BAD_ARG if rank == world - 1 else _ffi.TSH_E_PEER))
     say("big shards: usable afterwards", check_big(cs.search(q20, 10)))
     cs.close()
+    # ... and with ranks that send calls to their matrix cores (TSH_OPT_BATCH_MIN_NQ != 0, told to each other in the agreement) the
+    # same 20 queries go as ONE group -- a group is a batched call per shard --, also when one rank has no handle to ask
+    idx.set_batch_min_nq(1)
+    cs = CommSearcher(idx, world, rank, share_id("bigb"), 0)
+    b0 = idx.counters()["batch_launches"]
+    got = cs.search(q20, 10)
+    t = cs.timeline(reset=True)
+    say("big shards, batching ranks: 20 queries in %d group(s)" % t["groups"],
+        t["groups"] == 1 and check_big(got) and idx.counters()["batch_launches"] > b0)
+    try:
+        cs.search(q20, 10, shard=None if rank == world - 1 else ...)
+        verdict = "no error"
+    except _ffi.TshError as e:
+        verdict = e.code
+    say("big shards, batching ranks: failing rank -> %s" % verdict,
+        verdict == (_ffi.TSH_E_BAD_ARG if rank == world - 1 else _ffi.TSH_E_PEER))
+    say("big shards, batching ranks: usable afterwards", check_big(cs.search(q20, 10)))
+    cs.close()
     idx.close()

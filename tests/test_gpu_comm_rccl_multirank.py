@@ -70,8 +70,9 @@ def test_the_library_schedule_is_the_same_on_a_rank_without_a_handle(hip_lib):
                           {"WORKER_BIG_SHARDS": "1"})
     out = "\n".join(outs)
     assert all(rc == 0 for rc in rcs), out[-6000:]
-    assert "MISMATCH" not in out and out.count("big shards") == 2 * 3, out[-3000:]
+    assert "MISMATCH" not in out and out.count("big shards") == 2 * 6, out[-3000:]
     assert "20 queries in 3 groups ok" in out
+    assert "batching ranks: 20 queries in 1 group(s) ok" in out  # (round 6: a group is a batched call per shard)
 
 
 def test_small_slots_chunk_the_stand_in(hip_lib):
