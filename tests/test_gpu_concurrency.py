@@ -125,3 +125,63 @@ def test_submit_reports_busy_while_a_writer_waits(hip_lib):
         assert done.wait(10), "the writer did not run after the ticket was waited"
         w.join()
         assert idx.size == 5000
+
+
+def test_batched_searches_with_a_concurrent_writer(hip_lib, oracle_mod):
+    """Two threads send 96-query L2 calls to the matrix cores while a third appends rows past the handle's capacity: the fp16 copy
+    of the rows, its norm-grouped order (perm / psq, reallocated with the row store) and the blocks it is sorted in are kept
+    current under the handle's lock, call by call.  While the writer runs every answer must be SOUND (ids of rows that
+    exist, ascending exact distances, k of them); once it is done the answers must be the oracle's."""
+    import threading
+    import time
+
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(77)
+    n0, n1, d, k, nq = 20_000, 60_000, 64, 20, 96
+    rows = (rng.standard_normal((n1, d)) * rng.uniform(0.4, 2.5, (n1, 1))).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    with HipVectorIndex(d, 0) as idx:  # (no capacity given: the appends reallocate)
+        idx.append(0, rows[:n0])
+        idx.set_batch_min_nq(2)
+        idx.set_batch_kernel(2)
+        appended, errors, calls = [n0], [], [0, 0]
+        stop = threading.Event()
+
+        def reader(t):
+            try:
+                while not stop.is_set():
+                    upto = appended[0]  # rows that certainly exist when the call starts
+                    ids, dist, cnt = idx.search(qs, k)
+                    after = appended[0]
+                    assert (cnt == k).all() and (ids >= 0).all() and (ids < max(after, upto) + 1024).all()
+                    assert (np.diff(dist, axis=1) >= 0).all()
+                    calls[t] += 1
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        def writer():
+            try:
+                while appended[0] + 700 <= n1 and not errors:
+                    idx.append(appended[0], rows[appended[0]:appended[0] + 700])
+                    appended[0] += 700
+                    time.sleep(0.002)
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        th = [threading.Thread(target=reader, args=(0,)), threading.Thread(target=reader, args=(1,)), threading.Thread(target=writer)]
+        for t in th:
+            t.start()
+        th[2].join(timeout=120)
+        stop.set()
+        for t in th[:2]:
+            t.join(timeout=60)
+        assert not any(t.is_alive() for t in th), "a thread hangs"
+        assert not errors, errors[:3]
+        assert min(calls) > 3 and appended[0] > n0 + 20_000, (calls, appended)
+        c = idx.counters()
+        assert c["batch_launches"] >= sum(calls) and c["fallback_searches"] == 0
+        n = appended[0]
+        ids, dist, cnt = idx.search(qs, k)
+        ref = oracle_mod.search_heap_many_mt(rows[:n], qs, 0, k)
+        assert np.array_equal(ids, ref[0]) and np.array_equal(dist.view(np.uint64), ref[1].view(np.uint64))
