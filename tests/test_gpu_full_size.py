@@ -262,9 +262,18 @@ def test_c4_one_rank_at_size_over_real_rccl(c4, hip_lib):
         assert t["transport"] == "rccl" and t["calls"] == 1 and t["groups"] >= 2 and t["retries"] == 0
         assert _same(cs.search(qs[3], C4_K), tuple(x[3:4] for x in ref)), "a lone query"
         idx.set_batch_min_nq(2)
+        g0 = cs.timeline()["groups"]
         assert _same(cs.search(qs, C4_K), ref), "the same call on the matrix cores vs oracle"
+        assert cs.timeline()["groups"] - g0 == 1  # (ranks that batch: one group, one batched call on the shard)
+        # ... and as the head of a 1040-query call: two groups of 512 and one of 16, a batched call on the shard each
+        big = np.concatenate([qs, np.random.default_rng(5).standard_normal((1024, C4_D)).astype(np.float32)])
+        g0 = cs.timeline()["groups"]
+        got = cs.search(big, C4_K)
+        assert cs.timeline()["groups"] - g0 == 3
+        assert _same(tuple(x[:len(qs)] for x in got), ref), "the first 16 of a 1040-query sharded call vs oracle"
+        assert (got[2] == C4_K).all()
         c = idx.counters()
-        assert c["batch_launches"] >= 1 and c["fallback_searches"] == 0 and c["safe_mode"] == 0
+        assert c["batch_launches"] >= 4 and c["fallback_searches"] == 0 and c["safe_mode"] == 0
 
 
 def test_c4_two_ranks_at_size_over_the_rccl_branch(c4, hip_lib, tmp_path):
