@@ -506,3 +506,80 @@ def test_norm_grouped_plane(hip_lib, oracle_mod, metric):
             check(n1)
             ed = oracle_mod.search_heap(rows[:n1], qs[0], metric, k, None, np.packbits(alive, bitorder="little"))[1]
             check(n1, None, float(ed[len(ed) // 2]))
+
+
+@pytest.mark.parametrize("metric", [L2, IP, COS])
+def test_listed_batch_behind_selective_masks(hip_lib, oracle_mod, metric):
+    """Listed mode (round 6): a batched call behind a mask that keeps at most 16 384 rows, a small part of the shard, scores a
+    GATHERED fp16 copy of the kept rows -- no pass over the shard, no copy of the whole shard built -- and lists its
+    candidates under the rows' ids.  Masks by pointer and by handle, Bernoulli and one id range, fewer kept rows than k, rows
+    deleted after the handle was made, both query-tile shapes, a threshold; answers equal to the oracle's.  And the cost
+    model behind TSH_OPT_BATCH_MIN_NQ = 1: four queries behind such a mask go one by one (their kept rows' exact sums), sixty
+    go to the matrix cores."""
+    from tostore_amd import HipVectorIndex
+
+    rng = np.random.default_rng(1200 + metric)
+    n, d, k = 300_000, 64, 30
+    rows = _mk(n, d, 1201 + metric, scale=None if metric == COS else (0.5, 2.0))
+    with HipVectorIndex(d, metric, capacity_rows=n) as idx:
+        idx.append(0, rows)
+        idx.set_batch_min_nq(2)
+        r0 = idx.counters()["bytes_resident"]
+        alive = np.ones(n, bool)
+
+        def check(nq, keep, thr=None, handle=False, seed=0):
+            qs = _queries(oracle_mod, nq, d, 1300 + seed, metric)
+            bits = np.packbits(keep, bitorder="little")
+            em = np.packbits(keep & alive, bitorder="little")
+            c0 = idx.counters()
+            if handle:
+                with idx.make_mask(bits) as m:
+                    got = idx.search(qs, k, thr, m)
+            else:
+                got = idx.search(qs, k, thr, bits)
+            c1 = idx.counters()
+            assert c1["batch_launches"] > c0["batch_launches"] and c1["fallback_searches"] == c0["fallback_searches"]
+            ref = oracle_mod.search_heap_many_mt(rows, qs, metric, k, thr, em)
+            assert np.array_equal(got[2], ref[2])
+            for i in range(nq):
+                c = got[2][i]
+                assert np.array_equal(got[0][i, :c], ref[0][i, :c]), i
+                assert np.array_equal(got[1][i, :c].view(np.uint64), ref[1][i, :c].view(np.uint64)), i
+            return qs, got
+
+        keep_a = rng.random(n) < 0.005  # ~1500 rows
+        check(40, keep_a)
+        check(300, keep_a, handle=True, seed=1)
+        keep_b = np.zeros(n, bool)
+        keep_b[rng.choice(n, 12_000, replace=False)] = True
+        qs, got = check(70, keep_b, seed=2)
+        ed = oracle_mod.search_heap(rows, qs[0], metric, k, None, np.packbits(keep_b, bitorder="little"))[1]
+        check(70, keep_b, thr=float(ed[len(ed) // 2]), handle=True, seed=2)
+        keep_c = np.zeros(n, bool)
+        keep_c[123_457:123_457 + 3_000] = True  # WHERE id BETWEEN ...
+        check(33, keep_c, seed=3)
+        keep_d = np.zeros(n, bool)
+        keep_d[[5, 77_777, n - 1] + list(range(200_000, 200_011))] = True  # fewer kept rows than k
+        check(20, keep_d, handle=True, seed=4)
+        # no copy of the whole shard was built for any of these calls (300 k rows of 64 fp16 would be 38 MB)
+        assert idx.counters()["bytes_resident"] - r0 < 30_000_000
+        # rows deleted after a handle was made: the list still names them, the kernels look at their live bits
+        with idx.make_mask(np.packbits(keep_b, bitorder="little")) as m:
+            dead = np.flatnonzero(keep_b)[::4]
+            idx.set_deleted(dead)
+            alive[dead] = False
+            qs = _queries(oracle_mod, 50, d, 1400, metric)
+            got = idx.search(qs, k, None, m)
+            ref = oracle_mod.search_heap_many_mt(rows, qs, metric, k, None, np.packbits(keep_b & alive, bitorder="little"))
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64))
+        # the same selective mask with the library free to choose: a few queries one by one, many batched
+        idx.set_batch_min_nq(1)
+        bits = np.packbits(keep_a, bitorder="little")
+        c0 = idx.counters()
+        four = idx.search(_queries(oracle_mod, 4, d, 1500, metric), k, None, bits)
+        c1 = idx.counters()
+        assert c1["batch_launches"] == c0["batch_launches"] and c1["exact_scans"] - c0["exact_scans"] == 4
+        sixty = idx.search(_queries(oracle_mod, 60, d, 1501, metric), k, None, bits)
+        c2 = idx.counters()
+        assert c2["batch_launches"] == c1["batch_launches"] + 1 and c2["scan_launches"] == c1["scan_launches"]
+        assert (four[2] == k).all() and (sixty[2] == k).all()

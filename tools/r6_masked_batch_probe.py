@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """64-query masked calls on the matrix-core path (what bench.py's side.C5.*.library_default_path times), the fp16 plane
 grouped by norm and in row order, alternating on one index: 1 M x 768, L2, norms U(0.5, 2), k = 100, Bernoulli masks.
-  python tools/r6_masked_batch_probe.py [keeps=0.01,0.1,0.5] [calls=30]"""
+  python tools/r6_masked_batch_probe.py [keeps=0.01,0.1,0.5] [calls=30] [queries per call=64]"""
 import os
 import sys
 import time
@@ -16,7 +16,7 @@ from tostore_amd import HipVectorIndex  # noqa: E402
 
 keeps = [float(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0.01,0.1,0.5").split(",")]
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-n, d, k, nq = 1_000_000, 768, 100, 64
+n, d, k, nq = 1_000_000, 768, 100, int(sys.argv[3]) if len(sys.argv) > 3 else 64
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(5)
@@ -50,6 +50,6 @@ for keep in keeps:
                         ref = out
                     same = all(np.array_equal(a, b) for a, b in zip(out, ref))
                     c = idx.counters()
-                    print("keep %5.1f %% %-9s %-7s: %7.1f us per 64-query call = %6.1f k queries/s  same=%s fallbacks=%d kernel=%d"
+                    print("keep %5.2f %% %-9s %-7s: %7.1f us per call = %6.1f k queries/s  same=%s fallbacks=%d kernel=%d"
                           % (keep * 100, "grouped" if grouped else "row order", form, dt * 1e6, nq / dt / 1e3, same, c["fallback_searches"], c["batch_kernel_last"]), flush=True)
 idx.close()

@@ -143,6 +143,12 @@ static __global__ void __launch_bounds__(1024) plane_group_kernel(PlaneGroupArgs
   }
 }
 
+// out[i] = src[ids[i]] (the norms of a gathered copy's rows, by position)
+static __global__ void __launch_bounds__(256) gather_f32_kernel(const float *src, const uint32_t *ids, float *out, int32_t n) {
+  const int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  if (i < n) out[i] = src[ids[i]];
+}
+
 // one wave's 64 x 16 B from global (per-lane address) into LDS at lds_dst + 16 * lane (wave-uniform base in M0).
 // Invisible to the compiler's s_waitcnt bookkeeping: completion is counted by hand (f16_wait_dma).
 __device__ __forceinline__ void f16_dma16(const void *gsrc, uint32_t lds_dst) {

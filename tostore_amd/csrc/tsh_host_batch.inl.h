@@ -26,6 +26,13 @@ struct BatchCtx {
   int64_t mask_words = 0;
   float *d_dense2 = nullptr;  // the hub rows' dense keys (nq_pad x HUB_ROWS)
   int64_t dense2_cap = 0;
+  // a call behind a SELECTIVE mask (listed mode, shard_search_batch): the kept rows' ids, their fp16 copy and norms
+  uint32_t *d_list = nullptr, *h_list = nullptr;
+  int64_t list_cap = 0;
+  u32x4 *d_gplane = nullptr;
+  int64_t gplane_cap = 0;  // in u32x4 units
+  float *d_gsq = nullptr;
+  int64_t gsq_cap = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e_done = nullptr;
   hipEvent_t e_chunk[3] = {nullptr, nullptr, nullptr};  // tail chunks but the last
   hipEvent_t e_up = nullptr;  // the call's inputs have arrived (upload stream -> batch stream)
@@ -70,6 +77,10 @@ void batch_free(BatchCtx *b) {
   hipFree(b->d_mask);
   hipHostFree(b->h_mask);
   hipFree(b->d_dense2);
+  hipFree(b->d_list);
+  hipHostFree(b->h_list);
+  hipFree(b->d_gplane);
+  hipFree(b->d_gsq);
   hipFree(b->d_quar_out);
   hipHostFree(b->h_quar_out);
   hipHostFree(b->h_fin_ids);
@@ -413,9 +424,44 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // (the fp16 plane of an L2 / inner-product shard may be norm-grouped, plane_group_kernel: windows of whole blocks then.
   // Decided here from what is known before the key kernel is -- a superset; whole blocks suit every kernel)
   const bool want_group = s->batch_group && s->metric != TSH_METRIC_COSINE && want_kernel >= 2;
-  const int64_t n_sample = b->last_sample_force ? rows : batch_sample_rows(rows, k, want_group);
-  const int64_t ratio = rows / std::max<int64_t>(n_sample, 1) + 1;
-  int32_t k_est = batch_k_est(b, k, rows, n_sample);  // (with a mask: recomputed below from the KEPT rows)
+  int rc;
+  // ---- the mask, early: how many rows it keeps decides how the call is scored ---------------------------------------
+  const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
+  // (a mask handle's words are resident, host and device: no copy of them in this call's scratch)
+  if (mask.bytes && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
+  int64_t kept = -1;  // rows the mask keeps (tombstones not subtracted); -1: no mask
+  if (mask.part) {
+    kept = mask.part->kept;
+  } else if (mask.bytes) {
+    slice_mask(s, mask.bytes, b->h_mask, n_tiles_all);
+    if (rows & 63) b->h_mask[n_tiles_all - 1] &= (1ull << (rows & 63)) - 1ull;  // (bits past the last row keep nothing)
+    kept = popcount_words(b->h_mask, (size_t)n_tiles_all);
+  }
+  // LISTED mode (round 6): a mask that keeps at most LISTED_MAX rows, a small part of the shard.  Scoring all rows and
+  // dropping all but a percent in the epilogue is the wrong way round: the kept rows' fp16 copy is GATHERED (their ids are
+  // the mask as a list -- a handle's resident one, or this call's), and the dense pass scores just them: the "sample" is
+  // every row there is, its threshold proven (k_est = k), and no filtered pass follows.  1 M x 768, keep 1 %: a
+  // 64-query call 0.55 -> 0.2 ms, a 1024-query call 1.8 -> 0.3 ms.  fp16 keys only (the kernel that maps plane positions
+  // to row ids); everything behind the candidate lists sees row ids, as ever.
+  constexpr int64_t LISTED_MAX = 16384, LISTED_PART = 24;
+  bool listed = false;
+  if (kept >= 1 && kept <= LISTED_MAX && kept * LISTED_PART <= rows && !b->last_sample_force && want_kernel >= 2 &&
+      (!mask.part || (mask.part->d_list && mask.part->list_padded > 0))) {
+    bool f16_can = want_kernel == 2 || (want_kernel == 3 && s->metric == TSH_METRIC_COSINE);
+    if (!f16_can && want_kernel == 3 && s->f16_denied_calls.load() <= 0) {  // the automatic choice's rule (below), read-only
+      const double c_acc0 = (double)((s->dim + 63) / 64 + 12) * 1.1920928955078125e-07;
+      f16_can = s->metric != TSH_METRIC_L2 ||
+                (s->min_norm > 0.f && c_acc0 * (1.0 + (double)s->max_norm * (double)s->max_norm) <= 0.02 * (double)s->min_norm);
+    }
+    const float top0 = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;
+    int e0 = 0;
+    if (top0 > 0.f) std::frexp(top0, &e0);
+    listed = f16_can && 14 - e0 <= 55 && 14 - e0 >= -55;
+  }
+  const int64_t scan_rows = listed ? kept : rows;  // rows the key passes score
+  const int64_t n_sample = listed ? kept : (b->last_sample_force ? rows : batch_sample_rows(rows, k, want_group));
+  const int64_t ratio = scan_rows / std::max<int64_t>(n_sample, 1) + 1;
+  int32_t k_est = batch_k_est(b, k, scan_rows, n_sample);  // (with a mask: recomputed below from the KEPT rows)
   const int32_t cand_cap = (int32_t)std::min<int64_t>(65536, std::max<int64_t>(4096, round_up(4 * (int64_t)k * ratio, 64)));
   if (!b->e0) {
     const unsigned wait_flag = blocking_wait() ? hipEventBlockingSync : 0;
@@ -425,7 +471,6 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     for (hipEvent_t &e : b->e_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | wait_flag));
     HIPCHK(hipEventCreateWithFlags(&b->e_up, hipEventDisableTiming));
   }
-  int rc;
   if ((rc = regrow(&b->d_Q, &b->h_Q, &b->q_cap, (int64_t)nq_pad * ld, &b->bytes))) return rc;
   if ((rc = regrow(&b->d_qaux, &b->h_qaux, &b->aux_cap, (int64_t)nq_pad * 6, &b->bytes))) return rc;  // + thr, tau_est, kmax, alpha
   if ((rc = regrow(&b->d_dense, (float **)nullptr, &b->dense_cap, (int64_t)nq_pad * n_sample, &b->bytes))) return rc;
@@ -440,13 +485,10 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if ((rc = regrow(&b->d_blocks, &b->h_blocks, &b->blocks_cap, (int64_t)nq * (int64_t)bb, &b->bytes))) return rc;
   HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->h_blocks_dev), b->h_blocks, 0));
   if ((rc = regrow(&b->d_final, (uint32_t **)nullptr, &b->final_cap, (int64_t)nq * entries, &b->bytes))) return rc;
-  const int32_t n_tiles_all = (int32_t)((rows + 63) / 64);
   // The hub rows' bound (Shard::d_hub): fp16 keys of an L2 / inner-product shard whose norms differ at all, no caller
   // mask (the bound counts rows the mask may drop), big enough that sixteen more tiles are noise.  TSH_OPT_BATCH_HUB.
-  bool use_hub = s->batch_hub && !mask && !b->last_sample_force && s->metric != TSH_METRIC_COSINE && rows >= 16 * HUB_ROWS &&
+  bool use_hub = s->batch_hub && !mask && !listed && !b->last_sample_force && s->metric != TSH_METRIC_COSINE && rows >= 16 * HUB_ROWS &&
                  s->max_norm > 1.02f * s->min_norm && k <= HUB_ROWS / 4;
-  // (a mask handle's words are resident, host and device: no copy of them in this call's scratch)
-  if (mask.bytes && (rc = regrow(&b->d_mask, &b->h_mask, &b->mask_words, (int64_t)n_tiles_all, &b->bytes))) return rc;
 
   // ---- bf16x3 / f16 kernels: keep the converted planes of the rows current ----------------------
   // auto: cosine keys are scale-free (unit rows, unit query), so fp16's fixed relative precision gives a
@@ -472,6 +514,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   const bool l2_ok = s->min_norm > 0.f && c_acc * (1.0 + (double)s->max_norm * (double)s->max_norm) <= 0.02 * (double)s->min_norm;
   const bool f16_fits = f16_ok && (s->metric != TSH_METRIC_L2 || l2_ok);
   int kern = want_kernel == 3 ? ((s->metric == TSH_METRIC_COSINE || f16_fits) ? 2 : 1) : want_kernel;
+  if (listed) kern = 2;  // (decided above by the same rule; the scale's range was checked there too)
   int v_exp = 0;  // f16: rows are scaled by 2^v_exp so the largest magnitude lands in [2^13, 2^14)
   if (kern == 2) {
     const float top = s->metric == TSH_METRIC_COSINE ? 1.0f : s->max_abs;  // cosine planes hold unit rows
@@ -490,6 +533,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   if (use_planes &&
       (rc = regrow(&b->d_Qs, (u32x4 **)nullptr, &b->qs_cap, round_up(nq_pad, PLANE_GROUP) * hchunks * 8, &b->bytes)))
     return rc;  // (sized for the bf16 hi + lo planes; the fp16 ones are half of it)
+  if (listed) {  // the kept rows' fp16 copy (whole 256-row groups), their norms, their ids (a pointer mask's list: this call's)
+    const int64_t prow = round_up(kept, PLANE_GROUP);
+    if ((rc = regrow(&b->d_gplane, (u32x4 **)nullptr, &b->gplane_cap, prow * hchunks * 4, &b->bytes))) return rc;
+    if ((rc = regrow(&b->d_gsq, (float **)nullptr, &b->gsq_cap, prow, &b->bytes))) return rc;
+    if (!mask.part && (rc = regrow(&b->d_list, &b->h_list, &b->list_cap, kept + 64, &b->bytes))) return rc;
+  }
 
   // ---- host prep: padded queries, per-query bands ------------------------------------
   float *h_qsq = b->h_qaux, *h_d2 = b->h_qaux + nq_pad, *h_kmax = b->h_qaux + 4 * (size_t)nq_pad;
@@ -556,7 +605,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         }
     }
   }
-  if (mask.bytes) slice_mask(s, mask.bytes, b->h_mask, n_tiles_all);
+  // (a pointer mask was sliced at the top)
+  if (listed && !mask.part) list_mask_bits(b->h_mask, n_tiles_all, kept, b->h_list);  // ascending ids of the kept rows
   const uint64_t *h_mw = mask.part ? mask.part->h_words.data() : (mask.bytes ? b->h_mask : nullptr);  // this shard's slice,
   const uint64_t *d_mw = mask.part ? mask.part->d_words : (mask.bytes ? b->d_mask : nullptr);          // host and device
   // Where the sample sits.  The first n_sample rows serve any mask that keeps rows everywhere; a WHERE clause that
@@ -566,7 +616,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   // the most rows is taken instead -- candidates every half window -- and the first one on a tie.  The bound needs
   // nothing of the sample but k kept rows inside it; an estimate it makes unrepresentative is caught by B2 as ever.
   int64_t s0 = 0;
-  if (mask && n_sample < rows) {
+  if (mask && !listed && n_sample < rows) {
     // in 64-row mask words; 256-row aligned (whole blocks of a norm-grouped plane: PG_ROWS-aligned)
     const int64_t wa = want_group ? PG_ROWS / 64 : 4;
     const int64_t wt = n_sample / 64, step = std::max<int64_t>(wa, wt / 2 / wa * wa);
@@ -632,13 +682,14 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipMemcpyAsync(b->d_qaux, b->h_qaux, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));
     HIPCHK(hipMemcpyAsync(b->d_qaux + 4 * (size_t)nq_pad, h_kmax, (size_t)nq_pad * 2 * sizeof(float), hipMemcpyHostToDevice, up));  // kmax, alpha
     if (mask.bytes) HIPCHK(hipMemcpyAsync(b->d_mask, b->h_mask, (size_t)n_tiles_all * 8, hipMemcpyHostToDevice, up));
+    if (listed && !mask.part) HIPCHK(hipMemcpyAsync(b->d_list, b->h_list, (size_t)kept * 4, hipMemcpyHostToDevice, up));
     if (gpu_final) HIPCHK(hipMemcpyAsync(b->d_sqrt_mag, b->h_sqrt_mag, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, up));
     HIPCHK(hipEventRecord(b->e_up, up));
   }
   {
     std::lock_guard<std::mutex> enq(s->batch_enq_mu);  // one call's sequence at a time on the one in-order stream
     hipStream_t st = s->batch_stream;
-    if (use_planes) {
+    if (use_planes && !listed) {  // (listed: the call scores a gathered copy of its own -- the shard's copy is neither needed nor built)
       const int64_t row_bytes = (int64_t)hchunks * (use_f16 ? 64 : 128);  // fp16: 2 B per element, bf16 hi + lo: 4 B
       if (s->split_mode != kern || (use_f16 && s->split_exp != v_exp)) s->split_valid = 0;  // other format / scale
       if (s->split_cap < s->cap || s->split_mode != kern) {  // first use, other format, or the row store grew
@@ -759,7 +810,11 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
         const int64_t total = n * hchunks * 4;
         half_rows32_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 65536), 256, 0, st>>>(ha);
       };
-      if (s->split_valid < rows) {
+      const uint32_t *d_ids = listed ? (mask.part ? mask.part->d_list : b->d_list) : nullptr;
+      if (listed) {  // the kept rows, gathered: norms by list position, fp16 rows by list position
+        gather_f32_kernel<<<(unsigned)((kept + 255) / 256), 256, 0, st>>>(s->d_sqnorm, d_ids, b->d_gsq, (int32_t)kept);
+        half(s->d_rows, s->metric == TSH_METRIC_COSINE ? s->d_inv_norm : nullptr, 0, kept, b->d_gplane, v_exp, d_ids);
+      } else if (s->split_valid < rows) {
         int64_t from = s->split_valid;
         if (grouped) {  // whole blocks again from the one the first stale row sits in: positions [from, rows) and their rows
           from = from / PG_ROWS * PG_ROWS;
@@ -778,7 +833,8 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
       }
       half(b->d_Q, nullptr, 0, nq_pad, b->d_Qs, q_exp);
       a.Qs = b->d_Qs;
-      a.Vs = s->d_split;
+      a.Vs = listed ? b->d_gplane : s->d_split;
+      a.row_ids = d_ids;
       a.hchunks = hchunks;
       a.dot_scale = std::ldexp(1.0f, -(q_exp + v_exp));
 #ifdef TSH_PROBES
@@ -794,8 +850,12 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     a.Q = b->d_Q;
     a.V = s->d_rows;
     a.inv_norm = use_f16 ? nullptr : s->d_inv_norm;  // f16 planes of a cosine corpus hold unit rows
-    a.sqnorm = grouped ? s->d_psq : s->d_sqnorm;  // (by plane position, like everything the key kernel indexes by column)
-    a.row_ids = grouped ? s->d_perm : nullptr;
+    if (listed) {
+      a.sqnorm = b->d_gsq;
+    } else {
+      a.sqnorm = grouped ? s->d_psq : s->d_sqnorm;  // (by plane position, like everything the key kernel indexes by column)
+      a.row_ids = grouped ? s->d_perm : nullptr;
+    }
     a.qsq = d_qsq;
     a.thr = d_thr;
     a.kmax = b->d_qaux + 4 * (size_t)nq_pad;
@@ -805,8 +865,9 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     const bool roww = use_f16 && s->metric != TSH_METRIC_COSINE && !b->last_sample_force;
     const float chain2 = batch_chain2(s, kern);
     a.alpha = roww ? b->d_qaux + 5 * (size_t)nq_pad : nullptr;
-    a.live = s->all_live ? nullptr : s->d_live;
-    a.mask = d_mw;
+    // (listed: the list IS the mask; its rows' live bits are always looked up -- a handle's list may name rows deleted since)
+    a.live = listed ? s->d_live : (s->all_live ? nullptr : s->d_live);
+    a.mask = listed ? nullptr : d_mw;
     a.dense = b->d_dense;
     a.cand_key = b->d_ck;
     a.cand_row = b->d_cr;
@@ -877,13 +938,13 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     else batch_sample_select_kernel<BS_THREADS><<<nq, BS_THREADS, 0, st>>>(ss);
     // B1: everything else, filtered
     if (timed) HIPCHK(hipEventRecord(b->e2, st));
-    if (s0 > 0) {  // (a sample window inside the rows: the filtered pass runs on either side of it)
+    if (s0 > 0 && !listed) {  // (a sample window inside the rows: the filtered pass runs on either side of it)
       a.row0 = 0;
       a.row1 = (int32_t)s0;
       a.n_tiles = (int32_t)((s0 + tile_n - 1) / tile_n);
       launch_batch_score_m(s->metric, a, false, st, s->cus);
     }
-    if (rows > s0 + n_sample) {
+    if (!listed && rows > s0 + n_sample) {
       a.row0 = (int32_t)(s0 + n_sample);
       a.row1 = (int32_t)rows;
       a.n_tiles = (int32_t)((rows - s0 - n_sample + tile_n - 1) / tile_n);
@@ -1044,7 +1105,7 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
     HIPCHK(hipEventElapsedTime(&ms0, b->e0, b->e1));
     HIPCHK(hipEventElapsedTime(&ms1, b->e2, b->e3));
     b->last_gemm_us = ((double)ms0 + (double)ms1) * 1e3;
-    b->last_flops = 2.0 * nq * (double)rows * (double)s->dim;
+    b->last_flops = 2.0 * nq * (double)scan_rows * (double)s->dim;
   }
   // auto mode: fp16 keys whose band keeps overflowing the lists of this corpus (every overflow is a whole scan) give
   // way to bf16x3 ones, 25 x narrower, after two such calls (cosine keys are scale-free: never)
@@ -1115,17 +1176,46 @@ int shard_search_batch(Shard *s, BatchCtx *b, const float *queries, int32_t nq, 
   return TSH_OK;
 }
 
-// does a call of nq queries on this shard go to the matrix cores?
-bool shard_takes_batch(const Shard *s, int32_t batch_min_nq, int32_t nq, int32_t k) {
+// rows a caller's mask keeps on this shard (the pointer form, counted for the cost model below: 125 KB at 1 M rows, ~5 us)
+int64_t mask_kept_rows(const Shard *s, const uint8_t *bytes) {
+  const int64_t lo = s->row_base, hi = s->row_base + s->rows;
+  if (hi <= lo) return 0;
+  int64_t n = 0, i = lo;
+  for (; i < hi && (i & 7); ++i) n += (bytes[i >> 3] >> (i & 7)) & 1;
+  const int64_t whole = (hi - i) / 64;
+  for (int64_t w = 0; w < whole; ++w) {
+    uint64_t v;
+    memcpy(&v, bytes + (i >> 3) + 8 * w, 8);
+    n += __builtin_popcountll(v);
+  }
+  for (i += 64 * whole; i < hi; ++i) n += (bytes[i >> 3] >> (i & 7)) & 1;
+  return n;
+}
+
+// does a call of nq queries on this shard go to the matrix cores?  kept: rows a mask of the call keeps (-1: none / unknown)
+bool shard_takes_batch(const Shard *s, int32_t batch_min_nq, int32_t nq, int32_t k, int64_t kept = -1) {
   // batch_min_nq == 1: decide by cost.  Measured: a batched call costs about 0.30 ms plus one
   // pass over the converted rows at ~4 TB/s, whatever nq <= 128 is; pipelined single-query scans cost one
   // pass over the f32 rows at ~6.6 TB/s plus ~25 us each.  At 1 M x 768 that is 0.67 vs 1.04 ms for TWO queries.
+  // With a mask (round 6) both sides change: a query of its own reads the kept rows only -- from their exact sums in two
+  // dispatches when there are at most exact_rows of them (16.7 us per query at 10 k kept rows of 768 floats, pipelined),
+  // by a masked scan otherwise (57-65 us at 100 k) --, and a batched call behind a selective mask scores a gathered
+  // copy of the kept rows (listed mode, shard_search_batch: ~0.2 ms whatever nq <= 128 is).  Eight queries behind a 1 %
+  // mask of 1 M rows: 0.13 ms one by one, 0.2 ms batched (0.55 before the listed mode) -- the model used to send
+  // every masked call of two queries or more to the matrix cores.
   bool enough = batch_min_nq > 1 && nq >= batch_min_nq;
   if (batch_min_nq == 1 && nq >= 2) {
     const int kern = s->batch_kernel == 3 ? 2 : s->batch_kernel;
     const double plane_b = kern == 0 ? 4.0 : (kern == 1 ? 4.0 : 2.0);
-    const double t_batch = 300.0 + (double)s->rows * (double)s->dim * plane_b / 4.0e6 * ((nq + 127) / 128);
-    const double t_single = (double)nq * ((double)s->rows * (double)s->ld * 4.0 / 6.6e6 + 25.0);
+    double t_batch = 300.0 + (double)s->rows * (double)s->dim * plane_b / 4.0e6 * ((nq + 127) / 128);
+    double t_single = (double)nq * ((double)s->rows * (double)s->ld * 4.0 / 6.6e6 + 25.0);
+    if (kept >= 0 && kept < s->rows) {
+      const double kept_bytes = (double)std::max<int64_t>(kept, 1) * (double)s->ld * 4.0;
+      if (kept <= std::min<int64_t>(s->exact_rows, EX_MAX_ROWS)) t_single = (double)nq * (8.0 + kept_bytes / 3.5e6);
+      else t_single = (double)nq * (25.0 + kept_bytes / 5.5e6);
+      if (kern >= 2 && kept >= 1 && kept <= 16384 && kept * 24 <= s->rows)  // (listed mode's conditions, shard_search_batch)
+        t_batch = 180.0 + (double)kept * (double)s->dim * 2.0 / 4.0e6 * ((nq + 127) / 128) + 0.3 * (double)nq;
+    }
     enough = t_single > t_batch;
   }
   return enough && !s->safe_mode() && s->rows >= 4096 && k <= 1024 && s->rows < 0x7FFFFF00ll;
@@ -1135,7 +1225,10 @@ bool shard_takes_batch(const Shard *s, int32_t batch_min_nq, int32_t nq, int32_t
 // otherwise and for whatever the batch hands back.
 int shard_search_any(Shard *s, BatchCtx *b, int32_t batch_min_nq, const float *queries, int32_t nq, int32_t k,
                      const MaskSrc &mask, int32_t entries, SearchOut *out) {
-  const bool use_batch = shard_takes_batch(s, batch_min_nq, nq, k);
+  // (a mask's kept rows, for the cost model: a handle knows them; a pointer mask is counted when the answer can matter)
+  int64_t kept = -1;
+  if (mask && batch_min_nq == 1 && nq >= 2 && nq <= 512) kept = mask.part ? mask.part->kept : mask_kept_rows(s, mask.bytes);
+  const bool use_batch = shard_takes_batch(s, batch_min_nq, nq, k, kept);
   if (!use_batch) return shard_search_blocks(s, queries, nq, k, mask, entries, out, PIPE_DEPTH);
   std::vector<int32_t> redo;
   const size_t bb = (size_t)tsh_candidate_block_bytes(entries);
