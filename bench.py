@@ -626,7 +626,9 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
     1 / 10 / 50 / 100 % and one contiguous id range of 10 %."""
     out = {"workload": "C5: %dx%d f32, L2, k=%d, device-side row bitmask" % (n, d, k),
            "note": "value = every query scans its kept rows on its own (masked HBM scan, pipelined, 64 queries per "
-                   "call); library_default_path = the same calls with the library free to choose"}
+                   "call); library_default_path = the same calls with the library free to choose (64 queries: the matrix "
+                   "cores -- over a gathered copy of the kept rows when the mask keeps at most 16 384 of them, over the "
+                   "whole shard with the mask in the epilogue otherwise)"}
     idx.set_batch_min_nq(0)
     cnt = 1024
     sel = [i % len(queries) for i in range(cnt)]
@@ -676,7 +678,8 @@ def side_c5(env, idx, host_rows, queries, metric, n, d, k, check=100):
             ent["roofline"]["rocprofv3_source"] = prof.get("source")
         tail = tuple(np.concatenate([g[j] for g in got])[cnt - m:] for j in range(3)) if m else None
         # the same 64-query calls with the library's own choice of path (cost model: for a call of this size it
-        # scores all queries in one matrix-core pass and applies the mask in the epilogue)
+        # scores all queries in one matrix-core pass -- over the kept rows' gathered copy behind a selective mask, over the
+        # shard with the mask in the epilogue otherwise)
         tail2 = None
         try:
             idx.set_batch_min_nq(1)
